@@ -1,0 +1,402 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/*.npz  (build-container only).
+
+Imports the reference's OWN solver files, unmodified, from /root/reference over
+the numpy stand-in for `tensorflow` in tf_standin.py (TensorFlow itself is not
+installable here - SURVEY.md F1) and records inputs + outputs of
+
+  * the per-function contracts on the hot path:
+    _runge_kutta_step (rk_common.py:22-61) for each tableau, rk4_alt_step_func
+    (rk_common.py:73-81), _compute_error_ratio (misc.py:250-264), both
+    _optimal_step_size variants (misc.py:267-287, tsit5.py:53-62),
+    _select_initial_step (misc.py:183-247), _interp_fit/_interp_evaluate
+    (interp.py:6-67), _interp_eval_tsit5 (tsit5.py:45-50);
+  * whole odeint() runs with per-attempt traces (t0, dt, accepted, dt_next).
+
+Every fixture carries  oracle = "reference control-flow over numpy stand-in;
+TensorFlow absent".  Only data (inputs / expected outputs) is written; no
+reference source text is copied.  The reference never leaves this container:
+tests read the .npz files, not /root/reference.
+
+Run:  PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import numpy as np  # noqa: E402
+import tf_standin  # noqa: E402
+
+tf = tf_standin.install()
+_viz = types.ModuleType('tfdiffeq.viz_utils')
+for _n in ('plot_phase_portrait', 'plot_vector_field', 'plot_results'):
+    setattr(_viz, _n, None)
+sys.modules['tfdiffeq.viz_utils'] = _viz
+sys.path.insert(0, '/root/reference')
+
+import tfdiffeq  # noqa: E402
+from tfdiffeq import misc, rk_common, interp, dopri5, tsit5, bosh3  # noqa: E402
+
+LABEL = 'reference control-flow over numpy stand-in; TensorFlow absent'
+T = tf_standin.Tensor
+
+
+def tt(a, dtype=None):
+    a = np.asarray(a)
+    if dtype is not None:
+        a = a.astype(dtype)
+    return T(a)
+
+
+def save(name, meta, **arrays):
+    meta = dict(meta)
+    meta['oracle'] = LABEL
+    out = {}
+    for k, v in arrays.items():
+        out[k] = v._a if isinstance(v, T) else np.asarray(v)
+    out['meta'] = np.asarray(json.dumps(meta, sort_keys=True))
+    path = os.path.join(HERE, name + '.npz')
+    np.savez_compressed(path, **out)
+    print('%-34s %7.1f KB' % (name, os.path.getsize(path) / 1024.0))
+
+
+# --------------------------------------------------------------------------
+# RHS catalogue, written with tf ops (mirrored in oracle/rhs_numpy.py by name)
+# --------------------------------------------------------------------------
+class RHS(object):
+    def __init__(self, name, params, fn):
+        self.name, self.params, self.fn, self.nfe = name, params, fn, 0
+
+    def __call__(self, t, y):
+        self.nfe += 1
+        return self.fn(t, y)
+
+
+def rhs_sine():        # tests/problems.py:28-34
+    return RHS('sine', {}, lambda t, y: 2 * y / t + t ** 4 * tf.sin(2 * t) - t ** 2 + 4 * t ** 3)
+
+
+def rhs_constant():    # tests/problems.py:13-21
+    return RHS('constant', {'a': 0.2, 'b': 3.0}, lambda t, y: 0.2 + (y - (0.2 * t + 3.0)) ** 5)
+
+
+def rhs_cubic(A):      # examples/ode_demo.py:33-35   f = (y**3) @ A
+    At = tt(A)
+    return RHS('cubic_linear', {'W': np.asarray(A).tolist()}, lambda t, y: tf.matmul(y ** 3, At))
+
+
+def rhs_linear(W):     # f = y @ W   (config 4: W = A^T)
+    Wt = tt(W)
+    return RHS('linear', {'W': np.asarray(W).tolist()}, lambda t, y: tf.matmul(y, Wt))
+
+
+def rhs_lv(a=1.5, b=1.0, c=3.0, d=1.0):   # examples/ode_usage.ipynb cells 39-42, batched on last axis
+    def fn(t, y):
+        u, v = y[..., 0], y[..., 1]
+        return tf.stack([a * u - b * u * v, -c * v + d * u * v], axis=-1)
+    return RHS('lotka_volterra', {'a': a, 'b': b, 'c': c, 'd': d}, fn)
+
+
+def rhs_lorenz(sigma=10., beta=8. / 3., rho=28.):   # examples/lorenz_attractor.py:20-37, batched on last axis
+    def fn(t, y):
+        x0, x1, x2 = y[..., 0], y[..., 1], y[..., 2]
+        return tf.stack([sigma * (x1 - x0), x0 * (rho - x2) - x1, x0 * x1 - beta * x2], axis=-1)
+    return RHS('lorenz', {'sigma': sigma, 'beta': beta, 'rho': rho}, fn)
+
+
+def rhs_mlp(W1, b1, W2, b2, W3, b3):   # models/dense_odenet.py:41-92 (time-independent, tanh)
+    ws = [tt(w) for w in (W1, b1, W2, b2, W3, b3)]
+
+    def fn(t, y):
+        h = tf.tanh(tf.matmul(y, ws[0]) + ws[1])
+        h = tf.tanh(tf.matmul(h, ws[2]) + ws[3])
+        return tf.matmul(h, ws[4]) + ws[5]
+    return RHS('mlp_tanh', {}, fn)
+
+
+def rhs_tdep():        # genuinely time dependent, elementwise: used for per-function vectors
+    return RHS('tdep', {}, lambda t, y: tf.sin(y) * t - 0.5 * y + tf.cos(t))
+
+
+# --------------------------------------------------------------------------
+# per-function vectors
+# --------------------------------------------------------------------------
+def gen_function_vectors():
+    rng = np.random.default_rng(1234)
+    tableaus = {'dopri5': dopri5._DORMAND_PRINCE_SHAMPINE_TABLEAU,
+                'tsit5': tsit5._TSITOURAS_TABLEAU,
+                'bosh3': bosh3._BOGACKI_SHAMPINE_TABLEAU}
+    # verbatim tableau constants as the reference module holds them
+    tab = {}
+    for n, tb in tableaus.items():
+        S = len(tb.alpha)
+        beta = np.zeros((S, S))
+        for i, row in enumerate(tb.beta):
+            beta[i, :len(row)] = row
+        tab[n + '_alpha'] = np.asarray(tb.alpha, dtype=np.float64)
+        tab[n + '_beta'] = beta
+        tab[n + '_c_sol'] = np.asarray(tb.c_sol, dtype=np.float64)
+        tab[n + '_c_error'] = np.asarray(tb.c_error, dtype=np.float64)
+    tab['dopri5_c_mid'] = np.asarray(dopri5.DPS_C_MID, dtype=np.float64)
+    tab['bosh3_c_mid'] = np.asarray(bosh3.BS_C_MID, dtype=np.float64)
+    save('fn_tableaus', {'what': 'tableau constants exactly as held by the reference modules '
+                                 '(dopri5.py:11-36, tsit5.py:10-30, bosh3.py:10-20)'}, **tab)
+
+    for dt_name in ('float64', 'float32'):
+        npdt = np.dtype(dt_name)
+        out = {}
+        y0 = rng.standard_normal((7, 5)).astype(npdt)
+        f1_ = rhs_tdep()
+        f = lambda tm, ys, _f=f1_: (_f(tm, ys[0]),)  # noqa: E731  (tuple-state contract of rk_common)
+        t0 = 0.37
+        dt = 0.0625
+        f0 = f1_(tt(t0, npdt), tt(y0))
+        out['y0'], out['f0'], out['t0'], out['dt'] = y0, f0, np.float64(t0), np.float64(dt)
+        for n, tb in tableaus.items():
+            y1, f1, err, k = rk_common._runge_kutta_step(
+                f, (tt(y0),), (f0,), tt(t0, np.float64), tt(dt, np.float64), tb)
+            out[n + '_y1'], out[n + '_f1'], out[n + '_err'] = y1[0], f1[0], err[0]
+            out[n + '_k'] = np.stack([kk._a for kk in k[0]])
+            # error ratio through the shared helper (misc.py:250-264)
+            ratio = misc._compute_error_ratio(err, atol=[1e-6], rtol=[1e-4], y0=(tt(y0),), y1=y1)
+            out[n + '_ratio'] = ratio[0]
+        # dense output (dopri5.py:39-45, interp.py)
+        tb = tableaus['dopri5']
+        y1, f1, err, k = rk_common._runge_kutta_step(f, (tt(y0),), (f0,), tt(t0, np.float64), tt(dt, np.float64), tb)
+        coeff = dopri5._interp_fit_dopri5((tt(y0),), y1, k, tt(dt, np.float64))
+        out['dopri5_interp_coeff'] = np.stack([c[0]._a for c in coeff])
+        for j, te in enumerate((t0, t0 + 0.3 * dt, t0 + dt)):
+            out['dopri5_interp_eval%d' % j] = interp._interp_evaluate(
+                coeff, tt(t0, np.float64), tt(t0 + dt, np.float64), tt(te, np.float64))[0]
+        out['interp_eval_times'] = np.asarray([t0, t0 + 0.3 * dt, t0 + dt])
+        tb = tableaus['bosh3']
+        y1, f1, err, k = rk_common._runge_kutta_step(f, (tt(y0),), (f0,), tt(t0, np.float64), tt(dt, np.float64), tb)
+        coeff = bosh3._interp_fit_bosh3((tt(y0),), y1, k, tt(dt, np.float64))
+        out['bosh3_interp_coeff'] = np.stack([c[0]._a for c in coeff])
+        out['bosh3_interp_eval1'] = interp._interp_evaluate(
+            coeff, tt(t0, np.float64), tt(t0 + dt, np.float64), tt(t0 + 0.3 * dt, np.float64))[0]
+        # tsit5 dense output (tsit5.py:33-50) - note the reference starts from k[0] (= f0), F6(b)
+        tb = tableaus['tsit5']
+        y1, f1, err, k = rk_common._runge_kutta_step(f, (tt(y0),), (f0,), tt(t0, np.float64), tt(dt, np.float64), tb)
+        if npdt == np.float64:   # the reference mixes float64 time into the state dtype here; fp32 raises in TF
+            out['tsit5_interp_eval1'] = tsit5._interp_eval_tsit5(
+                tt(t0, np.float64), tt(t0 + dt, np.float64), k, tt(t0 + 0.3 * dt, np.float64))[0]
+        # rk4 3/8 rule + euler increment (rk_common.py:73-81, fixed_grid.py:6-7)
+        dy = rk_common.rk4_alt_step_func(f, tt(t0, npdt), tt(dt, npdt), (tt(y0),))
+        out['rk4_dy'] = dy[0]
+        # _select_initial_step for orders 4 (dopri5/tsit5) and 2 (bosh3)
+        for order in (4, 2):
+            h = misc._select_initial_step(f, tt(t0, np.float64), (tt(y0),), order, 1e-5, 1e-7, f0=(f0,))
+            out['init_step_order%d' % order] = h
+        # degenerate initial-step branches: y0 == 0 (d0 < 1e-5) and f == 0
+        z = lambda tm, ys: (ys[0] * 0.0,)  # noqa: E731
+        out['init_step_zero_f'] = misc._select_initial_step(z, tt(0.0, np.float64), (tt(y0),), 4, 1e-5, 1e-7)
+        out['init_step_zero_y'] = misc._select_initial_step(f, tt(t0, np.float64), (tt(y0 * 0),), 4, 1e-5, 1e-7)
+        save('fn_rkstep_' + dt_name, {'rhs': 'tdep', 'dtype': dt_name,
+                                       'ratio_rtol': 1e-4, 'ratio_atol': 1e-6,
+                                       'init_rtol': 1e-5, 'init_atol': 1e-7}, **out)
+
+    # step-size controllers on a grid of ratios, fp64 and fp32 ratio dtypes
+    ratios = np.concatenate([[0.0], np.logspace(-12, 6, 37), [0.999999, 1.0, 1.000001]])
+    out = {'ratios': ratios}
+    for order in (5, 3):
+        for dt_name in ('float64', 'float32'):
+            res = []
+            for r in ratios:
+                rt = tt(np.asarray(r), np.dtype(dt_name))
+                res.append(float(misc._optimal_step_size(
+                    tt(0.125, np.float64), (rt,), safety=tt(0.9, np.float64), ifactor=tt(10.0, np.float64),
+                    dfactor=tt(0.2, np.float64), order=order)._a))
+            out['misc_order%d_%s' % (order, dt_name)] = np.asarray(res)
+    res = []
+    for r in ratios:
+        res.append(float(tsit5._optimal_step_size(
+            tt(0.125, np.float64), tt(np.asarray(r), np.float64), tt(0.9, np.float64), tt(10.0, np.float64),
+            tt(0.2, np.float64), order=5)._a))
+    out['tsit5_order5_float64'] = np.asarray(res)
+    save('fn_step_controller', {'last_step': 0.125, 'safety': 0.9, 'ifactor': 10.0, 'dfactor': 0.2}, **out)
+
+
+# --------------------------------------------------------------------------
+# whole-run fixtures with per-attempt traces
+# --------------------------------------------------------------------------
+def _trace_solver(cls, step_name):
+    orig = getattr(cls, step_name)
+    log = []
+
+    def wrapped(self, rk_state):
+        new = orig(self, rk_state)
+        t_start = float(rk_state.t1._a)
+        log.append((t_start, float(np.asarray(rk_state.dt._a, dtype=np.float64)),
+                    1.0 if float(new.t1._a) > t_start else 0.0, float(new.dt._a)))
+        return new
+    setattr(cls, step_name, wrapped)
+    return orig, log
+
+
+TRACED = {'dopri5': (dopri5.Dopri5Solver, '_adaptive_dopri5_step'),
+          'bosh3': (bosh3.Bosh3Solver, '_adaptive_bosh3_step'),
+          'tsit5': (tsit5.Tsit5Solver, '_adaptive_tsit5_step')}
+
+
+class _StopAfter(Exception):
+    pass
+
+
+def run_case(name, rhs, y0, t, method, rtol=None, atol=None, options=None, max_attempts=None, note=''):
+    kw = {}
+    if rtol is not None:
+        kw['rtol'] = rtol
+    if atol is not None:
+        kw['atol'] = atol
+    if options is not None:
+        kw['options'] = options
+    log = None
+    if method in TRACED:
+        cls, step_name = TRACED[method]
+        orig, log = _trace_solver(cls, step_name)
+        if max_attempts is not None:
+            inner = getattr(cls, step_name)
+            last_state = {}
+
+            def limited(self, rk_state, _inner=inner):
+                if len(log) >= max_attempts:
+                    last_state['s'] = rk_state
+                    raise _StopAfter()
+                return _inner(self, rk_state)
+            setattr(cls, step_name, limited)
+    rhs.nfe = 0
+    y0_t = tuple(tt(a) for a in y0) if isinstance(y0, tuple) else tt(y0)
+    func = rhs
+    if isinstance(y0, tuple):
+        func = lambda tm, ys: tuple(rhs(tm, y_) for y_ in ys)  # noqa: E731
+    arrays = {}
+    try:
+        sol = tfdiffeq.odeint(func, y0_t, tt(t), method=method, **kw)
+        if isinstance(sol, tuple):
+            for i, s in enumerate(sol):
+                arrays['y_%d' % i] = s
+        else:
+            arrays['y'] = sol
+    except _StopAfter:
+        s = last_state['s']
+        arrays['y_after_attempts'] = s.y1[0]
+        arrays['t_after_attempts'] = s.t1
+    finally:
+        if method in TRACED:
+            setattr(cls, step_name, orig)
+    if isinstance(y0, tuple):
+        for i, a in enumerate(y0):
+            arrays['y0_%d' % i] = np.asarray(a)
+    else:
+        arrays['y0'] = np.asarray(y0)
+    arrays['t'] = np.asarray(t)
+    arrays['nfe'] = np.asarray(rhs.nfe)
+    if log is not None:
+        arrays['trace'] = np.asarray(log, dtype=np.float64).reshape(-1, 4)
+    meta = {'rhs': rhs.name, 'rhs_params': rhs.params, 'method': method,
+            'rtol': rtol, 'atol': atol, 'options': options, 'max_attempts': max_attempts,
+            'trace_columns': ['t0', 'dt', 'accepted', 'dt_next'], 'note': note,
+            'tuple_state': isinstance(y0, tuple)}
+    save(name, meta, **arrays)
+    return arrays
+
+
+def gen_runs():
+    f32t = np.linspace(1., 8., 10).astype(np.float32)     # tests/problems.py:78  (float32 linspace)
+    sine = rhs_sine()
+    y_exact_sine = lambda t: (-0.5 * t ** 4 * np.cos(2 * t) + 0.5 * t ** 3 * np.sin(2 * t)  # noqa: E731
+                              + 0.25 * t ** 2 * np.cos(2 * t) - t ** 3 + 2 * t ** 4 + (np.pi - 0.25) * t ** 2)
+    y0_sine = np.float64(y_exact_sine(np.float64(f32t[0])))
+    # reference unit-test problems (tests/odeint_tests.py)
+    run_case('run_sine_dopri5', sine, y0_sine, f32t, 'dopri5', note='tests/odeint_tests.py:93-98')
+    run_case('run_sine_rk4', sine, y0_sine, f32t, 'rk4')
+    run_case('run_sine_euler', sine, y0_sine, f32t, 'euler')
+    const = rhs_constant()
+    y0_c = np.float64(0.2 * np.float64(f32t[0]) + 3.0)
+    for m in ('dopri5', 'bosh3', 'rk4', 'euler'):
+        run_case('run_constant_' + m, const, y0_c, f32t, m)
+    # backwards in time (tests/odeint_tests.py:112-171)
+    run_case('run_constant_dopri5_reverse', const, np.float64(0.2 * np.float64(f32t[-1]) + 3.0), f32t[::-1].copy(), 'dopri5')
+    run_case('run_sine_dopri5_reverse', sine, np.float64(y_exact_sine(np.float64(f32t[-1]))), f32t[::-1].copy(), 'dopri5')
+    run_case('run_constant_rk4_reverse', const, np.float64(0.2 * np.float64(f32t[-1]) + 3.0), f32t[::-1].copy(), 'rk4')
+    # no integration (tests/odeint_tests.py:174-210)
+    run_case('run_constant_dopri5_noint', const, y0_c, f32t[0:1], 'dopri5')
+    # tuple state (tests/api_tests.py:26-36)
+    run_case('run_constant_dopri5_tuple', const, (y0_c, y0_c), f32t, 'dopri5')
+    # the degenerate LinearODE of tests/problems.py:43-68 (A == 0 exactly, F8)
+    run_case('run_linear0_dopri5', rhs_linear(np.zeros((10, 10))), np.ones((1, 10)), f32t, 'dopri5',
+             note='tests/problems.py LinearODE is A=0 (F8); stated here as y@W with W=0, y0=ones')
+    run_case('run_linear0_bosh3', rhs_linear(np.zeros((10, 10))), np.ones((1, 10)), f32t, 'bosh3')
+
+    # config 2: spiral (examples/ode_demo.py:27-39) - single trajectory, the SURVEY anchor
+    A = np.array([[-0.1, 2.0], [-2.0, -0.1]])
+    t_sp = np.linspace(0., 25., 1000).astype(np.float32)
+    run_case('run_spiral_dopri5_anchor', rhs_cubic(A), np.array([[2., 0.]]), t_sp[::37].copy(), 'dopri5',
+             note='ode_demo.py spiral, every 37th of the 1000 float32 output times')
+    rng = np.random.default_rng(0)
+    y0b = rng.uniform(-2, 2, size=(64, 2))
+    run_case('run_spiral_b64_dopri5', rhs_cubic(A), y0b, np.linspace(0., 25., 10), 'dopri5')
+    run_case('run_spiral_b64_dopri5_T2', rhs_cubic(A), y0b, np.array([0., 2.5]), 'dopri5')
+    run_case('run_spiral_b64_bosh3', rhs_cubic(A), y0b, np.array([0., 0.25]), 'bosh3', rtol=1e-4, atol=1e-6,
+             note='verbatim (typo) bosh3 tableau F5; short horizon because of its ~25x NFE')
+    run_case('run_spiral_b64_rk4', rhs_cubic(A), y0b, np.linspace(0., 2.5, 51), 'rk4')
+    run_case('run_spiral_b64_dopri5_f32', rhs_cubic(A.astype(np.float32)), y0b.astype(np.float32),
+             np.linspace(0., 5., 6), 'dopri5', rtol=1e-4, atol=1e-6)
+
+    # config 1: Lotka-Volterra rk4, 1000 steps (ode_usage.ipynb cells 39-42)
+    run_case('run_lv_rk4_1000', rhs_lv(), np.array([1., 1.]), np.linspace(0., 10., 1001), 'rk4',
+             note='config 1; stored every step')
+    run_case('run_lv_euler_1000', rhs_lv(), np.array([1., 1.]), np.linspace(0., 10., 1001), 'euler')
+    run_case('run_lv_dopri5', rhs_lv(), np.array([1., 1.]), np.linspace(0., 10., 1000)[::50].copy(), 'dopri5')
+    run_case('run_lv_b32_dopri5', rhs_lv(), 1.0 + 0.5 * rng.uniform(size=(32, 2)), np.linspace(0., 5., 6), 'dopri5')
+
+    # config 3: Lorenz batched (examples/lorenz_attractor.py:20-45), short horizon (chaos)
+    rng1 = np.random.default_rng(1)
+    y0l = np.array([1., 1., 1.]) + 1e-3 * rng1.standard_normal((64, 3))
+    run_case('run_lorenz_b64_dopri5', rhs_lorenz(), y0l, np.linspace(0., 1., 5), 'dopri5', rtol=1e-6, atol=1e-9)
+    run_case('run_lorenz_b64_tsit5_first40', rhs_lorenz(), y0l, np.array([0., 1.]), 'tsit5', rtol=1e-6, atol=1e-9,
+             max_attempts=40, note='reference tsit5 is defective (F6): dt collapses; first 40 attempts only')
+    run_case('run_lorenz_b64_tsit5_tiny', rhs_lorenz(), y0l, np.array([0., 2e-5, 5e-5]), 'tsit5', rtol=1e-6, atol=1e-9,
+             note='reference tsit5 end to end on a horizon it can finish; dense output starts from f0 (F6b)')
+    run_case('run_lorenz_single_dopri5', rhs_lorenz(), np.array([1., 1., 1.]), np.arange(0., 2.0, 0.01)[::20].copy(), 'dopri5',
+             note='lorenz_attractor.py workload, first 2 time units')
+
+    # config 4: linear y@A^T, reduced size B=48, D=16
+    rng2 = np.random.default_rng(2)
+    D = 16
+    S = rng2.standard_normal((D, D))
+    Amat = -0.5 * np.eye(D) + 0.5 * (S - S.T) / np.sqrt(D)
+    rng3 = np.random.default_rng(3)
+    y0lin = rng3.standard_normal((48, D))
+    run_case('run_linear_b48_d16_dopri5', rhs_linear(Amat.T.copy()), y0lin, np.array([0., 1.]), 'dopri5', rtol=1e-6, atol=1e-9)
+    run_case('run_linear_b48_d16_dopri5_T5', rhs_linear(Amat.T.copy()), y0lin, np.linspace(0., 2., 5), 'dopri5', rtol=1e-6, atol=1e-9)
+    run_case('run_linear_b48_d16_rk4', rhs_linear(Amat.T.copy()), y0lin, np.linspace(0., 1., 11), 'rk4')
+    run_case('run_linear_b48_d16_firststep', rhs_linear(Amat.T.copy()), y0lin, np.array([0., 1.]), 'dopri5',
+             options={'first_step': 0.05})
+
+    # config 5: MLP 8-16-16-8 tanh fp32 (ODEFunc shape, reduced), rtol=atol=1e-3 (ODEBlock default)
+    rng4 = np.random.default_rng(4)
+
+    def glorot(i, o):
+        lim = np.sqrt(6.0 / (i + o))
+        return rng4.uniform(-lim, lim, size=(i, o)).astype(np.float32)
+    W1, W2, W3 = glorot(8, 16), glorot(16, 16), glorot(16, 8)
+    b1, b2, b3 = (0.1 * rng4.standard_normal(16)).astype(np.float32), \
+        (0.1 * rng4.standard_normal(16)).astype(np.float32), (0.1 * rng4.standard_normal(8)).astype(np.float32)
+    rng5 = np.random.default_rng(5)
+    y0m = rng5.standard_normal((40, 8)).astype(np.float32)
+    arr = run_case('run_mlp_b40_dopri5_f32', rhs_mlp(W1, b1, W2, b2, W3, b3), y0m, np.array([0., 1.]), 'dopri5',
+                   rtol=1e-3, atol=1e-3)
+    save('run_mlp_weights', {'what': 'weights of run_mlp_b40_dopri5_f32'}, W1=W1, b1=b1, W2=W2, b2=b2, W3=W3, b3=b3)
+    del arr
+
+
+if __name__ == '__main__':
+    np.random.seed(0)
+    gen_function_vectors()
+    gen_runs()
