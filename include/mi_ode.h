@@ -1,0 +1,204 @@
+/*
+ * mi_ode.h - C ABI of the MI355X-native explicit Runge-Kutta ODE engine.
+ *
+ * This is the drop-in boundary underneath the reference's three Python
+ * contracts; the reference itself has no FFI, so each
+ * entry point cites the reference interface it replaces (paths relative to
+ * /root/reference/tfdiffeq/).  Plain C: integer status returns, raw device
+ * pointers + sizes, no exceptions, no torch types.  All work is enqueued on the
+ * caller's hipStream_t (passed as void*).  The caller owns every state / output
+ * buffer; a handle owns only its workspace (stage planes, block partials, the
+ * device-resident controller record).  One handle per host thread; no globals.
+ *
+ * Two families of entry points:
+ *
+ *  (A) fused engine  - the RHS f(t, y) is one of the device catalogue kinds and
+ *      is evaluated INSIDE each stage kernel (y_sigma is never materialised),
+ *      the step-size controller runs on the device, dense output is emitted by
+ *      a kernel.  Replaces, for a single [batch, dim] state tensor:
+ *        Dopri5Solver / Tsit5Solver / Bosh3Solver .before_integrate + .advance
+ *          (dopri5.py:70-121, tsit5.py:91-151, bosh3.py:53-99)
+ *        _runge_kutta_step                      (rk_common.py:22-61)
+ *        _compute_error_ratio / _optimal_step_size / _select_initial_step
+ *                                               (misc.py:183-287, tsit5.py:53-62)
+ *        _interp_fit / _interp_evaluate         (interp.py:6-67, tsit5.py:33-50)
+ *        FixedGridODESolver.integrate + Euler/RK4.step_func
+ *                                               (solvers.py:82-104, fixed_grid.py:4-46)
+ *
+ *  (B) stateless plane kernels - for an arbitrary Python callable f (evaluated
+ *      by the caller between launches) and tuple states.  They are the fused
+ *      equivalents of the reference's eager-op sequences:
+ *        mi_ode_lincomb        <- misc._scaled_dot_product (misc.py:118-121)
+ *        mi_ode_error_norms    <- misc._compute_error_ratio reductions (misc.py:256-263)
+ *        mi_ode_scaled_sumsq   <- misc._norm(x / scale)   (misc.py:170-175, 225-237)
+ *        mi_ode_interp_eval    <- interp._interp_fit + _interp_evaluate / tsit5._interp_eval_tsit5
+ */
+#ifndef MI_ODE_H
+#define MI_ODE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_ODE_ABI_VERSION 1
+#define MI_ODE_MAX_STAGES 6          /* rows of the tableau (dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3) */
+#define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
+#define MI_ODE_MAX_LINCOMB 13        /* stateless lincomb: up to 13 planes (dopri8-sized) */
+
+/* ---- status bits (also the bits of mi_ode_stats.status) --------------------------------- */
+#define MI_ODE_OK 0
+#define MI_ODE_ST_DT_UNDERFLOW 0x1u    /* assert t0 + dt > t0            (dopri5.py:98)      */
+#define MI_ODE_ST_NONFINITE 0x2u       /* assert _is_finite(abs(y0))     (dopri5.py:99-100)  */
+#define MI_ODE_ST_MAX_STEPS 0x4u       /* assert n_steps < max_num_steps (dopri5.py:85-86)   */
+#define MI_ODE_ST_BAD_T 0x8u           /* _assert_increasing / interpolation range (misc.py:158, interp.py:59) */
+/* negative returns: API errors */
+#define MI_ODE_E_INVALID (-1)          /* bad argument / unsupported combination */
+#define MI_ODE_E_HIP (-2)              /* a HIP runtime call failed (see mi_ode_last_error) */
+#define MI_ODE_E_NODEVICE (-3)
+#define MI_ODE_E_EXCHANGE (-4)         /* the multi-rank exchange callback failed */
+
+enum mi_ode_dtype { MI_ODE_F32 = 0, MI_ODE_F64 = 1 };
+
+/* Device RHS catalogue.  All are trajectory(row)-local on a [batch, dim] row-major state.      */
+enum mi_ode_rhs_kind {
+  MI_ODE_RHS_LINEAR = 1,         /* f = y @ W (+ b)            W [dim,dim] row-major  (config 4: W = A^T)  */
+  MI_ODE_RHS_CUBIC_LINEAR = 2,   /* f = (y**3) @ W             examples/ode_demo.py:33-35 (spiral)          */
+  MI_ODE_RHS_LOTKA_VOLTERRA = 3, /* dim 2: [a u - b u v, -c v + d u v]   scalars = {a,b,c,d}                */
+  MI_ODE_RHS_LORENZ = 4,         /* dim 3: examples/lorenz_attractor.py:20-37, scalars = {sigma,beta,rho}   */
+  MI_ODE_RHS_MLP_TANH = 5        /* dim->hidden->hidden->dim, tanh; models/dense_odenet.py:41-92            */
+};
+
+enum mi_ode_controller {
+  MI_ODE_CTRL_MISC = 0,          /* misc._optimal_step_size: sqrt + float32-rounded exponent (misc.py:267-287) */
+  MI_ODE_CTRL_TSIT5 = 1          /* tsit5._optimal_step_size: no sqrt, float64 exponent     (tsit5.py:53-62)  */
+};
+
+enum mi_ode_interp {
+  MI_ODE_INTERP_QUARTIC_MID = 0, /* interp._interp_fit/_interp_evaluate with y_mid from c_mid (dopri5, bosh3) */
+  MI_ODE_INTERP_TSIT5 = 1,       /* tsit5 seven-weight dense output from y0 (corrected)                       */
+  MI_ODE_INTERP_TSIT5_REF = 2    /* tsit5 dense output from k[0] = f0, exactly as tsit5.py:45-50 (defect F6b) */
+};
+
+/* _ButcherTableau(alpha, beta, c_sol, c_error) (rk_common.py:5) + the dense-output mid-point weights. */
+typedef struct mi_ode_tableau {
+  int32_t n_stages;                                   /* S = len(alpha) */
+  int32_t fsal;                                       /* 1 iff c_sol[-1]==0 and c_sol[:-1]==beta[-1] (rk_common.py:54) */
+  double alpha[MI_ODE_MAX_STAGES];
+  double beta[MI_ODE_MAX_STAGES][MI_ODE_MAX_STAGES];  /* row sigma uses entries [0..sigma] */
+  double c_sol[MI_ODE_MAX_K];
+  double c_error[MI_ODE_MAX_K];
+  double c_mid[MI_ODE_MAX_K];                         /* DPS_C_MID / BS_C_MID; unused for tsit5 */
+} mi_ode_tableau;
+
+typedef struct mi_ode_rhs {
+  int32_t kind;               /* enum mi_ode_rhs_kind */
+  int32_t hidden;             /* MLP hidden width (else 0) */
+  double sign;                /* +1, or -1 for a reversed time axis: f <- -f(-t, y) (misc.py:318-321) */
+  double scalars[8];          /* kind specific scalars */
+  const void* w[3];           /* device pointers, state dtype: LINEAR/CUBIC {W}; MLP {W1,W2,W3} ([in,out] row-major) */
+  const void* b[3];           /* device pointers (nullable): biases */
+} mi_ode_rhs;
+
+/* Exchange hook for batch-sharded runs: all-gather `count` doubles per rank.
+ * sendbuf/recvbuf are DEVICE pointers; the hook must enqueue the collective so that it is ordered
+ * after prior work on `stream` and before later work on it (RCCL via torch.distributed in the
+ * Python shim).  recvbuf holds world_size * count doubles in rank order.  Return 0 on success. */
+typedef int (*mi_ode_allgather_fn)(void* user, const void* sendbuf, void* recvbuf, int32_t count, void* stream);
+
+typedef struct mi_ode_desc {
+  int32_t dtype;              /* enum mi_ode_dtype: state dtype (time is always double in adaptive solvers) */
+  int32_t adaptive;           /* 1: adaptive tableau solver; 0: fixed grid (tableau = the RK scheme, c_error unused) */
+  int64_t batch;              /* rows held by THIS rank */
+  int64_t dim;                /* state width */
+  mi_ode_tableau tableau;
+  mi_ode_rhs rhs;
+  int32_t controller;         /* enum mi_ode_controller */
+  int32_t interp;             /* enum mi_ode_interp */
+  int32_t order;              /* controller order: 5 (dopri5, tsit5), 3 (bosh3)      (dopri5.py:68, bosh3.py:93) */
+  int32_t init_order;         /* order passed to _select_initial_step: 4 / 2         (dopri5.py:74, bosh3.py:56) */
+  double rtol, atol;          /* rtol[0], atol[0] of the reference's per-component lists */
+  double safety, ifactor, dfactor;   /* pass the float32-rounded values the reference ends up with (misc.py:137-144) */
+  double first_step;          /* NaN: select automatically (misc.py:183-247) */
+  int64_t max_num_steps;      /* per output time, rejected attempts included (dopri5.py:83-88) */
+  /* batch sharding (world_size 1: leave zero / NULL) */
+  int32_t world_size, rank;
+  mi_ode_allgather_fn allgather;
+  void* allgather_user;
+  double* exchange_send_dev;  /* optional caller-owned device buffers (8 doubles / world_size*8 doubles) that the */
+  double* exchange_recv_dev;  /* hook gathers from / into; NULL: the handle allocates its own */
+  /* tuning knobs (0 = default) */
+  int32_t linear_variant;     /* 0 auto, 1 force VALU fallback, 2 force MFMA tile kernel */
+  int32_t chunk_attempts;     /* attempts enqueued between host polls (0 = adaptive) */
+  int32_t use_graph;          /* 1: replay one captured hipGraph per attempt (world_size 1 only) */
+  int32_t reserved;
+} mi_ode_desc;
+
+typedef struct mi_ode_stats {
+  int64_t n_attempts, n_accepted, n_rejected, nfe;
+  double t, dt;               /* rk_state.t1 and the next step size */
+  double last_ratio;          /* last mean_sq_error_ratio */
+  uint32_t status;            /* MI_ODE_ST_* bits */
+  int32_t n_polls;            /* host synchronisations taken */
+  int64_t n_launches;         /* kernels enqueued */
+} mi_ode_stats;
+
+typedef struct mi_ode_solver* mi_ode_handle;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int mi_ode_abi_version(void);
+const char* mi_ode_status_string(uint32_t status_bits);   /* reference assertion text for the first set bit */
+const char* mi_ode_last_error(void);                      /* thread-local text of the last negative return */
+int64_t mi_ode_reduce_workspace_bytes(void);              /* scratch the stateless reductions need */
+int64_t mi_ode_sizeof(int32_t which);                     /* 0: mi_ode_desc, 1: mi_ode_stats, 2: mi_ode_tableau, 3: mi_ode_rhs
+                                                             (lets a foreign-language binding verify its struct layout) */
+
+/* ---- (A) fused engine ---------------------------------------------------------------------- */
+int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out);
+int mi_ode_destroy(mi_ode_handle h);
+
+/* Solver.before_integrate(t): load y0, evaluate f0, pick the first step (dopri5.py:70-79). */
+int mi_ode_begin(mi_ode_handle h, const void* y0_dev, double t0, void* stream);
+/* Solver.advance(next_t) for n_out strictly increasing times (dopri5.py:81-89); out_dev: [n_out, batch*dim].
+ * Blocks until the outputs are produced or a status bit is raised; returns status bits (>=0) or an error (<0). */
+int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t n_out, void* out_dev, void* stream);
+/* AdaptiveStepsizeODESolver.integrate(t) (solvers.py:27-35): out_dev [T, batch*dim], out[0] = y0. */
+int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const double* t_host, int32_t T, void* out_dev,
+                     mi_ode_stats* stats, void* stream);
+/* FixedGridODESolver.integrate(t) with grid = t (solvers.py:82-104); no host synchronisation inside. */
+int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, const double* t_host, int32_t T,
+                                void* out_dev, mi_ode_stats* stats, void* stream);
+/* One attempt with a given dt - the parity surface mirroring _runge_kutta_step (rk_common.py:22-61):
+ * y1/f1/err_norms outputs are device pointers (nullable); err_norms = {max|y0|, max|y1|, sum err^2, nonfinite}.
+ * k_out (nullable): [S+1, batch*dim] stage derivatives. */
+int mi_ode_rk_step_fused(mi_ode_handle h, const void* y0_dev, const void* f0_dev, double t0, double dt,
+                         void* y1_dev, void* f1_dev, double* err_norms_host, void* k_out_dev, void* stream);
+/* f(t, y) through the fused kernels (y0 -> f0), e.g. to seed mi_ode_rk_step_fused. */
+int mi_ode_eval_rhs(mi_ode_handle h, const void* y_dev, double t, void* f_dev, void* stream);
+int mi_ode_get_stats(mi_ode_handle h, mi_ode_stats* stats, void* stream);
+/* current rk_state: y1, f1 (device, nullable). */
+int mi_ode_get_state(mi_ode_handle h, void* y_dev, void* f_dev, void* stream);
+
+/* ---- (B) stateless plane kernels (arbitrary Python f, tuple states) ------------------------- */
+/* out[i] = (base ? base[i] : 0) + sum_j (scale * coef[j]) * xs[j][i]       (misc.py:118-121; zeros not skipped) */
+int mi_ode_lincomb(int32_t dtype, int64_t n, const void* base_dev, const void* const* xs_dev, const double* coef,
+                   int32_t nx, double scale, void* out_dev, void* stream);
+/* result_dev[4] (double) = {max|y0|, max|y1|, sum err^2, nonfinite(y0)}            (misc.py:256-263) */
+int mi_ode_error_norms(int32_t dtype, int64_t n, const void* err_dev, const void* y0_dev, const void* y1_dev,
+                       double* result_dev, void* workspace_dev, void* stream);
+/* result_dev[1] (double) = sum_i ((x[i] - (xsub ? xsub[i] : 0)) / (atol + |y0[i]| * rtol))^2   (misc.py:225-237) */
+int mi_ode_scaled_sumsq(int32_t dtype, int64_t n, const void* x_dev, const void* xsub_dev, const void* y0_dev,
+                        double rtol, double atol, double* result_dev, void* workspace_dev, void* stream);
+/* dense output at one time t in [t0, t1] from the accepted step's (y0, y1, k[0..nk-1]):
+ * interp = QUARTIC_MID: interp.py:6-67 with y_mid = y0 + dt*sum c_mid[j] k[j] (dt = the step size the step was
+ * taken with, dopri5.py:41); TSIT5 / TSIT5_REF: tsit5.py:33-50 */
+int mi_ode_interp_eval(int32_t dtype, int32_t interp, int64_t n, const void* y0_dev, const void* y1_dev,
+                       const void* const* ks_dev, int32_t nk, const double* c_mid, double dt, double t0, double t1,
+                       double t, void* out_dev, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_ODE_H */

@@ -1,0 +1,181 @@
+"""ctypes binding of libmi_ode.so (include/mi_ode.h) - the thin shim named by the north star.
+
+The library is built in-tree (`tfdiffeq_amd/libmi_ode.so`, see csrc/Makefile) for gfx950 only.
+There is no CPU fallback: every compute entry point of the package goes through this module and
+raises if the library is missing or no MI355X is visible.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libmi_ode.so')
+CSRC = os.path.join(_HERE, 'csrc')
+
+MAX_STAGES = 6
+MAX_K = MAX_STAGES + 1
+MAX_LINCOMB = 13
+REC = 8
+
+F32, F64 = 0, 1
+RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH = 1, 2, 3, 4, 5
+CTRL_MISC, CTRL_TSIT5 = 0, 1
+INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
+ST_DT_UNDERFLOW, ST_NONFINITE, ST_MAX_STEPS, ST_BAD_T = 1, 2, 4, 8
+
+
+class Tableau(C.Structure):
+    _fields_ = [('n_stages', C.c_int32), ('fsal', C.c_int32),
+                ('alpha', C.c_double * MAX_STAGES),
+                ('beta', (C.c_double * MAX_STAGES) * MAX_STAGES),
+                ('c_sol', C.c_double * MAX_K),
+                ('c_error', C.c_double * MAX_K),
+                ('c_mid', C.c_double * MAX_K)]
+
+
+class Rhs(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('hidden', C.c_int32), ('sign', C.c_double),
+                ('scalars', C.c_double * 8),
+                ('w', C.c_void_p * 3), ('b', C.c_void_p * 3)]
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+
+
+class Desc(C.Structure):
+    _fields_ = [('dtype', C.c_int32), ('adaptive', C.c_int32),
+                ('batch', C.c_int64), ('dim', C.c_int64),
+                ('tableau', Tableau), ('rhs', Rhs),
+                ('controller', C.c_int32), ('interp', C.c_int32),
+                ('order', C.c_int32), ('init_order', C.c_int32),
+                ('rtol', C.c_double), ('atol', C.c_double),
+                ('safety', C.c_double), ('ifactor', C.c_double), ('dfactor', C.c_double),
+                ('first_step', C.c_double),
+                ('max_num_steps', C.c_int64),
+                ('world_size', C.c_int32), ('rank', C.c_int32),
+                ('allgather', ALLGATHER_FN), ('allgather_user', C.c_void_p),
+                ('exchange_send_dev', C.c_void_p), ('exchange_recv_dev', C.c_void_p),
+                ('linear_variant', C.c_int32), ('chunk_attempts', C.c_int32),
+                ('use_graph', C.c_int32), ('reserved', C.c_int32)]
+
+
+class Stats(C.Structure):
+    _fields_ = [('n_attempts', C.c_int64), ('n_accepted', C.c_int64), ('n_rejected', C.c_int64), ('nfe', C.c_int64),
+                ('t', C.c_double), ('dt', C.c_double), ('last_ratio', C.c_double),
+                ('status', C.c_uint32), ('n_polls', C.c_int32), ('n_launches', C.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+# every symbol include/mi_ode.h declares: (restype, argtypes)
+_PROTOS = {
+    'mi_ode_abi_version': (C.c_int, []),
+    'mi_ode_status_string': (C.c_char_p, [C.c_uint32]),
+    'mi_ode_last_error': (C.c_char_p, []),
+    'mi_ode_reduce_workspace_bytes': (C.c_int64, []),
+    'mi_ode_sizeof': (C.c_int64, [C.c_int32]),
+    'mi_ode_create': (C.c_int, [C.POINTER(Desc), C.POINTER(C.c_void_p)]),
+    'mi_ode_destroy': (C.c_int, [C.c_void_p]),
+    'mi_ode_begin': (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    'mi_ode_advance': (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_void_p, C.c_void_p]),
+    'mi_ode_integrate': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_void_p,
+                                   C.POINTER(Stats), C.c_void_p]),
+    'mi_ode_fixed_grid_integrate': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_void_p,
+                                              C.POINTER(Stats), C.c_void_p]),
+    'mi_ode_rk_step_fused': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p,
+                                       C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
+    'mi_ode_eval_rhs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    'mi_ode_get_stats': (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    'mi_ode_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mi_ode_lincomb': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double),
+                                 C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
+    'mi_ode_error_norms': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    'mi_ode_scaled_sumsq': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                      C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mi_ode_interp_eval': (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
+                                     C.c_int32, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double,
+                                     C.c_double, C.c_void_p, C.c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(sorted(_PROTOS))
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def build(verbose=False):
+    """Compile libmi_ode.so for gfx950 with hipcc (cross-compiles without a GPU)."""
+    cmd = ['make', '-C', CSRC, '-j', str(min(8, os.cpu_count() or 1))]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-4000:])
+    if res.returncode != 0 or not os.path.exists(LIB_PATH):
+        raise NativeError('building libmi_ode.so failed (see output above)')
+    return LIB_PATH
+
+
+def load():
+    """dlopen libmi_ode.so (after torch, so that HIP symbols bind to torch's loaded libamdhip64)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeError('%s is missing: run `python -c "import __graft_entry__ as g; g.build()"` '
+                          '(or make -C tfdiffeq_amd/csrc). tfdiffeq_amd has no CPU/eager fallback.' % LIB_PATH)
+    import torch  # noqa: F401  (loads libamdhip64.so.7 first; our DT_NEEDED then resolves to the same runtime)
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)      # AttributeError here = the .so does not export what mi_ode.h declares
+        fn.restype = res
+        fn.argtypes = args
+    if lib.mi_ode_abi_version() != 1:
+        raise NativeError('libmi_ode.so ABI version mismatch')
+    for which, st in ((0, Desc), (1, Stats), (2, Tableau), (3, Rhs)):
+        if lib.mi_ode_sizeof(which) != C.sizeof(st):
+            raise NativeError('struct layout mismatch for %s: C %d vs ctypes %d'
+                              % (st.__name__, lib.mi_ode_sizeof(which), C.sizeof(st)))
+    _lib = lib
+    return lib
+
+
+def last_error():
+    return load().mi_ode_last_error().decode('utf-8', 'replace')
+
+
+def check(rc, what=''):
+    """Negative return codes are API errors; non-negative ones are status bits handled by the caller."""
+    if rc < 0:
+        raise NativeError('%s failed (%d): %s' % (what or 'libmi_ode call', rc, last_error()))
+    return rc
+
+
+def status_message(bits):
+    return load().mi_ode_status_string(bits).decode('utf-8')
+
+
+def require_gpu_tensor(x, what='y0'):
+    import torch
+    if not isinstance(x, torch.Tensor):
+        raise TypeError('%s must be a torch.Tensor' % what)
+    if not x.is_cuda:
+        raise NativeError('tfdiffeq_amd computes on MI355X only: %s is on %s. Move it to a CUDA (ROCm) device; '
+                          'there is no CPU fallback.' % (what, x.device))
+
+
+def dtype_code(dtype):
+    import torch
+    if dtype == torch.float64:
+        return F64
+    if dtype == torch.float32:
+        return F32
+    raise TypeError('`y0` must be a float32 or float64 Tensor for the MI355X kernels but is a {}'.format(dtype))
+
+
+def stream_ptr(device=None):
+    import torch
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,646 @@
+// libmi_ode.so - C ABI (include/mi_ode.h) of the MI355X-native explicit RK engine: handle
+// management, the host side of the attempt loop, and the stateless plane entry points.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mi_ode_control.h"
+#include "mi_ode_host.h"
+#include "mi_ode_plane.h"
+
+using namespace mi;
+
+// ------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+void mi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* mi_ode_last_error(void) { return g_err; }
+extern "C" int mi_ode_abi_version(void) { return MI_ODE_ABI_VERSION; }
+
+extern "C" const char* mi_ode_status_string(uint32_t s) {
+  if (s & MI_ODE_ST_BAD_T) return "t must be strictly increasing or decrasing";      // misc.py:159 (sic)
+  if (s & MI_ODE_ST_NONFINITE) return "non-finite values in state `y`";               // dopri5.py:100
+  if (s & MI_ODE_ST_MAX_STEPS) return "max_num_steps exceeded";                       // dopri5.py:85
+  if (s & MI_ODE_ST_DT_UNDERFLOW) return "underflow in dt";                           // dopri5.py:98
+  return "ok";
+}
+
+extern "C" int64_t mi_ode_reduce_workspace_bytes(void) { return (int64_t)kMaxBlocks * kRec * sizeof(double); }
+extern "C" int64_t mi_ode_sizeof(int32_t which) {
+  switch (which) {
+    case 0: return (int64_t)sizeof(mi_ode_desc);
+    case 1: return (int64_t)sizeof(mi_ode_stats);
+    case 2: return (int64_t)sizeof(mi_ode_tableau);
+    case 3: return (int64_t)sizeof(mi_ode_rhs);
+    default: return -1;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------------
+static inline int launch_stage(mi_ode_solver* h, int mode, int nk, StageArgs& A, hipStream_t st) {
+  return h->is_f32 ? mi_launch_stage_f32(h, mode, nk, A, st) : mi_launch_stage_f64(h, mode, nk, A, st);
+}
+
+static inline int streaming_grid(long long n) {
+  long long g = (n + 255) / 256;
+  if (g < 1) g = 1;
+  if (g > kMaxBlocks) g = kMaxBlocks;
+  return (int)g;
+}
+
+static void fill_common(mi_ode_solver* h, StageArgs& A) {
+  memset(&A, 0, sizeof(A));
+  A.ctl = h->ctl;
+  A.planes = h->planes;
+  A.stride = h->stride;
+  A.batch = h->d.batch;
+  A.dim = (int)h->d.dim;
+  A.rtol = h->d.rtol;
+  A.atol = h->d.atol;
+  A.partials = h->partials;
+  A.rhs = h->rhs;
+  A.k_out_slot = -1;
+}
+
+// stage sigma (1-based) of an adaptive attempt in controller (device-state) mode
+static int enqueue_adaptive_stage(mi_ode_solver* h, int sigma, hipStream_t st) {
+  const mi_ode_tableau& tb = h->d.tableau;
+  StageArgs A;
+  fill_common(h, A);
+  const int nk = sigma;
+  for (int j = 0; j < nk; ++j) A.a[j] = tb.beta[sigma - 1][j];
+  A.alpha = tb.alpha[sigma - 1];
+  A.k_out_slot = sigma;
+  int mode = M_STAGE;
+  if (sigma == h->S) {
+    mode = M_LAST_FSAL;
+    for (int j = 0; j <= nk; ++j) A.e[j] = tb.c_error[j];
+  }
+  return launch_stage(h, mode, nk, A, st);
+}
+
+// reduce -> (exchange) -> controller
+static int enqueue_controller(mi_ode_solver* h, int phase, hipStream_t st) {
+  const int nblocks = h->stage_grid;
+  if (h->d.world_size > 1) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, (const Ctl*)h->ctl, (const double*)h->partials,
+                       nblocks, h->n, h->rank_rec);
+    if (h->d.allgather == nullptr) {
+      mi_set_error("world_size > 1 needs an allgather hook");
+      return MI_ODE_E_INVALID;
+    }
+    const int rc = h->d.allgather(h->d.allgather_user, h->rank_rec, h->gathered, kRec, (void*)st);
+    if (rc != 0) {
+      mi_set_error("allgather hook returned %d", rc);
+      return MI_ODE_E_EXCHANGE;
+    }
+    hipLaunchKernelGGL(k_controller, dim3(1), dim3(256), 0, st, h->ctl, (const double*)nullptr, 0,
+                       (const double*)h->gathered, (int)h->d.world_size, phase, h->cp);
+    h->n_launches += 2;
+  } else {
+    hipLaunchKernelGGL(k_controller, dim3(1), dim3(256), 0, st, h->ctl, (const double*)h->partials, nblocks,
+                       (const double*)nullptr, 1, phase, h->cp);
+    h->n_launches += 1;
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    mi_set_error("controller launch failed: %s", hipGetErrorString(e));
+    return MI_ODE_E_HIP;
+  }
+  return 0;
+}
+
+template <typename T>
+static void launch_emit_t(mi_ode_solver* h, void* out, hipStream_t st) {
+  const int g = streaming_grid(h->n);
+  if (h->S + 1 == 7)
+    hipLaunchKernelGGL((k_emit<T, 7>), dim3(g), dim3(256), 0, st, (const Ctl*)h->ctl, (const char*)h->planes, h->stride,
+                       h->n, (const double*)h->t_out_dev, (T*)out, h->ip);
+  else
+    hipLaunchKernelGGL((k_emit<T, 4>), dim3(g), dim3(256), 0, st, (const Ctl*)h->ctl, (const char*)h->planes, h->stride,
+                       h->n, (const double*)h->t_out_dev, (T*)out, h->ip);
+}
+
+static int enqueue_emit(mi_ode_solver* h, void* out, hipStream_t st) {
+  if (h->is_f32) launch_emit_t<float>(h, out, st);
+  else launch_emit_t<double>(h, out, st);
+  h->n_launches += 1;
+  return 0;
+}
+
+static int poll_ctl(mi_ode_solver* h, hipStream_t st) {
+  MI_HIP(hipMemcpyAsync(h->ctl_host, h->ctl, sizeof(Ctl), hipMemcpyDeviceToHost, st));
+  MI_HIP(hipStreamSynchronize(st));
+  h->n_polls += 1;
+  return 0;
+}
+
+static void fill_stats(mi_ode_solver* h, mi_ode_stats* s) {
+  const Ctl* c = h->ctl_host;
+  s->n_attempts = c->n_attempt;
+  s->n_accepted = c->n_accept;
+  s->n_rejected = c->n_reject;
+  s->nfe = c->nfe;
+  s->t = c->t1;
+  s->dt = c->dt;
+  s->last_ratio = c->ratio;
+  s->status = c->status;
+  s->n_polls = h->n_polls;
+  s->n_launches = h->n_launches;
+}
+
+// ------------------------------------------------------------------------------------------------
+// create / destroy
+// ------------------------------------------------------------------------------------------------
+static int pick_family(mi_ode_solver* h) {
+  const mi_ode_rhs& r = h->d.rhs;
+  const int D = (int)h->d.dim;
+  const bool mfma_dim = (D == 16 || D == 32 || D == 64 || D == 128);
+  h->rhs.cube = 0;
+  switch (r.kind) {
+    case MI_ODE_RHS_LOTKA_VOLTERRA:
+      if (D != 2) { mi_set_error("lotka_volterra needs dim 2"); return MI_ODE_E_INVALID; }
+      h->family = FAM_LV; return 0;
+    case MI_ODE_RHS_LORENZ:
+      if (D != 3) { mi_set_error("lorenz needs dim 3"); return MI_ODE_E_INVALID; }
+      h->family = FAM_LORENZ; return 0;
+    case MI_ODE_RHS_CUBIC_LINEAR:
+    case MI_ODE_RHS_LINEAR: {
+      const bool cube = r.kind == MI_ODE_RHS_CUBIC_LINEAR;
+      if (r.w[0] == nullptr) { mi_set_error("linear RHS needs W"); return MI_ODE_E_INVALID; }
+      if (D == 2 && r.b[0] == nullptr && h->d.linear_variant == 0) {
+        // W travels by value (scalars[0..3] = W row-major); the caller fills them for dim 2
+        h->family = cube ? FAM_CUBIC2 : FAM_LINEAR2; return 0;
+      }
+      h->rhs.cube = cube ? 1 : 0;
+      if (!cube && mfma_dim && h->d.linear_variant != 1) { h->family = FAM_LINEAR_MFMA; return 0; }
+      if (h->d.linear_variant == 2) { mi_set_error("MFMA linear kernel needs dim in {16,32,64,128} and no cube"); return MI_ODE_E_INVALID; }
+      if (D > 256) { mi_set_error("fused linear RHS supports dim <= 256 (got %d)", D); return MI_ODE_E_INVALID; }
+      h->family = FAM_LINEAR_VALU; return 0;
+    }
+    default:
+      mi_set_error("RHS kind %d has no fused kernel yet", r.kind);
+      return MI_ODE_E_INVALID;
+  }
+}
+
+extern "C" int mi_ode_destroy(mi_ode_handle h) {
+  if (h == nullptr) return 0;
+  if (h->planes) (void)hipFree(h->planes);
+  if (h->partials) (void)hipFree(h->partials);
+  if (h->rank_rec && h->own_exchange) (void)hipFree(h->rank_rec);
+  if (h->gathered && h->own_exchange) (void)hipFree(h->gathered);
+  if (h->ctl) (void)hipFree(h->ctl);
+  if (h->t_out_dev) (void)hipFree(h->t_out_dev);
+  if (h->ctl_host) (void)hipHostFree(h->ctl_host);
+  if (h->t_out_host) (void)hipHostFree(h->t_out_host);
+  delete h;
+  return 0;
+}
+
+extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
+  if (desc == nullptr || out == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { mi_set_error("no HIP device"); return MI_ODE_E_NODEVICE; }
+  if (desc->dtype != MI_ODE_F32 && desc->dtype != MI_ODE_F64) { mi_set_error("bad dtype"); return MI_ODE_E_INVALID; }
+  if (desc->batch <= 0 || desc->dim <= 0) { mi_set_error("empty state"); return MI_ODE_E_INVALID; }
+  const mi_ode_tableau& tb = desc->tableau;
+  if (tb.n_stages < 0 || tb.n_stages > MI_ODE_MAX_STAGES) { mi_set_error("bad n_stages"); return MI_ODE_E_INVALID; }
+  if (desc->adaptive) {
+    if (!tb.fsal) { mi_set_error("fused adaptive engine needs an FSAL-shaped tableau (rk_common.py:54)"); return MI_ODE_E_INVALID; }
+    if (tb.n_stages != 3 && tb.n_stages != 6) { mi_set_error("fused adaptive engine supports 3- and 6-row tableaus"); return MI_ODE_E_INVALID; }
+    if (desc->interp != MI_ODE_INTERP_QUARTIC_MID && tb.n_stages != 6) { mi_set_error("tsit5 dense output needs 7 stage derivatives"); return MI_ODE_E_INVALID; }
+  }
+  mi_ode_solver* h = new mi_ode_solver();
+  memset(h, 0, sizeof(*h));
+  h->d = *desc;
+  if (h->d.world_size < 1) h->d.world_size = 1;
+  h->is_f32 = desc->dtype == MI_ODE_F32;
+  h->elt = h->is_f32 ? 4 : 8;
+  h->n = desc->batch * desc->dim;
+  h->stride = ((h->n * (long long)h->elt + 255) / 256) * 256;
+  h->S = tb.n_stages;
+  int dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    mi_set_error("cannot query device");
+    delete h;
+    return MI_ODE_E_HIP;
+  }
+  h->num_cus = prop.multiProcessorCount;
+  // RHS parameters
+  memcpy(h->rhs.s, desc->rhs.scalars, sizeof(h->rhs.s));
+  for (int i = 0; i < 3; ++i) { h->rhs.w[i] = desc->rhs.w[i]; h->rhs.b[i] = desc->rhs.b[i]; }
+  h->rhs.sign = desc->rhs.sign == 0.0 ? 1.0 : desc->rhs.sign;
+  h->rhs.hidden = desc->rhs.hidden;
+  int rc = pick_family(h);
+  if (rc != 0) { delete h; return rc; }
+  rc = h->is_f32 ? mi_stage_geometry_f32(h) : mi_stage_geometry_f64(h);
+  if (rc != 0) { delete h; return rc; }
+  // controller / dense-output parameters
+  h->cp.rtol = desc->rtol; h->cp.atol = desc->atol;
+  h->cp.safety = desc->safety; h->cp.ifactor = desc->ifactor; h->cp.dfactor = desc->dfactor;
+  h->cp.max_num_steps = desc->max_num_steps > 0 ? desc->max_num_steps : 2147483647LL;
+  h->cp.n_local = h->n;
+  h->cp.order = desc->order; h->cp.init_order = desc->init_order;
+  h->cp.controller = desc->controller;
+  h->cp.is_f32 = h->is_f32;
+  h->cp.n_stages = h->S;
+  h->cp.auto_first_step = isnan(desc->first_step) ? 1 : 0;
+  h->ip.kind = desc->interp;
+  h->ip.nk = h->S + 1;
+  for (int j = 0; j < kMaxK; ++j) h->ip.c_mid[j] = tb.c_mid[j];
+  // workspace
+  hipError_t e = hipSuccess;
+  e = hipMalloc((void**)&h->planes, (size_t)h->stride * kNumPlanes);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->partials, (size_t)kMaxBlocks * kRec * sizeof(double));
+  if (desc->exchange_send_dev != nullptr && desc->exchange_recv_dev != nullptr) {
+    h->rank_rec = desc->exchange_send_dev;
+    h->gathered = desc->exchange_recv_dev;
+    h->own_exchange = 0;
+  } else {
+    h->own_exchange = 1;
+    if (e == hipSuccess) e = hipMalloc((void**)&h->rank_rec, kRec * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->gathered, (size_t)h->d.world_size * kRec * sizeof(double));
+  }
+  if (e == hipSuccess) e = hipMalloc((void**)&h->ctl, sizeof(Ctl));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->ctl_host, sizeof(Ctl), hipHostMallocDefault);
+  if (e != hipSuccess) {
+    mi_set_error("workspace allocation failed: %s", hipGetErrorString(e));
+    mi_ode_destroy(h);
+    return MI_ODE_E_HIP;
+  }
+  memset(h->ctl_host, 0, sizeof(Ctl));
+  *out = h;
+  return 0;
+}
+
+static int ensure_t_out(mi_ode_solver* h, int n) {
+  if (n > h->t_out_cap) {
+    if (h->t_out_dev) (void)hipFree(h->t_out_dev);
+    h->t_out_dev = nullptr;
+    int cap = n < 64 ? 64 : n;
+    MI_HIP(hipMalloc((void**)&h->t_out_dev, (size_t)cap * sizeof(double)));
+    h->t_out_cap = cap;
+  }
+  if (n > h->t_out_host_cap) {
+    if (h->t_out_host) (void)hipHostFree(h->t_out_host);
+    h->t_out_host = nullptr;
+    int cap = n < 64 ? 64 : n;
+    MI_HIP(hipHostMalloc((void**)&h->t_out_host, (size_t)cap * sizeof(double), hipHostMallocDefault));
+    h->t_out_host_cap = cap;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// adaptive engine
+// ------------------------------------------------------------------------------------------------
+extern "C" int mi_ode_begin(mi_ode_handle h, const void* y0_dev, double t0, void* stream) {
+  if (h == nullptr || y0_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (!h->d.adaptive) { mi_set_error("mi_ode_begin on a fixed-grid handle"); return MI_ODE_E_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  MI_HIP(hipStreamSynchronize(st));            // the pinned staging record may still be in flight from a previous call
+  Ctl* c = h->ctl_host;
+  memset(c, 0, sizeof(Ctl));
+  c->t0 = c->t1 = t0;
+  c->dt = h->cp.auto_first_step ? 0.0 : h->d.first_step;
+  c->idx_y0 = 0; c->idx_y1 = 1;
+  for (int j = 0; j < kMaxK; ++j) c->idx_k[j] = 2 + j;
+  h->n_launches = 0; h->n_polls = 0;
+  MI_HIP(hipMemcpyAsync(h->ctl, c, sizeof(Ctl), hipMemcpyHostToDevice, st));
+  MI_HIP(hipMemcpyAsync(h->planes, y0_dev, (size_t)h->n * h->elt, hipMemcpyDeviceToDevice, st));
+  // f0 = f(t0, y0) with the norms of misc._select_initial_step riding along (dopri5.py:71-75)
+  StageArgs A;
+  fill_common(h, A);
+  A.k_out_slot = 0;
+  int rc = launch_stage(h, M_F0, 0, A, st);
+  if (rc != 0) return rc;
+  rc = enqueue_controller(h, PH_F0, st);
+  if (rc != 0) return rc;
+  if (h->cp.auto_first_step) {
+    fill_common(h, A);
+    A.k_out_slot = 1;                          // f(t0 + h0, y0 + h0 f0) lands in a scratch plane
+    A.alpha = 1.0;
+    rc = launch_stage(h, M_INITB, 1, A, st);
+    if (rc != 0) return rc;
+    rc = enqueue_controller(h, PH_INITB, st);
+    if (rc != 0) return rc;
+  }
+  h->begun = 1;
+  return 0;
+}
+
+extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t n_out, void* out_dev, void* stream) {
+  if (h == nullptr || (n_out > 0 && (t_out_host == nullptr || out_dev == nullptr))) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (!h->begun) { mi_set_error("mi_ode_advance before mi_ode_begin"); return MI_ODE_E_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  if (n_out <= 0) return 0;
+  for (int i = 1; i < n_out; ++i)
+    if (!(t_out_host[i] > t_out_host[i - 1])) { mi_set_error("output times must increase"); return MI_ODE_ST_BAD_T; }
+  int rc = ensure_t_out(h, n_out);
+  if (rc != 0) return rc;
+  MI_HIP(hipStreamSynchronize(st));
+  memcpy(h->t_out_host, t_out_host, (size_t)n_out * sizeof(double));
+  MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)n_out * sizeof(double), hipMemcpyHostToDevice, st));
+  h->cp.t_out = h->t_out_dev;
+  hipLaunchKernelGGL(k_set_outputs, dim3(1), dim3(64), 0, st, h->ctl, (int)n_out);
+  h->n_launches += 1;
+  const double t_end = t_out_host[n_out - 1];
+  int chunk = h->d.chunk_attempts > 0 ? h->d.chunk_attempts : 4;
+  for (;;) {
+    for (int a = 0; a < chunk; ++a) {
+      for (int sigma = 1; sigma <= h->S; ++sigma) {
+        rc = enqueue_adaptive_stage(h, sigma, st);
+        if (rc != 0) return rc;
+      }
+      rc = enqueue_controller(h, PH_ATTEMPT, st);
+      if (rc != 0) return rc;
+      rc = enqueue_emit(h, out_dev, st);
+      if (rc != 0) return rc;
+    }
+    rc = poll_ctl(h, st);
+    if (rc != 0) return rc;
+    const Ctl* c = h->ctl_host;
+    if (c->done) break;
+    if (h->d.chunk_attempts <= 0) {            // adaptive chunking: roughly the attempts still needed at the current dt
+      double est = c->dt > 0 ? ceil((t_end - c->t1) / c->dt) + 1.0 : 4.0;
+      if (!(est >= 1.0)) est = 1.0;
+      if (est > 32.0) est = 32.0;
+      chunk = (int)est;
+    }
+  }
+  return (int)h->ctl_host->status;
+}
+
+extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const double* t_host, int32_t T, void* out_dev,
+                                mi_ode_stats* stats, void* stream) {
+  if (h == nullptr || y0_dev == nullptr || t_host == nullptr || out_dev == nullptr || T < 1) { mi_set_error("bad argument"); return MI_ODE_E_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  for (int i = 1; i < T; ++i)
+    if (!(t_host[i] > t_host[i - 1])) {
+      if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = MI_ODE_ST_BAD_T; }
+      return MI_ODE_ST_BAD_T;                  // _assert_increasing (misc.py:158-159)
+    }
+  int rc = mi_ode_begin(h, y0_dev, t_host[0], stream);   // before_integrate runs even when T == 1 (solvers.py:31)
+  if (rc != 0) return rc;
+  MI_HIP(hipMemcpyAsync(out_dev, y0_dev, (size_t)h->n * h->elt, hipMemcpyDeviceToDevice, st));   // solution = [y0]
+  int status = 0;
+  if (T > 1) {
+    status = mi_ode_advance(h, t_host + 1, T - 1, (char*)out_dev + (size_t)h->n * h->elt, stream);
+    if (status < 0) return status;
+  } else {
+    rc = poll_ctl(h, st);
+    if (rc != 0) return rc;
+  }
+  if (stats) fill_stats(h, stats);
+  return status;
+}
+
+extern "C" int mi_ode_get_stats(mi_ode_handle h, mi_ode_stats* stats, void* stream) {
+  if (h == nullptr || stats == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  int rc = poll_ctl(h, (hipStream_t)stream);
+  if (rc != 0) return rc;
+  fill_stats(h, stats);
+  return 0;
+}
+
+extern "C" int mi_ode_get_state(mi_ode_handle h, void* y_dev, void* f_dev, void* stream) {
+  if (h == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  int rc = poll_ctl(h, st);
+  if (rc != 0) return rc;
+  const Ctl* c = h->ctl_host;
+  if (y_dev) MI_HIP(hipMemcpyAsync(y_dev, h->planes + (long long)c->idx_y0 * h->stride, (size_t)h->n * h->elt, hipMemcpyDeviceToDevice, st));
+  if (f_dev) MI_HIP(hipMemcpyAsync(f_dev, h->planes + (long long)c->idx_k[0] * h->stride, (size_t)h->n * h->elt, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// fixed grid (solvers.py:82-104): everything is known on the host, nothing synchronises
+// ------------------------------------------------------------------------------------------------
+extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, const double* t_host, int32_t T,
+                                           void* out_dev, mi_ode_stats* stats, void* stream) {
+  if (h == nullptr || y0_dev == nullptr || t_host == nullptr || out_dev == nullptr || T < 1) { mi_set_error("bad argument"); return MI_ODE_E_INVALID; }
+  if (h->d.adaptive) { mi_set_error("fixed-grid call on an adaptive handle"); return MI_ODE_E_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const bool euler = h->S == 0;
+  if (!euler && h->S != 3) { mi_set_error("fixed grid: tableau must be euler (0 rows) or rk4 3/8 (3 rows)"); return MI_ODE_E_INVALID; }
+  for (int i = 1; i < T; ++i)
+    if (!(t_host[i] > t_host[i - 1])) {
+      if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = MI_ODE_ST_BAD_T; }
+      return MI_ODE_ST_BAD_T;
+    }
+  h->n_launches = 0; h->n_polls = 0;
+  const size_t pbytes = (size_t)h->n * h->elt;
+  MI_HIP(hipMemcpyAsync(out_dev, y0_dev, pbytes, hipMemcpyDeviceToDevice, st));
+  char* k0 = h->planes + 2 * h->stride;
+  char* k1 = k0 + h->stride;
+  char* k2 = k1 + h->stride;
+  long long nfe = 0;
+  for (int i = 0; i + 1 < T; ++i) {
+    double t0, dt;                               // solvers.py:84: time is cast to the STATE dtype first
+    if (h->is_f32) { const float a = (float)t_host[i], b = (float)t_host[i + 1]; t0 = a; dt = (double)(b - a); }
+    else { t0 = t_host[i]; dt = t_host[i + 1] - t_host[i]; }
+    const char* yi = (const char*)out_dev + (size_t)i * pbytes;
+    char* yo = (char*)out_dev + (size_t)(i + 1) * pbytes;
+    StageArgs A;
+    fill_common(h, A);
+    A.explicit_mode = 1; A.ctl = nullptr;
+    A.x_y0 = yi; A.x_y1 = yo; A.x_t0 = t0; A.x_dt = dt;
+    int rc;
+    if (euler) {
+      A.x_kout = nullptr;
+      rc = launch_stage(h, M_FX_EULER, 0, A, st);
+      if (rc != 0) return rc;
+      nfe += 1;
+    } else {
+      A.x_kout = k0; A.alpha = 0.0;
+      rc = launch_stage(h, M_STAGE, 0, A, st);                    // k1 = f(t, y)
+      if (rc != 0) return rc;
+      A.x_k[0] = k0; A.x_kout = k1; A.alpha = 1.0 / 3.0;
+      rc = launch_stage(h, M_FX_RK4_2, 1, A, st);
+      if (rc != 0) return rc;
+      A.x_k[1] = k1; A.x_kout = k2; A.alpha = 2.0 / 3.0;
+      rc = launch_stage(h, M_FX_RK4_3, 2, A, st);
+      if (rc != 0) return rc;
+      A.x_k[2] = k2; A.x_kout = nullptr; A.alpha = 1.0;
+      rc = launch_stage(h, M_FX_RK4_4, 3, A, st);
+      if (rc != 0) return rc;
+      nfe += 4;
+    }
+  }
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->nfe = nfe;
+    stats->n_attempts = stats->n_accepted = T - 1;
+    stats->t = t_host[T - 1];
+    stats->n_launches = h->n_launches;
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// single-attempt parity surface (rk_common._runge_kutta_step)
+// ------------------------------------------------------------------------------------------------
+extern "C" int mi_ode_eval_rhs(mi_ode_handle h, const void* y_dev, double t, void* f_dev, void* stream) {
+  if (h == nullptr || y_dev == nullptr || f_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  StageArgs A;
+  fill_common(h, A);
+  A.explicit_mode = 1; A.ctl = nullptr;
+  A.x_y0 = y_dev; A.x_kout = f_dev; A.x_t0 = t; A.x_dt = 0.0;
+  return launch_stage(h, M_STAGE, 0, A, (hipStream_t)stream);
+}
+
+extern "C" int mi_ode_rk_step_fused(mi_ode_handle h, const void* y0_dev, const void* f0_dev, double t0, double dt,
+                                    void* y1_dev, void* f1_dev, double* err_norms_host, void* k_out_dev, void* stream) {
+  if (h == nullptr || y0_dev == nullptr || f0_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (!h->d.adaptive) { mi_set_error("rk_step_fused needs an adaptive handle"); return MI_ODE_E_INVALID; }
+  hipStream_t st = (hipStream_t)stream;
+  const mi_ode_tableau& tb = h->d.tableau;
+  const size_t pbytes = (size_t)h->n * h->elt;
+  char* kpl[kMaxK];
+  for (int j = 0; j < kMaxK; ++j) kpl[j] = h->planes + (long long)(2 + j) * h->stride;
+  char* y1w = y1_dev ? (char*)y1_dev : h->planes + h->stride;
+  for (int sigma = 1; sigma <= h->S; ++sigma) {
+    StageArgs A;
+    fill_common(h, A);
+    A.explicit_mode = 1; A.ctl = nullptr;
+    A.x_y0 = y0_dev; A.x_y1 = y1w; A.x_t0 = t0; A.x_dt = dt;
+    A.x_k[0] = f0_dev;
+    for (int j = 1; j < sigma; ++j) A.x_k[j] = kpl[j];
+    A.x_kout = kpl[sigma];
+    for (int j = 0; j < sigma; ++j) A.a[j] = tb.beta[sigma - 1][j];
+    A.alpha = tb.alpha[sigma - 1];
+    int mode = M_STAGE;
+    if (sigma == h->S) {
+      mode = M_LAST_FSAL;
+      for (int j = 0; j <= sigma; ++j) A.e[j] = tb.c_error[j];
+    }
+    int rc = launch_stage(h, mode, sigma, A, st);
+    if (rc != 0) return rc;
+  }
+  if (f1_dev) MI_HIP(hipMemcpyAsync(f1_dev, kpl[h->S], pbytes, hipMemcpyDeviceToDevice, st));
+  if (k_out_dev) {
+    MI_HIP(hipMemcpyAsync(k_out_dev, f0_dev, pbytes, hipMemcpyDeviceToDevice, st));
+    for (int j = 1; j <= h->S; ++j)
+      MI_HIP(hipMemcpyAsync((char*)k_out_dev + (size_t)j * pbytes, kpl[j], pbytes, hipMemcpyDeviceToDevice, st));
+  }
+  if (err_norms_host) {
+    hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, (const Ctl*)nullptr, (const double*)h->partials,
+                       h->stage_grid, h->n, h->rank_rec);
+    double rec[kRec];
+    MI_HIP(hipMemcpyAsync(rec, h->rank_rec, sizeof(rec), hipMemcpyDeviceToHost, st));
+    MI_HIP(hipStreamSynchronize(st));
+    err_norms_host[0] = rec[R_MAXA]; err_norms_host[1] = rec[R_MAXB]; err_norms_host[2] = rec[R_SUMA]; err_norms_host[3] = rec[R_FLAG];
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (B) stateless plane kernels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize_records(const double* part, int nblocks, double* result, int what) {
+  __shared__ double rec[kRec];
+  reduce_block_records(part, nblocks, rec);
+  if (threadIdx.x == 0) {
+    if (what == 0) { result[0] = rec[R_MAXA]; result[1] = rec[R_MAXB]; result[2] = rec[R_SUMA]; result[3] = rec[R_FLAG]; }
+    else result[0] = rec[R_SUMA];
+  }
+}
+
+extern "C" int mi_ode_lincomb(int32_t dtype, int64_t n, const void* base_dev, const void* const* xs_dev, const double* coef,
+                              int32_t nx, double scale, void* out_dev, void* stream) {
+  if (n < 0 || nx < 1 || nx > MI_ODE_MAX_LINCOMB || xs_dev == nullptr || coef == nullptr || out_dev == nullptr) {
+    mi_set_error("lincomb: bad argument");
+    return MI_ODE_E_INVALID;
+  }
+  if (n == 0) return 0;
+  LincombArgs A;
+  memset(&A, 0, sizeof(A));
+  A.base = base_dev; A.scale = scale; A.n = n; A.out = out_dev; A.nx = nx;
+  for (int j = 0; j < nx; ++j) { A.x[j] = xs_dev[j]; A.coef[j] = coef[j]; }
+  const int g = streaming_grid(n);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_ODE_F64) hipLaunchKernelGGL(k_lincomb<double>, dim3(g), dim3(256), 0, st, A);
+  else if (dtype == MI_ODE_F32) hipLaunchKernelGGL(k_lincomb<float>, dim3(g), dim3(256), 0, st, A);
+  else { mi_set_error("bad dtype"); return MI_ODE_E_INVALID; }
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mi_ode_error_norms(int32_t dtype, int64_t n, const void* err_dev, const void* y0_dev, const void* y1_dev,
+                                  double* result_dev, void* workspace_dev, void* stream) {
+  if (n <= 0 || !err_dev || !y0_dev || !y1_dev || !result_dev || !workspace_dev) { mi_set_error("error_norms: bad argument"); return MI_ODE_E_INVALID; }
+  const int g = streaming_grid(n);
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)workspace_dev;
+  if (dtype == MI_ODE_F64) hipLaunchKernelGGL(k_error_norms<double>, dim3(g), dim3(256), 0, st, (const double*)err_dev, (const double*)y0_dev, (const double*)y1_dev, (long long)n, part);
+  else if (dtype == MI_ODE_F32) hipLaunchKernelGGL(k_error_norms<float>, dim3(g), dim3(256), 0, st, (const float*)err_dev, (const float*)y0_dev, (const float*)y1_dev, (long long)n, part);
+  else { mi_set_error("bad dtype"); return MI_ODE_E_INVALID; }
+  hipLaunchKernelGGL(k_finalize_records, dim3(1), dim3(256), 0, st, (const double*)part, g, result_dev, 0);
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mi_ode_scaled_sumsq(int32_t dtype, int64_t n, const void* x_dev, const void* xsub_dev, const void* y0_dev,
+                                   double rtol, double atol, double* result_dev, void* workspace_dev, void* stream) {
+  if (n <= 0 || !x_dev || !y0_dev || !result_dev || !workspace_dev) { mi_set_error("scaled_sumsq: bad argument"); return MI_ODE_E_INVALID; }
+  const int g = streaming_grid(n);
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)workspace_dev;
+  if (dtype == MI_ODE_F64) hipLaunchKernelGGL(k_scaled_sumsq<double>, dim3(g), dim3(256), 0, st, (const double*)x_dev, (const double*)xsub_dev, (const double*)y0_dev, (long long)n, rtol, atol, part);
+  else if (dtype == MI_ODE_F32) hipLaunchKernelGGL(k_scaled_sumsq<float>, dim3(g), dim3(256), 0, st, (const float*)x_dev, (const float*)xsub_dev, (const float*)y0_dev, (long long)n, rtol, atol, part);
+  else { mi_set_error("bad dtype"); return MI_ODE_E_INVALID; }
+  hipLaunchKernelGGL(k_finalize_records, dim3(1), dim3(256), 0, st, (const double*)part, g, result_dev, 1);
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+static int interp_eval_t(int32_t interp, int64_t n, const void* y0, const void* y1, const void* const* ks, int32_t nk,
+                         const double* c_mid, double dt, double t0, double t1, double t, void* out, hipStream_t st) {
+  InterpPtrs P;
+  memset(&P, 0, sizeof(P));
+  P.y0 = y0; P.y1 = y1;
+  for (int j = 0; j < nk; ++j) P.k[j] = ks[j];
+  InterpParams I;
+  memset(&I, 0, sizeof(I));
+  I.kind = interp; I.nk = nk;
+  if (c_mid) for (int j = 0; j < nk && j < kMaxK; ++j) I.c_mid[j] = c_mid[j];
+  const int g = streaming_grid(n);
+  // the quartic fit takes the step's own dt (dopri5.py:41), not t1 - t0; hand it over through t1' = t0 + dt semantics
+  if (nk == 7) hipLaunchKernelGGL((k_interp_eval<T, 7>), dim3(g), dim3(256), 0, st, P, (long long)n, t0, t1, t, dt, (T*)out, I);
+  else if (nk == 4) hipLaunchKernelGGL((k_interp_eval<T, 4>), dim3(g), dim3(256), 0, st, P, (long long)n, t0, t1, t, dt, (T*)out, I);
+  else if (nk == 3) hipLaunchKernelGGL((k_interp_eval<T, 3>), dim3(g), dim3(256), 0, st, P, (long long)n, t0, t1, t, dt, (T*)out, I);
+  else { mi_set_error("interp_eval: nk must be 3, 4 or 7"); return MI_ODE_E_INVALID; }
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mi_ode_interp_eval(int32_t dtype, int32_t interp, int64_t n, const void* y0_dev, const void* y1_dev,
+                                  const void* const* ks_dev, int32_t nk, const double* c_mid, double dt, double t0, double t1,
+                                  double t, void* out_dev, void* stream) {
+  if (n <= 0 || !y0_dev || !ks_dev || !out_dev) { mi_set_error("interp_eval: bad argument"); return MI_ODE_E_INVALID; }
+  if (interp == MI_ODE_INTERP_QUARTIC_MID && (!y1_dev || !c_mid)) { mi_set_error("interp_eval: quartic needs y1 and c_mid"); return MI_ODE_E_INVALID; }
+  if (interp != MI_ODE_INTERP_QUARTIC_MID && nk != 7) { mi_set_error("interp_eval: tsit5 needs nk == 7"); return MI_ODE_E_INVALID; }
+  if (!(t0 <= t && t <= t1)) { mi_set_error("invalid interpolation, fails `t0 <= t <= t1`"); return MI_ODE_ST_BAD_T; }   // interp.py:59
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_ODE_F64) return interp_eval_t<double>(interp, n, y0_dev, y1_dev, ks_dev, nk, c_mid, dt, t0, t1, t, out_dev, st);
+  if (dtype == MI_ODE_F32) return interp_eval_t<float>(interp, n, y0_dev, y1_dev, ks_dev, nk, c_mid, dt, t0, t1, t, out_dev, st);
+  mi_set_error("bad dtype");
+  return MI_ODE_E_INVALID;
+}

@@ -1,0 +1,73 @@
+// Host-side solver object shared by the translation units of libmi_ode.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "mi_ode_dev.h"
+
+namespace mi {
+
+enum Family {
+  FAM_NONE = 0,
+  FAM_CUBIC2,        // rowlocal, dim 2: (y**3) @ W
+  FAM_LINEAR2,       // rowlocal, dim 2: y @ W
+  FAM_LV,            // rowlocal, dim 2
+  FAM_LORENZ,        // rowlocal, dim 3
+  FAM_LINEAR_VALU,   // any dim <= 256, optional cube / bias
+  FAM_LINEAR_MFMA    // dim in {16, 32, 64, 128}
+};
+
+struct LaunchInfo {   // filled per (mode) at create time
+  int grid;
+  int block;
+  size_t lds;
+};
+
+}  // namespace mi
+
+struct mi_ode_solver {
+  mi_ode_desc d;
+  mi::Family family;
+  int is_f32;
+  size_t elt;                 // sizeof(state dtype)
+  long long n;                // batch * dim (this rank)
+  long long stride;           // bytes between planes
+  int S;                      // tableau rows
+  int num_cus;
+  // device workspace
+  char* planes;
+  double* partials;           // [kMaxBlocks][kRec]
+  double* rank_rec;           // [kRec]
+  double* gathered;           // [world][kRec]
+  mi::Ctl* ctl;
+  double* t_out_dev;
+  int t_out_cap;
+  // pinned host staging
+  mi::Ctl* ctl_host;
+  double* t_out_host;
+  int t_out_host_cap;
+  // launch geometry of the stage kernels
+  int stage_grid, stage_block;
+  // bookkeeping
+  long long n_launches;
+  int n_polls;
+  int begun;
+  int own_exchange;
+  mi::RhsParams rhs;
+  mi::CtrlParams cp;
+  mi::InterpParams ip;
+};
+
+// implemented once per state dtype (mi_ode_launch_f64.hip / mi_ode_launch_f32.hip)
+int mi_launch_stage_f64(mi_ode_solver* h, int mode, int nk, mi::StageArgs& A, hipStream_t st);
+int mi_launch_stage_f32(mi_ode_solver* h, int mode, int nk, mi::StageArgs& A, hipStream_t st);
+int mi_stage_geometry_f64(mi_ode_solver* h);
+int mi_stage_geometry_f32(mi_ode_solver* h);
+
+void mi_set_error(const char* fmt, ...);
+#define MI_HIP(call)                                                                     \
+  do {                                                                                   \
+    hipError_t e_ = (call);                                                              \
+    if (e_ != hipSuccess) {                                                              \
+      mi_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+      return MI_ODE_E_HIP;                                                               \
+    }                                                                                    \
+  } while (0)

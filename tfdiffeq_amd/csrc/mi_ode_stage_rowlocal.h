@@ -1,0 +1,120 @@
+// Fused RK stage kernel for trajectory-local right-hand sides of tiny width (dim 2..4):
+// one thread owns one trajectory (row), every value of the stage lives in registers.
+//   reads  y0, k_0..k_{NK-1}      (NK+1 planes)
+//   writes k_out (and y1 for the last stage)
+// => (NK + 2) planes of traffic per stage, +1 for the last: the 34-units-per-attempt
+// structure of SURVEY.md 8(d).  Bound: HBM (a handful of flops per element).
+#pragma once
+#include "mi_ode_dev.h"
+
+namespace mi {
+
+// ---- right-hand sides (device catalogue, dim <= 4) -------------------------------------------
+// (y**3) @ W with W [2,2] row-major: examples/ode_demo.py:33-35
+template <typename T>
+struct RhsCubic2 {
+  static constexpr int D = 2;
+  T w00, w01, w10, w11;
+  __device__ explicit RhsCubic2(const RhsParams& p)
+      : w00((T)p.s[0]), w01((T)p.s[1]), w10((T)p.s[2]), w11((T)p.s[3]) {}
+  __device__ __forceinline__ void operator()(T, const T* y, T* f) const {
+    const T c0 = y[0] * y[0] * y[0], c1 = y[1] * y[1] * y[1];
+    f[0] = c0 * w00 + c1 * w10;
+    f[1] = c0 * w01 + c1 * w11;
+  }
+};
+
+// y @ W with W [2,2] (2-D linear systems of examples/ode_usage.ipynb)
+template <typename T>
+struct RhsLinear2 {
+  static constexpr int D = 2;
+  T w00, w01, w10, w11;
+  __device__ explicit RhsLinear2(const RhsParams& p)
+      : w00((T)p.s[0]), w01((T)p.s[1]), w10((T)p.s[2]), w11((T)p.s[3]) {}
+  __device__ __forceinline__ void operator()(T, const T* y, T* f) const {
+    f[0] = y[0] * w00 + y[1] * w10;
+    f[1] = y[0] * w01 + y[1] * w11;
+  }
+};
+
+// Lotka-Volterra, examples/ode_usage.ipynb cells 39-42 / README.md:67-82
+template <typename T>
+struct RhsLotkaVolterra {
+  static constexpr int D = 2;
+  T a, b, c, d;
+  __device__ explicit RhsLotkaVolterra(const RhsParams& p) : a((T)p.s[0]), b((T)p.s[1]), c((T)p.s[2]), d((T)p.s[3]) {}
+  __device__ __forceinline__ void operator()(T, const T* y, T* f) const {
+    const T u = y[0], v = y[1];
+    f[0] = a * u - b * u * v;
+    f[1] = -c * v + d * u * v;
+  }
+};
+
+// Lorenz, examples/lorenz_attractor.py:28-37
+template <typename T>
+struct RhsLorenz {
+  static constexpr int D = 3;
+  T sigma, beta, rho;
+  __device__ explicit RhsLorenz(const RhsParams& p) : sigma((T)p.s[0]), beta((T)p.s[1]), rho((T)p.s[2]) {}
+  __device__ __forceinline__ void operator()(T, const T* y, T* f) const {
+    f[0] = sigma * (y[1] - y[0]);
+    f[1] = y[0] * (rho - y[2]) - y[1];
+    f[2] = y[0] * y[1] - beta * y[2];
+  }
+};
+
+template <typename T, int D>
+struct alignas((D * sizeof(T)) % 16 == 0 ? 16 : ((D * sizeof(T)) % 8 == 0 ? 8 : sizeof(T))) RowVec {
+  T v[D];
+};
+
+template <typename T, int NK, int MODE, class RHS>
+__global__ __launch_bounds__(256) void k_stage_rowlocal(StageArgs A) {
+  constexpr int D = RHS::D;
+  using Row = RowVec<T, D>;
+  Resolved<T> R;
+  if (!resolve<T, NK, MODE>(A, R)) return;
+  const RHS rhs(A.rhs);
+  const T sign = (T)A.rhs.sign;
+  Acc acc;
+  const long long nrows = A.batch;
+  for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < nrows;
+       row += (long long)gridDim.x * blockDim.x) {
+    const Row y0 = *(const Row*)(R.y0 + row * D);
+    Row kj[NK > 0 ? NK : 1];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) kj[j] = *(const Row*)(R.k[j] + row * D);
+    T ys[D], aux[D], kn[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      T kk[NK > 0 ? NK : 1];
+#pragma unroll
+      for (int j = 0; j < NK; ++j) kk[j] = kj[j].v[d];
+      ys[d] = combine_elem<T, NK, MODE>(y0.v[d], kk, R.hs, A, aux[d]);
+      reduce_flat<T, MODE>(y0.v[d], ys[d], A, acc);
+    }
+    rhs(sign * R.ts, ys, kn);                     // reversed time: f <- -f(-t, y) (misc.py:318-321)
+#pragma unroll
+    for (int d = 0; d < D; ++d) kn[d] = sign * kn[d];
+    if (R.k_out != nullptr) {
+      Row o;
+#pragma unroll
+      for (int d = 0; d < D; ++d) o.v[d] = kn[d];
+      *(Row*)(R.k_out + row * D) = o;
+    }
+    Row y1;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const T k0 = NK > 0 ? kj[0].v[d] : (T)0;
+      const T v = epilogue_elem<T, NK, MODE>(y0.v[d], k0, kn[d], aux[d], R.hs, A, acc);
+      y1.v[d] = (MODE == M_LAST_FSAL) ? ys[d] : v;
+    }
+    if constexpr (mode_writes_y1(MODE)) *(Row*)(R.y1 + row * D) = y1;
+  }
+  if constexpr (mode_has_reduction(MODE)) {
+    __shared__ double red[80];
+    block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
+  }
+}
+
+}  // namespace mi

@@ -1,0 +1,53 @@
+"""Mirror of tfdiffeq/odeint.py: the `odeint` entry point and the SOLVERS registry (B1/B2)."""
+from .bosh3 import Bosh3Solver
+from .dopri5 import Dopri5Solver
+from .fixed_grid import Euler, Midpoint, RK4, Heun
+from .misc import _check_inputs
+from .tsit5 import Tsit5Solver
+
+# odeint.py:11-25.  In scope of this build: dopri5, tsit5, bosh3, euler, rk4 (+ the two
+# other fixed-grid one-liners).  The remaining reference keys (adams, explicit_adams, fixed_adams, dopri8,
+# adaptive_heun) are listed in SURVEY.md 8(f) as "next"; asking for them raises KeyError like any unknown name.
+SOLVERS = {
+    'tsit5': Tsit5Solver,
+    'dopri5': Dopri5Solver,
+    'bosh3': Bosh3Solver,
+    'euler': Euler,
+    'midpoint': Midpoint,
+    'rk4': RK4,
+    'huen': Heun,
+    'heun': Heun,
+}
+
+
+def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
+    """Integrate a system of ordinary differential equations (odeint.py:28-81).
+
+        dy/dt = func(t, y),  y(t[0]) = y0
+
+    func: callable (t: 0-d tensor in the state dtype, y) -> dy, or a `tfdiffeq_amd.rhs.DeviceRHS` (fused kernels).
+    y0:   torch.Tensor on the MI355X (any shape; [batch, dim] for the fused kernels) or a tuple of them.
+    t:    1-D, strictly monotone (either direction); converted to float64 (adaptive) / the state dtype (fixed).
+    Returns a tensor [len(t), *y0.shape] (or a tuple of them) whose first entry is y0.
+
+    Raises ValueError (options without method), KeyError (unknown method), TypeError (non-floating inputs),
+    AssertionError (non-monotone t, dt underflow, non-finite state, max_num_steps) - as the reference does.
+    """
+    tensor_input, func, y0, t = _check_inputs(func, y0, t)
+
+    if options is None:
+        options = {}
+    elif method is None:
+        raise ValueError('cannot supply `options` without specifying `method`')
+
+    if method is None:
+        method = 'dopri5'
+    solver = SOLVERS[method](func, y0, rtol=rtol, atol=atol, **options)
+    solution = solver.integrate(t)
+    odeint.last_stats = getattr(solver, 'stats', {})
+    if tensor_input:
+        solution = solution[0]
+    return solution
+
+
+odeint.last_stats = {}

@@ -1,0 +1,194 @@
+"""Device right-hand-side catalogue.
+
+A `DeviceRHS` is an ordinary `func(t, y)` callable (so it also works through the generic plane-kernel
+path and can be compared against any other implementation), that additionally carries the descriptor
+(`mi_ode_rhs`, include/mi_ode.h) which lets `odeint` evaluate it INSIDE the fused stage kernels.
+
+Workload definitions follow the reference's examples:
+  Linear          f = y @ W (+ b)              BASELINE config 4 (W = A^T for f = A y)
+  CubicLinear     f = (y**3) @ W               examples/ode_demo.py:33-35 (spiral)
+  LotkaVolterra   examples/ode_usage.ipynb cells 39-42 / README.md:67-82, batched on the last axis
+  Lorenz          examples/lorenz_attractor.py:20-37, batched on the last axis
+  MLPTanh         tfdiffeq/models/dense_odenet.py:41-92 (ODEFunc, time independent, tanh)
+"""
+import torch
+
+from . import _native as N
+
+
+class DeviceRHS(object):
+    kind = 0
+    dim = None
+
+    def __init__(self):
+        self.sign = 1.0
+        self.nfe = 0          # evaluations through the Python __call__ path only (cf. dense_odenet.py:38,78)
+        self._cache = {}
+
+    # -- python path -------------------------------------------------------------------------
+    def forward(self, t, y):
+        raise NotImplementedError
+
+    def __call__(self, t, y):
+        self.nfe += 1
+        if self.sign < 0:                       # misc.py:318-321: f <- -f(-t, y)
+            return -self.forward(-t, y)
+        return self.forward(t, y)
+
+    def reversed(self):
+        import copy
+        r = copy.copy(self)
+        r._cache = {}
+        r.sign = -self.sign
+        return r
+
+    # -- device path -------------------------------------------------------------------------
+    def _dev(self, x, dtype, device):
+        key = (id(x), dtype, str(device))
+        if key not in self._cache:
+            self._cache[key] = x.detach().to(device=device, dtype=dtype).contiguous()
+        return self._cache[key]
+
+    def supports(self, y0):
+        """True when the fused kernels can take this state tensor."""
+        return y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
+
+    def fill(self, rhs, dtype, device):
+        """Fill a _native.Rhs struct; returns objects that must stay alive as long as the handle."""
+        rhs.kind = self.kind
+        rhs.sign = self.sign
+        rhs.hidden = 0
+        return []
+
+
+class _MatRHS(DeviceRHS):
+    def __init__(self, W, b=None):
+        super(_MatRHS, self).__init__()
+        W = torch.as_tensor(W)
+        assert W.dim() == 2 and W.shape[0] == W.shape[1], 'W must be square [dim, dim]'
+        self.W = W
+        self.b = None if b is None else torch.as_tensor(b)
+        self.dim = int(W.shape[0])
+
+    def fill(self, rhs, dtype, device):
+        keep = super(_MatRHS, self).fill(rhs, dtype, device)
+        Wd = self._dev(self.W, dtype, device)
+        rhs.w[0] = Wd.data_ptr()
+        keep.append(Wd)
+        if self.b is not None:
+            bd = self._dev(self.b, dtype, device)
+            rhs.b[0] = bd.data_ptr()
+            keep.append(bd)
+        if self.dim == 2:                        # tiny systems travel by value (row-local kernels)
+            flat = self.W.detach().to(torch.float64).reshape(-1).tolist()
+            for i in range(4):
+                rhs.scalars[i] = flat[i]
+        return keep
+
+
+class Linear(_MatRHS):
+    """f(t, y) = y @ W (+ b)."""
+    kind = N.RHS_LINEAR
+
+    @classmethod
+    def from_matrix(cls, A, b=None):
+        """f(t, y) = A y for row-vector states, i.e. y @ A^T."""
+        return cls(torch.as_tensor(A).t().contiguous(), b)
+
+    def forward(self, t, y):
+        W = self._dev(self.W, y.dtype, y.device)
+        out = torch.matmul(y, W)
+        if self.b is not None:
+            out = out + self._dev(self.b, y.dtype, y.device)
+        return out
+
+
+class CubicLinear(_MatRHS):
+    """f(t, y) = (y ** 3) @ W  (the spiral of examples/ode_demo.py)."""
+    kind = N.RHS_CUBIC_LINEAR
+
+    def __init__(self, W):
+        super(CubicLinear, self).__init__(W, None)
+
+    def forward(self, t, y):
+        return torch.matmul(y ** 3, self._dev(self.W, y.dtype, y.device))
+
+
+class LotkaVolterra(DeviceRHS):
+    kind = N.RHS_LOTKA_VOLTERRA
+    dim = 2
+
+    def __init__(self, a=1.5, b=1.0, c=3.0, d=1.0):
+        super(LotkaVolterra, self).__init__()
+        self.p = (float(a), float(b), float(c), float(d))
+
+    def forward(self, t, y):
+        a, b, c, d = self.p
+        u, v = y[..., 0], y[..., 1]
+        return torch.stack([a * u - b * u * v, -c * v + d * u * v], dim=-1)
+
+    def fill(self, rhs, dtype, device):
+        keep = super(LotkaVolterra, self).fill(rhs, dtype, device)
+        for i, v in enumerate(self.p):
+            rhs.scalars[i] = v
+        return keep
+
+
+class Lorenz(DeviceRHS):
+    kind = N.RHS_LORENZ
+    dim = 3
+
+    def __init__(self, sigma=10., beta=8. / 3., rho=28.):
+        super(Lorenz, self).__init__()
+        self.p = (float(sigma), float(beta), float(rho))
+
+    def forward(self, t, y):
+        s, be, r = self.p
+        x0, x1, x2 = y[..., 0], y[..., 1], y[..., 2]
+        return torch.stack([s * (x1 - x0), x0 * (r - x2) - x1, x0 * x1 - be * x2], dim=-1)
+
+    def fill(self, rhs, dtype, device):
+        keep = super(Lorenz, self).fill(rhs, dtype, device)
+        for i, v in enumerate(self.p):
+            rhs.scalars[i] = v
+        return keep
+
+
+class MLPTanh(DeviceRHS):
+    """ODEFunc-shaped MLP dim -> hidden -> hidden -> dim with tanh, time independent
+    (tfdiffeq/models/dense_odenet.py:41-92).  Weights are [in, out] (Keras Dense layout)."""
+    kind = N.RHS_MLP_TANH
+
+    def __init__(self, W1, b1, W2, b2, W3, b3):
+        super(MLPTanh, self).__init__()
+        self.Ws = [torch.as_tensor(w) for w in (W1, W2, W3)]
+        self.bs = [None if b is None else torch.as_tensor(b) for b in (b1, b2, b3)]
+        self.dim = int(self.Ws[0].shape[0])
+        self.hidden = int(self.Ws[0].shape[1])
+        assert self.Ws[1].shape == (self.hidden, self.hidden) and self.Ws[2].shape == (self.hidden, self.dim)
+
+    def forward(self, t, y):
+        h = y
+        for i in range(3):
+            h = torch.matmul(h, self._dev(self.Ws[i], y.dtype, y.device))
+            if self.bs[i] is not None:
+                h = h + self._dev(self.bs[i], y.dtype, y.device)
+            if i < 2:
+                h = torch.tanh(h)
+        return h
+
+    def supports(self, y0):
+        return False          # no fused stage kernel yet: runs through the plane kernels + torch matmul
+
+    def fill(self, rhs, dtype, device):
+        keep = super(MLPTanh, self).fill(rhs, dtype, device)
+        rhs.hidden = self.hidden
+        for i in range(3):
+            Wd = self._dev(self.Ws[i], dtype, device)
+            rhs.w[i] = Wd.data_ptr()
+            keep.append(Wd)
+            if self.bs[i] is not None:
+                bd = self._dev(self.bs[i], dtype, device)
+                rhs.b[i] = bd.data_ptr()
+                keep.append(bd)
+        return keep

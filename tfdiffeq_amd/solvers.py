@@ -1,0 +1,476 @@
+"""Mirror of tfdiffeq/solvers.py: the solver-registry plugin contract (B2 in SURVEY.md 8(b)).
+
+    cls(func, y0_tuple, rtol=, atol=, **options).integrate(t) -> tuple of stacked tensors
+
+Adaptive subclasses supply `before_integrate(t)` + `advance(next_t)`; fixed-grid subclasses supply
+`step_func(func, t, dt, y) -> dy` + `order`  (solvers.py:20-25, 73-80).
+
+Two execution engines sit behind that contract:
+  * fused   - `func` carries a DeviceRHS and the state is one [batch, dim] tensor: the whole integrate()
+              runs inside libmi_ode (`_FusedEngine`): f evaluated in the stage kernels, controller and
+              dense output on device, host polls a done flag.
+  * planes  - any Python callable / tuple state: the Python loops below, every state-sized operation being
+              a libmi_ode plane kernel.  One host synchronisation per step attempt.
+There is no CPU path: state tensors must live on the MI355X.
+"""
+import abc
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _native as N
+from .misc import (_assert_increasing, _handle_unused_kwargs, _lincomb, _np_dtype, _scalar_tensor, _Exchange)
+
+
+# ---------------------------------------------------------------------------------------------
+# fused engine wrapper
+# ---------------------------------------------------------------------------------------------
+def _fill_tableau(tb_struct, tableau, c_mid):
+    S = len(tableau.alpha)
+    if S > N.MAX_STAGES:
+        raise ValueError('fused engine supports at most %d tableau rows' % N.MAX_STAGES)
+    tb_struct.n_stages = S
+    from .rk_common import _is_fsal_shaped
+    tb_struct.fsal = 1 if (S > 0 and _is_fsal_shaped(tableau)) else 0
+    for i in range(S):
+        tb_struct.alpha[i] = float(tableau.alpha[i])
+        for j, v in enumerate(tableau.beta[i]):
+            tb_struct.beta[i][j] = float(v)
+    for j, v in enumerate(tableau.c_sol):
+        tb_struct.c_sol[j] = float(v)
+    for j, v in enumerate(tableau.c_error):
+        tb_struct.c_error[j] = float(v)
+    if c_mid is not None:
+        for j, v in enumerate(c_mid):
+            tb_struct.c_mid[j] = float(v)
+
+
+class _FusedEngine(object):
+    """Owns one mi_ode_handle.  y0: a contiguous [batch, dim] (or [dim]) device tensor."""
+
+    def __init__(self, device_rhs, y0, adaptive, tableau, c_mid=None, rtol=1e-7, atol=1e-9, controller=N.CTRL_MISC,
+                 interp=N.INTERP_QUARTIC_MID, order=5, init_order=4, safety=0.9, ifactor=10.0, dfactor=0.2,
+                 first_step=None, max_num_steps=2 ** 31 - 1, process_group=None, linear_variant=0, chunk_attempts=0):
+        N.require_gpu_tensor(y0, 'y0')
+        self.lib = N.load()
+        self.y0 = y0.contiguous()
+        self.shape = tuple(y0.shape)
+        self.dim = int(y0.shape[-1])
+        self.batch = int(y0.numel() // self.dim)
+        self.device = y0.device
+        self.dtype = y0.dtype
+        d = N.Desc()
+        d.dtype = N.dtype_code(y0.dtype)
+        d.adaptive = 1 if adaptive else 0
+        d.batch, d.dim = self.batch, self.dim
+        _fill_tableau(d.tableau, tableau, c_mid)
+        self._keep = device_rhs.fill(d.rhs, y0.dtype, y0.device)
+        d.controller, d.interp, d.order, d.init_order = controller, interp, order, init_order
+        d.rtol, d.atol = float(rtol), float(atol)
+        d.safety, d.ifactor, d.dfactor = float(safety), float(ifactor), float(dfactor)
+        d.first_step = float('nan') if first_step is None else float(first_step)
+        d.max_num_steps = int(max_num_steps)
+        d.linear_variant = int(linear_variant)
+        d.chunk_attempts = int(chunk_attempts)
+        self._hook = None
+        if process_group is not None:
+            import torch.distributed as dist
+            world = dist.get_world_size(process_group)
+            if world > 1:
+                d.world_size, d.rank = world, dist.get_rank(process_group)
+                self._send = torch.zeros(N.REC, dtype=torch.float64, device=self.device)
+                self._recv = torch.zeros(world * N.REC, dtype=torch.float64, device=self.device)
+                d.exchange_send_dev = self._send.data_ptr()
+                d.exchange_recv_dev = self._recv.data_ptr()
+                send, recv, group = self._send, self._recv, process_group
+
+                def hook(_user, _sendbuf, _recvbuf, _count, _stream):
+                    # RCCL all-gather of one 8-double record per rank, stream-ordered with the kernels around it
+                    try:
+                        dist.all_gather_into_tensor(recv, send, group=group)
+                        return 0
+                    except Exception:          # pragma: no cover - surfaces as MI_ODE_E_EXCHANGE
+                        import traceback
+                        traceback.print_exc()
+                        return 1
+                self._hook = N.ALLGATHER_FN(hook)
+                d.allgather = self._hook
+        self.desc = d
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(self.lib.mi_ode_create(C.byref(d), C.byref(h)), 'mi_ode_create')
+        self.h = h
+        self.stats = N.Stats()
+
+    def close(self):
+        if getattr(self, 'h', None) is not None and self.h:
+            self.lib.mi_ode_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _stream(self):
+        return N.stream_ptr(self.device)
+
+    @staticmethod
+    def _times(t):
+        arr = np.ascontiguousarray(np.asarray(t, dtype=np.float64))
+        return arr, arr.ctypes.data_as(C.POINTER(C.c_double))
+
+    def _raise_for_status(self, bits):
+        if bits == 0:
+            return
+        msg = N.status_message(bits)
+        if bits & N.ST_MAX_STEPS:
+            msg = 'max_num_steps exceeded ({}>={})'.format(self.desc.max_num_steps, self.desc.max_num_steps)
+        if bits & N.ST_DT_UNDERFLOW:
+            msg = 'underflow in dt {}'.format(self.stats.dt)
+        raise AssertionError(msg)          # the reference raises AssertionError for all of these
+
+    def integrate(self, t):
+        arr, p = self._times(t)
+        T = arr.shape[0]
+        out = torch.empty((T,) + self.shape, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            fn = self.lib.mi_ode_integrate if self.desc.adaptive else self.lib.mi_ode_fixed_grid_integrate
+            rc = N.check(fn(self.h, C.c_void_p(self.y0.data_ptr()), p, T, C.c_void_p(out.data_ptr()),
+                            C.byref(self.stats), self._stream()), 'mi_ode_integrate')
+        self._raise_for_status(rc)
+        return out
+
+    def begin(self, t0):
+        with torch.cuda.device(self.device):
+            N.check(self.lib.mi_ode_begin(self.h, C.c_void_p(self.y0.data_ptr()), float(t0), self._stream()), 'mi_ode_begin')
+
+    def advance(self, times):
+        arr, p = self._times(times)
+        out = torch.empty((arr.shape[0],) + self.shape, dtype=self.dtype, device=self.device)
+        with torch.cuda.device(self.device):
+            rc = N.check(self.lib.mi_ode_advance(self.h, p, arr.shape[0], C.c_void_p(out.data_ptr()), self._stream()),
+                         'mi_ode_advance')
+            N.check(self.lib.mi_ode_get_stats(self.h, C.byref(self.stats), self._stream()), 'mi_ode_get_stats')
+        self._raise_for_status(rc)
+        return out
+
+    def eval_rhs(self, y, t=0.0):
+        f = torch.empty_like(y)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.mi_ode_eval_rhs(self.h, C.c_void_p(y.data_ptr()), float(t), C.c_void_p(f.data_ptr()),
+                                             self._stream()), 'mi_ode_eval_rhs')
+        return f
+
+    def rk_step(self, y0, f0, t0, dt, want_k=False):
+        """One attempt with a given dt: (y1, f1, norms[4], k or None) - the _runge_kutta_step parity surface."""
+        y1, f1 = torch.empty_like(y0), torch.empty_like(y0)
+        S = self.desc.tableau.n_stages
+        k = torch.empty((S + 1,) + tuple(y0.shape), dtype=y0.dtype, device=y0.device) if want_k else None
+        norms = (C.c_double * 4)()
+        with torch.cuda.device(self.device):
+            N.check(self.lib.mi_ode_rk_step_fused(self.h, C.c_void_p(y0.data_ptr()), C.c_void_p(f0.data_ptr()), float(t0),
+                                                  float(dt), C.c_void_p(y1.data_ptr()), C.c_void_p(f1.data_ptr()), norms,
+                                                  C.c_void_p(k.data_ptr()) if want_k else C.c_void_p(0), self._stream()),
+                    'mi_ode_rk_step_fused')
+        return y1, f1, [norms[i] for i in range(4)], k
+
+
+def _fusable(func, y0):
+    """The DeviceRHS behind `func` if the fused engine can run this problem, else None."""
+    rhs = getattr(func, 'device_rhs', None)
+    if rhs is None or len(y0) != 1:
+        return None
+    y = y0[0]
+    if not (isinstance(y, torch.Tensor) and y.is_cuda and y.dim() in (1, 2) and rhs.supports(y)):
+        return None
+    return rhs
+
+
+# ---------------------------------------------------------------------------------------------
+# base classes
+# ---------------------------------------------------------------------------------------------
+class AdaptiveStepsizeODESolver(object):
+    __metaclass__ = abc.ABCMeta
+
+    def __init__(self, func, y0, atol, rtol, **unused_kwargs):
+        _handle_unused_kwargs(self, unused_kwargs)
+        del unused_kwargs
+        self.func = func
+        self.y0 = y0
+        self.atol = atol
+        self.rtol = rtol
+
+    def before_integrate(self, t):
+        pass
+
+    @abc.abstractmethod
+    def advance(self, next_t):
+        raise NotImplementedError
+
+    def integrate(self, t):
+        """solvers.py:27-35."""
+        _assert_increasing(t)
+        solution = [self.y0]
+        t = t.to(torch.float64)                       # :30 time is ALWAYS float64 in adaptive solvers
+        self.before_integrate(t)
+        for i in range(1, t.shape[0]):
+            y = self.advance(t[i])
+            solution.append(y)
+        return tuple(map(torch.stack, tuple(zip(*solution))))
+
+
+class FixedGridODESolver(object):
+    __metaclass__ = abc.ABCMeta
+
+    def __init__(self, func, y0, step_size=None, grid_constructor=None, eps=0.0, **unused_kwargs):
+        unused_kwargs.pop('rtol', None)
+        unused_kwargs.pop('atol', None)
+        self._pg = unused_kwargs.pop('process_group', None)     # accepted for symmetry; fixed grid needs no exchange
+        _handle_unused_kwargs(self, unused_kwargs)
+        del unused_kwargs
+        self.func = func
+        self.y0 = y0
+        self.eps = eps
+        if step_size is not None and grid_constructor is None:
+            self.grid_constructor = self._grid_constructor_from_step_size(step_size)
+        elif grid_constructor is None:
+            self.grid_constructor = lambda f, y0, t: t
+            self._default_grid = True
+        else:
+            raise ValueError("step_size and grid_constructor are exclusive arguments.")     # solvers.py:56
+
+    def _grid_constructor_from_step_size(self, step_size):
+        # The reference's version (solvers.py:58-71) is dead code (F7: .item() / item assignment on TF tensors).
+        # This is the evident intent: a uniform grid of `step_size` clipped to t[-1].
+        def _grid_constructor(func, y0, t):
+            start_time, end_time = t[0], t[-1]
+            niters = int(math.ceil(float((end_time - start_time) / step_size + 1)))
+            t_infer = torch.arange(0, niters, dtype=t.dtype) * step_size + start_time
+            if t_infer[-1] > t[-1]:
+                t_infer[-1] = t[-1]
+            return t_infer
+        return _grid_constructor
+
+    @property
+    @abc.abstractmethod
+    def order(self):
+        pass
+
+    @abc.abstractmethod
+    def step_func(self, func, t, dt, y):
+        pass
+
+    _fused_tableau = None      # subclasses with a fused kernel set a _ButcherTableau here
+
+    def integrate(self, t):
+        """solvers.py:82-104."""
+        _assert_increasing(t)
+        t = t.to(self.y0[0].dtype)                    # :84 time in the STATE dtype here
+        rhs = _fusable(self.func, self.y0)
+        if (rhs is not None and self._fused_tableau is not None and getattr(self, '_default_grid', False)
+                and self.eps == 0.0):
+            eng = _FusedEngine(rhs, self.y0[0], False, self._fused_tableau)
+            try:
+                out = eng.integrate(t.to(torch.float64).numpy())
+                self.stats = eng.stats.as_dict()
+            finally:
+                eng.close()
+            return (out,)
+        time_grid = self.grid_constructor(self.func, self.y0, t)
+        assert bool(time_grid[0] == t[0]) and bool(time_grid[-1] == t[-1])
+        for y_ in self.y0:
+            N.require_gpu_tensor(y_, 'y0')
+        solution = [self.y0]
+        j = 1
+        y0 = self.y0
+        grid = time_grid.numpy()
+        tt = t.numpy()
+        for t0, t1 in zip(grid[:-1], grid[1:]):
+            dy = self.step_func(self.func, t0, t1 - t0, y0)
+            y1 = tuple(_lincomb(y0_, [1.0], [dy_], 1.0) for y0_, dy_ in zip(y0, dy))
+            while j < tt.shape[0] and t1 >= tt[j]:
+                solution.append(self._linear_interp(t0, t1, y0, y1, tt[j]))
+                j += 1
+            y0 = y1
+        return tuple(map(torch.stack, tuple(zip(*solution))))
+
+    def _linear_interp(self, t0, t1, y0, y1, t):
+        """solvers.py:106-115."""
+        if t == t0:
+            return y0
+        if t == t1:
+            return y1
+        w = (t - t0) / (t1 - t0)
+        return tuple(_lincomb(y0_, [-w, w], [y0_, y1_], 1.0) for y0_, y1_ in zip(y0, y1))
+
+
+# ---------------------------------------------------------------------------------------------
+# shared adaptive Runge-Kutta driver (dopri5.py:48-121, bosh3.py:34-99, tsit5.py:69-151)
+# ---------------------------------------------------------------------------------------------
+class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
+    tableau = None
+    c_mid = None
+    order = 5
+    init_order = 4
+    controller = N.CTRL_MISC
+    interp = N.INTERP_QUARTIC_MID
+    pooled_ratio = False          # tsit5 pools all components into one mean (tsit5.py:134-137)
+
+    def _setup(self, func, y0, rtol, atol, first_step, safety, ifactor, dfactor, max_num_steps, unused_kwargs):
+        from .misc import _convert_to_tensor, _is_iterable
+        self._pg = unused_kwargs.pop('process_group', None)
+        self._linear_variant = unused_kwargs.pop('linear_variant', 0)
+        self._chunk_attempts = unused_kwargs.pop('chunk_attempts', 0)
+        self._force_planes = unused_kwargs.pop('force_plane_kernels', False)
+        _handle_unused_kwargs(self, unused_kwargs)
+        self.func = func
+        self.y0 = y0
+        if self.pooled_ratio:
+            self.rtol, self.atol = rtol, atol                                     # tsit5.py:81-82
+        else:
+            self.rtol = rtol if _is_iterable(rtol) else [rtol] * len(y0)          # dopri5.py:60-61
+            self.atol = atol if _is_iterable(atol) else [atol] * len(y0)
+        self.first_step = first_step
+        # dopri5.py:63-66 through misc.py:137-144: python float -> float32 -> float64
+        self.safety = _convert_to_tensor(safety, dtype=np.float64)
+        self.ifactor = _convert_to_tensor(ifactor, dtype=np.float64)
+        self.dfactor = _convert_to_tensor(dfactor, dtype=np.float64)
+        self.max_num_steps = int(max_num_steps)
+        self._engine = None
+        self._exchange = _Exchange(self._pg) if self._pg is not None else None
+        self.stats = {}
+
+    # -- fused engine ----------------------------------------------------------------------------
+    def _make_engine(self):
+        rhs = None if self._force_planes else _fusable(self.func, self.y0)
+        if rhs is None:
+            return None
+        from .rk_common import _is_fsal_shaped
+        if not _is_fsal_shaped(self.tableau) or len(self.tableau.alpha) not in (3, 6):
+            return None
+        rtol0 = self.rtol if self.pooled_ratio else self.rtol[0]
+        atol0 = self.atol if self.pooled_ratio else self.atol[0]
+        first = None
+        if self.first_step is not None:
+            from .misc import _convert_to_tensor
+            first = float(_convert_to_tensor(self.first_step, dtype=np.float64))   # dopri5.py:77: float32 detour
+        return _FusedEngine(rhs, self.y0[0], True, self.tableau, self.c_mid, rtol0, atol0, self.controller, self.interp,
+                            self.order, self.init_order, float(self.safety), float(self.ifactor), float(self.dfactor),
+                            first, self.max_num_steps, self._pg, self._linear_variant, self._chunk_attempts)
+
+    def integrate(self, t):
+        _assert_increasing(t)
+        eng = self._make_engine()
+        if eng is None:
+            return super(_AdaptiveRKSolver, self).integrate(t)
+        try:
+            out = eng.integrate(t.to(torch.float64).numpy())
+            self.stats = eng.stats.as_dict()
+        finally:
+            self.stats = eng.stats.as_dict()
+            eng.close()
+        return (out,)
+
+    # -- plane-kernel path (any callable, tuple states) -------------------------------------------
+    def before_integrate(self, t):
+        from .misc import _convert_to_tensor, _select_initial_step
+        from .rk_common import _RungeKuttaState
+        for y_ in self.y0:
+            N.require_gpu_tensor(y_, 'y0')
+        like = self.y0[0]
+        t0 = float(t[0])
+        if self.pooled_ratio:                                                     # tsit5.py:91-103
+            if self.first_step is None:
+                first = np.float64(_select_initial_step(self.func, t0, self.y0, self.init_order, self.rtol, self.atol,
+                                                        exchange=self._exchange))
+            else:
+                first = _convert_to_tensor(self.first_step, dtype=np.float64)
+            f0 = self.func(torch.full((), t0, dtype=torch.float64, device=like.device), self.y0)   # :99 t[0] un-cast
+        else:                                                                     # dopri5.py:70-79
+            f0 = self.func(_scalar_tensor(_np_dtype(like.dtype).type(t0), like), self.y0)
+            if self.first_step is None:
+                first = np.float64(_select_initial_step(self.func, t0, self.y0, self.init_order, self.rtol[0],
+                                                        self.atol[0], f0=f0, exchange=self._exchange))
+            else:
+                first = _convert_to_tensor(self.first_step, dtype=np.float64)
+        self.rk_state = _RungeKuttaState(self.y0, f0, np.float64(t0), np.float64(t0), first, interp_coeff=None)
+        self._n_attempts = self._n_accepted = 0
+
+    def advance(self, next_t):
+        """Interpolate through the next time point, integrating as necessary (dopri5.py:81-89)."""
+        next_t = np.float64(float(next_t))
+        n_steps = 0
+        while next_t > self.rk_state.t1:
+            assert n_steps < self.max_num_steps, 'max_num_steps exceeded ({}>={})'.format(n_steps, self.max_num_steps)
+            self.rk_state = self._adaptive_step(self.rk_state)
+            n_steps += 1
+        return self._dense_output(self.rk_state, next_t)
+
+    def _dense_output(self, rk_state, next_t):
+        from .interp import _interp_eval_step
+        ic = rk_state.interp_coeff
+        if ic is None:                   # no accepted step yet: the reference's [y0] * 5 placeholder evaluates to y0
+            return rk_state.y1
+        y0, y1, k, dt = ic
+        return _interp_eval_step(self.interp, y0, y1, k, self.c_mid, dt, rk_state.t0, rk_state.t1, next_t)
+
+    def _adaptive_step(self, rk_state):
+        """Take an adaptive Runge-Kutta step (dopri5.py:91-121 / bosh3.py:70-99 / tsit5.py:113-151)."""
+        from .misc import _compute_error_ratio, _optimal_step_size, _ratio_from_norms
+        from .rk_common import _RungeKuttaState, _runge_kutta_step
+        y0, f0, _, t0, dt, interp_coeff = rk_state
+        dt = np.float64(dt)
+        assert t0 + dt > t0, 'underflow in dt {}'.format(dt)
+        y1, f1, y1_error, k = _runge_kutta_step(self.func, y0, f0, t0, dt, tableau=self.tableau)
+        if self.pooled_ratio:
+            ratios = self._pooled_ratio(y1_error, y0, y1)
+            accept_step = bool(ratios[0] <= 1.)
+            dt_next = self._tsit5_step_size(dt, ratios[0])
+        else:
+            ratios = _compute_error_ratio(y1_error, atol=self.atol, rtol=self.rtol, y0=y0, y1=y1, exchange=self._exchange)
+            accept_step = bool(np.all(np.asarray([float(r) for r in ratios]) <= 1))
+            dt_next = _optimal_step_size(dt, ratios, safety=self.safety, ifactor=self.ifactor, dfactor=self.dfactor,
+                                         order=self.order)
+        assert not _compute_error_ratio.last_nonfinite, 'non-finite values in state `y`'       # dopri5.py:99-100
+        self._n_attempts += 1
+        if accept_step:
+            self._n_accepted += 1
+            return _RungeKuttaState(y1, f1, t0, t0 + dt, dt_next, (y0, y1, k, dt))
+        return _RungeKuttaState(y0, f0, t0, t0, dt_next, interp_coeff)
+
+    def _pooled_ratio(self, y1_error, y0, y1):
+        """tsit5.py:126-138: scalar rtol/atol, one mean over ALL components."""
+        from .misc import _error_norms
+        recs = torch.stack([_error_norms(e, a, b) for e, a, b in zip(y1_error, y0, y1)])
+        counts = torch.tensor([[float(e.numel())] for e in y1_error], dtype=torch.float64, device=recs.device)
+        recs = torch.cat([recs, counts], dim=1)
+        if self._exchange is not None:
+            recs = self._exchange.combine(recs, max_slots=(0, 1, 3))
+        host = recs.cpu().numpy()
+        from .misc import _compute_error_ratio
+        _compute_error_ratio.last_nonfinite = bool((host[:, 3] != 0).any())
+        dt_ = _np_dtype(y0[0].dtype).type
+        num, den = 0.0, 0.0
+        with np.errstate(all='ignore'):
+            for i in range(host.shape[0]):
+                tol = dt_(self.atol) + dt_(self.rtol) * dt_(max(host[i, 0], host[i, 1]))
+                num += host[i, 2] / (float(tol) * float(tol))
+                den += host[i, 4]
+            return (dt_(num / den),)
+
+    def _tsit5_step_size(self, last_step, mean_error_ratio):
+        """tsit5.py:53-62."""
+        ifactor, dfactor, safety = self.ifactor, self.dfactor, self.safety
+        if mean_error_ratio == 0:
+            return np.float64(last_step * ifactor)
+        if mean_error_ratio < 1:
+            dfactor = np.float64(1.)
+        with np.errstate(all='ignore'):
+            error_ratio = np.float64(mean_error_ratio)
+            exponent = np.float64(1. / self.order)
+            factor = np.maximum(np.float64(1. / ifactor), np.minimum((error_ratio ** exponent) / safety, np.float64(1. / dfactor)))
+            return np.float64(last_step / factor)
