@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py - BASELINE.json's headline metric on its headline configuration.
+
+A "step" is one whole `odeint` call of config 4: linear f(t, y) = A y, dim 128,
+batch 65536 PER GPU (weak scaling; the global error norm couples all ranks through one RCCL all-gather
+of an 8-double record per step attempt), Dopri5, float64, rtol 1e-6, atol 1e-9, t = [0, 1].  Inputs are
+resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+roofline:     dominant kernel = the fused Dopri5 last stage (stage + error kernel, k_stage_linear_mfma<double,128,6,LAST_FSAL>):
+              reads y0, k1..k6, writes k7, y1  = 9 planes = 9 * batch*dim*8 B algorithmic bytes per launch; its duration is
+              measured with hipEvents on the launch stream inside libmi_ode (desc.profile).  HBM bound.
+cpu_baseline: the oracle (numpy restatement of the reference algorithm, kind "port") on a bounded sample of the
+              same workload on this host's cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+BATCH_PER_GPU = 65536
+DIM = 128
+RTOL, ATOL = 1e-6, 1e-9
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+
+
+def config4(batch, dim, seed_y):
+    g2 = torch.Generator().manual_seed(2)
+    S = torch.randn(dim, dim, generator=g2, dtype=torch.float64)
+    A = -0.5 * torch.eye(dim, dtype=torch.float64) + 0.5 * (S - S.t()) / np.sqrt(dim)
+    g3 = torch.Generator().manual_seed(seed_y)
+    y0 = torch.randn(batch, dim, generator=g3, dtype=torch.float64)
+    return A, y0
+
+
+def cpu_baseline(sample_batch=65536, repeats=2):
+    """Oracle (numpy) on a bounded sample of config 4, single core (BLAS pinned to one thread)."""
+    from oracle import ode_numpy as O
+    try:
+        from threadpoolctl import threadpool_limits
+    except Exception:           # pragma: no cover
+        threadpool_limits = None
+    A, y0 = config4(sample_batch, DIM, 3)
+    W = A.t().contiguous().numpy()
+    y0 = y0.numpy()
+    f = lambda t, y: y @ W  # noqa: E731
+    t = np.array([0., 1.])
+
+    def run():
+        t0 = time.perf_counter()
+        _, st = O.odeint(f, y0, t, rtol=RTOL, atol=ATOL, method='dopri5', return_stats=True)
+        return time.perf_counter() - t0, st
+    ctx = threadpool_limits(limits=1) if threadpool_limits is not None else None
+    if ctx is not None:
+        ctx.__enter__()
+    try:
+        run()                                           # warm-up
+        times, st = [], None
+        for _ in range(repeats):
+            dt, st = run()
+            times.append(dt)
+    finally:
+        if ctx is not None:
+            ctx.__exit__(None, None, None)
+    wall = float(np.median(times))
+    return {'value': sample_batch * DIM / wall, 'unit': 'state-elements/s', 'cores': 1, 'kind': 'port',
+            'sample': 'config 4 at batch %d x dim %d (1/%d of one GPU shard), whole odeint call, numpy oracle, '
+                      'median of %d runs, %.2f s each, %d attempts' % (sample_batch, DIM, BATCH_PER_GPU // sample_batch,
+                                                                       repeats, wall, st.n_attempts),
+            'element_steps_per_s': sample_batch * DIM * st.n_attempts / wall,
+            'host_cpus': os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='rows per GPU (default: config 4)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--linear-variant', type=int, default=0)
+    args = ap.parse_args()
+
+    import torch.distributed as dist
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group(backend='nccl', device_id=dev)
+        group = dist.group.WORLD
+    n_gpus = world
+    if args.gpus != n_gpus and rank == 0:
+        print('warning: --gpus %d but WORLD_SIZE %d; using %d' % (args.gpus, world, world), file=sys.stderr)
+
+    from tfdiffeq_amd import odeint, rhs
+    A, y0 = config4(args.batch, DIM, 3 + rank)
+    f = rhs.Linear.from_matrix(A)
+    y0 = y0.to(dev)
+    t = torch.tensor([0., 1.], dtype=torch.float64)
+    opts = {'profile': True, 'linear_variant': args.linear_variant}
+    if group is not None:
+        opts['process_group'] = group
+
+    def step():
+        out = odeint(f, y0, t, rtol=RTOL, atol=ATOL, method='dopri5', options=opts)
+        return out, dict(odeint.last_stats)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    prof_last_ms = prof_all_ms = 0.0
+    prof_n = 0
+    stats = {}
+    for _ in range(args.steps):
+        out, stats = step()
+        p = stats.get('profile', [0, 0, 0, 0])
+        prof_last_ms += p[0]
+        prof_all_ms += p[2]
+        prof_n += int(p[1])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        elapsed = float(el.item())
+
+    if rank == 0:
+        n_elem_rank = args.batch * DIM
+        n_elem_global = n_elem_rank * n_gpus
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = n_elem_global * args.steps / elapsed
+        attempts = int(stats.get('n_attempts', 0))
+        last_ms = prof_last_ms / max(prof_n, 1)
+        all_ms = prof_all_ms / max(prof_n, 1)
+        bytes_last = 9 * n_elem_rank * 8                    # y0,k1..k6 in; k7,y1 out
+        bytes_attempt = 34 * n_elem_rank * 8                # 34 units per Dopri5 attempt
+        ach = bytes_last / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0
+        res = {
+            'metric': 'state-elements/sec (batch x dim / wall-s) Dopri5 float64',
+            'value': value, 'unit': 'state-elements/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f64', 'data': 'synthetic',
+            'config': {'workload': 'config 4: linear f=Ay, dim 128, batch %d per GPU (global %d), Dopri5 fp64, '
+                                   'rtol 1e-6 atol 1e-9, t=[0,1], one odeint call per step' % (args.batch, args.batch * n_gpus),
+                       'parallelism': 'batch-sharded x%d, one 8-double all-gather per attempt' % n_gpus,
+                       'attempts_per_step': attempts, 'accepted': int(stats.get('n_accepted', 0)),
+                       'nfe': int(stats.get('nfe', 0)), 'host_polls': int(stats.get('n_polls', 0)),
+                       'kernel_launches': int(stats.get('n_launches', 0)),
+                       'element_steps_per_s': n_elem_global * attempts * args.steps / elapsed,
+                       'all_stage_kernels_ms_per_attempt': all_ms,
+                       'all_stage_kernels_GBps': (bytes_attempt / (all_ms * 1e-3) / 1e9) if all_ms > 0 else 0.0},
+            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                         'frac': ach / HBM_PEAK_GBS, 'traffic': None,
+                         'kernel': 'k_stage_linear_mfma<double,128,6,LAST_FSAL> (Dopri5 stage 6 + error norms)',
+                         'algorithmic_bytes_per_launch': bytes_last, 'avg_launch_ms': last_ms, 'launches_timed': prof_n},
+        }
+        if not args.no_cpu_baseline and n_gpus == 1:
+            res['cpu_baseline'] = cpu_baseline()
+        else:
+            res['cpu_baseline'] = None
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

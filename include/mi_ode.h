@@ -133,7 +133,7 @@ typedef struct mi_ode_desc {
   int32_t linear_variant;     /* 0 auto, 1 force VALU fallback, 2 force MFMA tile kernel */
   int32_t chunk_attempts;     /* attempts enqueued between host polls (0 = adaptive) */
   int32_t use_graph;          /* 1: replay one captured hipGraph per attempt (world_size 1 only) */
-  int32_t reserved;
+  int32_t profile;            /* 1: bracket the stage kernels of every attempt with HIP events (mi_ode_get_profile) */
 } mi_ode_desc;
 
 typedef struct mi_ode_stats {
@@ -178,6 +178,10 @@ int mi_ode_rk_step_fused(mi_ode_handle h, const void* y0_dev, const void* f0_dev
 /* f(t, y) through the fused kernels (y0 -> f0), e.g. to seed mi_ode_rk_step_fused. */
 int mi_ode_eval_rhs(mi_ode_handle h, const void* y_dev, double t, void* f_dev, void* stream);
 int mi_ode_get_stats(mi_ode_handle h, mi_ode_stats* stats, void* stream);
+/* Kernel timing collected with hipEvents on the launch stream when desc.profile = 1 (real attempts only):
+ * out[0] = sum of last-stage (stage+error kernel) durations [ms], out[1] = number of those launches,
+ * out[2] = sum over attempts of the span first-stage-start .. last-stage-end [ms], out[3] = attempts counted. */
+int mi_ode_get_profile(mi_ode_handle h, double* out4);
 /* current rk_state: y1, f1 (device, nullable). */
 int mi_ode_get_state(mi_ode_handle h, void* y_dev, void* f_dev, void* stream);
 

@@ -1,0 +1,436 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against
+  (1) the oracle (oracle/ode_numpy.py) on the same seeded inputs,
+  (2) the golden fixtures captured from the reference's own solver files (tests/golden),
+  (3) size-independent properties at BASELINE.json's full sizes.
+
+Bar: fp64 within rtol=1e-5 / atol=1e-6 of the reference path (north star); most checks are far tighter
+because the kernels reproduce the reference's operation order (no FMA contraction) - the tolerance that
+is actually asserted is written next to each check.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ode_numpy as O
+from oracle.rhs_numpy import make_rhs
+from tests.golden_util import load, mlp_weights, run_cases
+from tests.rhs_util import device_rhs, sine_exact, torch_rhs
+
+pytestmark = pytest.mark.gpu
+
+RTOL, ATOL = 1e-5, 1e-6          # north-star parity band
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def to_dev(a, dtype=None):
+    t = torch.as_tensor(np.asarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev())
+
+
+def assert_band(got, ref, rtol=RTOL, atol=ATOL, what=''):
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, '%s shape %s vs %s' % (what, got.shape, ref.shape)
+    bad = np.abs(got - ref) > atol + rtol * np.abs(ref)
+    assert not bad.any(), '%s: %d/%d outside band, max abs diff %.3e' % (what, bad.sum(), bad.size, np.abs(got - ref).max())
+
+
+# ---------------------------------------------------------------------------------------------
+# (B) stateless plane kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_plane_kernels_against_numpy(dtype):
+    from tfdiffeq_amd import misc
+    rng = np.random.default_rng(7)
+    n = 100003                       # odd size: exercises grid-stride tails
+    xs = [rng.standard_normal(n).astype(dtype) for _ in range(7)]
+    base = rng.standard_normal(n).astype(dtype)
+    coefs = [0.3, 0.0, -1.25, 2.0 / 3.0, 1e-3, -7.5, 0.5]
+    scale = dtype(0.0625)
+    ref = base + O.scaled_dot_product(scale, coefs, xs)
+    got = misc._lincomb(to_dev(base), coefs, [to_dev(x) for x in xs], scale).cpu().numpy()
+    assert got.dtype == dtype
+    np.testing.assert_array_equal(got, ref)          # same operation order, no FMA: bit-exact
+    got0 = misc._scaled_dot_product(scale, coefs[:3], [to_dev(x) for x in xs[:3]]).cpu().numpy()
+    np.testing.assert_array_equal(got0, O.scaled_dot_product(scale, coefs[:3], xs[:3]))
+    # error norms (misc.py:256-263)
+    err, y0, y1 = xs[0] * dtype(1e-3), xs[1], xs[2]
+    rec = misc._error_norms(to_dev(err), to_dev(y0), to_dev(y1)).cpu().numpy()
+    assert rec[0] == np.abs(y0).max() and rec[1] == np.abs(y1).max() and rec[3] == 0
+    np.testing.assert_allclose(rec[2], np.sum(err.astype(np.float64) ** 2), rtol=1e-12)
+    y0bad = y0.copy()
+    y0bad[17] = np.inf
+    assert misc._error_norms(to_dev(err), to_dev(y0bad), to_dev(y1)).cpu().numpy()[3] == 1
+    # scaled sum of squares (misc.py:225-237)
+    rtol, atol = 1e-4, 1e-6
+    sc = (atol + np.abs(y0) * rtol).astype(dtype)
+    ref_s = np.sum(((xs[3] - xs[4]) / sc).astype(np.float64) ** 2)
+    got_s = misc._scaled_sumsq(to_dev(xs[3]), to_dev(xs[4]), to_dev(y0), rtol, atol).cpu().numpy()[0]
+    np.testing.assert_allclose(got_s, ref_s, rtol=1e-12 if dtype == np.float64 else 1e-6)
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_runge_kutta_step_contract_against_reference_vectors(dtype):
+    """rk_common._runge_kutta_step (B3) with a Python callable, against tests/golden/fn_rkstep_*.npz."""
+    from tfdiffeq_amd import misc, interp as I
+    from tfdiffeq_amd import _native as N
+    from tfdiffeq_amd.rk_common import _runge_kutta_step, rk4_alt_step_func
+    from tfdiffeq_amd.dopri5 import _DORMAND_PRINCE_SHAMPINE_TABLEAU as DP, DPS_C_MID
+    from tfdiffeq_amd.bosh3 import _BOGACKI_SHAMPINE_TABLEAU as BS, BS_C_MID
+    from tfdiffeq_amd.tsit5 import _TSITOURAS_TABLEAU as TS
+    d, meta = load('fn_rkstep_' + dtype)
+    tol = 1e-13 if dtype == 'float64' else 3e-6
+    f_ = torch_rhs('tdep', {})
+    func = lambda t, ys: (f_(t, ys[0]),)  # noqa: E731
+    y0 = to_dev(d['y0'])
+    t0, dt = float(d['t0']), float(d['dt'])
+    f0 = f_(torch.full((), t0, dtype=y0.dtype, device=y0.device), y0)
+    assert_band(f0.cpu(), d['f0'], tol, tol, 'f0')
+    for name, tb in (('dopri5', DP), ('tsit5', TS), ('bosh3', BS)):
+        y1, f1, err, k = _runge_kutta_step(func, (y0,), (f0,), t0, dt, tb)
+        assert_band(y1[0].cpu(), d[name + '_y1'], tol, tol, name + ' y1')
+        assert_band(f1[0].cpu(), d[name + '_f1'], tol, tol, name + ' f1')
+        assert_band(err[0].cpu(), d[name + '_err'], tol, tol * 1e-2, name + ' err')
+        assert_band(torch.stack(k[0]).cpu(), d[name + '_k'], tol, tol, name + ' k')
+        ratio = misc._compute_error_ratio(err, rtol=[meta['ratio_rtol']], atol=[meta['ratio_atol']], y0=(y0,), y1=y1)
+        np.testing.assert_allclose(float(ratio[0]), float(d[name + '_ratio']), rtol=1e-10 if dtype == 'float64' else 1e-4)
+    # dense output: fused fit+evaluate kernel against interp.py vectors
+    y1, f1, err, k = _runge_kutta_step(func, (y0,), (f0,), t0, dt, DP)
+    for j, te in enumerate(d['interp_eval_times']):
+        out = I._interp_eval_step(N.INTERP_QUARTIC_MID, (y0,), y1, k, DPS_C_MID, dt, t0, t0 + dt, float(te))
+        assert_band(out[0].cpu(), d['dopri5_interp_eval%d' % j], tol * 20, tol * 20, 'dopri5 dense %d' % j)
+    # the reference-shaped _interp_fit/_interp_evaluate pair as well
+    ymid = tuple(misc._lincomb(y0, DPS_C_MID, k[0], np.dtype(dtype).type(dt)) for _ in (0,))
+    coeff = I._interp_fit((y0,), y1, ymid, (k[0][0],), (k[0][-1],), dt)
+    assert_band(torch.stack([c[0] for c in coeff]).cpu(), d['dopri5_interp_coeff'], tol * 20, tol * 20, 'interp coeff')
+    out = I._interp_evaluate(coeff, t0, t0 + dt, float(d['interp_eval_times'][1]))
+    assert_band(out[0].cpu(), d['dopri5_interp_eval1'], tol * 20, tol * 20, '_interp_evaluate')
+    y1, f1, err, k = _runge_kutta_step(func, (y0,), (f0,), t0, dt, BS)
+    out = I._interp_eval_step(N.INTERP_QUARTIC_MID, (y0,), y1, k, BS_C_MID, dt, t0, t0 + dt, t0 + 0.3 * dt)
+    assert_band(out[0].cpu(), d['bosh3_interp_eval1'], tol * 200, tol * 200, 'bosh3 dense')
+    if dtype == 'float64':
+        y1, f1, err, k = _runge_kutta_step(func, (y0,), (f0,), t0, dt, TS)
+        out = I._interp_eval_step(N.INTERP_TSIT5_REF, (y0,), y1, k, None, dt, t0, t0 + dt, t0 + 0.3 * dt)
+        assert_band(out[0].cpu(), d['tsit5_interp_eval1'], tol, tol, 'tsit5 dense (reference behaviour, from f0)')
+    dy = rk4_alt_step_func(func, t0, dt, (y0,))
+    assert_band(dy[0].cpu(), d['rk4_dy'], tol * 10, tol, 'rk4 3/8 dy')
+    for order in (4, 2):
+        h = misc._select_initial_step(func, t0, (y0,), order, meta['init_rtol'], meta['init_atol'], f0=(f0,))
+        np.testing.assert_allclose(float(h), float(d['init_step_order%d' % order]), rtol=1e-10 if dtype == 'float64' else 1e-4)
+    z = lambda t, ys: (ys[0] * 0.0,)  # noqa: E731
+    h = misc._select_initial_step(z, 0.0, (y0,), 4, meta['init_rtol'], meta['init_atol'])
+    np.testing.assert_allclose(float(h), float(d['init_step_zero_f']), rtol=1e-6)
+    h = misc._select_initial_step(func, t0, (y0 * 0,), 4, meta['init_rtol'], meta['init_atol'])
+    np.testing.assert_allclose(float(h), float(d['init_step_zero_y']), rtol=1e-6)
+
+
+# ---------------------------------------------------------------------------------------------
+# (A) fused engine: RHS evaluation and the single-attempt surface against the oracle
+# ---------------------------------------------------------------------------------------------
+def _fused_cases():
+    rng = np.random.default_rng(11)
+    A2 = np.array([[-0.1, 2.0], [-2.0, -0.1]])
+    cases = []
+    cases.append(('cubic2', 'cubic_linear', {'W': A2.tolist()}, rng.uniform(-2, 2, (777, 2)), 0))
+    cases.append(('linear2', 'linear', {'W': A2.tolist()}, rng.uniform(-2, 2, (300, 2)), 0))
+    cases.append(('lv', 'lotka_volterra', {'a': 1.5, 'b': 1.0, 'c': 3.0, 'd': 1.0}, 1 + rng.uniform(0, 1, (1000, 2)), 0))
+    cases.append(('lorenz', 'lorenz', {'sigma': 10., 'beta': 8. / 3., 'rho': 28.}, 1 + 0.1 * rng.standard_normal((1031, 3)), 0))
+    for D, B, var in ((16, 48, 0), (16, 75, 1), (10, 33, 0), (32, 70, 0), (64, 100, 0), (128, 257, 0), (128, 96, 1), (5, 40, 0)):
+        S = rng.standard_normal((D, D))
+        W = (-0.5 * np.eye(D) + 0.5 * (S - S.T) / np.sqrt(D)).T.copy()
+        cases.append(('linear_d%d_v%d' % (D, var), 'linear', {'W': W.tolist()}, rng.standard_normal((B, D)), var))
+    S = rng.standard_normal((6, 6))
+    cases.append(('cubic6', 'cubic_linear', {'W': (0.3 * S).tolist()}, 0.5 * rng.standard_normal((50, 6)), 0))
+    return cases
+
+
+@pytest.mark.parametrize('case', _fused_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+def test_fused_rk_attempt_against_oracle(case, dtype):
+    """mi_ode_eval_rhs + mi_ode_rk_step_fused (every tableau) against oracle.runge_kutta_step."""
+    from tfdiffeq_amd.solvers import _FusedEngine
+    from tfdiffeq_amd import _native as N
+    from tfdiffeq_amd.dopri5 import _DORMAND_PRINCE_SHAMPINE_TABLEAU as DP, DPS_C_MID
+    from tfdiffeq_amd.bosh3 import _BOGACKI_SHAMPINE_TABLEAU as BS, BS_C_MID
+    from tfdiffeq_amd.tsit5 import _TSITOURAS_TABLEAU as TS
+    name, rname, params, y0_np, variant = case
+    y0_np = y0_np.astype(dtype)
+    f_np = make_rhs(rname, params, dtype=dtype)
+    func = lambda t, ys: (f_np(t, ys[0]),)  # noqa: E731
+    rhs = device_rhs(rname, params)
+    y0 = to_dev(y0_np)
+    matmul = rname in ('linear', 'cubic_linear')
+    vt = (1e-12 if matmul else 1e-14) if dtype == np.float64 else 2e-5
+    t0, dt = 0.25, 0.03125
+    for tb_o, tb_p, cmid, order, init_order in ((O.DOPRI5, DP, DPS_C_MID, 5, 4), (O.TSIT5_REF, TS, None, 5, 4),
+                                                 (O.BOSH3, BS, BS_C_MID, 3, 2)):
+        eng = _FusedEngine(rhs, y0, True, tb_p, cmid, 1e-6, 1e-9, N.CTRL_MISC,
+                           N.INTERP_QUARTIC_MID if cmid is not None else N.INTERP_TSIT5, order, init_order,
+                           linear_variant=variant)
+        try:
+            f0 = eng.eval_rhs(y0, t0)
+            f0_ref = f_np(dtype(t0), y0_np)
+            assert_band(f0.cpu(), f0_ref, vt, vt, name + ' f0')
+            y1, f1, norms, k = eng.rk_step(y0, f0, t0, dt, want_k=True)
+            ry1, rf1, rerr, rk = O.runge_kutta_step(func, (y0_np,), (f0.cpu().numpy(),), t0, dt, tb_o)
+            assert_band(y1.cpu(), ry1[0], vt, vt, name + ' y1')
+            assert_band(f1.cpu(), rf1[0], vt * 10, vt * 10, name + ' f1')
+            assert_band(k.cpu(), np.stack(rk[0]), vt * 10, vt * 10, name + ' k')
+            assert norms[0] == np.abs(y0_np).max()
+            np.testing.assert_allclose(norms[1], np.abs(ry1[0]).max(), rtol=1e-12 if dtype == np.float64 else 1e-5)
+            ref_ss = np.sum(rerr[0].astype(np.float64) ** 2)
+            if dtype == np.float64:
+                np.testing.assert_allclose(norms[2], ref_ss, rtol=1e-6)
+            else:            # at this dt the fp32 error estimate is mostly roundoff: same magnitude is all one can ask
+                assert 0.1 * ref_ss <= norms[2] <= 10 * ref_ss + 1e-30
+            assert norms[3] == 0
+        finally:
+            eng.close()
+
+
+# ---------------------------------------------------------------------------------------------
+# whole runs against the golden fixtures (both engines)
+# ---------------------------------------------------------------------------------------------
+def _run_product(name, engine):
+    from tfdiffeq_amd import odeint
+    d, meta = load(name)
+    weights = mlp_weights() if meta['rhs'] == 'mlp_tanh' else None
+    if engine == 'fused':
+        f = device_rhs(meta['rhs'], meta['rhs_params'], weights)
+    else:
+        f = torch_rhs(meta['rhs'], meta['rhs_params'], weights)
+    kw = {}
+    if meta['rtol'] is not None:
+        kw['rtol'] = meta['rtol']
+    if meta['atol'] is not None:
+        kw['atol'] = meta['atol']
+    opts = dict(meta['options'] or {})
+    if meta['method'] == 'tsit5':
+        opts['refcompat'] = True                       # the fixtures hold the reference's (defective) tsit5
+    if opts:
+        kw['options'] = opts
+    if meta['tuple_state']:
+        y0 = (to_dev(d['y0_0']), to_dev(d['y0_1']))
+        func = lambda t, ys: tuple(f(t, y_) for y_ in ys)  # noqa: E731
+    else:
+        y0, func = to_dev(d['y0']), f
+    sol = odeint(func, y0, torch.as_tensor(d['t']), method=meta['method'], **kw)
+    return d, meta, sol, dict(odeint.last_stats)
+
+
+FUSED_RHS = ('cubic_linear', 'linear', 'lotka_volterra', 'lorenz')
+
+
+def _cases(engine):
+    out = []
+    for n in run_cases():
+        _, meta = load(n)
+        if meta['max_attempts'] is not None:
+            continue
+        if engine == 'fused' and (meta['rhs'] not in FUSED_RHS or meta['tuple_state']):
+            continue
+        if engine == 'planes' and n in ('run_lorenz_b64_tsit5_tiny', 'run_constant_bosh3', 'run_lv_rk4_1000',
+                                        'run_lv_euler_1000'):
+            continue                                    # hundreds of attempts x one host sync each: covered by fused
+        out.append(n)
+    return out
+
+
+@pytest.mark.parametrize('name', _cases('fused'))
+def test_fused_engine_reproduces_reference_runs(name):
+    d, meta, sol, stats = _run_product(name, 'fused')
+    f32 = d['y0'].dtype == np.float32
+    assert tuple(sol.shape) == d['y'].shape and sol.dtype == (torch.float32 if f32 else torch.float64)
+    if f32:
+        assert_band(sol.cpu(), d['y'], 2e-3, 2e-4, name)      # fp32 state: roundoff-limited
+    else:
+        assert_band(sol.cpu(), d['y'], RTOL, ATOL, name)
+    if 'trace' in d.files and not f32:
+        ref_att, ref_acc = len(d['trace']), int(d['trace'][:, 2].sum())
+        # step sequences may fork where ratio ~ 1 (reduction order differs); they must stay close
+        assert abs(stats['n_attempts'] - ref_att) <= max(2, ref_att // 20), (stats, ref_att)
+        assert abs(stats['n_accepted'] - ref_acc) <= max(2, ref_acc // 20), (stats, ref_acc)
+    assert stats['status'] == 0
+
+
+@pytest.mark.parametrize('name', _cases('planes'))
+def test_plane_kernel_engine_reproduces_reference_runs(name):
+    d, meta, sol, stats = _run_product(name, 'planes')
+    if meta['tuple_state']:
+        assert_band(sol[0].cpu(), d['y_0'], RTOL, ATOL, name)
+        assert_band(sol[1].cpu(), d['y_1'], RTOL, ATOL, name)
+        return
+    f32 = d['y0'].dtype == np.float32
+    assert tuple(sol.shape) == d['y'].shape
+    if f32:
+        assert_band(sol.cpu(), d['y'], 2e-3, 2e-4, name)
+    else:
+        assert_band(sol.cpu(), d['y'], RTOL, ATOL, name)
+
+
+def test_tsit5_refcompat_first_attempts_match_reference_trace():
+    """The reference's defective tsit5 (F6): first 40 attempts of the Lorenz run, step for step."""
+    from tfdiffeq_amd.solvers import _FusedEngine
+    from tfdiffeq_amd import _native as N
+    from tfdiffeq_amd.tsit5 import _TSITOURAS_TABLEAU as TS
+    d, meta = load('run_lorenz_b64_tsit5_first40')
+    y0 = to_dev(d['y0'])
+    eng = _FusedEngine(device_rhs('lorenz', meta['rhs_params']), y0, True, TS, None, meta['rtol'], meta['atol'],
+                       N.CTRL_TSIT5, N.INTERP_TSIT5_REF, 5, 4, float(np.float32(0.9)), 10.0, float(np.float32(0.2)),
+                       chunk_attempts=1, max_num_steps=40)
+    try:
+        eng.begin(0.0)
+        with pytest.raises(AssertionError):              # max_num_steps reached after exactly 40 attempts
+            eng.advance([1.0])
+        st = eng.stats
+        assert st.n_attempts == 40
+        assert st.n_accepted == int(d['trace'][:, 2].sum())
+        np.testing.assert_allclose(st.t, float(d['t_after_attempts']), rtol=1e-9)
+        np.testing.assert_allclose(st.dt, d['trace'][-1, 3], rtol=1e-6)
+    finally:
+        eng.close()
+
+
+def test_corrected_tsit5_is_accurate_and_cheap():
+    """method='tsit5' (published coefficients) on config 3's Lorenz batch against the oracle extension."""
+    from tfdiffeq_amd import odeint, rhs
+    d, meta = load('run_lorenz_b64_dopri5')
+    y0 = to_dev(d['y0'])
+    t = np.linspace(0., 1., 5)
+    sol = odeint(rhs.Lorenz(), y0, torch.as_tensor(t), rtol=1e-6, atol=1e-9, method='tsit5')
+    ref, st = O.odeint(make_rhs('lorenz', meta['rhs_params']), d['y0'], t, rtol=1e-6, atol=1e-9, method='tsit5',
+                       options={'tsit5_fixed': True}, return_stats=True)
+    assert_band(sol.cpu(), ref, RTOL, ATOL, 'tsit5 corrected vs oracle extension')
+    assert_band(sol.cpu(), d['y'], 1e-4, 1e-5, 'tsit5 corrected vs dopri5 reference run')
+    assert abs(odeint.last_stats['n_attempts'] - st.n_attempts) <= 3
+
+
+# ---------------------------------------------------------------------------------------------
+# reference unit tests (tests/odeint_tests.py) through the product
+# ---------------------------------------------------------------------------------------------
+def _problem(ode, reverse=False):
+    t = np.linspace(1., 8., 10).astype(np.float32)          # tests/problems.py:78
+    t64 = t.astype(np.float64)
+    sol = (0.2 * t64 + 3.0) if ode == 'constant' else sine_exact(t64)
+    if reverse:
+        t, sol = t[::-1].copy(), sol[::-1].copy()
+    return torch_rhs(ode, {}), to_dev(np.float64(sol[0])), torch.as_tensor(t), sol
+
+
+@pytest.mark.parametrize('method,odes', [('euler', ['constant']), ('midpoint', ['constant']), ('huen', ['constant']),
+                                         ('rk4', ['constant']), ('bosh3', ['constant']), ('dopri5', ['constant', 'sine'])])
+@pytest.mark.parametrize('reverse', [False, True])
+def test_reference_unit_tests(method, odes, reverse):
+    """TestSolverError / TestSolverBackwardsInTimeError (tests/odeint_tests.py:25-171): rel error < 1e-4."""
+    from tfdiffeq_amd import odeint
+    for ode in odes:
+        if method == 'bosh3' and reverse:
+            continue
+        f, y0, t, sol = _problem(ode, reverse)
+        y = odeint(f, y0, t, method=method)
+        assert float(np.max(np.abs((sol - y.cpu().numpy()) / sol))) < 1e-4
+
+
+@pytest.mark.parametrize('method', ['rk4', 'dopri5', 'euler', 'bosh3'])
+def test_no_integration(method):
+    """TestNoIntegration (tests/odeint_tests.py:174-210): t_points[0:1] -> y0."""
+    from tfdiffeq_amd import odeint
+    f, y0, t, sol = _problem('constant')
+    y = odeint(f, y0, t[0:1], method=method)
+    assert float(torch.max(torch.abs(y - y0))) == 0.0 and tuple(y.shape) == (1,)
+
+
+def test_tuple_state_api():
+    """tests/api_tests.py:26-36."""
+    from tfdiffeq_amd import odeint
+    f, y0, t, sol = _problem('constant')
+    tuple_f = lambda t_, y: (f(t_, y[0]), f(t_, y[1]))  # noqa: E731
+    ys = odeint(tuple_f, (y0, y0), t, method='dopri5')
+    assert float(np.max(sol - ys[0].cpu().numpy())) < 1e-5 and float(np.max(sol - ys[1].cpu().numpy())) < 1e-5
+
+
+def test_assertions_surface_like_the_reference():
+    from tfdiffeq_amd import odeint, rhs
+    y0 = to_dev(np.ones((8, 3)))
+    with pytest.raises(AssertionError, match='max_num_steps'):
+        odeint(rhs.Lorenz(), y0, torch.tensor([0., 5.]), method='dopri5', options={'max_num_steps': 3})
+    bad = y0.clone()
+    bad[3, 1] = float('nan')
+    with pytest.raises(AssertionError, match='non-finite'):
+        odeint(rhs.Lorenz(), bad, torch.tensor([0., 1.]), method='dopri5')
+    with pytest.raises(AssertionError, match='max_num_steps'):
+        odeint(lambda t, y: y * y, to_dev(np.float64(1.0)), torch.tensor([0., 2.]), method='dopri5',
+               options={'max_num_steps': 5})
+    # y' = y^2 blows up at t = 1: the step size underflows (dopri5.py:98)
+    with pytest.raises(AssertionError, match='underflow|non-finite'):
+        odeint(rhs.CubicLinear(torch.eye(2, dtype=torch.float64)), to_dev(np.ones((4, 2))), torch.tensor([0., 2.]),
+               method='dopri5')
+
+
+# ---------------------------------------------------------------------------------------------
+# full-size properties (BASELINE.json configs 2-4)
+# ---------------------------------------------------------------------------------------------
+def _config4(batch=65536, D=128):
+    g2 = torch.Generator().manual_seed(2)
+    S = torch.randn(D, D, generator=g2, dtype=torch.float64)
+    A = -0.5 * torch.eye(D, dtype=torch.float64) + 0.5 * (S - S.t()) / np.sqrt(D)
+    g3 = torch.Generator().manual_seed(3)
+    y0 = torch.randn(batch, D, generator=g3, dtype=torch.float64)
+    return A, y0
+
+
+def test_config4_full_size_against_matrix_exponential():
+    """Linear f = A y, batch 65536 x dim 128 fp64 dopri5: y(t) = y0 expm(A^T t); and linearity of the flow."""
+    from tfdiffeq_amd import odeint, rhs
+    A, y0 = _config4()
+    f = rhs.Linear.from_matrix(A)
+    y0d, t = y0.to(dev()), torch.tensor([0., 0.5, 1.0])
+    sol = odeint(f, y0d, t, rtol=1e-6, atol=1e-9, method='dopri5')
+    st = dict(odeint.last_stats)
+    assert st['status'] == 0 and 3 <= st['n_attempts'] <= 60
+    Ad = A.to(dev())
+    for i, ti in enumerate([0.5, 1.0]):
+        exact = y0d @ torch.matrix_exp(Ad.t() * ti)
+        err = (sol[i + 1] - exact).abs().max().item()
+        assert err < 5e-5, 't=%g max err %.3e' % (ti, err)
+    # the VALU fallback kernel must agree with the MFMA tile kernel
+    sol_v = odeint(f, y0d[:4096], t, rtol=1e-6, atol=1e-9, method='dopri5', options={'linear_variant': 1})
+    sol_m = odeint(f, y0d[:4096], t, rtol=1e-6, atol=1e-9, method='dopri5', options={'linear_variant': 2})
+    assert (sol_v - sol_m).abs().max().item() < 1e-9
+    # fixed grid rk4: linearity  Phi(a y0 + b z0) = a Phi(y0) + b Phi(z0)  (exact up to roundoff for a linear RHS)
+    tt = torch.linspace(0., 1., 6, dtype=torch.float64)
+    a, b = 0.75, -1.5
+    ya, za = y0d[:8192], y0d[8192:16384]
+    lhs = odeint(f, a * ya + b * za, tt, method='rk4')
+    rhs_ = a * odeint(f, ya, tt, method='rk4') + b * odeint(f, za, tt, method='rk4')
+    assert (lhs - rhs_).abs().max().item() < 1e-11
+
+
+def test_config2_config3_full_size_properties():
+    from tfdiffeq_amd import odeint, rhs
+    # config 2: spiral batch 4096 x 2: |y|^4 decays monotonically; forward-then-backward returns to y0
+    rng = np.random.default_rng(0)
+    y0 = to_dev(rng.uniform(-2, 2, size=(4096, 2)))
+    f = rhs.CubicLinear(torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64))
+    t = torch.linspace(0., 25., 10, dtype=torch.float64)
+    sol = odeint(f, y0, t)
+    q = (sol ** 4).sum(-1)
+    assert bool((q[1:] <= q[:-1] * (1 + 1e-9)).all())
+    back = odeint(f, sol[3], torch.tensor([float(t[3]), 0.0]), rtol=1e-9, atol=1e-11)
+    fwd = odeint(f, y0, torch.tensor([0.0, float(t[3])]), rtol=1e-9, atol=1e-11)
+    back2 = odeint(f, fwd[1], torch.tensor([float(t[3]), 0.0]), rtol=1e-9, atol=1e-11)
+    assert (back2[1] - y0).abs().max().item() < 1e-5 and back.shape == (2, 4096, 2)
+    # config 3: Lorenz batch 65536 x 3, short horizon: fused engine vs the plane-kernel engine on a slice
+    rng1 = np.random.default_rng(1)
+    y0l = to_dev(np.array([1., 1., 1.]) + 1e-3 * rng1.standard_normal((65536, 3)))
+    s1 = odeint(rhs.Lorenz(), y0l, torch.tensor([0., 0.5]), rtol=1e-6, atol=1e-9, method='tsit5')
+    s2 = odeint(rhs.Lorenz(), y0l, torch.tensor([0., 0.5]), rtol=1e-6, atol=1e-9, method='dopri5')
+    assert (s1[1] - s2[1]).abs().max().item() < 1e-4
+    ref = O.odeint(make_rhs('lorenz', {'sigma': 10., 'beta': 8. / 3., 'rho': 28.}), y0l[:256].cpu().numpy(),
+                   np.array([0., 0.5]), rtol=1e-9, atol=1e-12, method='dopri5')
+    assert np.abs(s2[1, :256].cpu().numpy() - ref[1]).max() < 1e-4

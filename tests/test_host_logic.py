@@ -1,0 +1,160 @@
+"""CPU tests: host logic of the product package, the C-ABI library's symbols and struct layout.
+No compute calls (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import tfdiffeq_amd
+from tfdiffeq_amd import _native as N
+from tfdiffeq_amd import misc, odeint, rhs
+from tfdiffeq_amd.bosh3 import _BOGACKI_SHAMPINE_TABLEAU, BS_C_MID
+from tfdiffeq_amd.dopri5 import _DORMAND_PRINCE_SHAMPINE_TABLEAU, DPS_C_MID
+from tfdiffeq_amd.tsit5 import _TSITOURAS_TABLEAU, _TSITOURAS_TABLEAU_PUBLISHED
+from tests.golden_util import load
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _tab_arrays(tb):
+    S = len(tb.alpha)
+    beta = np.zeros((S, S))
+    for i, row in enumerate(tb.beta):
+        beta[i, :len(row)] = row
+    return np.asarray(tb.alpha, dtype=np.float64), beta, np.asarray(tb.c_sol, dtype=np.float64), \
+        np.asarray(tb.c_error, dtype=np.float64)
+
+
+def test_library_exports_every_declared_symbol_and_layout_matches():
+    lib = N.load()                               # raises if a prototype is missing or a struct size differs
+    header = open(os.path.join(ROOT, 'include', 'mi_ode.h')).read()
+    declared = sorted(set(re.findall(r'^(?:int|int64_t|const char\*)\s+(mi_ode_[a-z_0-9]+)\(', header, flags=re.M)))
+    assert declared == list(N.EXPORTED_SYMBOLS), (declared, N.EXPORTED_SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mi_ode_abi_version() == 1
+    assert lib.mi_ode_sizeof(0) == C.sizeof(N.Desc) and lib.mi_ode_sizeof(1) == C.sizeof(N.Stats)
+    assert lib.mi_ode_status_string(N.ST_MAX_STEPS).decode().startswith('max_num_steps exceeded')
+    assert lib.mi_ode_status_string(N.ST_DT_UNDERFLOW).decode().startswith('underflow in dt')
+    assert lib.mi_ode_status_string(N.ST_NONFINITE).decode().startswith('non-finite values in state')
+
+
+def test_create_without_device_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    lib = N.load()
+    d, h = N.Desc(), C.c_void_p()
+    assert lib.mi_ode_create(C.byref(d), C.byref(h)) < 0
+    assert 'HIP device' in N.last_error() or 'bad' in N.last_error()
+
+
+def test_no_cpu_fallback():
+    """The product path must refuse CPU tensors instead of silently computing somewhere else."""
+    if torch.cuda.is_available():
+        pytest.skip('GPU present')
+    for m in ('dopri5', 'rk4', 'euler', 'bosh3', 'tsit5'):
+        with pytest.raises(N.NativeError):
+            odeint(lambda t, y: -y, torch.ones(3, dtype=torch.float64), torch.tensor([0., 1.]), method=m)
+        with pytest.raises(N.NativeError):
+            odeint(rhs.Lorenz(), torch.ones(4, 3, dtype=torch.float64), torch.tensor([0., 1.]), method=m)
+
+
+def test_product_does_not_import_the_oracle():
+    import sys
+    pkg = os.path.join(ROOT, 'tfdiffeq_amd')
+    for fn in os.listdir(pkg):
+        if fn.endswith('.py'):
+            src = open(os.path.join(pkg, fn)).read()
+            assert 'oracle' not in src.replace('oracle/', ''), fn + ' mentions the oracle'
+    assert not any(m.startswith('oracle') for m in sys.modules if 'tfdiffeq_amd' in m)
+
+
+def test_tableaus_equal_the_reference_modules():
+    d, _ = load('fn_tableaus')
+    for name, tb in (('dopri5', _DORMAND_PRINCE_SHAMPINE_TABLEAU), ('tsit5', _TSITOURAS_TABLEAU),
+                     ('bosh3', _BOGACKI_SHAMPINE_TABLEAU)):
+        a, b, cs, ce = _tab_arrays(tb)
+        assert np.array_equal(a, d[name + '_alpha']) and np.array_equal(b, d[name + '_beta'])
+        assert np.array_equal(cs, d[name + '_c_sol']) and np.array_equal(ce, d[name + '_c_error'])
+    assert np.array_equal(np.asarray(DPS_C_MID), d['dopri5_c_mid'])
+    assert np.array_equal(np.asarray(BS_C_MID), d['bosh3_c_mid'])
+    assert abs(sum(_TSITOURAS_TABLEAU_PUBLISHED.c_error)) < 1e-14          # the corrected tsit5 error weights
+    assert abs(sum(_TSITOURAS_TABLEAU.c_error) - 0.9697) < 1e-3            # the reference's (F6a)
+
+
+def test_solver_registry_and_api_errors():
+    assert set(tfdiffeq_amd.SOLVERS) >= {'dopri5', 'tsit5', 'bosh3', 'euler', 'rk4'}
+    y0, t = torch.ones(3, dtype=torch.float64), torch.tensor([0., 1.])
+    with pytest.raises(ValueError):            # odeint.py:72-73
+        odeint(lambda t_, y: -y, y0, t, options={'first_step': 0.1})
+    with pytest.raises(KeyError):              # odeint.py:77
+        odeint(lambda t_, y: -y, y0, t, method='not_a_solver')
+    with pytest.raises(TypeError):             # misc.py:323-325
+        odeint(lambda t_, y: -y, torch.ones(3, dtype=torch.int64), t)
+    with pytest.raises(TypeError):             # misc.py:326-327
+        odeint(lambda t_, y: -y, y0, torch.tensor([0, 1]))
+    with pytest.raises(AssertionError):        # misc.py:305
+        odeint(lambda t_, y: -y, [y0], t)
+    with pytest.raises(AssertionError):        # misc.py:158-159 (before any device work)
+        odeint(lambda t_, y: -y, y0, torch.tensor([0., 2., 1.]), method='dopri5')
+    with warnings.catch_warnings(record=True) as w:     # misc.py:178-181
+        warnings.simplefilter('always')
+        try:
+            odeint(lambda t_, y: -y, y0, t, method='dopri5', options={'bogus_option': 1})
+        except N.NativeError:
+            pass
+        assert any('Unexpected arguments' in str(x.message) for x in w)
+
+
+def test_check_inputs_reversal_and_tuple_lifting():
+    f = rhs.Lorenz()
+    y0 = torch.ones(2, 3, dtype=torch.float64)
+    tensor_input, func, y0t, t = misc._check_inputs(f, y0, torch.tensor([3., 2., 1.]))
+    assert tensor_input and isinstance(y0t, tuple) and torch.equal(t, torch.tensor([-3., -2., -1.]))
+    assert func.device_rhs is not None and func.device_rhs.sign == -1.0 and f.sign == 1.0
+    out = func(torch.tensor(-3.0, dtype=torch.float64), y0t)          # -f(-t, y)
+    assert torch.allclose(out[0], -f.forward(torch.tensor(3.0), y0))
+    # length-1 t is "decreasing" vacuously, like the reference (misc.py:153-155)
+    _, func1, _, t1 = misc._check_inputs(f, y0, torch.tensor([5.]))
+    assert float(t1[0]) == -5.0 and func1.device_rhs.sign == -1.0
+    # tuple states keep plain callables
+    g = lambda t_, ys: tuple(-y for y in ys)  # noqa: E731
+    ti, func2, y2, _ = misc._check_inputs(g, (y0, y0), torch.tensor([0., 1.]))
+    assert not ti and func2 is g and len(y2) == 2
+
+
+def test_host_controller_matches_reference_vectors():
+    """misc._optimal_step_size (host) against the vectors captured from the reference (F4 exponent included)."""
+    d, meta = load('fn_step_controller')
+    for order in (5, 3):
+        for dt_name in ('float64', 'float32'):
+            got = [misc._optimal_step_size(np.float64(meta['last_step']), (np.dtype(dt_name).type(r),), meta['safety'],
+                                           meta['ifactor'], meta['dfactor'], order) for r in d['ratios']]
+            np.testing.assert_allclose(got, d['misc_order%d_%s' % (order, dt_name)], rtol=1e-14, atol=0)
+
+
+def test_convert_to_tensor_float32_detour():
+    assert float(misc._convert_to_tensor(0.9, dtype=np.float64)) == 0.8999999761581421
+    assert float(misc._convert_to_tensor(0.2, dtype=np.float64)) == 0.20000000298023224
+    assert float(misc._convert_to_tensor(10.0, dtype=np.float64)) == 10.0
+
+
+def test_device_rhs_python_paths_match_numpy():
+    from oracle.rhs_numpy import make_rhs
+    rng = np.random.default_rng(0)
+    y = rng.standard_normal((5, 3))
+    np.testing.assert_allclose(rhs.Lorenz()(None, torch.tensor(y)).numpy(),
+                               make_rhs('lorenz', {'sigma': 10., 'beta': 8. / 3., 'rho': 28.})(None, y), rtol=1e-15)
+    y2 = rng.standard_normal((5, 2))
+    np.testing.assert_allclose(rhs.LotkaVolterra()(None, torch.tensor(y2)).numpy(),
+                               make_rhs('lotka_volterra', {'a': 1.5, 'b': 1., 'c': 3., 'd': 1.})(None, y2), rtol=1e-15)
+    A = rng.standard_normal((4, 4))
+    y4 = rng.standard_normal((6, 4))
+    np.testing.assert_allclose(rhs.Linear.from_matrix(torch.tensor(A))(None, torch.tensor(y4)).numpy(), y4 @ A.T, rtol=1e-13)
+    np.testing.assert_allclose(rhs.CubicLinear(torch.tensor(A))(None, torch.tensor(y4)).numpy(), (y4 ** 3) @ A, rtol=1e-13)
+    rev = rhs.Lorenz().reversed()
+    np.testing.assert_allclose(rev(torch.tensor(1.0), torch.tensor(y)).numpy(), -rhs.Lorenz()(None, torch.tensor(y)).numpy())

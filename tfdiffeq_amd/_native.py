@@ -56,7 +56,7 @@ class Desc(C.Structure):
                 ('allgather', ALLGATHER_FN), ('allgather_user', C.c_void_p),
                 ('exchange_send_dev', C.c_void_p), ('exchange_recv_dev', C.c_void_p),
                 ('linear_variant', C.c_int32), ('chunk_attempts', C.c_int32),
-                ('use_graph', C.c_int32), ('reserved', C.c_int32)]
+                ('use_graph', C.c_int32), ('profile', C.c_int32)]
 
 
 class Stats(C.Structure):
@@ -88,6 +88,7 @@ _PROTOS = {
     'mi_ode_eval_rhs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
     'mi_ode_get_stats': (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     'mi_ode_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mi_ode_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     'mi_ode_lincomb': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double),
                                  C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
     'mi_ode_error_norms': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

@@ -147,6 +147,23 @@ static int poll_ctl(mi_ode_solver* h, hipStream_t st) {
   return 0;
 }
 
+// after a poll (stream idle): fold the event pairs of the attempts that really ran into the totals
+static void harvest_profile(mi_ode_solver* h) {
+  if (!h->d.profile || !h->ev_ready) return;
+  const long long real = h->ctl_host->n_attempt;
+  for (long long g = h->prof_done; g < h->enq_attempts; ++g) {
+    if (g < real) {
+      const int i = (int)(g % 64);
+      float ms_last = 0.f, ms_all = 0.f;
+      if (hipEventElapsedTime(&ms_last, h->ev_b[i], h->ev_c[i]) == hipSuccess &&
+          hipEventElapsedTime(&ms_all, h->ev_a[i], h->ev_c[i]) == hipSuccess) {
+        h->prof_last_ms += ms_last; h->prof_all_ms += ms_all; h->prof_n += 1;
+      }
+    }
+  }
+  h->prof_done = h->enq_attempts;
+}
+
 static void fill_stats(mi_ode_solver* h, mi_ode_stats* s) {
   const Ctl* c = h->ctl_host;
   s->n_attempts = c->n_attempt;
@@ -204,6 +221,7 @@ extern "C" int mi_ode_destroy(mi_ode_handle h) {
   if (h->gathered && h->own_exchange) (void)hipFree(h->gathered);
   if (h->ctl) (void)hipFree(h->ctl);
   if (h->t_out_dev) (void)hipFree(h->t_out_dev);
+  if (h->ev_ready) for (int i = 0; i < 64; ++i) { (void)hipEventDestroy(h->ev_a[i]); (void)hipEventDestroy(h->ev_b[i]); (void)hipEventDestroy(h->ev_c[i]); }
   if (h->ctl_host) (void)hipHostFree(h->ctl_host);
   if (h->t_out_host) (void)hipHostFree(h->t_out_host);
   delete h;
@@ -284,6 +302,15 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     return MI_ODE_E_HIP;
   }
   memset(h->ctl_host, 0, sizeof(Ctl));
+  if (h->d.profile) {
+    for (int i = 0; i < 64 && e == hipSuccess; ++i) {
+      e = hipEventCreate(&h->ev_a[i]);
+      if (e == hipSuccess) e = hipEventCreate(&h->ev_b[i]);
+      if (e == hipSuccess) e = hipEventCreate(&h->ev_c[i]);
+    }
+    if (e != hipSuccess) { mi_set_error("event creation failed"); mi_ode_destroy(h); return MI_ODE_E_HIP; }
+    h->ev_ready = 1;
+  }
   *out = h;
   return 0;
 }
@@ -321,6 +348,7 @@ extern "C" int mi_ode_begin(mi_ode_handle h, const void* y0_dev, double t0, void
   c->idx_y0 = 0; c->idx_y1 = 1;
   for (int j = 0; j < kMaxK; ++j) c->idx_k[j] = 2 + j;
   h->n_launches = 0; h->n_polls = 0;
+  h->enq_attempts = 0; h->prof_done = 0;
   MI_HIP(hipMemcpyAsync(h->ctl, c, sizeof(Ctl), hipMemcpyHostToDevice, st));
   MI_HIP(hipMemcpyAsync(h->planes, y0_dev, (size_t)h->n * h->elt, hipMemcpyDeviceToDevice, st));
   // f0 = f(t0, y0) with the norms of misc._select_initial_step riding along (dopri5.py:71-75)
@@ -362,11 +390,18 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
   const double t_end = t_out_host[n_out - 1];
   int chunk = h->d.chunk_attempts > 0 ? h->d.chunk_attempts : 4;
   for (;;) {
+    if (chunk > 64) chunk = 64;
     for (int a = 0; a < chunk; ++a) {
+      const int ei = (int)(h->enq_attempts % 64);
+      const bool prof = h->d.profile && h->ev_ready;
+      if (prof) (void)hipEventRecord(h->ev_a[ei], st);
       for (int sigma = 1; sigma <= h->S; ++sigma) {
+        if (prof && sigma == h->S) (void)hipEventRecord(h->ev_b[ei], st);
         rc = enqueue_adaptive_stage(h, sigma, st);
         if (rc != 0) return rc;
       }
+      if (prof) (void)hipEventRecord(h->ev_c[ei], st);
+      h->enq_attempts += 1;
       rc = enqueue_controller(h, PH_ATTEMPT, st);
       if (rc != 0) return rc;
       rc = enqueue_emit(h, out_dev, st);
@@ -374,6 +409,7 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
     }
     rc = poll_ctl(h, st);
     if (rc != 0) return rc;
+    harvest_profile(h);
     const Ctl* c = h->ctl_host;
     if (c->done) break;
     if (h->d.chunk_attempts <= 0) {            // adaptive chunking: roughly the attempts still needed at the current dt
@@ -415,6 +451,12 @@ extern "C" int mi_ode_get_stats(mi_ode_handle h, mi_ode_stats* stats, void* stre
   int rc = poll_ctl(h, (hipStream_t)stream);
   if (rc != 0) return rc;
   fill_stats(h, stats);
+  return 0;
+}
+
+extern "C" int mi_ode_get_profile(mi_ode_handle h, double* out4) {
+  if (h == nullptr || out4 == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  out4[0] = h->prof_last_ms; out4[1] = (double)h->prof_n; out4[2] = h->prof_all_ms; out4[3] = (double)h->prof_n;
   return 0;
 }
 

@@ -51,6 +51,13 @@ struct mi_ode_solver {
   int n_polls;
   int begun;
   int own_exchange;
+  // optional event profiling (desc.profile)
+  hipEvent_t ev_a[64], ev_b[64], ev_c[64];
+  int ev_ready;
+  long long enq_attempts;       // attempts enqueued since begin
+  long long prof_done;          // attempts already harvested
+  double prof_last_ms, prof_all_ms;
+  long long prof_n;
   mi::RhsParams rhs;
   mi::CtrlParams cp;
   mi::InterpParams ip;

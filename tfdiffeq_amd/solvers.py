@@ -52,7 +52,8 @@ class _FusedEngine(object):
 
     def __init__(self, device_rhs, y0, adaptive, tableau, c_mid=None, rtol=1e-7, atol=1e-9, controller=N.CTRL_MISC,
                  interp=N.INTERP_QUARTIC_MID, order=5, init_order=4, safety=0.9, ifactor=10.0, dfactor=0.2,
-                 first_step=None, max_num_steps=2 ** 31 - 1, process_group=None, linear_variant=0, chunk_attempts=0):
+                 first_step=None, max_num_steps=2 ** 31 - 1, process_group=None, linear_variant=0, chunk_attempts=0,
+                 profile=False):
         N.require_gpu_tensor(y0, 'y0')
         self.lib = N.load()
         self.y0 = y0.contiguous()
@@ -74,6 +75,7 @@ class _FusedEngine(object):
         d.max_num_steps = int(max_num_steps)
         d.linear_variant = int(linear_variant)
         d.chunk_attempts = int(chunk_attempts)
+        d.profile = 1 if profile else 0
         self._hook = None
         if process_group is not None:
             import torch.distributed as dist
@@ -157,6 +159,12 @@ class _FusedEngine(object):
             N.check(self.lib.mi_ode_get_stats(self.h, C.byref(self.stats), self._stream()), 'mi_ode_get_stats')
         self._raise_for_status(rc)
         return out
+
+    def profile(self):
+        """(last-stage kernel ms total, launches, all-stages ms total, attempts) - needs profile=True."""
+        out = (C.c_double * 4)()
+        N.check(self.lib.mi_ode_get_profile(self.h, out), 'mi_ode_get_profile')
+        return [out[i] for i in range(4)]
 
     def eval_rhs(self, y, t=0.0):
         f = torch.empty_like(y)
@@ -326,6 +334,7 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         self._linear_variant = unused_kwargs.pop('linear_variant', 0)
         self._chunk_attempts = unused_kwargs.pop('chunk_attempts', 0)
         self._force_planes = unused_kwargs.pop('force_plane_kernels', False)
+        self._profile = unused_kwargs.pop('profile', False)
         _handle_unused_kwargs(self, unused_kwargs)
         self.func = func
         self.y0 = y0
@@ -360,7 +369,7 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             first = float(_convert_to_tensor(self.first_step, dtype=np.float64))   # dopri5.py:77: float32 detour
         return _FusedEngine(rhs, self.y0[0], True, self.tableau, self.c_mid, rtol0, atol0, self.controller, self.interp,
                             self.order, self.init_order, float(self.safety), float(self.ifactor), float(self.dfactor),
-                            first, self.max_num_steps, self._pg, self._linear_variant, self._chunk_attempts)
+                            first, self.max_num_steps, self._pg, self._linear_variant, self._chunk_attempts, self._profile)
 
     def integrate(self, t):
         _assert_increasing(t)
@@ -369,9 +378,10 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             return super(_AdaptiveRKSolver, self).integrate(t)
         try:
             out = eng.integrate(t.to(torch.float64).numpy())
-            self.stats = eng.stats.as_dict()
         finally:
             self.stats = eng.stats.as_dict()
+            if self._profile:
+                self.stats['profile'] = eng.profile()
             eng.close()
         return (out,)
 
