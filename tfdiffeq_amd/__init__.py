@@ -8,7 +8,8 @@ See DESIGN.md for the path, its boundary and the kernels; INTEGRATION.md for the
 from .odeint import odeint, SOLVERS
 from .misc import move_to_device
 from . import rhs
+from .solvers import clear_engine_cache
 
-__all__ = ['odeint', 'SOLVERS', 'move_to_device', 'rhs']
+__all__ = ['odeint', 'SOLVERS', 'move_to_device', 'rhs', 'clear_engine_cache']
 
 __version__ = '0.1.0'

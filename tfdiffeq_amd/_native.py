@@ -9,7 +9,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libmi_ode.so')
+LIB_PATH = os.environ.get('TFDIFFEQ_AMD_LIB') or os.path.join(_HERE, 'libmi_ode.so')   # env override: kernel-variant sweeps
 CSRC = os.path.join(_HERE, 'csrc')
 
 MAX_STAGES = 6

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Print VGPR/SGPR/LDS/occupancy per kernel: python kernel_usage.py mi_ode_launch_f64.hip [filter]"""
-import re, subprocess, sys
+import os, re, subprocess, sys
 src = sys.argv[1]; flt = sys.argv[2] if len(sys.argv) > 2 else ''
-cmd = ['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-c', src,
+cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off"] + os.environ.get("EXTRA", "").split() + ["-c", src,
        '-o', '/dev/null', '-Rpass-analysis=kernel-resource-usage']
 out = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur = None; rows = []

@@ -336,7 +336,15 @@ static int ensure_t_out(mi_ode_solver* h, int n) {
 // ------------------------------------------------------------------------------------------------
 // adaptive engine
 // ------------------------------------------------------------------------------------------------
+static int begin_impl(mi_ode_handle h, const void* y0_dev, double t0, void* first_out_dev, void* stream);
+
 extern "C" int mi_ode_begin(mi_ode_handle h, const void* y0_dev, double t0, void* stream) {
+  return begin_impl(h, y0_dev, t0, nullptr, stream);
+}
+
+// before_integrate: the F0 kernel reads y0 straight from the caller's buffer, evaluates f0 and the initial-step
+// norms, and in the same pass seeds the workspace state plane (and solution[0] when first_out_dev is given).
+static int begin_impl(mi_ode_handle h, const void* y0_dev, double t0, void* first_out_dev, void* stream) {
   if (h == nullptr || y0_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
   if (!h->d.adaptive) { mi_set_error("mi_ode_begin on a fixed-grid handle"); return MI_ODE_E_INVALID; }
   hipStream_t st = (hipStream_t)stream;
@@ -350,11 +358,14 @@ extern "C" int mi_ode_begin(mi_ode_handle h, const void* y0_dev, double t0, void
   h->n_launches = 0; h->n_polls = 0;
   h->enq_attempts = 0; h->prof_done = 0;
   MI_HIP(hipMemcpyAsync(h->ctl, c, sizeof(Ctl), hipMemcpyHostToDevice, st));
-  MI_HIP(hipMemcpyAsync(h->planes, y0_dev, (size_t)h->n * h->elt, hipMemcpyDeviceToDevice, st));
   // f0 = f(t0, y0) with the norms of misc._select_initial_step riding along (dopri5.py:71-75)
   StageArgs A;
   fill_common(h, A);
-  A.k_out_slot = 0;
+  A.explicit_mode = 1; A.ctl = nullptr;
+  A.x_y0 = y0_dev; A.x_t0 = t0; A.x_dt = 0.0;
+  A.x_kout = h->planes + 2 * h->stride;          // idx_k[0]
+  A.copy_a = h->planes;                          // idx_y0
+  A.copy_b = first_out_dev;
   int rc = launch_stage(h, M_F0, 0, A, st);
   if (rc != 0) return rc;
   rc = enqueue_controller(h, PH_F0, st);
@@ -413,7 +424,7 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
     const Ctl* c = h->ctl_host;
     if (c->done) break;
     if (h->d.chunk_attempts <= 0) {            // adaptive chunking: roughly the attempts still needed at the current dt
-      double est = c->dt > 0 ? ceil((t_end - c->t1) / c->dt) + 1.0 : 4.0;
+      double est = c->dt > 0 ? ceil((t_end - c->t1) / c->dt) : 4.0;
       if (!(est >= 1.0)) est = 1.0;
       if (est > 32.0) est = 32.0;
       chunk = (int)est;
@@ -431,9 +442,8 @@ extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const doubl
       if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = MI_ODE_ST_BAD_T; }
       return MI_ODE_ST_BAD_T;                  // _assert_increasing (misc.py:158-159)
     }
-  int rc = mi_ode_begin(h, y0_dev, t_host[0], stream);   // before_integrate runs even when T == 1 (solvers.py:31)
-  if (rc != 0) return rc;
-  MI_HIP(hipMemcpyAsync(out_dev, y0_dev, (size_t)h->n * h->elt, hipMemcpyDeviceToDevice, st));   // solution = [y0]
+  int rc = begin_impl(h, y0_dev, t_host[0], out_dev, stream);   // before_integrate runs even when T == 1 (solvers.py:31);
+  if (rc != 0) return rc;                                        // solution = [y0] is written by the same kernel
   int status = 0;
   if (T > 1) {
     status = mi_ode_advance(h, t_host + 1, T - 1, (char*)out_dev + (size_t)h->n * h->elt, stream);

@@ -82,6 +82,8 @@ struct StageArgs {
   double alpha;
   double rtol, atol;         // scale of the initial-step norms
   double* partials;          // [gridDim.x][kRec]
+  void* copy_a;              // F0 only: also store y0 here (the workspace state plane) ...
+  void* copy_b;              // ... and here (solution[0]); saves two plane-sized copy launches
   RhsParams rhs;
 };
 

@@ -8,7 +8,15 @@
 // so the contraction has to run at >= ~45 % of the fp64 peak UNDER the memory stream; that is
 // what the MFMA tile kernel below is for.  The VALU kernel is the any-dim fallback.
 #pragma once
+#include <type_traits>
 #include "mi_ode_dev.h"
+
+#ifndef MI_PF_MAX
+#define MI_PF_MAX 6      // planes prefetched during the MFMA phase (stages with more planes: see MI_PF_LAST)
+#endif
+#ifndef MI_PF_LAST
+#define MI_PF_LAST 4     // ... for the last stage (7 planes would spill)
+#endif
 
 namespace mi {
 
@@ -42,6 +50,10 @@ __global__ __launch_bounds__(256) void k_stage_linear_valu(StageArgs A, int dim_
       for (int j = 0; j < NK; ++j) kk[j] = R.k[j][idx];
       ys = combine_elem<T, NK, MODE>(y0, kk, R.hs, A, aux);
       reduce_flat<T, MODE>(y0, ys, A, acc);
+      if constexpr (MODE == M_F0) {
+        if (A.copy_a != nullptr) ((T*)A.copy_a)[idx] = y0;
+        if (A.copy_b != nullptr) ((T*)A.copy_b)[idx] = y0;
+      }
       tile[r * D + c] = cube ? ys * ys * ys : ys;
     }
     __syncthreads();
@@ -135,43 +147,69 @@ __global__ __launch_bounds__(D * 4) void k_stage_linear_mfma(StageArgs A) {
 
   Acc acc;
   const long long ntiles = (A.batch + R_ - 1) / R_;
+
+  // Registers of the tile in flight.  Plane p = 0 is y0, plane p = j + 1 is k_j.  The loads of the first PF
+  // planes of tile i+1 are issued right after tile i has been handed to LDS, so they travel while the matrix
+  // pipe works on tile i: with one 8-wave workgroup per CU this is what overlaps the HBM stream with the MFMA
+  // phase (without it a stage costs T_mem + T_mfma).  The MFMA phase lasts about as long as ~3 planes take to
+  // stream, so PF is capped where the register file would spill (last stage: 7 planes x 16 VGPRs).
+  constexpr int NP = NK + 1;
+  constexpr int PF = (NP <= MI_PF_MAX) ? NP : ((MODE == M_LAST_FSAL) ? MI_PF_LAST : MI_PF_MAX);
+  CH pl[NP][CPT];
+  auto load_planes = [&](long long t_i, auto p_begin, auto p_end) {
+    constexpr int P0 = decltype(p_begin)::value, P1 = decltype(p_end)::value;
+    const long long base = t_i * R_ * D;
+    const long long left = (A.batch - t_i * R_) * D;
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      const int e0 = (c * NT + tid) * VEC;
+      const bool ok = e0 < left;                             // D % VEC == 0: chunks never straddle the end
+#pragma unroll
+      for (int p = P0; p < P1; ++p) {
+        if (ok) {
+          pl[p][c] = *(const CH*)((p == 0 ? R.y0 : R.k[p > 0 ? p - 1 : 0]) + base + e0);
+        } else {
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) pl[p][c].v[v] = (T)0;
+        }
+      }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using IPF = std::integral_constant<int, PF>;
+  using INP = std::integral_constant<int, NP>;
+  if ((long long)blockIdx.x < ntiles) load_planes(blockIdx.x, I0{}, IPF{});
+
   for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
     const long long row0 = tile_i * R_;
     const long long tile_base = row0 * D;                    // tile rows are contiguous in memory
     const long long elems_left = (A.batch - row0) * D;       // valid elements from tile_base on
+    if constexpr (PF < NP) load_planes(tile_i, IPF{}, INP{});   // the planes that were not prefetched
     if (tile_i != (long long)blockIdx.x) __syncthreads();    // previous tile's LDS reads are done
 
-    // ---- flat phase -----------------------------------------------------------------------
+    // ---- flat phase: combine the landed planes, park ys (and the partial error sum) in LDS ------
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       const int e0 = (c * NT + tid) * VEC;                   // element offset inside the tile
-      const bool ok = e0 < elems_left;                       // D % VEC == 0: chunks never straddle
-      CH y0c, ysc, auxc, kc[NK > 0 ? NK : 1];
-      if (ok) {
-        y0c = *(const CH*)(R.y0 + tile_base + e0);
-#pragma unroll
-        for (int j = 0; j < NK; ++j) kc[j] = *(const CH*)(R.k[j] + tile_base + e0);
-      } else {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) y0c.v[v] = (T)0;
-#pragma unroll
-        for (int j = 0; j < NK; ++j)
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) kc[j].v[v] = (T)0;
-      }
+      const bool ok = e0 < elems_left;
+      CH ysc, auxc;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
         T kk[NK > 0 ? NK : 1];
 #pragma unroll
-        for (int j = 0; j < NK; ++j) kk[j] = kc[j].v[v];
+        for (int j = 0; j < NK; ++j) kk[j] = pl[j + 1][c].v[v];
         T aux;
-        const T ys = combine_elem<T, NK, MODE>(y0c.v[v], kk, R.hs, A, aux);
-        if (ok) reduce_flat<T, MODE>(y0c.v[v], ys, A, acc);
+        const T ys = combine_elem<T, NK, MODE>(pl[0][c].v[v], kk, R.hs, A, aux);
+        if (ok) reduce_flat<T, MODE>(pl[0][c].v[v], ys, A, acc);
         ysc.v[v] = ys;
         auxc.v[v] = aux;
       }
       if constexpr (MODE == M_LAST_FSAL) {
         if (ok) *(CH*)(R.y1 + tile_base + e0) = ysc;         // y1 = y_last (rk_common.py:58)
+      }
+      if constexpr (MODE == M_F0) {                          // ys == y0: seed the state plane and solution[0]
+        if (ok && A.copy_a != nullptr) *(CH*)((T*)A.copy_a + tile_base + e0) = ysc;
+        if (ok && A.copy_b != nullptr) *(CH*)((T*)A.copy_b + tile_base + e0) = ysc;
       }
       const int rr = e0 / D, cc = e0 % D;
       if constexpr (CUBE) {
@@ -182,6 +220,7 @@ __global__ __launch_bounds__(D * 4) void k_stage_linear_mfma(StageArgs A) {
       if constexpr (NEED_AUX) *(CH*)(s_aux + rr * LD + cc) = auxc;
     }
     __syncthreads();
+    if (tile_i + gridDim.x < ntiles) load_planes(tile_i + gridDim.x, I0{}, IPF{});   // prefetch: in flight during the MFMA phase
 
     // ---- MFMA phase: two 16-row blocks per wave, interleaved for issue-level parallelism ------
     acc_t c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};

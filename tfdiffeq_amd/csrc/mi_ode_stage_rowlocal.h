@@ -93,6 +93,10 @@ __global__ __launch_bounds__(256) void k_stage_rowlocal(StageArgs A) {
       ys[d] = combine_elem<T, NK, MODE>(y0.v[d], kk, R.hs, A, aux[d]);
       reduce_flat<T, MODE>(y0.v[d], ys[d], A, acc);
     }
+    if constexpr (MODE == M_F0) {
+      if (A.copy_a != nullptr) *(Row*)((T*)A.copy_a + row * D) = y0;
+      if (A.copy_b != nullptr) *(Row*)((T*)A.copy_b + row * D) = y0;
+    }
     rhs(sign * R.ts, ys, kn);                     // reversed time: f <- -f(-t, y) (misc.py:318-321)
 #pragma unroll
     for (int d = 0; d < D; ++d) kn[d] = sign * kn[d];

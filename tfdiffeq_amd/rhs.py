@@ -44,10 +44,26 @@ class DeviceRHS(object):
 
     # -- device path -------------------------------------------------------------------------
     def _dev(self, x, dtype, device):
-        key = (id(x), dtype, str(device))
-        if key not in self._cache:
-            self._cache[key] = x.detach().to(device=device, dtype=dtype).contiguous()
-        return self._cache[key]
+        """x on `device` in `dtype`, contiguous.  A tensor that already qualifies is used as is (in-place updates
+        stay visible to the kernels); otherwise a converted copy is cached until x is modified (x._version)."""
+        if x.device == torch.device(device) and x.dtype == dtype and x.is_contiguous():
+            return x.detach()
+        key = (id(x), dtype, str(device))            # id of the long-lived parameter object itself
+        hit = self._cache.get(key)
+        if hit is None or hit[0] != x._version or hit[2] is not x:
+            hit = (x._version, x.detach().to(device=device, dtype=dtype).contiguous(), x)
+            self._cache[key] = hit
+        return hit[1]
+
+    def _params_key(self):
+        return ()
+
+    def cache_key(self, dtype, device):
+        """Identity of the fused engine this RHS needs: kind, sign, by-value scalars, device pointers."""
+        r = N.Rhs()
+        self.fill(r, dtype, device)       # (the engine built from this key keeps the tensors behind the pointers alive)
+        return (self.kind, self.dim, float(self.sign), tuple(r.scalars), tuple(int(v or 0) for v in r.w),
+                tuple(int(v or 0) for v in r.b), int(r.hidden))
 
     def supports(self, y0):
         """True when the fused kernels can take this state tensor."""

@@ -14,6 +14,7 @@ Two execution engines sit behind that contract:
 There is no CPU path: state tensors must live on the MI355X.
 """
 import abc
+import collections
 import ctypes as C
 import math
 
@@ -135,20 +136,30 @@ class _FusedEngine(object):
             msg = 'underflow in dt {}'.format(self.stats.dt)
         raise AssertionError(msg)          # the reference raises AssertionError for all of these
 
-    def integrate(self, t):
+    def _check_y0(self, y0):
+        if y0 is None:
+            return self.y0
+        N.require_gpu_tensor(y0, 'y0')
+        if tuple(y0.shape) != self.shape or y0.dtype != self.dtype or y0.device != self.device:
+            raise ValueError('engine was created for %s %s on %s' % (self.shape, self.dtype, self.device))
+        return y0.contiguous()
+
+    def integrate(self, t, y0=None):
+        y0 = self._check_y0(y0)
         arr, p = self._times(t)
         T = arr.shape[0]
         out = torch.empty((T,) + self.shape, dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
             fn = self.lib.mi_ode_integrate if self.desc.adaptive else self.lib.mi_ode_fixed_grid_integrate
-            rc = N.check(fn(self.h, C.c_void_p(self.y0.data_ptr()), p, T, C.c_void_p(out.data_ptr()),
+            rc = N.check(fn(self.h, C.c_void_p(y0.data_ptr()), p, T, C.c_void_p(out.data_ptr()),
                             C.byref(self.stats), self._stream()), 'mi_ode_integrate')
         self._raise_for_status(rc)
         return out
 
-    def begin(self, t0):
+    def begin(self, t0, y0=None):
+        y0 = self._check_y0(y0)
         with torch.cuda.device(self.device):
-            N.check(self.lib.mi_ode_begin(self.h, C.c_void_p(self.y0.data_ptr()), float(t0), self._stream()), 'mi_ode_begin')
+            N.check(self.lib.mi_ode_begin(self.h, C.c_void_p(y0.data_ptr()), float(t0), self._stream()), 'mi_ode_begin')
 
     def advance(self, times):
         arr, p = self._times(times)
@@ -185,6 +196,36 @@ class _FusedEngine(object):
                                                   C.c_void_p(k.data_ptr()) if want_k else C.c_void_p(0), self._stream()),
                     'mi_ode_rk_step_fused')
         return y1, f1, [norms[i] for i in range(4)], k
+
+
+# Engines (workspace + handle) are cached across odeint() calls: a call then costs no hipMalloc/hipFree
+# (hipFree synchronises the device) - ODEBlock-style callers integrate the same shapes over and over.
+_ENGINE_CACHE = collections.OrderedDict()
+_ENGINE_CACHE_MAX = 8
+
+
+def clear_engine_cache():
+    while _ENGINE_CACHE:
+        _, eng = _ENGINE_CACHE.popitem()
+        eng.close()
+
+
+def _cached_engine(key, factory):
+    eng = _ENGINE_CACHE.get(key)
+    if eng is not None:
+        _ENGINE_CACHE.move_to_end(key)
+        return eng
+    eng = factory()
+    _ENGINE_CACHE[key] = eng
+    while len(_ENGINE_CACHE) > _ENGINE_CACHE_MAX:
+        _, old = _ENGINE_CACHE.popitem(last=False)
+        old.close()
+    return eng
+
+
+def _tableau_key(tb, c_mid):
+    return (tuple(tb.alpha), tuple(tuple(r) for r in tb.beta), tuple(tb.c_sol), tuple(tb.c_error),
+            None if c_mid is None else tuple(c_mid))
 
 
 def _fusable(func, y0):
@@ -281,12 +322,12 @@ class FixedGridODESolver(object):
         rhs = _fusable(self.func, self.y0)
         if (rhs is not None and self._fused_tableau is not None and getattr(self, '_default_grid', False)
                 and self.eps == 0.0):
-            eng = _FusedEngine(rhs, self.y0[0], False, self._fused_tableau)
-            try:
-                out = eng.integrate(t.to(torch.float64).numpy())
-                self.stats = eng.stats.as_dict()
-            finally:
-                eng.close()
+            y = self.y0[0]
+            key = ('fixed', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
+                   _tableau_key(self._fused_tableau, None))
+            eng = _cached_engine(key, lambda: _FusedEngine(rhs, y, False, self._fused_tableau))
+            out = eng.integrate(t.to(torch.float64).numpy(), y)
+            self.stats = eng.stats.as_dict()
             return (out,)
         time_grid = self.grid_constructor(self.func, self.y0, t)
         assert bool(time_grid[0] == t[0]) and bool(time_grid[-1] == t[-1])
@@ -367,22 +408,28 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         if self.first_step is not None:
             from .misc import _convert_to_tensor
             first = float(_convert_to_tensor(self.first_step, dtype=np.float64))   # dopri5.py:77: float32 detour
-        return _FusedEngine(rhs, self.y0[0], True, self.tableau, self.c_mid, rtol0, atol0, self.controller, self.interp,
-                            self.order, self.init_order, float(self.safety), float(self.ifactor), float(self.dfactor),
-                            first, self.max_num_steps, self._pg, self._linear_variant, self._chunk_attempts, self._profile)
+        y = self.y0[0]
+        args = (float(rtol0), float(atol0), self.controller, self.interp, self.order, self.init_order, float(self.safety),
+                float(self.ifactor), float(self.dfactor), first, self.max_num_steps)
+        key = ('adaptive', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
+               _tableau_key(self.tableau, self.c_mid), args, id(self._pg) if self._pg is not None else None,
+               self._linear_variant, self._chunk_attempts, bool(self._profile))
+        return _cached_engine(key, lambda: _FusedEngine(
+            rhs, y, True, self.tableau, self.c_mid, *args, process_group=self._pg, linear_variant=self._linear_variant,
+            chunk_attempts=self._chunk_attempts, profile=self._profile))
 
     def integrate(self, t):
         _assert_increasing(t)
         eng = self._make_engine()
         if eng is None:
             return super(_AdaptiveRKSolver, self).integrate(t)
+        prof0 = eng.profile() if self._profile else None
         try:
-            out = eng.integrate(t.to(torch.float64).numpy())
+            out = eng.integrate(t.to(torch.float64).numpy(), self.y0[0])
         finally:
             self.stats = eng.stats.as_dict()
             if self._profile:
-                self.stats['profile'] = eng.profile()
-            eng.close()
+                self.stats['profile'] = [a - b for a, b in zip(eng.profile(), prof0)]
         return (out,)
 
     # -- plane-kernel path (any callable, tuple states) -------------------------------------------
