@@ -10,7 +10,7 @@ rm -rf gpurun_out/prof
 echo "rocprof exit $?"
 find gpurun_out/prof -type f | head -20
 for f in $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); do cut -c1-250 "$f" | head -30; done
-find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete
+find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete; true
 if [ "${1:-}" = "pmc" ]; then
   for C in FETCH_SIZE WRITE_SIZE; do
     rm -rf gpurun_out/pmc_$C

@@ -435,3 +435,56 @@ def test_config2_config3_full_size_properties():
     ref = O.odeint(make_rhs('lorenz', {'sigma': 10., 'beta': 8. / 3., 'rho': 28.}), y0l[:256].cpu().numpy(),
                    np.array([0., 0.5]), rtol=1e-9, atol=1e-12, method='dopri5')
     assert np.abs(s2[1, :256].cpu().numpy() - ref[1]).max() < 1e-4
+
+
+# ---------------------------------------------------------------------------------------------
+# the batch-sharded path's exchange hook, on one GPU (1-rank RCCL group)
+# ---------------------------------------------------------------------------------------------
+_HOOK_SCRIPT = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['REPO'])
+from tfdiffeq_amd import odeint, rhs
+torch.cuda.set_device(0)
+dist.init_process_group('nccl', rank=0, world_size=1, device_id=torch.device('cuda', 0))
+rng = np.random.default_rng(1)
+y0 = torch.tensor(np.array([1., 1., 1.]) + 1e-3 * rng.standard_normal((4096, 3)), device='cuda:0')
+t = torch.tensor([0., 0.25, 0.5])
+a = odeint(rhs.Lorenz(), y0, t, rtol=1e-6, atol=1e-9, method='dopri5')
+sa = dict(odeint.last_stats)
+b = odeint(rhs.Lorenz(), y0, t, rtol=1e-6, atol=1e-9, method='dopri5', options={'process_group': dist.group.WORLD})
+sb = dict(odeint.last_stats)
+g2 = torch.Generator().manual_seed(2)
+S = torch.randn(128, 128, generator=g2, dtype=torch.float64)
+A = -0.5 * torch.eye(128, dtype=torch.float64) + 0.5 * (S - S.t()) / np.sqrt(128)
+y4 = torch.randn(8192, 128, generator=torch.Generator().manual_seed(3), dtype=torch.float64).cuda()
+c = odeint(rhs.Linear.from_matrix(A), y4, torch.tensor([0., 1.]), rtol=1e-6, atol=1e-9, method='dopri5')
+d = odeint(rhs.Linear.from_matrix(A), y4, torch.tensor([0., 1.]), rtol=1e-6, atol=1e-9, method='dopri5',
+           options={'process_group': dist.group.WORLD})
+print(json.dumps({'diff': float((a - b).abs().max()), 'att_a': sa['n_attempts'], 'att_b': sb['n_attempts'],
+                  'launch_a': sa['n_launches'], 'launch_b': sb['n_launches'], 'diff4': float((c - d).abs().max())}))
+dist.destroy_process_group()
+"""
+
+
+def test_exchange_hook_path_on_one_gpu():
+    """The N > 1 control path (k_reduce_partials -> RCCL all-gather hook -> k_controller over rank records) with a
+    1-rank group must reproduce the hook-free path bit for bit."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+               HSA_ENABLE_IPC_MODE_LEGACY='0')
+    res = subprocess.run([sys.executable, '-c', _HOOK_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"diff"')]
+    assert lines, (res.stdout[-2000:], res.stderr[-2000:])
+    out = json.loads(lines[-1])
+    assert out['diff'] == 0.0 and out['diff4'] == 0.0, out
+    assert out['att_a'] == out['att_b'] and out['launch_b'] > out['launch_a'], out

@@ -94,7 +94,7 @@ static int enqueue_adaptive_stage(mi_ode_solver* h, int sigma, hipStream_t st) {
 // reduce -> (exchange) -> controller
 static int enqueue_controller(mi_ode_solver* h, int phase, hipStream_t st) {
   const int nblocks = h->stage_grid;
-  if (h->d.world_size > 1) {
+  if (h->d.world_size > 1 || h->d.allgather != nullptr) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, (const Ctl*)h->ctl, (const double*)h->partials,
                        nblocks, h->n, h->rank_rec);
     if (h->d.allgather == nullptr) {

@@ -81,7 +81,7 @@ class _FusedEngine(object):
         if process_group is not None:
             import torch.distributed as dist
             world = dist.get_world_size(process_group)
-            if world > 1:
+            if world >= 1:                     # a 1-rank group still goes through the hook (lets one GPU test the path)
                 d.world_size, d.rank = world, dist.get_rank(process_group)
                 self._send = torch.zeros(N.REC, dtype=torch.float64, device=self.device)
                 self._recv = torch.zeros(world * N.REC, dtype=torch.float64, device=self.device)
