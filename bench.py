@@ -32,6 +32,21 @@ BATCH_PER_GPU = 65536
 DIM = 128
 RTOL, ATOL = 1e-6, 1e-9
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+FP64_MFMA_PEAK_TFLOPS = 78.6     # AMD MI355X datasheet, FP64 matrix (= FP64 vector); the guide lists no fp64 figure
+
+
+def pmc_traffic(kernel_substr):
+    """HBM bytes per launch of a kernel from the committed PMC summary (scripts/pmc_summary.py), or None."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json')), reverse=True):
+        try:
+            pm = json.load(open(f)).get('pmc', {})
+        except Exception:
+            continue
+        for k, v in pm.items():
+            if kernel_substr in k and 'hbm_bytes_per_launch' in v:
+                return v['hbm_bytes_per_launch']
+    return None
 
 
 def config4(batch, dim, seed_y):
@@ -89,6 +104,8 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='rows per GPU (default: config 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--linear-variant', type=int, default=0)
+    ap.add_argument('--fusion', default='auto', choices=['auto', 'stage', 'step'],
+                    help="'stage': one kernel per RK stage (34 planes/attempt, HBM-bound); 'step'/'auto': whole attempt in one kernel")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -113,7 +130,7 @@ def main():
     f = rhs.Linear.from_matrix(A)
     y0 = y0.to(dev)
     t = torch.tensor([0., 1.], dtype=torch.float64)
-    opts = {'profile': True, 'linear_variant': args.linear_variant}
+    opts = {'profile': True, 'linear_variant': args.linear_variant, 'fusion': args.fusion}
     if group is not None:
         opts['process_group'] = group
 
@@ -153,27 +170,42 @@ def main():
         attempts = int(stats.get('n_attempts', 0))
         last_ms = prof_last_ms / max(prof_n, 1)
         all_ms = prof_all_ms / max(prof_n, 1)
-        bytes_last = 9 * n_elem_rank * 8                    # y0,k1..k6 in; k7,y1 out
-        bytes_attempt = 34 * n_elem_rank * 8                # 34 units per Dopri5 attempt
-        ach = bytes_last / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0
+        step_fused = int(stats.get('n_launches', 0)) < 6 * max(attempts, 1)      # whole-attempt kernel in use
+        bytes_attempt = 34 * n_elem_rank * 8                # 34 planes per Dopri5 attempt (per-stage structure)
+        cfg = {'workload': 'config 4: linear f=Ay, dim 128, batch %d per GPU (global %d), Dopri5 fp64, '
+                           'rtol 1e-6 atol 1e-9, t=[0,1], one odeint call per step' % (args.batch, args.batch * n_gpus),
+               'parallelism': 'batch-sharded x%d, one 8-double all-gather per attempt' % n_gpus,
+               'fusion': 'step (whole attempt in one kernel)' if step_fused else 'stage (one kernel per RK stage)',
+               'attempts_per_step': attempts, 'accepted': int(stats.get('n_accepted', 0)),
+               'nfe': int(stats.get('nfe', 0)), 'host_polls': int(stats.get('n_polls', 0)),
+               'kernel_launches': int(stats.get('n_launches', 0)),
+               'element_steps_per_s': n_elem_global * attempts * args.steps / elapsed,
+               'attempt_kernels_ms': all_ms}
+        if step_fused:
+            # k_step_linear_mfma<double,128,6>: 6 stages x 2*dim flop per element on the fp64 matrix pipe;
+            # HBM traffic is only 5 planes (y0,f0 in; y1,f1,y_mid out), so the bound is the fp64 MFMA rate.
+            flops = 6 * 2 * DIM * n_elem_rank
+            ach = flops / (last_ms * 1e-3) / 1e12 if last_ms > 0 else 0.0
+            roof = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'kernel': 'k_step_linear_mfma<double,128,6> (all 6 Dopri5 stages + error norms + y_mid, v_mfma_f64_16x16x4_f64)',
+                    'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': 5 * n_elem_rank * 8,
+                    'hbm_GBps_at_algorithmic_bytes': (5 * n_elem_rank * 8) / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0,
+                    'avg_launch_ms': last_ms, 'launches_timed': prof_n,
+                    'peak_source': 'AMD MI355X datasheet FP64 matrix 78.6 TFLOP/s (not listed in MI355X_MICROARCH.md)'}
+        else:
+            bytes_last = 9 * n_elem_rank * 8                # y0,k1..k6 in; k7,y1 out
+            ach = bytes_last / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0
+            cfg['all_stage_kernels_GBps'] = (bytes_attempt / (all_ms * 1e-3) / 1e9) if all_ms > 0 else 0.0
+            roof = {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                    'frac': ach / HBM_PEAK_GBS, 'traffic': pmc_traffic('k_stage_linear_mfma<double, 128, 6, 1, false>'),
+                    'kernel': 'k_stage_linear_mfma<double,128,6,LAST_FSAL> (Dopri5 stage 6 + error norms)',
+                    'algorithmic_bytes_per_launch': bytes_last, 'avg_launch_ms': last_ms, 'launches_timed': prof_n}
         res = {
             'metric': 'state-elements/sec (batch x dim / wall-s) Dopri5 float64',
             'value': value, 'unit': 'state-elements/s', 'n_gpus': n_gpus, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
-            'config': {'workload': 'config 4: linear f=Ay, dim 128, batch %d per GPU (global %d), Dopri5 fp64, '
-                                   'rtol 1e-6 atol 1e-9, t=[0,1], one odeint call per step' % (args.batch, args.batch * n_gpus),
-                       'parallelism': 'batch-sharded x%d, one 8-double all-gather per attempt' % n_gpus,
-                       'attempts_per_step': attempts, 'accepted': int(stats.get('n_accepted', 0)),
-                       'nfe': int(stats.get('nfe', 0)), 'host_polls': int(stats.get('n_polls', 0)),
-                       'kernel_launches': int(stats.get('n_launches', 0)),
-                       'element_steps_per_s': n_elem_global * attempts * args.steps / elapsed,
-                       'all_stage_kernels_ms_per_attempt': all_ms,
-                       'all_stage_kernels_GBps': (bytes_attempt / (all_ms * 1e-3) / 1e9) if all_ms > 0 else 0.0},
-            'roofline': {'bound': 'hbm', 'achieved': ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': ach / HBM_PEAK_GBS, 'traffic': None,
-                         'kernel': 'k_stage_linear_mfma<double,128,6,LAST_FSAL> (Dopri5 stage 6 + error norms)',
-                         'algorithmic_bytes_per_launch': bytes_last, 'avg_launch_ms': last_ms, 'launches_timed': prof_n},
+            'dtype': 'f64', 'data': 'synthetic', 'config': cfg, 'roofline': roof,
         }
         if not args.no_cpu_baseline and n_gpus == 1:
             res['cpu_baseline'] = cpu_baseline()

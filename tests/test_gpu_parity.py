@@ -197,7 +197,7 @@ def test_fused_rk_attempt_against_oracle(case, dtype):
 # ---------------------------------------------------------------------------------------------
 # whole runs against the golden fixtures (both engines)
 # ---------------------------------------------------------------------------------------------
-def _run_product(name, engine):
+def _run_product(name, engine, fusion=None):
     from tfdiffeq_amd import odeint
     d, meta = load(name)
     weights = mlp_weights() if meta['rhs'] == 'mlp_tanh' else None
@@ -213,6 +213,8 @@ def _run_product(name, engine):
     opts = dict(meta['options'] or {})
     if meta['method'] == 'tsit5':
         opts['refcompat'] = True                       # the fixtures hold the reference's (defective) tsit5
+    if fusion is not None and meta['method'] in ('dopri5', 'bosh3', 'tsit5'):
+        opts['fusion'] = fusion
     if opts:
         kw['options'] = opts
     if meta['tuple_state']:
@@ -242,9 +244,16 @@ def _cases(engine):
     return out
 
 
+@pytest.mark.parametrize('fusion', ['step', 'stage'])
 @pytest.mark.parametrize('name', _cases('fused'))
-def test_fused_engine_reproduces_reference_runs(name):
-    d, meta, sol, stats = _run_product(name, 'fused')
+def test_fused_engine_reproduces_reference_runs(name, fusion):
+    """fusion='stage': one kernel per RK stage (34 planes per attempt); 'step': whole attempt in one kernel."""
+    _, meta0 = load(name)
+    if fusion == 'step' and meta0['rhs'] == 'linear' and len(meta0['rhs_params']['W']) not in (2, 16, 32, 64, 128):
+        fusion = 'auto'                                 # no whole-attempt kernel for the VALU fallback family
+    if meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') and fusion == 'stage':
+        pytest.skip('fixed grid has one path')
+    d, meta, sol, stats = _run_product(name, 'fused', fusion)
     f32 = d['y0'].dtype == np.float32
     assert tuple(sol.shape) == d['y'].shape and sol.dtype == (torch.float32 if f32 else torch.float64)
     if f32:
@@ -488,3 +497,44 @@ def test_exchange_hook_path_on_one_gpu():
     out = json.loads(lines[-1])
     assert out['diff'] == 0.0 and out['diff4'] == 0.0, out
     assert out['att_a'] == out['att_b'] and out['launch_b'] > out['launch_a'], out
+
+
+# ---------------------------------------------------------------------------------------------
+# whole-attempt fused kernels vs one-kernel-per-stage: same arithmetic, different schedule
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('method', ['dopri5', 'bosh3', 'tsit5'])
+@pytest.mark.parametrize('problem', ['lorenz', 'lv', 'spiral', 'linear16', 'linear128', 'linear64_f32'])
+def test_step_fused_equals_stage_fused(problem, method):
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(5)
+    dtype = torch.float64
+    if problem == 'lorenz':
+        f, y0, t = rhs.Lorenz(), np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((3000, 3)), [0., 0.1, 0.3]
+    elif problem == 'lv':
+        f, y0, t = rhs.LotkaVolterra(), 1 + 0.5 * rng.uniform(size=(2000, 2)), [0., 0.5, 1.0]
+    elif problem == 'spiral':
+        f = rhs.CubicLinear(torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64))
+        y0, t = rng.uniform(-2, 2, size=(1500, 2)), [0., 0.7, 1.5]
+    else:
+        D = {'linear16': 16, 'linear128': 128, 'linear64_f32': 64}[problem]
+        S = rng.standard_normal((D, D))
+        A = -0.5 * np.eye(D) + 0.5 * (S - S.T) / np.sqrt(D)
+        f, y0, t = rhs.Linear.from_matrix(torch.tensor(A)), rng.standard_normal((1000 if D < 128 else 3000, D)), [0., 0.4, 1.0]
+        if problem.endswith('f32'):
+            dtype = torch.float32
+    if method == 'bosh3':
+        t = [t[0], t[0] + 0.05 * (t[1] - t[0]), t[0] + 0.1 * (t[1] - t[0])]     # the typo tableau is ~25x more expensive
+    y0 = to_dev(y0, dtype)
+    tt = torch.tensor(t, dtype=torch.float64)
+    tol = dict(rtol=1e-6, atol=1e-9) if dtype == torch.float64 else dict(rtol=1e-4, atol=1e-6)
+    a = odeint(f, y0, tt, method=method, options={'fusion': 'stage'}, **tol)
+    sa = dict(odeint.last_stats)
+    b = odeint(f, y0, tt, method=method, options={'fusion': 'step'}, **tol)
+    sb = dict(odeint.last_stats)
+    assert sb['n_launches'] < sa['n_launches']
+    if dtype == torch.float64:
+        assert sa['n_attempts'] == sb['n_attempts'] and sa['n_accepted'] == sb['n_accepted'], (sa, sb)
+        assert (a - b).abs().max().item() <= 1e-12 * max(1.0, a.abs().max().item())
+    else:
+        assert abs(sa['n_attempts'] - sb['n_attempts']) <= 2
+        assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())

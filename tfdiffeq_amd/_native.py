@@ -56,7 +56,8 @@ class Desc(C.Structure):
                 ('allgather', ALLGATHER_FN), ('allgather_user', C.c_void_p),
                 ('exchange_send_dev', C.c_void_p), ('exchange_recv_dev', C.c_void_p),
                 ('linear_variant', C.c_int32), ('chunk_attempts', C.c_int32),
-                ('use_graph', C.c_int32), ('profile', C.c_int32)]
+                ('use_graph', C.c_int32), ('profile', C.c_int32),
+                ('fusion', C.c_int32), ('reserved', C.c_int32)]
 
 
 class Stats(C.Structure):

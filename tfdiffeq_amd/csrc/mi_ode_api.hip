@@ -9,6 +9,7 @@
 #include "mi_ode_control.h"
 #include "mi_ode_host.h"
 #include "mi_ode_plane.h"
+#include "mi_ode_step_fused.h"
 
 using namespace mi;
 
@@ -91,9 +92,34 @@ static int enqueue_adaptive_stage(mi_ode_solver* h, int sigma, hipStream_t st) {
   return launch_stage(h, mode, nk, A, st);
 }
 
+// all S stages of one attempt: six stage launches, or one whole-attempt launch
+static int enqueue_attempt_kernels(mi_ode_solver* h, hipStream_t st, hipEvent_t ev_last) {
+  if (h->step_fused) {
+    const mi_ode_tableau& tb = h->d.tableau;
+    StepArgs A;
+    memset(&A, 0, sizeof(A));
+    A.ctl = h->ctl; A.planes = h->planes; A.stride = h->stride; A.batch = h->d.batch; A.dim = (int)h->d.dim;
+    A.ymid_slot = h->allk ? -1 : 1;
+    for (int i = 0; i < h->S; ++i) {
+      A.alpha[i] = tb.alpha[i];
+      for (int j = 0; j <= i; ++j) A.beta[i][j] = tb.beta[i][j];
+    }
+    for (int j = 0; j <= h->S; ++j) { A.e[j] = tb.c_error[j]; A.cmid[j] = tb.c_mid[j]; }
+    A.partials = h->partials; A.rhs = h->rhs;
+    if (ev_last) (void)hipEventRecord(ev_last, st);
+    return h->is_f32 ? mi_launch_step_f32(h, A, st) : mi_launch_step_f64(h, A, st);
+  }
+  for (int sigma = 1; sigma <= h->S; ++sigma) {
+    if (ev_last && sigma == h->S) (void)hipEventRecord(ev_last, st);
+    int rc = enqueue_adaptive_stage(h, sigma, st);
+    if (rc != 0) return rc;
+  }
+  return 0;
+}
+
 // reduce -> (exchange) -> controller
 static int enqueue_controller(mi_ode_solver* h, int phase, hipStream_t st) {
-  const int nblocks = h->stage_grid;
+  const int nblocks = (phase == PH_ATTEMPT && h->step_fused) ? h->step_grid : h->stage_grid;
   if (h->d.world_size > 1 || h->d.allgather != nullptr) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, (const Ctl*)h->ctl, (const double*)h->partials,
                        nblocks, h->n, h->rank_rec);
@@ -134,7 +160,15 @@ static void launch_emit_t(mi_ode_solver* h, void* out, hipStream_t st) {
 }
 
 static int enqueue_emit(mi_ode_solver* h, void* out, hipStream_t st) {
-  if (h->is_f32) launch_emit_t<float>(h, out, st);
+  if (h->step_fused && !h->allk) {
+    const int g = streaming_grid(h->n);
+    if (h->is_f32)
+      hipLaunchKernelGGL(k_emit_mid<float>, dim3(g), dim3(256), 0, st, (const Ctl*)h->ctl, (const char*)h->planes, h->stride,
+                         h->n, (const double*)h->t_out_dev, (float*)out, h->S, 1);
+    else
+      hipLaunchKernelGGL(k_emit_mid<double>, dim3(g), dim3(256), 0, st, (const Ctl*)h->ctl, (const char*)h->planes, h->stride,
+                         h->n, (const double*)h->t_out_dev, (double*)out, h->S, 1);
+  } else if (h->is_f32) launch_emit_t<float>(h, out, st);
   else launch_emit_t<double>(h, out, st);
   h->n_launches += 1;
   return 0;
@@ -268,6 +302,13 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   if (rc != 0) { delete h; return rc; }
   rc = h->is_f32 ? mi_stage_geometry_f32(h) : mi_stage_geometry_f64(h);
   if (rc != 0) { delete h; return rc; }
+  {   // whole-attempt fusion: row-local families and the MFMA linear family, adaptive FSAL tableaus
+    const bool can = desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
+                                        h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA);
+    if (desc->fusion == 2 && !can) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); delete h; return MI_ODE_E_INVALID; }
+    h->step_fused = (can && desc->fusion != 1) ? 1 : 0;
+    h->allk = (desc->interp != MI_ODE_INTERP_QUARTIC_MID) ? 1 : 0;
+  }
   // controller / dense-output parameters
   h->cp.rtol = desc->rtol; h->cp.atol = desc->atol;
   h->cp.safety = desc->safety; h->cp.ifactor = desc->ifactor; h->cp.dfactor = desc->dfactor;
@@ -406,11 +447,8 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
       const int ei = (int)(h->enq_attempts % 64);
       const bool prof = h->d.profile && h->ev_ready;
       if (prof) (void)hipEventRecord(h->ev_a[ei], st);
-      for (int sigma = 1; sigma <= h->S; ++sigma) {
-        if (prof && sigma == h->S) (void)hipEventRecord(h->ev_b[ei], st);
-        rc = enqueue_adaptive_stage(h, sigma, st);
-        if (rc != 0) return rc;
-      }
+      rc = enqueue_attempt_kernels(h, st, prof ? h->ev_b[ei] : nullptr);
+      if (rc != 0) return rc;
       if (prof) (void)hipEventRecord(h->ev_c[ei], st);
       h->enq_attempts += 1;
       rc = enqueue_controller(h, PH_ATTEMPT, st);

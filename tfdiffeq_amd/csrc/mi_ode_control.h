@@ -198,20 +198,24 @@ __device__ __forceinline__ void tsit5_weights(double t, double* b) {
   b[6] = 2.5 * (t - 1) * (t - 0.6) * t2;
 }
 
-// interp._interp_fit (interp.py:6-36) for one element: quartic coefficients a..e
-template <typename T, int NK>
-__device__ __forceinline__ void quartic_fit(T y0, T y1, const T* k, T dt, const InterpParams& I, T* co) {
-  T ym = (dt * (T)I.c_mid[0]) * k[0];                     // dopri5.py:42 via misc.py:121
-#pragma unroll
-  for (int j = 1; j < NK; ++j) ym = ym + (dt * (T)I.c_mid[j]) * k[j];
-  ym = y0 + ym;
-  const T f0 = k[0], f1 = k[NK - 1];
+// interp._interp_fit (interp.py:6-36) for one element, given y_mid: quartic coefficients a..e
+template <typename T>
+__device__ __forceinline__ void quartic_from_mid(T y0, T y1, T ym, T f0, T f1, T dt, T* co) {
   // _dot_product = python sum(): ((((0 + c0*f0) + c1*f1) + c2*y0) + c3*y1) + c4*ym
   co[0] = ((((T)-2 * dt) * f0 + ((T)2 * dt) * f1) + (T)-8 * y0 + (T)-8 * y1) + (T)16 * ym;
   co[1] = ((((T)5 * dt) * f0 + ((T)-3 * dt) * f1) + (T)18 * y0 + (T)14 * y1) + (T)-32 * ym;
   co[2] = ((((T)-4 * dt) * f0 + dt * f1) + (T)-11 * y0 + (T)-5 * y1) + (T)16 * ym;
   co[3] = dt * f0;
   co[4] = y0;
+}
+
+template <typename T, int NK>
+__device__ __forceinline__ void quartic_fit(T y0, T y1, const T* k, T dt, const InterpParams& I, T* co) {
+  T ym = (dt * (T)I.c_mid[0]) * k[0];                     // dopri5.py:42 via misc.py:121
+#pragma unroll
+  for (int j = 1; j < NK; ++j) ym = ym + (dt * (T)I.c_mid[j]) * k[j];
+  ym = y0 + ym;
+  quartic_from_mid<T>(y0, y1, ym, k[0], k[NK - 1], dt, co);
 }
 
 // interp._interp_evaluate (interp.py:39-67): x in the STATE dtype
@@ -265,6 +269,27 @@ __global__ __launch_bounds__(256) void k_emit(const Ctl* c, const char* planes, 
     } else {
       for (int j = lo; j < hi; ++j) out[(long long)j * n + i] = tsit5_dense<T, NK>(y0, k, t0, t1, t_out[j], I.kind);
     }
+  }
+}
+
+// Emission for the whole-attempt fused kernels: the step kernel already wrote y_mid (plane idx_k[ymid_slot]),
+// so the quartic needs 5 planes (y0, y1, f0, f1, y_mid) instead of 9.
+template <typename T>
+__global__ __launch_bounds__(256) void k_emit_mid(const Ctl* c, const char* planes, long long stride, long long n,
+                                                  const double* t_out, T* out, int last_slot, int ymid_slot) {
+  const int lo = c->emit_lo, hi = c->emit_hi;
+  if (hi <= lo || c->accepted == 0) return;
+  const T* y0p = (const T*)(planes + (long long)c->emit_y0 * stride);
+  const T* y1p = (const T*)(planes + (long long)c->emit_y1 * stride);
+  const T* f0p = (const T*)(planes + (long long)c->emit_k[0] * stride);
+  const T* f1p = (const T*)(planes + (long long)c->emit_k[last_slot] * stride);
+  const T* ymp = (const T*)(planes + (long long)c->emit_k[ymid_slot] * stride);
+  const double t0 = c->emit_t0, t1 = c->emit_t1;
+  const T dtT = (T)c->emit_dt;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    T co[5];
+    quartic_from_mid<T>(y0p[i], y1p[i], ymp[i], f0p[i], f1p[i], dtT, co);
+    for (int j = lo; j < hi; ++j) out[(long long)j * n + i] = quartic_eval<T>(co, interp_x<T>(t0, t1, t_out[j]));
   }
 }
 

@@ -4,6 +4,7 @@
 #include "mi_ode_dev.h"
 
 namespace mi {
+struct StepArgs;
 
 enum Family {
   FAM_NONE = 0,
@@ -46,6 +47,9 @@ struct mi_ode_solver {
   int t_out_host_cap;
   // launch geometry of the stage kernels
   int stage_grid, stage_block;
+  int step_fused;             // 1: whole-attempt kernel in use
+  int step_grid, step_block;
+  int allk;                   // step kernel writes every k plane (tsit5 dense output)
   // bookkeeping
   long long n_launches;
   int n_polls;
@@ -66,6 +70,8 @@ struct mi_ode_solver {
 // implemented once per state dtype (mi_ode_launch_f64.hip / mi_ode_launch_f32.hip)
 int mi_launch_stage_f64(mi_ode_solver* h, int mode, int nk, mi::StageArgs& A, hipStream_t st);
 int mi_launch_stage_f32(mi_ode_solver* h, int mode, int nk, mi::StageArgs& A, hipStream_t st);
+int mi_launch_step_f64(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
+int mi_launch_step_f32(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
 int mi_stage_geometry_f64(mi_ode_solver* h);
 int mi_stage_geometry_f32(mi_ode_solver* h);
 

@@ -185,6 +185,7 @@ __global__ __launch_bounds__(D * 4) void k_stage_linear_mfma(StageArgs A) {
     const long long tile_base = row0 * D;                    // tile rows are contiguous in memory
     const long long elems_left = (A.batch - row0) * D;       // valid elements from tile_base on
     if constexpr (PF < NP) load_planes(tile_i, IPF{}, INP{});   // the planes that were not prefetched
+    const T hs = R.hs;
     if (tile_i != (long long)blockIdx.x) __syncthreads();    // previous tile's LDS reads are done
 
     // ---- flat phase: combine the landed planes, park ys (and the partial error sum) in LDS ------
@@ -199,7 +200,7 @@ __global__ __launch_bounds__(D * 4) void k_stage_linear_mfma(StageArgs A) {
 #pragma unroll
         for (int j = 0; j < NK; ++j) kk[j] = pl[j + 1][c].v[v];
         T aux;
-        const T ys = combine_elem<T, NK, MODE>(pl[0][c].v[v], kk, R.hs, A, aux);
+        const T ys = combine_elem<T, NK, MODE>(pl[0][c].v[v], kk, hs, A, aux);
         if (ok) reduce_flat<T, MODE>(pl[0][c].v[v], ys, A, acc);
         ysc.v[v] = ys;
         auxc.v[v] = aux;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(D * 4) void k_stage_linear_mfma(StageArgs A) {
           if constexpr (mode_needs_y0_epi(MODE)) y0v = R.y0[idx];
           if constexpr (MODE == M_INITB) k0v = R.k[0][idx];
           if constexpr (NEED_AUX) auxv = s_aux[rr * LD + col];
-          const T v = epilogue_elem<T, NK, MODE>(y0v, k0v, kn, auxv, R.hs, A, acc);
+          const T v = epilogue_elem<T, NK, MODE>(y0v, k0v, kn, auxv, hs, A, acc);
           if constexpr (MODE == M_FX_EULER || MODE == M_FX_RK4_4) R.y1[idx] = v;
         }
       }

@@ -1,0 +1,289 @@
+// Whole-attempt fused kernels: all S stages of one adaptive RK attempt for a tile of trajectories stay on chip.
+//
+// Legal because every catalogue RHS is trajectory(row)-local: k_2..k_S never have to visit HBM.  Traffic per
+// attempt drops from 34 planes (per-stage structure) to
+//     reads  y0, f0                       2 planes
+//     writes y1, f1, y_mid                3 planes      (y_mid = y0 + dt*sum c_mid_j k_j feeds the quartic dense output)
+//   = 5 planes  (tsit5's seven-weight dense output needs every k: 2 + 8 = 10 planes with ALLK).
+// The arithmetic is the per-stage kernels' arithmetic, operation for operation (same combine order, same MFMA
+// accumulation order), so both paths produce identical bits; only the schedule differs.
+// Bound: tiny systems (dim 2-3) stay HBM/latency-bound; the linear RHS at dim 128 becomes fp64-MFMA-bound
+// (6 x 256 flop per element per attempt against 40 B).
+#pragma once
+#include <type_traits>
+#include "mi_ode_dev.h"
+#include "mi_ode_stage_linear.h"
+#include "mi_ode_stage_rowlocal.h"
+
+namespace mi {
+
+struct StepArgs {
+  Ctl* ctl;
+  char* planes;
+  long long stride;
+  long long batch;
+  int dim;
+  int ymid_slot;               // idx_k slot that receives y_mid (quartic dense output); -1: none
+  double beta[MI_ODE_MAX_STAGES][MI_ODE_MAX_STAGES];
+  double alpha[MI_ODE_MAX_STAGES];
+  double e[kMaxK];             // c_error
+  double cmid[kMaxK];          // dense-output mid-point weights
+  double* partials;
+  RhsParams rhs;
+};
+
+template <typename T, int S>
+struct StepPlanes {
+  const T* y0;
+  const T* f0;
+  T* y1;
+  T* k[S + 1];                 // k[j] for j >= 1: output planes (ALLK), k[S] = f1
+  T* ymid;
+  T hs, t0;
+};
+
+template <typename T, int S>
+__device__ __forceinline__ bool resolve_step(const StepArgs& A, StepPlanes<T, S>& P) {
+  const Ctl* c = A.ctl;
+  if (c->done) return false;
+  char* base = A.planes;
+  P.y0 = (const T*)(base + (long long)c->idx_y0 * A.stride);
+  P.y1 = (T*)(base + (long long)c->idx_y1 * A.stride);
+  P.f0 = (const T*)(base + (long long)c->idx_k[0] * A.stride);
+#pragma unroll
+  for (int j = 0; j <= S; ++j) P.k[j] = (T*)(base + (long long)c->idx_k[j] * A.stride);
+  P.ymid = A.ymid_slot >= 0 ? (T*)(base + (long long)c->idx_k[A.ymid_slot] * A.stride) : nullptr;
+  P.hs = (T)c->dt;                               // rk_common.py:46
+  P.t0 = (T)c->t1;                               // rk_common.py:45
+  return true;
+}
+
+// y_sigma for stage SG (1-based) from y0 and k[0..SG-1]: misc._scaled_dot_product order (rk_common.py:51)
+template <typename T, int SG>
+__device__ __forceinline__ T step_combine(T y0, const T* k, T hs, const StepArgs& A) {
+  T acc = (hs * (T)A.beta[SG - 1][0]) * k[0];
+#pragma unroll
+  for (int j = 1; j < SG; ++j) acc = acc + (hs * (T)A.beta[SG - 1][j]) * k[j];
+  return y0 + acc;
+}
+
+// err (rk_common.py:60) and y_mid (dopri5.py:42) from all S+1 stage derivatives
+template <typename T, int S>
+__device__ __forceinline__ void step_finish(T y0, const T* k, T hs, const StepArgs& A, T& err, T& ymid) {
+  T er = (hs * (T)A.e[0]) * k[0];
+#pragma unroll
+  for (int j = 1; j <= S; ++j) er = er + (hs * (T)A.e[j]) * k[j];
+  err = er;
+  T ym = (hs * (T)A.cmid[0]) * k[0];
+#pragma unroll
+  for (int j = 1; j <= S; ++j) ym = ym + (hs * (T)A.cmid[j]) * k[j];
+  ymid = y0 + ym;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1) tiny row-local systems: one thread per trajectory, everything in registers, one launch per attempt
+// ------------------------------------------------------------------------------------------------
+template <typename T, int S, bool ALLK, class RHS>
+__global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
+  constexpr int D = RHS::D;
+  using Row = RowVec<T, D>;
+  StepPlanes<T, S> P;
+  if (!resolve_step<T, S>(A, P)) return;
+  const RHS rhs(A.rhs);
+  const T sign = (T)A.rhs.sign;
+  const T hs = P.hs;
+  Acc acc;
+  for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < A.batch;
+       row += (long long)gridDim.x * blockDim.x) {
+    const Row y0 = *(const Row*)(P.y0 + row * D);
+    T k[S + 1][D];
+    {
+      const Row f0 = *(const Row*)(P.f0 + row * D);
+#pragma unroll
+      for (int d = 0; d < D; ++d) k[0][d] = f0.v[d];
+    }
+    T ys[D];
+    auto stage = [&](auto sg_c) {
+      constexpr int SG = decltype(sg_c)::value;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        T kk[SG];
+#pragma unroll
+        for (int j = 0; j < SG; ++j) kk[j] = k[j][d];
+        ys[d] = step_combine<T, SG>(y0.v[d], kk, hs, A);
+      }
+      T kn[D];
+      rhs(sign * (P.t0 + (T)A.alpha[SG - 1] * hs), ys, kn);
+#pragma unroll
+      for (int d = 0; d < D; ++d) k[SG][d] = sign * kn[d];
+    };
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{});
+    if constexpr (S == 6) {
+      stage(std::integral_constant<int, 4>{});
+      stage(std::integral_constant<int, 5>{});
+      stage(std::integral_constant<int, 6>{});
+    }
+    Row y1, f1, ym;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      T kk[S + 1];
+#pragma unroll
+      for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
+      T err, ymid;
+      step_finish<T, S>(y0.v[d], kk, hs, A, err, ymid);
+      y1.v[d] = ys[d];                                       // FSAL: y1 = y_S (rk_common.py:58)
+      f1.v[d] = k[S][d];
+      ym.v[d] = ymid;
+      acc.maxa = fmax(acc.maxa, (double)fabs(y0.v[d]));
+      acc.maxb = fmax(acc.maxb, (double)fabs(ys[d]));
+      acc.suma += (double)err * (double)err;
+    }
+    *(Row*)(P.y1 + row * D) = y1;
+    *(Row*)(P.k[S] + row * D) = f1;
+    if constexpr (ALLK) {
+#pragma unroll
+      for (int j = 1; j < S; ++j) {
+        Row kj;
+#pragma unroll
+        for (int d = 0; d < D; ++d) kj.v[d] = k[j][d];
+        *(Row*)(P.k[j] + row * D) = kj;
+      }
+    } else {
+      if (P.ymid != nullptr) *(Row*)(P.ymid + row * D) = ym;
+    }
+  }
+  __shared__ double red[80];
+  block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
+}
+
+// ------------------------------------------------------------------------------------------------
+// (2) linear RHS, dim D in {16, 32, 64, 128}: the MFMA tile kernel with the stage loop inside.
+//     Tile = 16 rows; each thread owns the 4 accumulator-layout elements (row = acc_row(lane, i), col = 16w + lane&15)
+//     of every stage derivative k_1..k_{S+1} in registers; per stage: combine in registers -> y_sigma tile to LDS ->
+//     barrier -> 32 MFMA steps against the wave's resident W slice -> k_{sigma+1} (registers) -> barrier.
+//     y0 / f0 of the NEXT tile are prefetched into registers during the stages of the current one.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, int S, bool ALLK>
+__global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
+  using TR = MfmaTraits<T>;
+  using acc_t = typename TR::acc_t;
+  constexpr int VEC = TR::VEC;
+  constexpr int R_ = 16;
+  constexpr int LD = D + VEC;
+  constexpr int KS = D / 4;
+  using CH = Chunk<T, VEC>;
+
+  StepPlanes<T, S> P;
+  if (!resolve_step<T, S>(A, P)) return;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* s_ys = (T*)smem_raw;                                   // [R_][LD]
+  double* red = (double*)(s_ys + R_ * LD);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const T* W = (const T*)A.rhs.w[0];
+  const T* bias = (const T*)A.rhs.b[0];
+  const T sign = (T)A.rhs.sign;
+  const int col = 16 * wave + li;
+
+  T bf[KS];
+#pragma unroll
+  for (int s = 0; s < KS; ++s) bf[s] = W[(long long)(lg * KS + s) * D + col];
+  const T bias_v = bias != nullptr ? bias[col] : (T)0;
+
+  Acc acc;
+  const long long ntiles = (A.batch + R_ - 1) / R_;
+  T y0n[4], f0n[4];                                          // prefetched next tile (accumulator layout)
+  auto fetch = [&](long long t_i) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long row = t_i * R_ + TR::acc_row(lane, i);
+      const bool ok = row < A.batch;
+      y0n[i] = ok ? P.y0[row * D + col] : (T)0;
+      f0n[i] = ok ? P.f0[row * D + col] : (T)0;
+    }
+  };
+  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
+
+  for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+    const long long row0 = tile_i * R_;
+    // keep the ~35 dt*coefficient products out of the register file: without this LICM hoists them out of the
+    // tile loop (fp64 has no scalar ALU, so each product would pin a VGPR pair for the whole kernel)
+    T hs = P.hs;
+    asm volatile("" : "+v"(hs));
+    T y0e[4], k[S + 1][4], ys[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { y0e[i] = y0n[i]; k[0][i] = f0n[i]; }
+    if (tile_i + gridDim.x < ntiles) fetch(tile_i + gridDim.x);
+
+    auto stage = [&](auto sg_c) {
+      constexpr int SG = decltype(sg_c)::value;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        T kk[SG];
+#pragma unroll
+        for (int j = 0; j < SG; ++j) kk[j] = k[j][i];
+        ys[i] = step_combine<T, SG>(y0e[i], kk, hs, A);
+        s_ys[TR::acc_row(lane, i) * LD + col] = ys[i];
+      }
+      __syncthreads();
+      acc_t c0 = {0, 0, 0, 0};
+      const T* ap = s_ys + li * LD + lg * KS;
+#pragma unroll
+      for (int m = 0; m < KS / VEC; ++m) {
+        const CH a0 = *(const CH*)(ap + m * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], bf[m * VEC + v], c0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        T kn = c0[i];
+        if (bias != nullptr) kn = kn + bias_v;
+        k[SG][i] = sign * kn;
+      }
+      __syncthreads();                                       // every wave is done reading the tile
+    };
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{});
+    if constexpr (S == 6) {
+      stage(std::integral_constant<int, 4>{});
+      stage(std::integral_constant<int, 5>{});
+      stage(std::integral_constant<int, 6>{});
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long row = row0 + TR::acc_row(lane, i);
+      if (row < A.batch) {
+        T kk[S + 1];
+#pragma unroll
+        for (int j = 0; j <= S; ++j) kk[j] = k[j][i];
+        T err, ymid;
+        step_finish<T, S>(y0e[i], kk, hs, A, err, ymid);
+        const long long idx = row * D + col;
+        P.y1[idx] = ys[i];
+        P.k[S][idx] = k[S][i];
+        if constexpr (ALLK) {
+#pragma unroll
+          for (int j = 1; j < S; ++j) P.k[j][idx] = k[j][i];
+        } else {
+          if (P.ymid != nullptr) P.ymid[idx] = ymid;
+        }
+        acc.maxa = fmax(acc.maxa, (double)fabs(y0e[i]));
+        acc.maxb = fmax(acc.maxb, (double)fabs(ys[i]));
+        acc.suma += (double)err * (double)err;
+      }
+    }
+  }
+  block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
+}
+
+template <typename T, int D>
+constexpr size_t step_linear_lds_bytes() {
+  return (size_t)16 * (D + MfmaTraits<T>::VEC) * sizeof(T) + 80 * sizeof(double);
+}
+
+}  // namespace mi

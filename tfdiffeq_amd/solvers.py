@@ -54,7 +54,7 @@ class _FusedEngine(object):
     def __init__(self, device_rhs, y0, adaptive, tableau, c_mid=None, rtol=1e-7, atol=1e-9, controller=N.CTRL_MISC,
                  interp=N.INTERP_QUARTIC_MID, order=5, init_order=4, safety=0.9, ifactor=10.0, dfactor=0.2,
                  first_step=None, max_num_steps=2 ** 31 - 1, process_group=None, linear_variant=0, chunk_attempts=0,
-                 profile=False):
+                 profile=False, fusion=0):
         N.require_gpu_tensor(y0, 'y0')
         self.lib = N.load()
         self.y0 = y0.contiguous()
@@ -77,6 +77,7 @@ class _FusedEngine(object):
         d.linear_variant = int(linear_variant)
         d.chunk_attempts = int(chunk_attempts)
         d.profile = 1 if profile else 0
+        d.fusion = {'auto': 0, 'stage': 1, 'step': 2}.get(fusion, fusion)
         self._hook = None
         if process_group is not None:
             import torch.distributed as dist
@@ -376,6 +377,7 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         self._chunk_attempts = unused_kwargs.pop('chunk_attempts', 0)
         self._force_planes = unused_kwargs.pop('force_plane_kernels', False)
         self._profile = unused_kwargs.pop('profile', False)
+        self._fusion = unused_kwargs.pop('fusion', 0)
         _handle_unused_kwargs(self, unused_kwargs)
         self.func = func
         self.y0 = y0
@@ -413,10 +415,10 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
                 float(self.ifactor), float(self.dfactor), first, self.max_num_steps)
         key = ('adaptive', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
                _tableau_key(self.tableau, self.c_mid), args, id(self._pg) if self._pg is not None else None,
-               self._linear_variant, self._chunk_attempts, bool(self._profile))
+               self._linear_variant, self._chunk_attempts, bool(self._profile), self._fusion)
         return _cached_engine(key, lambda: _FusedEngine(
             rhs, y, True, self.tableau, self.c_mid, *args, process_group=self._pg, linear_variant=self._linear_variant,
-            chunk_attempts=self._chunk_attempts, profile=self._profile))
+            chunk_attempts=self._chunk_attempts, profile=self._profile, fusion=self._fusion))
 
     def integrate(self, t):
         _assert_increasing(t)
