@@ -226,7 +226,7 @@ def _run_product(name, engine, fusion=None):
     return d, meta, sol, dict(odeint.last_stats)
 
 
-FUSED_RHS = ('cubic_linear', 'linear', 'lotka_volterra', 'lorenz')
+FUSED_RHS = ('cubic_linear', 'linear', 'lotka_volterra', 'lorenz', 'mlp_tanh')
 
 
 def _cases(engine):
@@ -253,6 +253,8 @@ def test_fused_engine_reproduces_reference_runs(name, fusion):
         fusion = 'auto'                                 # no whole-attempt kernel for the VALU fallback family
     if meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') and fusion == 'stage':
         pytest.skip('fixed grid has one path')
+    if meta0['rhs'] == 'mlp_tanh' and fusion == 'stage':
+        pytest.skip('the MLP family only has the whole-attempt kernel')
     d, meta, sol, stats = _run_product(name, 'fused', fusion)
     f32 = d['y0'].dtype == np.float32
     assert tuple(sol.shape) == d['y'].shape and sol.dtype == (torch.float32 if f32 else torch.float64)
@@ -538,3 +540,35 @@ def test_step_fused_equals_stage_fused(problem, method):
     else:
         assert abs(sa['n_attempts'] - sb['n_attempts']) <= 2
         assert (a - b).abs().max().item() <= 1e-4 * max(1.0, a.abs().max().item())
+
+
+def test_config5_mlp_fused_kernel_full_size():
+    """BASELINE config 5: ODEFunc-shaped MLP 64-128-128-64 tanh, batch 32768, fp32, dopri5 rtol=atol=1e-3.
+    The fused MFMA kernel against (a) the plane-kernel engine with torch matmul and (b) the oracle on a slice."""
+    from tfdiffeq_amd import odeint, rhs
+    g = torch.Generator().manual_seed(4)
+
+    def glorot(i, o):
+        lim = (6.0 / (i + o)) ** 0.5
+        return (torch.rand(i, o, generator=g) * 2 - 1) * lim
+    Ws = [glorot(64, 128), glorot(128, 128), glorot(128, 64)]
+    bs = [0.1 * torch.randn(128, generator=g), 0.1 * torch.randn(128, generator=g), 0.1 * torch.randn(64, generator=g)]
+    f = rhs.MLPTanh(Ws[0].to(dev()), bs[0].to(dev()), Ws[1].to(dev()), bs[1].to(dev()), Ws[2].to(dev()), bs[2].to(dev()))
+    y0 = torch.randn(32768, 64, generator=torch.Generator().manual_seed(5)).to(dev())
+    t = torch.tensor([0., 0.5, 1.0])
+    a = odeint(f, y0, t, rtol=1e-3, atol=1e-3, method='dopri5')
+    sa = dict(odeint.last_stats)
+    assert sa['status'] == 0 and sa['n_launches'] < 40            # one launch per attempt (+ controller, emit, init)
+    b = odeint(f, y0, t, rtol=1e-3, atol=1e-3, method='dopri5', options={'force_plane_kernels': True})
+    assert (a - b).abs().max().item() < 2e-4 * max(1.0, b.abs().max().item())
+    # tight tolerance on a slice against the numpy oracle (fp32 arithmetic on both sides)
+    w = {'W1': Ws[0].numpy(), 'b1': bs[0].numpy(), 'W2': Ws[1].numpy(), 'b2': bs[1].numpy(), 'W3': Ws[2].numpy(), 'b3': bs[2].numpy()}
+    fo = make_rhs('mlp_tanh', {}, dtype=np.float32, weights=w)
+    ys = y0[:512]
+    c = odeint(f, ys, t, rtol=1e-5, atol=1e-6, method='dopri5')
+    ref = O.odeint(fo, ys.cpu().numpy(), t.numpy().astype(np.float64), rtol=1e-5, atol=1e-6, method='dopri5')
+    assert_band(c.cpu(), ref, 2e-4, 2e-5, 'fused MLP vs oracle')
+    # ragged batch (not a multiple of the 32-row tile) and tsit5 (all k planes written)
+    d1 = odeint(f, y0[:1000], t, rtol=1e-3, atol=1e-3, method='tsit5')
+    d2 = odeint(f, y0[:1000], t, rtol=1e-3, atol=1e-3, method='tsit5', options={'force_plane_kernels': True})
+    assert (d1 - d2).abs().max().item() < 5e-4 * max(1.0, d2.abs().max().item())

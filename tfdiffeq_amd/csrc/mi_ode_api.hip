@@ -10,6 +10,7 @@
 #include "mi_ode_host.h"
 #include "mi_ode_plane.h"
 #include "mi_ode_step_fused.h"
+#include "mi_ode_mlp.h"
 
 using namespace mi;
 
@@ -92,20 +93,20 @@ static int enqueue_adaptive_stage(mi_ode_solver* h, int sigma, hipStream_t st) {
   return launch_stage(h, mode, nk, A, st);
 }
 
+static void fill_step_args(mi_ode_solver* h, StepArgs& A);
+static void fill_mlp_args(mi_ode_solver* h, MlpArgs& M);
+
 // all S stages of one attempt: six stage launches, or one whole-attempt launch
 static int enqueue_attempt_kernels(mi_ode_solver* h, hipStream_t st, hipEvent_t ev_last) {
+  if (h->family == FAM_MLP) {
+    MlpArgs M;
+    fill_mlp_args(h, M);
+    if (ev_last) (void)hipEventRecord(ev_last, st);
+    return mi_launch_mlp_f32(h, MLP_STEP, M, st);
+  }
   if (h->step_fused) {
-    const mi_ode_tableau& tb = h->d.tableau;
     StepArgs A;
-    memset(&A, 0, sizeof(A));
-    A.ctl = h->ctl; A.planes = h->planes; A.stride = h->stride; A.batch = h->d.batch; A.dim = (int)h->d.dim;
-    A.ymid_slot = h->allk ? -1 : 1;
-    for (int i = 0; i < h->S; ++i) {
-      A.alpha[i] = tb.alpha[i];
-      for (int j = 0; j <= i; ++j) A.beta[i][j] = tb.beta[i][j];
-    }
-    for (int j = 0; j <= h->S; ++j) { A.e[j] = tb.c_error[j]; A.cmid[j] = tb.c_mid[j]; }
-    A.partials = h->partials; A.rhs = h->rhs;
+    fill_step_args(h, A);
     if (ev_last) (void)hipEventRecord(ev_last, st);
     return h->is_f32 ? mi_launch_step_f32(h, A, st) : mi_launch_step_f64(h, A, st);
   }
@@ -241,10 +242,41 @@ static int pick_family(mi_ode_solver* h) {
       if (D > 256) { mi_set_error("fused linear RHS supports dim <= 256 (got %d)", D); return MI_ODE_E_INVALID; }
       h->family = FAM_LINEAR_VALU; return 0;
     }
+    case MI_ODE_RHS_MLP_TANH: {
+      const int hd = r.hidden;
+      if (!h->is_f32) { mi_set_error("fused MLP kernel is fp32 only"); return MI_ODE_E_INVALID; }
+      if (!h->d.adaptive) { mi_set_error("fused MLP kernel: adaptive solvers only"); return MI_ODE_E_INVALID; }
+      if (D < 1 || D > 64 || hd < 1 || hd > 128 || !r.w[0] || !r.w[1] || !r.w[2]) {
+        mi_set_error("fused MLP kernel supports dim <= 64, hidden <= 128 (got %d, %d)", D, hd);
+        return MI_ODE_E_INVALID;
+      }
+      h->mlp_dp = D <= 16 ? 16 : 64;
+      h->mlp_hp = hd <= 16 ? 16 : 128;
+      h->family = FAM_MLP; return 0;
+    }
     default:
       mi_set_error("RHS kind %d has no fused kernel yet", r.kind);
       return MI_ODE_E_INVALID;
   }
+}
+
+static void fill_step_args(mi_ode_solver* h, StepArgs& A) {
+  const mi_ode_tableau& tb = h->d.tableau;
+  memset(&A, 0, sizeof(A));
+  A.ctl = h->ctl; A.planes = h->planes; A.stride = h->stride; A.batch = h->d.batch; A.dim = (int)h->d.dim;
+  A.ymid_slot = h->allk ? -1 : 1;
+  for (int i = 0; i < h->S; ++i) {
+    A.alpha[i] = tb.alpha[i];
+    for (int j = 0; j <= i; ++j) A.beta[i][j] = tb.beta[i][j];
+  }
+  for (int j = 0; j <= h->S; ++j) { A.e[j] = tb.c_error[j]; A.cmid[j] = tb.c_mid[j]; }
+  A.partials = h->partials; A.rhs = h->rhs;
+}
+
+static void fill_mlp_args(mi_ode_solver* h, MlpArgs& M) {
+  memset(&M, 0, sizeof(M));
+  fill_step_args(h, M.step);
+  M.rtol = h->d.rtol; M.atol = h->d.atol; M.hidden = h->d.rhs.hidden;
 }
 
 extern "C" int mi_ode_destroy(mi_ode_handle h) {
@@ -304,7 +336,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   if (rc != 0) { delete h; return rc; }
   {   // whole-attempt fusion: row-local families and the MFMA linear family, adaptive FSAL tableaus
     const bool can = desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
-                                        h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA);
+                                        h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP);
+    if (h->family == FAM_MLP && desc->fusion == 1) { mi_set_error("the MLP family only has a whole-attempt kernel"); delete h; return MI_ODE_E_INVALID; }
     if (desc->fusion == 2 && !can) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); delete h; return MI_ODE_E_INVALID; }
     h->step_fused = (can && desc->fusion != 1) ? 1 : 0;
     h->allk = (desc->interp != MI_ODE_INTERP_QUARTIC_MID) ? 1 : 0;
@@ -399,6 +432,24 @@ static int begin_impl(mi_ode_handle h, const void* y0_dev, double t0, void* firs
   h->n_launches = 0; h->n_polls = 0;
   h->enq_attempts = 0; h->prof_done = 0;
   MI_HIP(hipMemcpyAsync(h->ctl, c, sizeof(Ctl), hipMemcpyHostToDevice, st));
+  if (h->family == FAM_MLP) {
+    MlpArgs M;
+    fill_mlp_args(h, M);
+    M.x_y0 = y0_dev; M.copy_a = h->planes; M.copy_b = first_out_dev;
+    int rcm = mi_launch_mlp_f32(h, MLP_F0, M, st);
+    if (rcm != 0) return rcm;
+    rcm = enqueue_controller(h, PH_F0, st);
+    if (rcm != 0) return rcm;
+    if (h->cp.auto_first_step) {
+      fill_mlp_args(h, M);
+      rcm = mi_launch_mlp_f32(h, MLP_INITB, M, st);
+      if (rcm != 0) return rcm;
+      rcm = enqueue_controller(h, PH_INITB, st);
+      if (rcm != 0) return rcm;
+    }
+    h->begun = 1;
+    return 0;
+  }
   // f0 = f(t0, y0) with the norms of misc._select_initial_step riding along (dopri5.py:71-75)
   StageArgs A;
   fill_common(h, A);
@@ -588,6 +639,7 @@ extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, 
 // ------------------------------------------------------------------------------------------------
 extern "C" int mi_ode_eval_rhs(mi_ode_handle h, const void* y_dev, double t, void* f_dev, void* stream) {
   if (h == nullptr || y_dev == nullptr || f_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (h->family == FAM_MLP) { mi_set_error("eval_rhs: not available for the MLP family"); return MI_ODE_E_INVALID; }
   StageArgs A;
   fill_common(h, A);
   A.explicit_mode = 1; A.ctl = nullptr;
@@ -599,6 +651,7 @@ extern "C" int mi_ode_rk_step_fused(mi_ode_handle h, const void* y0_dev, const v
                                     void* y1_dev, void* f1_dev, double* err_norms_host, void* k_out_dev, void* stream) {
   if (h == nullptr || y0_dev == nullptr || f0_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
   if (!h->d.adaptive) { mi_set_error("rk_step_fused needs an adaptive handle"); return MI_ODE_E_INVALID; }
+  if (h->family == FAM_MLP) { mi_set_error("rk_step_fused: not available for the MLP family"); return MI_ODE_E_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   const mi_ode_tableau& tb = h->d.tableau;
   const size_t pbytes = (size_t)h->n * h->elt;

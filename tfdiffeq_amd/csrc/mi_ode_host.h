@@ -5,6 +5,7 @@
 
 namespace mi {
 struct StepArgs;
+struct MlpArgs;
 
 enum Family {
   FAM_NONE = 0,
@@ -13,7 +14,8 @@ enum Family {
   FAM_LV,            // rowlocal, dim 2
   FAM_LORENZ,        // rowlocal, dim 3
   FAM_LINEAR_VALU,   // any dim <= 256, optional cube / bias
-  FAM_LINEAR_MFMA    // dim in {16, 32, 64, 128}
+  FAM_LINEAR_MFMA,   // dim in {16, 32, 64, 128}
+  FAM_MLP            // fp32 dim<=64, hidden<=128: whole-attempt MFMA kernel only
 };
 
 struct LaunchInfo {   // filled per (mode) at create time
@@ -50,6 +52,7 @@ struct mi_ode_solver {
   int step_fused;             // 1: whole-attempt kernel in use
   int step_grid, step_block;
   int allk;                   // step kernel writes every k plane (tsit5 dense output)
+  int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation
   // bookkeeping
   long long n_launches;
   int n_polls;
@@ -72,6 +75,7 @@ int mi_launch_stage_f64(mi_ode_solver* h, int mode, int nk, mi::StageArgs& A, hi
 int mi_launch_stage_f32(mi_ode_solver* h, int mode, int nk, mi::StageArgs& A, hipStream_t st);
 int mi_launch_step_f64(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
 int mi_launch_step_f32(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
+int mi_launch_mlp_f32(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st);
 int mi_stage_geometry_f64(mi_ode_solver* h);
 int mi_stage_geometry_f32(mi_ode_solver* h);
 

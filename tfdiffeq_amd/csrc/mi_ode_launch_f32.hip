@@ -2,3 +2,37 @@
 #define MI_T float
 #define MI_SUFFIX f32
 #include "mi_ode_launch.inc"
+
+// ---- fused MLP kernels (fp32 only) ---------------------------------------------------------------------------
+#include "mi_ode_mlp.h"
+
+namespace {
+template <int DP, int HP>
+int launch_mlp_dims(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st) {
+  using G = mi::MlpGeom<DP, HP>;
+  const size_t lds = G::lds_bytes();
+  const dim3 grid(h->step_grid), block(64 * G::NW);
+  const bool s6 = h->S == 6;
+  if (mode == mi::MLP_F0) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_F0, 6, false>), grid, block, lds, st, M);
+  else if (mode == mi::MLP_INITB) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_INITB, 6, false>), grid, block, lds, st, M);
+  else if (s6 && !h->allk) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 6, false>), grid, block, lds, st, M);
+  else if (s6 && h->allk) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 6, true>), grid, block, lds, st, M);
+  else if (!h->allk) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 3, false>), grid, block, lds, st, M);
+  else hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 3, true>), grid, block, lds, st, M);
+  return 0;
+}
+}  // namespace
+
+int mi_launch_mlp_f32(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st) {
+  int rc = MI_ODE_E_INVALID;
+  if (h->mlp_dp == 16 && h->mlp_hp == 16) rc = launch_mlp_dims<16, 16>(h, mode, M, st);
+  else if (h->mlp_dp == 16 && h->mlp_hp == 128) rc = launch_mlp_dims<16, 128>(h, mode, M, st);
+  else if (h->mlp_dp == 64 && h->mlp_hp == 16) rc = launch_mlp_dims<64, 16>(h, mode, M, st);
+  else if (h->mlp_dp == 64 && h->mlp_hp == 128) rc = launch_mlp_dims<64, 128>(h, mode, M, st);
+  else { mi_set_error("MLP kernel: unsupported padded dims"); return MI_ODE_E_INVALID; }
+  if (rc != 0) return rc;
+  h->n_launches += 1;
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { mi_set_error("MLP kernel launch failed: %s", hipGetErrorString(e)); return MI_ODE_E_HIP; }
+  return 0;
+}

@@ -65,6 +65,8 @@ class DeviceRHS(object):
         return (self.kind, self.dim, float(self.sign), tuple(r.scalars), tuple(int(v or 0) for v in r.w),
                 tuple(int(v or 0) for v in r.b), int(r.hidden))
 
+    fixed_grid_fused = True
+
     def supports(self, y0):
         """True when the fused kernels can take this state tensor."""
         return y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
@@ -193,8 +195,11 @@ class MLPTanh(DeviceRHS):
                 h = torch.tanh(h)
         return h
 
+    fixed_grid_fused = False     # the fused MLP kernel is the whole-attempt (adaptive) kernel only
+
     def supports(self, y0):
-        return False          # no fused stage kernel yet: runs through the plane kernels + torch matmul
+        return (y0.dim() == 2 and y0.shape[-1] == self.dim and y0.dtype == torch.float32
+                and self.dim <= 64 and self.hidden <= 128)
 
     def fill(self, rhs, dtype, device):
         keep = super(MLPTanh, self).fill(rhs, dtype, device)

@@ -321,8 +321,8 @@ class FixedGridODESolver(object):
         _assert_increasing(t)
         t = t.to(self.y0[0].dtype)                    # :84 time in the STATE dtype here
         rhs = _fusable(self.func, self.y0)
-        if (rhs is not None and self._fused_tableau is not None and getattr(self, '_default_grid', False)
-                and self.eps == 0.0):
+        if (rhs is not None and rhs.fixed_grid_fused and self._fused_tableau is not None
+                and getattr(self, '_default_grid', False) and self.eps == 0.0):
             y = self.y0[0]
             key = ('fixed', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
                    _tableau_key(self._fused_tableau, None))
