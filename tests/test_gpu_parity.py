@@ -213,7 +213,7 @@ def _run_product(name, engine, fusion=None):
     opts = dict(meta['options'] or {})
     if meta['method'] == 'tsit5':
         opts['refcompat'] = True                       # the fixtures hold the reference's (defective) tsit5
-    if fusion is not None and meta['method'] in ('dopri5', 'bosh3', 'tsit5'):
+    if fusion is not None and (meta['method'] in ('dopri5', 'bosh3', 'tsit5') or engine == 'fused'):
         opts['fusion'] = fusion
     if opts:
         kw['options'] = opts
@@ -251,8 +251,10 @@ def test_fused_engine_reproduces_reference_runs(name, fusion):
     _, meta0 = load(name)
     if fusion == 'step' and meta0['rhs'] == 'linear' and len(meta0['rhs_params']['W']) not in (2, 16, 32, 64, 128):
         fusion = 'auto'                                 # no whole-attempt kernel for the VALU fallback family
-    if meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') and fusion == 'stage':
-        pytest.skip('fixed grid has one path')
+    if meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') and meta0['rhs'] == 'linear':
+        if fusion == 'stage':
+            pytest.skip('fixed grid + linear RHS has one path (per-stage MFMA kernels)')
+        fusion = 'auto'
     if meta0['rhs'] == 'mlp_tanh' and fusion == 'stage':
         pytest.skip('the MLP family only has the whole-attempt kernel')
     d, meta, sol, stats = _run_product(name, 'fused', fusion)

@@ -161,15 +161,8 @@ static void launch_emit_t(mi_ode_solver* h, void* out, hipStream_t st) {
 }
 
 static int enqueue_emit(mi_ode_solver* h, void* out, hipStream_t st) {
-  if (h->step_fused && !h->allk) {
-    const int g = streaming_grid(h->n);
-    if (h->is_f32)
-      hipLaunchKernelGGL(k_emit_mid<float>, dim3(g), dim3(256), 0, st, (const Ctl*)h->ctl, (const char*)h->planes, h->stride,
-                         h->n, (const double*)h->t_out_dev, (float*)out, h->S, 1);
-    else
-      hipLaunchKernelGGL(k_emit_mid<double>, dim3(g), dim3(256), 0, st, (const Ctl*)h->ctl, (const char*)h->planes, h->stride,
-                         h->n, (const double*)h->t_out_dev, (double*)out, h->S, 1);
-  } else if (h->is_f32) launch_emit_t<float>(h, out, st);
+  if (h->step_fused) return 0;                 // the whole-attempt kernels emit from registers
+  if (h->is_f32) launch_emit_t<float>(h, out, st);
   else launch_emit_t<double>(h, out, st);
   h->n_launches += 1;
   return 0;
@@ -264,7 +257,7 @@ static void fill_step_args(mi_ode_solver* h, StepArgs& A) {
   const mi_ode_tableau& tb = h->d.tableau;
   memset(&A, 0, sizeof(A));
   A.ctl = h->ctl; A.planes = h->planes; A.stride = h->stride; A.batch = h->d.batch; A.dim = (int)h->d.dim;
-  A.ymid_slot = h->allk ? -1 : 1;
+  A.interp = h->d.interp; A.out = h->cur_out; A.t_out = h->t_out_dev; A.n_plane = h->n;
   for (int i = 0; i < h->S; ++i) {
     A.alpha[i] = tb.alpha[i];
     for (int j = 0; j <= i; ++j) A.beta[i][j] = tb.beta[i][j];
@@ -338,7 +331,9 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     const bool can = desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
                                         h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP);
     if (h->family == FAM_MLP && desc->fusion == 1) { mi_set_error("the MLP family only has a whole-attempt kernel"); delete h; return MI_ODE_E_INVALID; }
-    if (desc->fusion == 2 && !can) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); delete h; return MI_ODE_E_INVALID; }
+    const bool can_fixed = !desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
+                                               h->family == FAM_LORENZ);
+    if (desc->fusion == 2 && !can && !can_fixed) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); delete h; return MI_ODE_E_INVALID; }
     h->step_fused = (can && desc->fusion != 1) ? 1 : 0;
     h->allk = (desc->interp != MI_ODE_INTERP_QUARTIC_MID) ? 1 : 0;
   }
@@ -488,6 +483,7 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
   memcpy(h->t_out_host, t_out_host, (size_t)n_out * sizeof(double));
   MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)n_out * sizeof(double), hipMemcpyHostToDevice, st));
   h->cp.t_out = h->t_out_dev;
+  h->cur_out = out_dev;
   hipLaunchKernelGGL(k_set_outputs, dim3(1), dim3(64), 0, st, h->ctl, (int)n_out);
   h->n_launches += 1;
   const double t_end = t_out_host[n_out - 1];
@@ -587,6 +583,28 @@ extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, 
     }
   h->n_launches = 0; h->n_polls = 0;
   const size_t pbytes = (size_t)h->n * h->elt;
+  if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ) &&
+      h->d.fusion != 1) {
+    // tiny row-local systems: the whole integration is ONE launch (k_fixed_rowlocal)
+    int rcf = ensure_t_out(h, T);
+    if (rcf != 0) return rcf;
+    MI_HIP(hipStreamSynchronize(st));
+    memcpy(h->t_out_host, t_host, (size_t)T * sizeof(double));
+    MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)T * sizeof(double), hipMemcpyHostToDevice, st));
+    FixedArgs F;
+    memset(&F, 0, sizeof(F));
+    F.y0 = y0_dev; F.out = out_dev; F.t = h->t_out_dev; F.batch = h->d.batch; F.T = T; F.rk4 = euler ? 0 : 1; F.rhs = h->rhs;
+    rcf = h->is_f32 ? mi_launch_fixed_f32(h, F, st) : mi_launch_fixed_f64(h, F, st);
+    if (rcf != 0) return rcf;
+    if (stats) {
+      memset(stats, 0, sizeof(*stats));
+      stats->nfe = (long long)(euler ? 1 : 4) * (T - 1);
+      stats->n_attempts = stats->n_accepted = T - 1;
+      stats->t = t_host[T - 1];
+      stats->n_launches = h->n_launches;
+    }
+    return 0;
+  }
   MI_HIP(hipMemcpyAsync(out_dev, y0_dev, pbytes, hipMemcpyDeviceToDevice, st));
   char* k0 = h->planes + 2 * h->stride;
   char* k1 = k0 + h->stride;

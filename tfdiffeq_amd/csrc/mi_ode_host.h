@@ -6,6 +6,7 @@
 namespace mi {
 struct StepArgs;
 struct MlpArgs;
+struct FixedArgs;
 
 enum Family {
   FAM_NONE = 0,
@@ -42,6 +43,7 @@ struct mi_ode_solver {
   double* gathered;           // [world][kRec]
   mi::Ctl* ctl;
   double* t_out_dev;
+  void* cur_out;              // solution rows of the advance() call in progress
   int t_out_cap;
   // pinned host staging
   mi::Ctl* ctl_host;
@@ -75,6 +77,8 @@ int mi_launch_stage_f64(mi_ode_solver* h, int mode, int nk, mi::StageArgs& A, hi
 int mi_launch_stage_f32(mi_ode_solver* h, int mode, int nk, mi::StageArgs& A, hipStream_t st);
 int mi_launch_step_f64(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
 int mi_launch_step_f32(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
+int mi_launch_fixed_f64(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
+int mi_launch_fixed_f32(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
 int mi_launch_mlp_f32(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st);
 int mi_stage_geometry_f64(mi_ode_solver* h);
 int mi_stage_geometry_f32(mi_ode_solver* h);

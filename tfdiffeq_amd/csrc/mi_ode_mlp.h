@@ -4,7 +4,7 @@
 // The whole RK attempt runs per 32-row tile: the three layers go through v_mfma_f32_16x16x4_f32 (exact fp32), every
 // wave keeps its 16-column slices of W1/W2/W3 in registers, activations travel through LDS, the stage derivatives
 // k_1..k_{S+1} of the tile stay in registers (accumulator layout of layer 3).  HBM traffic per attempt: y0, f0 in;
-// y1, f1, y_mid out = 5 planes.  Bound: fp32 matrix pipe (1024 flop per state element per stage vs 20 B).
+// y1, f1 out = 4 planes (+ speculative dense output, see mi_ode_step_fused.h).  Bound: fp32 matrix pipe (1024 flop per state element per stage vs 20 B).
 // DP / HP are the padded widths (multiples of 16) the kernel is instantiated for; the real dim / hidden may be smaller
 // (weights are zero-padded in registers, state columns are masked).
 #pragma once
@@ -104,16 +104,15 @@ struct MlpArgs {
   int hidden;                // real hidden width
 };
 
-template <int DP, int HP, int MODE, int S, bool ALLK>
+template <int DP, int HP, int MODE, int S, bool TS>
 __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
   using G = MlpGeom<DP, HP>;
   const StepArgs& A = M.step;
   StepPlanes<float, S> P;
   if (MODE == MLP_F0) {
     P.y0 = (const float*)M.x_y0;
-    P.f0 = nullptr; P.y1 = nullptr; P.ymid = nullptr; P.hs = 0.f; P.t0 = 0.f;
-    for (int j = 0; j <= S; ++j) P.k[j] = nullptr;
-    P.k[0] = (float*)(A.planes + 2 * A.stride);             // idx_k[0] of a fresh handle
+    P.f0 = nullptr; P.y1 = nullptr; P.hs = 0.f; P.t0 = 0.f; P.j_lo = P.j_hi = 0;
+    P.f1 = (float*)(A.planes + 2 * A.stride);               // F0 writes f0 into idx_k[0] of a fresh handle
   } else {
     if (!resolve_step<float, S>(A, P)) return;
     if (MODE == MLP_INITB) P.hs = (float)A.ctl->h0;
@@ -198,7 +197,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
         const long long row = row0 + rbase + i;
         if (owner && row < A.batch) {
           const float f0 = sign * kn[i];
-          P.k[0][row * d + col] = f0;
+          P.f1[row * d + col] = f0;
           const float sc = (float)M.atol + fabsf(y0e[i]) * (float)M.rtol;      // misc.py:225
           const double q0 = (double)(y0e[i] / sc), q1 = (double)(f0 / sc);
           acc.suma += q0 * q0; acc.sumb += q1 * q1;
@@ -259,13 +258,8 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
         step_finish<float, S>(y0e[i], kk, hs, A, err, ymid);
         const long long idx = row * d + col;
         P.y1[idx] = ys[i];
-        P.k[S][idx] = k[S][i];
-        if constexpr (ALLK) {
-#pragma unroll
-          for (int j = 1; j < S; ++j) P.k[j][idx] = k[j][i];
-        } else {
-          if (P.ymid != nullptr) P.ymid[idx] = ymid;
-        }
+        P.f1[idx] = k[S][i];
+        step_emit<float, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx);
         acc.maxa = fmax(acc.maxa, (double)fabsf(y0e[i]));
         acc.maxb = fmax(acc.maxb, (double)fabsf(ys[i]));
         acc.suma += (double)err * (double)err;

@@ -3,14 +3,18 @@
 // Legal because every catalogue RHS is trajectory(row)-local: k_2..k_S never have to visit HBM.  Traffic per
 // attempt drops from 34 planes (per-stage structure) to
 //     reads  y0, f0                       2 planes
-//     writes y1, f1, y_mid                3 planes      (y_mid = y0 + dt*sum c_mid_j k_j feeds the quartic dense output)
-//   = 5 planes  (tsit5's seven-weight dense output needs every k: 2 + 8 = 10 planes with ALLK).
+//     writes y1, f1                       2 planes
+//     (+ one plane per requested output time that falls into (t0, t0+dt])
+// Dense output is evaluated HERE, from registers (y0, y1, k_1..k_{S+1} are all live at the end of the attempt), and
+// written speculatively: if the attempt is rejected, the same output indices are simply overwritten by the
+// accepted step that eventually covers those times (the output cursor only advances on accept).
 // The arithmetic is the per-stage kernels' arithmetic, operation for operation (same combine order, same MFMA
 // accumulation order), so both paths produce identical bits; only the schedule differs.
 // Bound: tiny systems (dim 2-3) stay HBM/latency-bound; the linear RHS at dim 128 becomes fp64-MFMA-bound
 // (6 x 256 flop per element per attempt against 40 B).
 #pragma once
 #include <type_traits>
+#include "mi_ode_dense.h"
 #include "mi_ode_dev.h"
 #include "mi_ode_stage_linear.h"
 #include "mi_ode_stage_rowlocal.h"
@@ -23,7 +27,10 @@ struct StepArgs {
   long long stride;
   long long batch;
   int dim;
-  int ymid_slot;               // idx_k slot that receives y_mid (quartic dense output); -1: none
+  int interp;                  // MI_ODE_INTERP_* of the solver
+  void* out;                   // [n_out, n_plane] solution rows of the current advance() call
+  const double* t_out;         // device: requested output times
+  long long n_plane;           // batch * dim
   double beta[MI_ODE_MAX_STAGES][MI_ODE_MAX_STAGES];
   double alpha[MI_ODE_MAX_STAGES];
   double e[kMaxK];             // c_error
@@ -37,9 +44,10 @@ struct StepPlanes {
   const T* y0;
   const T* f0;
   T* y1;
-  T* k[S + 1];                 // k[j] for j >= 1: output planes (ALLK), k[S] = f1
-  T* ymid;
+  T* f1;                       // plane idx_k[S]
   T hs, t0;
+  double t_start, t_new, dt64; // attempt interval in float64 (dopri5.py:113-116)
+  int j_lo, j_hi;              // requested outputs in (t_start, t_new]
 };
 
 template <typename T, int S>
@@ -50,11 +58,15 @@ __device__ __forceinline__ bool resolve_step(const StepArgs& A, StepPlanes<T, S>
   P.y0 = (const T*)(base + (long long)c->idx_y0 * A.stride);
   P.y1 = (T*)(base + (long long)c->idx_y1 * A.stride);
   P.f0 = (const T*)(base + (long long)c->idx_k[0] * A.stride);
-#pragma unroll
-  for (int j = 0; j <= S; ++j) P.k[j] = (T*)(base + (long long)c->idx_k[j] * A.stride);
-  P.ymid = A.ymid_slot >= 0 ? (T*)(base + (long long)c->idx_k[A.ymid_slot] * A.stride) : nullptr;
+  P.f1 = (T*)(base + (long long)c->idx_k[S] * A.stride);
   P.hs = (T)c->dt;                               // rk_common.py:46
   P.t0 = (T)c->t1;                               // rk_common.py:45
+  P.t_start = c->t1; P.dt64 = c->dt; P.t_new = c->t1 + c->dt;
+  int j = c->next_out;
+  P.j_lo = j;
+  if (A.t_out != nullptr)
+    while (j < c->n_out && !(A.t_out[j] > P.t_new)) ++j;     // same test as the controller's output cursor
+  P.j_hi = j;
   return true;
 }
 
@@ -80,10 +92,27 @@ __device__ __forceinline__ void step_finish(T y0, const T* k, T hs, const StepAr
   ymid = y0 + ym;
 }
 
+// speculative dense output of one element for every requested time inside the attempt
+template <typename T, int S, bool TS>
+__device__ __forceinline__ void step_emit(const StepArgs& A, const StepPlanes<T, S>& P, T y0, T y1, const T* k, T ymid,
+                                          long long idx) {
+  if (P.j_hi <= P.j_lo) return;
+  T* out = (T*)A.out;
+  if constexpr (TS) {
+    for (int j = P.j_lo; j < P.j_hi; ++j)
+      out[(long long)j * A.n_plane + idx] = tsit5_dense<T, S + 1>(y0, k, P.t_start, P.t_new, A.t_out[j], A.interp);
+  } else {
+    T co[5];
+    quartic_from_mid<T>(y0, y1, ymid, k[0], k[S], (T)P.dt64, co);
+    for (int j = P.j_lo; j < P.j_hi; ++j)
+      out[(long long)j * A.n_plane + idx] = quartic_eval<T>(co, interp_x<T>(P.t_start, P.t_new, A.t_out[j]));
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // (1) tiny row-local systems: one thread per trajectory, everything in registers, one launch per attempt
 // ------------------------------------------------------------------------------------------------
-template <typename T, int S, bool ALLK, class RHS>
+template <typename T, int S, bool TS, class RHS>
 __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
   constexpr int D = RHS::D;
   using Row = RowVec<T, D>;
@@ -125,7 +154,7 @@ __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
       stage(std::integral_constant<int, 5>{});
       stage(std::integral_constant<int, 6>{});
     }
-    Row y1, f1, ym;
+    Row y1, f1;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       T kk[S + 1];
@@ -135,27 +164,76 @@ __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
       step_finish<T, S>(y0.v[d], kk, hs, A, err, ymid);
       y1.v[d] = ys[d];                                       // FSAL: y1 = y_S (rk_common.py:58)
       f1.v[d] = k[S][d];
-      ym.v[d] = ymid;
       acc.maxa = fmax(acc.maxa, (double)fabs(y0.v[d]));
       acc.maxb = fmax(acc.maxb, (double)fabs(ys[d]));
       acc.suma += (double)err * (double)err;
+      step_emit<T, S, TS>(A, P, y0.v[d], ys[d], kk, ymid, row * D + d);
     }
     *(Row*)(P.y1 + row * D) = y1;
-    *(Row*)(P.k[S] + row * D) = f1;
-    if constexpr (ALLK) {
-#pragma unroll
-      for (int j = 1; j < S; ++j) {
-        Row kj;
-#pragma unroll
-        for (int d = 0; d < D; ++d) kj.v[d] = k[j][d];
-        *(Row*)(P.k[j] + row * D) = kj;
-      }
-    } else {
-      if (P.ymid != nullptr) *(Row*)(P.ymid + row * D) = ym;
-    }
+    *(Row*)(P.f1 + row * D) = f1;
   }
   __shared__ double red[80];
   block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1b) fixed grid (solvers.py:82-104) for the tiny row-local systems: trajectories never interact on a fixed grid,
+//      so the WHOLE integration is one launch: a thread carries its trajectory through every grid interval in
+//      registers (Euler: fixed_grid.py:6-7, RK4 3/8 rule: rk_common.py:73-81, literally) and streams solution[i+1].
+//      Traffic = y0 in + T solution rows out; no k planes, no per-step launches.
+// ------------------------------------------------------------------------------------------------
+struct FixedArgs {
+  const void* y0;
+  void* out;                   // [T, batch*D]
+  const double* t;             // device: the grid (= requested times), float64
+  long long batch;
+  int T;
+  int rk4;                     // 0: Euler, 1: RK4 (3/8 rule)
+  RhsParams rhs;
+};
+
+template <typename T, class RHS>
+__global__ __launch_bounds__(256) void k_fixed_rowlocal(FixedArgs A) {
+  constexpr int D = RHS::D;
+  using Row = RowVec<T, D>;
+  const RHS rhs(A.rhs);
+  const T sign = (T)A.rhs.sign;
+  const long long n = A.batch * D;
+  const T* y0p = (const T*)A.y0;
+  T* out = (T*)A.out;
+  for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < A.batch;
+       row += (long long)gridDim.x * blockDim.x) {
+    Row y = *(const Row*)(y0p + row * D);
+    *(Row*)(out + row * D) = y;                              // solution = [y0]
+    for (int i = 0; i + 1 < A.T; ++i) {
+      const T t0 = (T)A.t[i];                                // solvers.py:84: the grid is cast to the STATE dtype
+      const T dt = (T)A.t[i + 1] - t0;
+      T k1[D], k2[D], k3[D], k4[D], ys[D];
+      rhs(sign * t0, y.v, k1);
+#pragma unroll
+      for (int d = 0; d < D; ++d) k1[d] = sign * k1[d];
+      if (!A.rk4) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) y.v[d] = y.v[d] + dt * k1[d];                       // fixed_grid.py:7
+      } else {
+#pragma unroll
+        for (int d = 0; d < D; ++d) ys[d] = y.v[d] + dt * k1[d] / (T)3;                 // rk_common.py:77
+        rhs(sign * (t0 + dt / (T)3), ys, k2);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { k2[d] = sign * k2[d]; ys[d] = y.v[d] + dt * (k1[d] / (T)-3 + k2[d]); }   // :78
+        rhs(sign * (t0 + dt * (T)2 / (T)3), ys, k3);
+#pragma unroll
+        for (int d = 0; d < D; ++d) { k3[d] = sign * k3[d]; ys[d] = y.v[d] + dt * (k1[d] - k2[d] + k3[d]); }   // :79
+        rhs(sign * (t0 + dt), ys, k4);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          k4[d] = sign * k4[d];
+          y.v[d] = y.v[d] + (k1[d] + (T)3 * k2[d] + (T)3 * k3[d] + k4[d]) * (dt / (T)8);                       // :81
+        }
+      }
+      *(Row*)(out + (long long)(i + 1) * n + row * D) = y;
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -165,7 +243,7 @@ __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
 //     barrier -> 32 MFMA steps against the wave's resident W slice -> k_{sigma+1} (registers) -> barrier.
 //     y0 / f0 of the NEXT tile are prefetched into registers during the stages of the current one.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D, int S, bool ALLK>
+template <typename T, int D, int S, bool TS>
 __global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
   using TR = MfmaTraits<T>;
   using acc_t = typename TR::acc_t;
@@ -265,13 +343,8 @@ __global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
         step_finish<T, S>(y0e[i], kk, hs, A, err, ymid);
         const long long idx = row * D + col;
         P.y1[idx] = ys[i];
-        P.k[S][idx] = k[S][i];
-        if constexpr (ALLK) {
-#pragma unroll
-          for (int j = 1; j < S; ++j) P.k[j][idx] = k[j][i];
-        } else {
-          if (P.ymid != nullptr) P.ymid[idx] = ymid;
-        }
+        P.f1[idx] = k[S][i];
+        step_emit<T, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx);
         acc.maxa = fmax(acc.maxa, (double)fabs(y0e[i]));
         acc.maxb = fmax(acc.maxb, (double)fabs(ys[i]));
         acc.suma += (double)err * (double)err;

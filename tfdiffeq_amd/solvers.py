@@ -280,6 +280,7 @@ class FixedGridODESolver(object):
         unused_kwargs.pop('rtol', None)
         unused_kwargs.pop('atol', None)
         self._pg = unused_kwargs.pop('process_group', None)     # accepted for symmetry; fixed grid needs no exchange
+        self._fusion = unused_kwargs.pop('fusion', 0)
         _handle_unused_kwargs(self, unused_kwargs)
         del unused_kwargs
         self.func = func
@@ -325,8 +326,8 @@ class FixedGridODESolver(object):
                 and getattr(self, '_default_grid', False) and self.eps == 0.0):
             y = self.y0[0]
             key = ('fixed', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
-                   _tableau_key(self._fused_tableau, None))
-            eng = _cached_engine(key, lambda: _FusedEngine(rhs, y, False, self._fused_tableau))
+                   _tableau_key(self._fused_tableau, None), self._fusion)
+            eng = _cached_engine(key, lambda: _FusedEngine(rhs, y, False, self._fused_tableau, fusion=self._fusion))
             out = eng.integrate(t.to(torch.float64).numpy(), y)
             self.stats = eng.stats.as_dict()
             return (out,)
