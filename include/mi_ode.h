@@ -135,7 +135,8 @@ typedef struct mi_ode_desc {
   int32_t use_graph;          /* 1: replay one captured hipGraph per attempt (world_size 1 only) */
   int32_t profile;            /* 1: bracket the stage kernels of every attempt with HIP events (mi_ode_get_profile) */
   int32_t fusion;             /* 0 auto, 1 one kernel per RK stage (34 planes/attempt), 2 whole attempt in one kernel
-                                 (5 planes/attempt; row-local RHS keep k_2..k_S on chip) */
+                                 (4 planes/attempt; row-local RHS keep k_2..k_S on chip; single rank: the controller
+                                 runs in the kernel's last workgroup), 3 as 2 but with the controller as its own launch */
   int32_t reserved;
 } mi_ode_desc;
 

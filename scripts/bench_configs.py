@@ -8,7 +8,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tfdiffeq_amd import odeint, rhs  # noqa: E402
 
 dev = torch.device('cuda:0')

@@ -574,3 +574,38 @@ def test_config5_mlp_fused_kernel_full_size():
     d1 = odeint(f, y0[:1000], t, rtol=1e-3, atol=1e-3, method='tsit5')
     d2 = odeint(f, y0[:1000], t, rtol=1e-3, atol=1e-3, method='tsit5', options={'force_plane_kernels': True})
     assert (d1 - d2).abs().max().item() < 5e-4 * max(1.0, d2.abs().max().item())
+
+
+@pytest.mark.parametrize('problem', ['lorenz_big', 'spiral_small', 'linear128', 'mlp'])
+def test_in_kernel_controller_is_bit_identical_to_the_separate_launch(problem):
+    """fusion='step' runs the controller in the last workgroup of the whole-attempt kernel (agent-scope
+    release/acquire hand-off of the reduction records); 'step_split' launches k_controller separately.
+    Same records, same reduction order, same scalar code => identical bits, every time (repeated to catch a
+    stale-read hand-off, which would show up as run-to-run differences)."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(9)
+    kw = dict(rtol=1e-6, atol=1e-9, method='dopri5')
+    if problem == 'lorenz_big':
+        f, y0, t = rhs.Lorenz(), to_dev(np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((300000, 3))), [0., 0.2, 0.5]
+    elif problem == 'spiral_small':
+        f = rhs.CubicLinear(torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64))
+        y0, t = to_dev(rng.uniform(-2, 2, size=(4096, 2))), list(np.linspace(0., 5., 7))
+    elif problem == 'linear128':
+        S = rng.standard_normal((128, 128))
+        A = -0.5 * np.eye(128) + 0.5 * (S - S.T) / np.sqrt(128)
+        f, y0, t = rhs.Linear.from_matrix(torch.tensor(A)), to_dev(rng.standard_normal((20000, 128))), [0., 0.5, 1.0]
+    else:
+        g = torch.Generator().manual_seed(4)
+        mk = lambda i, o: ((torch.rand(i, o, generator=g) * 2 - 1) * (6.0 / (i + o)) ** 0.5).to(dev())  # noqa: E731
+        f = rhs.MLPTanh(mk(64, 128), None, mk(128, 128), None, mk(128, 64), None)
+        y0, t = torch.randn(5000, 64, generator=torch.Generator().manual_seed(5)).to(dev()), [0., 0.5, 1.0]
+        kw = dict(rtol=1e-4, atol=1e-5, method='dopri5')
+    tt = torch.tensor(t, dtype=torch.float64)
+    ref = odeint(f, y0, tt, options={'fusion': 'step_split'}, **kw)
+    s_ref = dict(odeint.last_stats)
+    for _ in range(12):
+        got = odeint(f, y0, tt, options={'fusion': 'step'}, **kw)
+        s_got = dict(odeint.last_stats)
+        assert torch.equal(got, ref)
+        assert s_got['n_attempts'] == s_ref['n_attempts'] and s_got['n_accepted'] == s_ref['n_accepted']
+        assert s_got['n_launches'] < s_ref['n_launches']

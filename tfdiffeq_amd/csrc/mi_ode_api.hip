@@ -264,6 +264,8 @@ static void fill_step_args(mi_ode_solver* h, StepArgs& A) {
   }
   for (int j = 0; j <= h->S; ++j) { A.e[j] = tb.c_error[j]; A.cmid[j] = tb.c_mid[j]; }
   A.partials = h->partials; A.rhs = h->rhs;
+  A.ticket = h->fused_ctl ? h->ticket : nullptr;
+  A.cp = h->cp;
 }
 
 static void fill_mlp_args(mi_ode_solver* h, MlpArgs& M) {
@@ -279,6 +281,7 @@ extern "C" int mi_ode_destroy(mi_ode_handle h) {
   if (h->rank_rec && h->own_exchange) (void)hipFree(h->rank_rec);
   if (h->gathered && h->own_exchange) (void)hipFree(h->gathered);
   if (h->ctl) (void)hipFree(h->ctl);
+  if (h->ticket) (void)hipFree(h->ticket);
   if (h->t_out_dev) (void)hipFree(h->t_out_dev);
   if (h->ev_ready) for (int i = 0; i < 64; ++i) { (void)hipEventDestroy(h->ev_a[i]); (void)hipEventDestroy(h->ev_b[i]); (void)hipEventDestroy(h->ev_c[i]); }
   if (h->ctl_host) (void)hipHostFree(h->ctl_host);
@@ -336,6 +339,12 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     if (desc->fusion == 2 && !can && !can_fixed) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); delete h; return MI_ODE_E_INVALID; }
     h->step_fused = (can && desc->fusion != 1) ? 1 : 0;
     h->allk = (desc->interp != MI_ODE_INTERP_QUARTIC_MID) ? 1 : 0;
+    // In-kernel controller (last workgroup): measured equal or better than a separate k_controller launch for the
+    // heavy MFMA / MLP kernels and for small grids; for the feather-weight row-local kernels on many workgroups the
+    // serial tail (ticket + sc1 record reads) costs more than the extra launch (13.6 vs 15.5 us/attempt at config 3).
+    const bool light_many = (h->family != FAM_LINEAR_MFMA && h->family != FAM_MLP) && h->step_grid > 32;
+    h->fused_ctl = (h->step_fused && h->d.world_size <= 1 && desc->allgather == nullptr && desc->fusion != 3 &&
+                    !(light_many && desc->fusion == 0)) ? 1 : 0;
   }
   // controller / dense-output parameters
   h->cp.rtol = desc->rtol; h->cp.atol = desc->atol;
@@ -364,6 +373,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     if (e == hipSuccess) e = hipMalloc((void**)&h->gathered, (size_t)h->d.world_size * kRec * sizeof(double));
   }
   if (e == hipSuccess) e = hipMalloc((void**)&h->ctl, sizeof(Ctl));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->ticket, 64);
+  if (e == hipSuccess) e = hipMemset(h->ticket, 0, 64);
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->ctl_host, sizeof(Ctl), hipHostMallocDefault);
   if (e != hipSuccess) {
     mi_set_error("workspace allocation failed: %s", hipGetErrorString(e));
@@ -484,6 +495,7 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
   MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)n_out * sizeof(double), hipMemcpyHostToDevice, st));
   h->cp.t_out = h->t_out_dev;
   h->cur_out = out_dev;
+  MI_HIP(hipMemsetAsync(h->ticket, 0, 4, st));
   hipLaunchKernelGGL(k_set_outputs, dim3(1), dim3(64), 0, st, h->ctl, (int)n_out);
   h->n_launches += 1;
   const double t_end = t_out_host[n_out - 1];
@@ -498,8 +510,10 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
       if (rc != 0) return rc;
       if (prof) (void)hipEventRecord(h->ev_c[ei], st);
       h->enq_attempts += 1;
-      rc = enqueue_controller(h, PH_ATTEMPT, st);
-      if (rc != 0) return rc;
+      if (!h->fused_ctl) {                       // otherwise the whole-attempt kernel's last workgroup ran it
+        rc = enqueue_controller(h, PH_ATTEMPT, st);
+        if (rc != 0) return rc;
+      }
       rc = enqueue_emit(h, out_dev, st);
       if (rc != 0) return rc;
     }
@@ -511,7 +525,7 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
     if (h->d.chunk_attempts <= 0) {            // adaptive chunking: roughly the attempts still needed at the current dt
       double est = c->dt > 0 ? ceil((t_end - c->t1) / c->dt) : 4.0;
       if (!(est >= 1.0)) est = 1.0;
-      if (est > 32.0) est = 32.0;
+      if (est > 64.0) est = 64.0;
       chunk = (int)est;
     }
   }

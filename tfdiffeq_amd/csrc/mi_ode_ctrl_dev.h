@@ -1,0 +1,156 @@
+// Device-side controller arithmetic shared by k_controller (own launch) and the whole-attempt kernels
+// (last-workgroup-done epilogue): block-record reduction in a FIXED order and the reference's scalar logic.
+#pragma once
+#include "mi_ode_dev.h"
+
+namespace mi {
+
+// Reduce per-block records: slot s (0..255) takes blocks s, s+256, ...; then an LDS tree over the occupied slots.
+// The order does not depend on blockDim, so every caller (any workgroup size) produces the same bits.  All threads of
+// the workgroup must call it; the result is valid in thread 0.  SC1: read the records with agent-scope (sc1) loads -
+// the consumer side of the write-through hand-off used by the whole-attempt kernels' last workgroup.
+template <bool SC1>
+__device__ __forceinline__ double rec_load(const double* p) {
+  if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else return *p;
+}
+
+template <bool SC1 = false>
+__device__ __forceinline__ void reduce_block_records(const double* part, int nblocks, double* out /*[kRec]*/) {
+  __shared__ double s[5][256];
+  const int nt = (int)blockDim.x;
+  int width = 1;                                   // occupied slots, rounded up to a power of two (<= 256)
+  while (width < nblocks && width < 256) width <<= 1;
+  for (int slot = threadIdx.x; slot < width; slot += nt) {
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+    for (int b = slot; b < nblocks; b += 256) {
+      const double* p = part + (long long)b * kRec;
+      v0 = fmax(v0, rec_load<SC1>(p + R_MAXA)); v1 = fmax(v1, rec_load<SC1>(p + R_MAXB));
+      v2 += rec_load<SC1>(p + R_SUMA); v3 += rec_load<SC1>(p + R_SUMB); v4 = fmax(v4, rec_load<SC1>(p + R_FLAG));
+    }
+    s[0][slot] = v0; s[1][slot] = v1; s[2][slot] = v2; s[3][slot] = v3; s[4][slot] = v4;
+  }
+  __syncthreads();
+  for (int off = width >> 1; off > 0; off >>= 1) {
+    for (int slot = threadIdx.x; slot < off; slot += nt) {
+      s[0][slot] = fmax(s[0][slot], s[0][slot + off]);
+      s[1][slot] = fmax(s[1][slot], s[1][slot + off]);
+      s[2][slot] += s[2][slot + off];
+      s[3][slot] += s[3][slot + off];
+      s[4][slot] = fmax(s[4][slot], s[4][slot + off]);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[R_MAXA] = s[0][0]; out[R_MAXB] = s[1][0]; out[R_SUMA] = s[2][0]; out[R_SUMB] = s[3][0]; out[R_FLAG] = s[4][0];
+    out[R_N] = 0; out[6] = 0; out[7] = 0;
+  }
+}
+
+// NaN-propagating min / max, as tf.reduce_min / tf.reduce_max (and numpy) behave
+__device__ __forceinline__ double nan_min(double a, double b) { return (isnan(a) || isnan(b)) ? NAN : fmin(a, b); }
+__device__ __forceinline__ double nan_max(double a, double b) { return (isnan(a) || isnan(b)) ? NAN : fmax(a, b); }
+
+// misc._optimal_step_size (misc.py:267-287) / tsit5._optimal_step_size (tsit5.py:53-62)
+__device__ __forceinline__ double optimal_step(double last_step, double ratio, const CtrlParams& P) {
+  if (ratio == 0.0) return last_step * P.ifactor;
+  const double dfac = (ratio < 1.0) ? 1.0 : P.dfactor;
+  double er, expo;
+  if (P.controller == MI_ODE_CTRL_TSIT5) {
+    er = ratio;                                            // no sqrt (tsit5.py:59)
+    expo = 1.0 / (double)P.order;                          // true float64 exponent (tsit5.py:60)
+  } else {
+    er = P.is_f32 ? (double)sqrtf((float)ratio) : sqrt(ratio);   // sqrt in the ratio's dtype (misc.py:277-278)
+    expo = (double)(float)(1.0 / (double)P.order);         // float32 detour, F4 (misc.py:281-282)
+  }
+  const double factor = nan_max(1.0 / P.ifactor, nan_min(pow(er, expo) / P.safety, 1.0 / dfac));
+  return last_step / factor;
+}
+
+// One thread: apply the phase logic to the combined record `rec` with exactly the reference's scalar arithmetic.
+__device__ __forceinline__ void controller_apply(Ctl* c, const double* rec, int phase, const CtrlParams& P) {
+  const double N = rec[R_N];
+
+  if (phase == PH_F0) {                                    // misc.py:227-233
+    c->nfe += 1;
+    c->y0_nonfinite = rec[R_FLAG] != 0.0;
+    double d0, d1, h0;
+    if (P.is_f32) {
+      const float f0 = sqrtf((float)rec[R_SUMA]) / powf((float)N, 0.5f);
+      const float f1 = sqrtf((float)rec[R_SUMB]) / powf((float)N, 0.5f);
+      const float h = (f0 < 1e-5f || f1 < 1e-5f) ? 1e-6f : 0.01f * (f0 / f1);
+      d0 = f0; d1 = f1; h0 = h;
+    } else {
+      d0 = sqrt(rec[R_SUMA]) / pow(N, 0.5);
+      d1 = sqrt(rec[R_SUMB]) / pow(N, 0.5);
+      h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * (d0 / d1);
+    }
+    c->d0 = d0; c->d1 = d1; c->h0 = h0;
+    return;
+  }
+  if (phase == PH_INITB) {                                 // misc.py:236-245
+    c->nfe += 1;
+    double first;
+    if (P.is_f32) {
+      const float h0 = (float)c->h0, d1 = (float)c->d1;
+      const float d2 = (sqrtf((float)rec[R_SUMA]) / powf((float)N, 0.5f)) / h0;
+      float h1;
+      if (d1 <= 1e-15f && d2 <= 1e-15f) h1 = fmaxf(1e-6f, h0 * 1e-3f);
+      else h1 = powf(0.01f / fmaxf(d1, d2), (float)(1.0 / (double)(P.init_order + 1)));
+      first = (double)fminf(100.0f * h0, h1);
+    } else {
+      const double h0 = c->h0, d1 = c->d1;
+      const double d2 = (sqrt(rec[R_SUMA]) / pow(N, 0.5)) / h0;
+      double h1;
+      if (d1 <= 1e-15 && d2 <= 1e-15) h1 = fmax(1e-6, h0 * 1e-3);
+      else h1 = pow(0.01 / fmax(d1, d2), 1.0 / (double)(P.init_order + 1));
+      first = fmin(100.0 * h0, h1);
+    }
+    c->dt = first;
+    return;
+  }
+
+  // ---- PH_ATTEMPT: dopri5.py:103-121 -------------------------------------------------------
+  c->n_attempt += 1;
+  c->nfe += P.n_stages;
+  c->n_steps_out += 1;
+  const double dt = c->dt, t_start = c->t1;
+  double ratio;
+  if (P.is_f32) {                                          // misc.py:256-263 in the state dtype
+    const float tol = (float)P.atol + (float)P.rtol * (float)fmax(rec[R_MAXA], rec[R_MAXB]);
+    ratio = (double)(float)(rec[R_SUMA] / (N * (double)tol * (double)tol));
+  } else {
+    const double tol = P.atol + P.rtol * fmax(rec[R_MAXA], rec[R_MAXB]);
+    ratio = rec[R_SUMA] / (N * tol * tol);
+  }
+  c->ratio = ratio;
+  const bool accept = ratio <= 1.0;                        // NaN -> rejected (dopri5.py:108)
+  const double dt_next = optimal_step(dt, ratio, P);
+  c->accepted = accept ? 1 : 0;
+  c->emit_lo = c->emit_hi = c->next_out;
+  if (accept) {
+    c->n_accept += 1;
+    const double t_new = t_start + dt;
+    // the step's planes, for dense output
+    c->emit_y0 = c->idx_y0; c->emit_y1 = c->idx_y1;
+    for (int j = 0; j <= P.n_stages; ++j) c->emit_k[j] = c->idx_k[j];
+    c->emit_t0 = t_start; c->emit_t1 = t_new; c->emit_dt = dt;
+    // rotate: y1 becomes the state, k_S (= f1, FSAL) becomes f0
+    const int iy = c->idx_y0; c->idx_y0 = c->idx_y1; c->idx_y1 = iy;
+    const int ik = c->idx_k[0]; c->idx_k[0] = c->idx_k[P.n_stages]; c->idx_k[P.n_stages] = ik;
+    c->t0 = t_start; c->t1 = t_new;
+    // outputs that fall into (t_start, t_new]   (`while next_t > t1` exits, dopri5.py:84)
+    int nx = c->next_out;
+    while (nx < c->n_out && !(P.t_out[nx] > t_new)) ++nx;
+    if (nx > c->next_out) { c->emit_hi = nx; c->next_out = nx; c->n_steps_out = 0; }
+  } else {
+    c->n_reject += 1;
+    c->t0 = t_start;                                       // rejected: rk_state.t0 == rk_state.t1
+  }
+  c->dt = dt_next;
+  if (c->next_out >= c->n_out) { c->done = 1; return; }
+  if (c->n_steps_out >= P.max_num_steps) { c->status |= MI_ODE_ST_MAX_STEPS; c->done = 1; return; }   // dopri5.py:85
+  if (!(c->t1 + dt_next > c->t1)) { c->status |= MI_ODE_ST_DT_UNDERFLOW; c->done = 1; }               // dopri5.py:98
+}
+
+}  // namespace mi

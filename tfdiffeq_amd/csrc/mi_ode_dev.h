@@ -233,6 +233,9 @@ __device__ __forceinline__ double wave_max(double v) {
 }
 
 // Block-reduce an Acc and let thread 0 write one record.  `red` is >= 5*16 doubles of LDS.
+// SC1: store the record write-through with agent-scope (sc1) stores - the producer side of the in-kernel hand-off
+// to the last workgroup (no release fence needed; the caller drains vmcnt before taking its ticket).
+template <bool SC1 = false>
 __device__ __forceinline__ void block_reduce_store(const Acc& a, double* red, double* rec_out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   double v0 = wave_max(a.maxa), v1 = wave_max(a.maxb), v2 = wave_sum(a.suma), v3 = wave_sum(a.sumb);
@@ -248,8 +251,16 @@ __device__ __forceinline__ void block_reduce_store(const Acc& a, double* red, do
       r0 = fmax(r0, red[w]); r1 = fmax(r1, red[16 + w]); r2 += red[32 + w]; r3 += red[48 + w];
       r4 = fmax(r4, red[64 + w]);
     }
-    rec_out[R_MAXA] = r0; rec_out[R_MAXB] = r1; rec_out[R_SUMA] = r2; rec_out[R_SUMB] = r3;
-    rec_out[R_FLAG] = r4; rec_out[R_N] = 0; rec_out[6] = 0; rec_out[7] = 0;
+    if constexpr (SC1) {
+      __hip_atomic_store(rec_out + R_MAXA, r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rec_out + R_MAXB, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rec_out + R_SUMA, r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rec_out + R_SUMB, r3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rec_out + R_FLAG, r4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      rec_out[R_MAXA] = r0; rec_out[R_MAXB] = r1; rec_out[R_SUMA] = r2; rec_out[R_SUMB] = r3;
+      rec_out[R_FLAG] = r4; rec_out[R_N] = 0; rec_out[6] = 0; rec_out[7] = 0;
+    }
   }
 }
 

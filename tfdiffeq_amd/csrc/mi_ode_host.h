@@ -42,6 +42,8 @@ struct mi_ode_solver {
   double* rank_rec;           // [kRec]
   double* gathered;           // [world][kRec]
   mi::Ctl* ctl;
+  unsigned* ticket;           // last-workgroup-done counter of the whole-attempt kernels
+  int fused_ctl;              // 1: the whole-attempt kernel also runs the controller (single rank)
   double* t_out_dev;
   void* cur_out;              // solution rows of the advance() call in progress
   int t_out_cap;

@@ -267,7 +267,8 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
     }
     __syncthreads();
   }
-  block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
+  if constexpr (MODE == MLP_STEP) finish_attempt(A, acc, red);
+  else block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
 }
 
 }  // namespace mi

@@ -14,6 +14,7 @@
 // (6 x 256 flop per element per attempt against 40 B).
 #pragma once
 #include <type_traits>
+#include "mi_ode_ctrl_dev.h"
 #include "mi_ode_dense.h"
 #include "mi_ode_dev.h"
 #include "mi_ode_stage_linear.h"
@@ -37,7 +38,41 @@ struct StepArgs {
   double cmid[kMaxK];          // dense-output mid-point weights
   double* partials;
   RhsParams rhs;
+  // single-rank runs: the last workgroup to finish runs the step controller itself (one launch per attempt)
+  unsigned* ticket;            // device word, zero between launches; nullptr: the controller is a separate launch
+  CtrlParams cp;
 };
+
+// Epilogue of a whole-attempt kernel.  Every workgroup publishes its reduction record; the LAST one to arrive
+// (device-scope ticket) reduces all records and applies the controller.  Inter-workgroup visibility follows the
+// gfx950 write-through recipe (cdna_hip_programming.md Guideline 16, R1): the record is stored with agent-scope
+// (sc1, write-through) stores, the storing lane drains vmcnt, then takes a relaxed agent-scope ticket; the last
+// arriver reads the records with sc1 loads (which bypass its L1).  No release/acquire fence - a per-workgroup
+// `buffer_wbl2` costs microseconds here and made this path slower than a separate controller launch.
+// No workgroup reads Ctl after the controller modified it: every workgroup takes its ticket at its very end and
+// Ctl is only read at kernel start.
+__device__ __forceinline__ void finish_attempt(const StepArgs& A, const Acc& acc, double* red) {
+  if (A.ticket == nullptr) {
+    block_reduce_store<false>(acc, red, A.partials + (long long)blockIdx.x * kRec);
+    return;
+  }
+  block_reduce_store<true>(acc, red, A.partials + (long long)blockIdx.x * kRec);
+  __shared__ int s_last;
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(A.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __shared__ double rec[kRec];
+  reduce_block_records<true>(A.partials, (int)gridDim.x, rec);
+  if (threadIdx.x == 0) {
+    rec[R_N] = (double)A.cp.n_local;
+    controller_apply(A.ctl, rec, PH_ATTEMPT, A.cp);
+    __hip_atomic_store(A.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
 
 template <typename T, int S>
 struct StepPlanes {
@@ -173,7 +208,7 @@ __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
     *(Row*)(P.f1 + row * D) = f1;
   }
   __shared__ double red[80];
-  block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
+  finish_attempt(A, acc, red);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,7 +386,7 @@ __global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
       }
     }
   }
-  block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
+  finish_attempt(A, acc, red);
 }
 
 template <typename T, int D>

@@ -77,7 +77,7 @@ class _FusedEngine(object):
         d.linear_variant = int(linear_variant)
         d.chunk_attempts = int(chunk_attempts)
         d.profile = 1 if profile else 0
-        d.fusion = {'auto': 0, 'stage': 1, 'step': 2}.get(fusion, fusion)
+        d.fusion = {'auto': 0, 'stage': 1, 'step': 2, 'step_split': 3}.get(fusion, fusion)
         self._hook = None
         if process_group is not None:
             import torch.distributed as dist
