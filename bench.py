@@ -9,9 +9,13 @@ resident in HBM before the timed region.  Prints ONE JSON line on rank 0.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-roofline:     dominant kernel = the fused Dopri5 last stage (stage + error kernel, k_stage_linear_mfma<double,128,6,LAST_FSAL>):
-              reads y0, k1..k6, writes k7, y1  = 9 planes = 9 * batch*dim*8 B algorithmic bytes per launch; its duration is
-              measured with hipEvents on the launch stream inside libmi_ode (desc.profile).  HBM bound.
+roofline:     default (--fusion auto/step): the whole-attempt kernel k_step_linear_mfma<double,128,6> - all six Dopri5
+              stages, error norms and dense output for a 16-row tile stay on chip, 4 planes of HBM traffic per attempt, so the
+              bound is the fp64 matrix pipe: achieved = 6 * 2*dim flop per element per launch / launch duration.
+              --fusion stage: one kernel per RK stage (the structure the north star describes, 34 planes per attempt);
+              dominant kernel = stage 6 + error norms, 9 planes = 9 * batch*dim*8 B per launch, HBM bound.
+              Durations are measured with hipEvents on the launch stream inside libmi_ode (desc.profile); `traffic` is the
+              PMC figure of the committed rocprofv3 passes (profiles/*_summary.json).
 cpu_baseline: the oracle (numpy restatement of the reference algorithm, kind "port") on a bounded sample of the
               same workload on this host's cores.
 """
@@ -187,7 +191,7 @@ def main():
             flops = 6 * 2 * DIM * n_elem_rank
             ach = flops / (last_ms * 1e-3) / 1e12 if last_ms > 0 else 0.0
             roof = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': None,
+                    'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic('k_step_linear_mfma<double, 128, 6'),
                     'kernel': 'k_step_linear_mfma<double,128,6> (all 6 Dopri5 stages + error norms + y_mid, v_mfma_f64_16x16x4_f64)',
                     'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': 5 * n_elem_rank * 8,
                     'hbm_GBps_at_algorithmic_bytes': (5 * n_elem_rank * 8) / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0,

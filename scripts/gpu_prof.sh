@@ -1,21 +1,18 @@
 #!/bin/bash
-# rocprofv3 kernel trace (+ optional PMC passes) of bench.py; CSV summaries land in gpurun_out/prof*/
+# rocprofv3 of bench.py: kernel trace + stats, then separate PMC passes (FETCH_SIZE, WRITE_SIZE).
+# usage: gpu_prof.sh <tag> [bench args...]   -> gpurun_out/prof_<tag>/, gpurun_out/pmc_<tag>_<COUNTER>/
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 R=$PWD
-rm -rf gpurun_out/prof
-(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof" -o r01 -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/rocprof.log" 2>&1)
-echo "rocprof exit $?"
-find gpurun_out/prof -type f | head -20
-for f in $(find gpurun_out/prof -name "*kernel_stats.csv" | head -1); do cut -c1-250 "$f" | head -30; done
-find gpurun_out/prof -name "*kernel_trace.csv" -size +20M -delete; true
-if [ "${1:-}" = "pmc" ]; then
-  for C in FETCH_SIZE WRITE_SIZE; do
-    rm -rf gpurun_out/pmc_$C
-    (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d "$R/gpurun_out/pmc_$C" -o r01 -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/pmc_$C.log" 2>&1)
-    echo "pmc $C exit $?"
-    find gpurun_out/pmc_$C -name "*counter_collection.csv" | head -2
-  done
-fi
+TAG=${1:-default}; shift || true
+rm -rf gpurun_out/prof_$TAG
+(cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/prof_$TAG" -o r -- python "$R/bench.py" --steps 5 --warmup 1 --no-cpu-baseline "$@" > "$R/gpurun_out/rocprof_$TAG.log" 2>&1)
+echo "rocprof[$TAG] exit $?"
+for f in $(find gpurun_out/prof_$TAG -name "*kernel_stats.csv" | head -1); do cut -c1-200 "$f" | head -12; done
+for C in FETCH_SIZE WRITE_SIZE; do
+  rm -rf gpurun_out/pmc_${TAG}_$C
+  (cd /tmp && timeout 600 rocprofv3 --pmc $C --output-format csv -d "$R/gpurun_out/pmc_${TAG}_$C" -o r -- python "$R/bench.py" --steps 2 --warmup 1 --no-cpu-baseline "$@" > "$R/gpurun_out/pmc_${TAG}_$C.log" 2>&1)
+  echo "pmc[$TAG] $C exit $?"
+done

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 output of bench.py into profiles/: per-kernel durations (kernel trace) and HBM traffic per
 launch from the FETCH_SIZE / WRITE_SIZE PMC passes, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
 prescribes for gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> x2; WRITE_SIZE as is; both in KiB.
-Usage: python scripts/pmc_summary.py gpurun_out profiles/r01"""
+Usage: python scripts/pmc_summary.py gpurun_out <tag> profiles/r01_<tag>"""
 import collections
 import csv
 import json
@@ -10,13 +10,13 @@ import os
 import shutil
 import sys
 
-src, dst = sys.argv[1], sys.argv[2]
+src, tag, dst = sys.argv[1], sys.argv[2], sys.argv[3]
 os.makedirs(os.path.dirname(dst) or '.', exist_ok=True)
 out = {'note': 'real launches only (no-op launches after done are excluded by taking values >= 50% of the max)'}
-ks = os.path.join(src, 'prof', 'r01_kernel_stats.csv')
+ks = os.path.join(src, 'prof_' + tag, 'r_kernel_stats.csv')
 if os.path.exists(ks):
     shutil.copy(ks, dst + '_kernel_stats.csv')
-tr = os.path.join(src, 'prof', 'r01_kernel_trace.csv')
+tr = os.path.join(src, 'prof_' + tag, 'r_kernel_trace.csv')
 if os.path.exists(tr):
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(tr)):
@@ -28,7 +28,7 @@ if os.path.exists(tr):
                                'max_us': max(v), 'min_real_us': min(real)}
 pm = {}
 for C in ('FETCH_SIZE', 'WRITE_SIZE'):
-    f = os.path.join(src, 'pmc_' + C, 'r01_counter_collection.csv')
+    f = os.path.join(src, 'pmc_' + tag + '_' + C, 'r_counter_collection.csv')
     if not os.path.exists(f):
         continue
     shutil.copy(f, dst + '_pmc_' + C + '.csv')
