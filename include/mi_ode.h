@@ -46,7 +46,7 @@ extern "C" {
 #define MI_ODE_ABI_VERSION 1
 #define MI_ODE_MAX_STAGES 6          /* rows of the tableau (dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
-#define MI_ODE_MAX_LINCOMB 13        /* stateless lincomb: up to 13 planes (dopri8-sized) */
+#define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
 
 /* ---- status bits (also the bits of mi_ode_stats.status) --------------------------------- */
 #define MI_ODE_OK 0
@@ -132,7 +132,7 @@ typedef struct mi_ode_desc {
   /* tuning knobs (0 = default) */
   int32_t linear_variant;     /* 0 auto, 1 force VALU fallback, 2 force MFMA tile kernel */
   int32_t chunk_attempts;     /* attempts enqueued between host polls (0 = adaptive) */
-  int32_t use_graph;          /* 1: replay one captured hipGraph per attempt (world_size 1 only) */
+  int32_t reserved0;          /* (was a hipGraph knob: the attempt chain is GPU-latency-bound, not launch-bound - DESIGN.md) */
   int32_t profile;            /* 1: bracket the stage kernels of every attempt with HIP events (mi_ode_get_profile) */
   int32_t fusion;             /* 0 auto, 1 one kernel per RK stage (34 planes/attempt), 2 whole attempt in one kernel
                                  (4 planes/attempt; row-local RHS keep k_2..k_S on chip; single rank: the controller

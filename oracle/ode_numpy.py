@@ -67,6 +67,23 @@ TSIT5_FIXED = ButcherTableau(alpha=_TS_ALPHA, beta=_TS_BETA, c_sol=_TS_B + [0.],
                              c_error=list(_TS_X) + [-1. / 66.])
 
 
+# adaptive_huen.py:11-25
+ADAPTIVE_HEUN = ButcherTableau(alpha=[1.], beta=[[1.]], c_sol=[0.5, 0.5], c_error=[0.5, -0.5])
+ADAPTIVE_HEUN_C_MID = [0.5, 0.]
+
+
+def load_dopri8():
+    """dopri8.py:12-77 (Prince-Dormand RK8(7)13M): the float64 values captured from the reference module
+    (tests/golden/fn_tableaus_next.npz) - (tableau, c_mid)."""
+    import os
+    d = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests', 'golden',
+                             'fn_tableaus_next.npz'))
+    alpha = d['dopri8_alpha'].tolist()
+    beta = [d['dopri8_beta'][i, :i + 1].tolist() for i in range(len(alpha))]
+    return (ButcherTableau(alpha=alpha, beta=beta, c_sol=d['dopri8_c_sol'].tolist(), c_error=d['dopri8_c_error'].tolist()),
+            d['dopri8_c_mid'].tolist())
+
+
 def tableau_arrays(tb):
     """(alpha[S], beta[S,S] zero padded, c_sol[S+1], c_error[S+1]) as float64 arrays."""
     S = len(tb.alpha)
@@ -321,6 +338,10 @@ class AdaptiveRK(object):
                 self.c_mid, self.init_order, self.order = DOPRI5_C_MID, 4, 5
             elif method == 'bosh3':
                 self.tableau, self.c_mid, self.init_order, self.order = BOSH3, BOSH3_C_MID, 2, 3
+            elif method == 'dopri8':                         # dopri8.py:119-121, 163-165
+                (self.tableau, self.c_mid), self.init_order, self.order = load_dopri8(), 7, 8
+            elif method == 'adaptive_heun':                  # adaptive_huen.py:70-71, 112 (order=5 is the reference's)
+                self.tableau, self.c_mid, self.init_order, self.order = ADAPTIVE_HEUN, ADAPTIVE_HEUN_C_MID, 1, 5
             else:
                 raise KeyError(method)
         self.tsit5_fixed = tsit5_fixed
@@ -466,7 +487,7 @@ class FixedGrid(object):
         return tuple(a + s * (t - t0) for a, s in zip(y0, slope))
 
 
-ADAPTIVE = ('dopri5', 'bosh3', 'tsit5')
+ADAPTIVE = ('dopri5', 'bosh3', 'tsit5', 'dopri8', 'adaptive_heun')
 FIXED = ('euler', 'rk4', 'midpoint')
 
 

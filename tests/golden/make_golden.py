@@ -39,7 +39,7 @@ sys.modules['tfdiffeq.viz_utils'] = _viz
 sys.path.insert(0, '/root/reference')
 
 import tfdiffeq  # noqa: E402
-from tfdiffeq import misc, rk_common, interp, dopri5, tsit5, bosh3  # noqa: E402
+from tfdiffeq import misc, rk_common, interp, dopri5, tsit5, bosh3, dopri8, adaptive_huen  # noqa: E402
 
 LABEL = 'reference control-flow over numpy stand-in; TensorFlow absent'
 T = tf_standin.Tensor
@@ -238,7 +238,9 @@ def _trace_solver(cls, step_name):
     return orig, log
 
 
-TRACED = {'dopri5': (dopri5.Dopri5Solver, '_adaptive_dopri5_step'),
+TRACED = {'dopri8': (dopri8.Dopri8Solver, '_adaptive_dopri8_step'),
+          'adaptive_heun': (adaptive_huen.AdaptiveHeunSolver, '_adaptive_heun_step'),
+          'dopri5': (dopri5.Dopri5Solver, '_adaptive_dopri5_step'),
           'bosh3': (bosh3.Bosh3Solver, '_adaptive_bosh3_step'),
           'tsit5': (tsit5.Tsit5Solver, '_adaptive_tsit5_step')}
 
@@ -396,7 +398,68 @@ def gen_runs():
     del arr
 
 
+def _tab_dict(prefix, tb, c_mid):
+    S = len(tb.alpha)
+    beta = np.zeros((S, S))
+    for i, row in enumerate(tb.beta):
+        beta[i, :len(row)] = row
+    return {prefix + '_alpha': np.asarray(tb.alpha, dtype=np.float64), prefix + '_beta': beta,
+            prefix + '_c_sol': np.asarray(tb.c_sol, dtype=np.float64), prefix + '_c_error': np.asarray(tb.c_error, dtype=np.float64),
+            prefix + '_c_mid': np.asarray(c_mid, dtype=np.float64)}
+
+
+def gen_next_solvers():
+    """dopri8 (dopri8.py) and adaptive_heun (adaptive_huen.py) - same _runge_kutta_step path."""
+    tab = {}
+    tab.update(_tab_dict('dopri8', dopri8._DOPRI8_TABLEAU, dopri8.c_mid))
+    tab.update(_tab_dict('adaptive_heun', adaptive_huen._ADAPTIVE_HEUN_TABLEAU, adaptive_huen.AH_C_MID))
+    save('fn_tableaus_next', {'what': 'dopri8.py:12-77 and adaptive_huen.py:11-25 tableau constants as float64 values'}, **tab)
+    # the same numbers as a data file for the product package (values only, no source text)
+    import json as _json
+    out = {k: np.asarray(v).tolist() for k, v in _tab_dict('dopri8', dopri8._DOPRI8_TABLEAU, dopri8.c_mid).items()}
+    path = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'tfdiffeq_amd', 'tableaus', 'dopri8.json')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'w') as fh:
+        _json.dump({'source': 'Prince & Dormand RK8(7)13M coefficients as float64 values (dopri8.py:12-77)', **out}, fh, indent=0)
+    # function-level vectors
+    rng = np.random.default_rng(77)
+    y0 = rng.standard_normal((6, 4))
+    f1_ = rhs_tdep()
+    f = lambda tm, ys, _f=f1_: (_f(tm, ys[0]),)  # noqa: E731
+    t0, dt = 0.4, 0.125
+    f0 = f1_(tt(t0, np.float64), tt(y0))
+    out = {'y0': y0, 'f0': f0, 't0': np.float64(t0), 'dt': np.float64(dt)}
+    for n, tb, fit in (('dopri8', dopri8._DOPRI8_TABLEAU, dopri8._interp_fit_dopri8),
+                       ('adaptive_heun', adaptive_huen._ADAPTIVE_HEUN_TABLEAU, adaptive_huen._interp_fit_adaptive_heun)):
+        y1, f1, err, k = rk_common._runge_kutta_step(f, (tt(y0),), (f0,), tt(t0, np.float64), tt(dt, np.float64), tb)
+        out[n + '_y1'], out[n + '_f1'], out[n + '_err'] = y1[0], f1[0], err[0]
+        out[n + '_k'] = np.stack([kk._a for kk in k[0]])
+        coeff = fit((tt(y0),), y1, k, tt(dt, np.float64))
+        out[n + '_interp_eval'] = interp._interp_evaluate(coeff, tt(t0, np.float64), tt(t0 + dt, np.float64),
+                                                         tt(t0 + 0.3 * dt, np.float64))[0]
+    save('fn_rkstep_next_float64', {'rhs': 'tdep', 'dtype': 'float64'}, **out)
+    # whole runs: the reference's own unit-test configurations (tests/odeint_tests.py:62-68, 51-60)
+    f32t = np.linspace(1., 8., 10).astype(np.float32)
+    const = rhs_constant()
+    y0_c = np.float64(0.2 * np.float64(f32t[0]) + 3.0)
+    sine = rhs_sine()
+    y_exact_sine = lambda t: (-0.5 * t ** 4 * np.cos(2 * t) + 0.5 * t ** 3 * np.sin(2 * t)  # noqa: E731
+                              + 0.25 * t ** 2 * np.cos(2 * t) - t ** 3 + 2 * t ** 4 + (np.pi - 0.25) * t ** 2)
+    run_case('run_constant_dopri8', const, y0_c, f32t, 'dopri8', rtol=1e-12, atol=1e-14)
+    run_case('run_sine_dopri8', sine, np.float64(y_exact_sine(np.float64(f32t[0]))), f32t, 'dopri8', rtol=1e-12, atol=1e-14)
+    run_case('run_linear0_dopri8', rhs_linear(np.zeros((10, 10))), np.ones((1, 10)), f32t, 'dopri8', rtol=1e-12, atol=1e-14)
+    run_case('run_constant_adaptive_heun', const, y0_c, f32t, 'adaptive_heun')
+    run_case('run_linear0_adaptive_heun', rhs_linear(np.zeros((10, 10))), np.ones((1, 10)), f32t, 'adaptive_heun')
+    A = np.array([[-0.1, 2.0], [-2.0, -0.1]])
+    rng0 = np.random.default_rng(0)
+    y0b = rng0.uniform(-2, 2, size=(64, 2))
+    run_case('run_spiral_b64_dopri8', rhs_cubic(A), y0b, np.linspace(0., 5., 6), 'dopri8', rtol=1e-9, atol=1e-11)
+    run_case('run_spiral_b64_adaptive_heun', rhs_cubic(A), y0b, np.array([0., 0.5, 1.0]), 'adaptive_heun', rtol=1e-5, atol=1e-7)
+
+
 if __name__ == '__main__':
     np.random.seed(0)
-    gen_function_vectors()
-    gen_runs()
+    if '--next-only' not in sys.argv:
+        gen_function_vectors()
+        gen_runs()
+    gen_next_solvers()

@@ -609,3 +609,31 @@ def test_in_kernel_controller_is_bit_identical_to_the_separate_launch(problem):
         assert torch.equal(got, ref)
         assert s_got['n_attempts'] == s_ref['n_attempts'] and s_got['n_accepted'] == s_ref['n_accepted']
         assert s_got['n_launches'] < s_ref['n_launches']
+
+
+def test_next_solvers_rk_step_contract():
+    """SURVEY 8(f) rank 1 on the GPU: _runge_kutta_step with the 13-stage dopri8 tableau (14-plane lincomb) and the
+    non-FSAL adaptive_heun tableau, plus their dense output, against the reference vectors."""
+    from tfdiffeq_amd import interp as I
+    from tfdiffeq_amd import _native as N
+    from tfdiffeq_amd.rk_common import _runge_kutta_step, _is_fsal_shaped
+    from tfdiffeq_amd.dopri8 import _DOPRI8_TABLEAU, c_mid as C8
+    from tfdiffeq_amd.adaptive_huen import _ADAPTIVE_HEUN_TABLEAU, AH_C_MID
+    d, _ = load('fn_rkstep_next_float64')
+    tn, _ = load('fn_tableaus_next')
+    assert np.array_equal(np.asarray(_DOPRI8_TABLEAU.alpha), tn['dopri8_alpha'])
+    assert np.array_equal(np.asarray(_DOPRI8_TABLEAU.c_error), tn['dopri8_c_error']) and np.array_equal(np.asarray(C8), tn['dopri8_c_mid'])
+    assert not _is_fsal_shaped(_ADAPTIVE_HEUN_TABLEAU)
+    f_ = torch_rhs('tdep', {})
+    func = lambda t, ys: (f_(t, ys[0]),)  # noqa: E731
+    y0 = to_dev(d['y0'])
+    t0, dt = float(d['t0']), float(d['dt'])
+    f0 = f_(torch.full((), t0, dtype=y0.dtype, device=y0.device), y0)
+    for name, tb, cm in (('dopri8', _DOPRI8_TABLEAU, C8), ('adaptive_heun', _ADAPTIVE_HEUN_TABLEAU, AH_C_MID)):
+        y1, f1, err, k = _runge_kutta_step(func, (y0,), (f0,), t0, dt, tb)
+        assert_band(y1[0].cpu(), d[name + '_y1'], 1e-13, 1e-13, name + ' y1')
+        assert_band(f1[0].cpu(), d[name + '_f1'], 1e-13, 1e-13, name + ' f1')
+        assert_band(err[0].cpu(), d[name + '_err'], 1e-12, 1e-16, name + ' err')
+        assert_band(torch.stack(k[0]).cpu(), d[name + '_k'], 1e-13, 1e-13, name + ' k')
+        out = I._interp_eval_step(N.INTERP_QUARTIC_MID, (y0,), y1, k, cm, dt, t0, t0 + dt, t0 + 0.3 * dt)
+        assert_band(out[0].cpu(), d[name + '_interp_eval'], 1e-11, 1e-11, name + ' dense output')

@@ -14,7 +14,7 @@ CSRC = os.path.join(_HERE, 'csrc')
 
 MAX_STAGES = 6
 MAX_K = MAX_STAGES + 1
-MAX_LINCOMB = 13
+MAX_LINCOMB = 14
 REC = 8
 
 F32, F64 = 0, 1
@@ -56,7 +56,7 @@ class Desc(C.Structure):
                 ('allgather', ALLGATHER_FN), ('allgather_user', C.c_void_p),
                 ('exchange_send_dev', C.c_void_p), ('exchange_recv_dev', C.c_void_p),
                 ('linear_variant', C.c_int32), ('chunk_attempts', C.c_int32),
-                ('use_graph', C.c_int32), ('profile', C.c_int32),
+                ('reserved0', C.c_int32), ('profile', C.c_int32),
                 ('fusion', C.c_int32), ('reserved', C.c_int32)]
 
 

@@ -338,7 +338,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
                                                h->family == FAM_LORENZ);
     if (desc->fusion == 2 && !can && !can_fixed) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); delete h; return MI_ODE_E_INVALID; }
     h->step_fused = (can && desc->fusion != 1) ? 1 : 0;
-    h->allk = (desc->interp != MI_ODE_INTERP_QUARTIC_MID) ? 1 : 0;
+    h->ts_dense = (desc->interp != MI_ODE_INTERP_QUARTIC_MID) ? 1 : 0;
     // In-kernel controller (last workgroup): measured equal or better than a separate k_controller launch for the
     // heavy MFMA / MLP kernels and for small grids; for the feather-weight row-local kernels on many workgroups the
     // serial tail (ticket + sc1 record reads) costs more than the extra launch (13.6 vs 15.5 us/attempt at config 3).
@@ -795,13 +795,15 @@ static int interp_eval_t(int32_t interp, int64_t n, const void* y0, const void* 
   InterpParams I;
   memset(&I, 0, sizeof(I));
   I.kind = interp; I.nk = nk;
-  if (c_mid) for (int j = 0; j < nk && j < kMaxK; ++j) I.c_mid[j] = c_mid[j];
+  if (c_mid) for (int j = 0; j < nk && j < MI_ODE_MAX_LINCOMB; ++j) I.c_mid[j] = c_mid[j];
   const int g = streaming_grid(n);
   // the quartic fit takes the step's own dt (dopri5.py:41), not t1 - t0; hand it over through t1' = t0 + dt semantics
   if (nk == 7) hipLaunchKernelGGL((k_interp_eval<T, 7>), dim3(g), dim3(256), 0, st, P, (long long)n, t0, t1, t, dt, (T*)out, I);
   else if (nk == 4) hipLaunchKernelGGL((k_interp_eval<T, 4>), dim3(g), dim3(256), 0, st, P, (long long)n, t0, t1, t, dt, (T*)out, I);
   else if (nk == 3) hipLaunchKernelGGL((k_interp_eval<T, 3>), dim3(g), dim3(256), 0, st, P, (long long)n, t0, t1, t, dt, (T*)out, I);
-  else { mi_set_error("interp_eval: nk must be 3, 4 or 7"); return MI_ODE_E_INVALID; }
+  else if (nk == 2) hipLaunchKernelGGL((k_interp_eval<T, 2>), dim3(g), dim3(256), 0, st, P, (long long)n, t0, t1, t, dt, (T*)out, I);
+  else if (nk == 14) hipLaunchKernelGGL((k_interp_eval<T, 14>), dim3(g), dim3(256), 0, st, P, (long long)n, t0, t1, t, dt, (T*)out, I);
+  else { mi_set_error("interp_eval: nk must be 2, 3, 4, 7 or 14"); return MI_ODE_E_INVALID; }
   MI_HIP(hipGetLastError());
   return 0;
 }

@@ -127,10 +127,6 @@ __device__ __forceinline__ bool resolve(const StageArgs& A, Resolved<T>& R) {
 // ------------------------------------------------------------------------------------------
 // per-element stage math (shared by every kernel shape)
 // ------------------------------------------------------------------------------------------
-struct ElemOut {   // what the flat (load) phase hands to the epilogue besides ys
-  double aux;      // LAST_FSAL: sum_{j<NK} (hs*e_j) k_j ; FX_RK4_4: k1 + 3*k2 + 3*k3
-};
-
 // ys and the auxiliary partial sum, from y0 and the NK loaded stage derivatives.
 template <typename T, int NK, int MODE>
 __device__ __forceinline__ T combine_elem(T y0, const T* k, T hs, const StageArgs& A, T& aux) {
@@ -282,7 +278,7 @@ struct CtrlParams {
 struct InterpParams {
   int kind;                   // MI_ODE_INTERP_*
   int nk;                     // S + 1
-  double c_mid[kMaxK];
+  double c_mid[MI_ODE_MAX_LINCOMB];   // up to 14 stage derivatives (dopri8) for the stateless dense output
 };
 
 }  // namespace mi

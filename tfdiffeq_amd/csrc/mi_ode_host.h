@@ -55,7 +55,7 @@ struct mi_ode_solver {
   int stage_grid, stage_block;
   int step_fused;             // 1: whole-attempt kernel in use
   int step_grid, step_block;
-  int allk;                   // step kernel writes every k plane (tsit5 dense output)
+  int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)
   int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation
   // bookkeeping
   long long n_launches;

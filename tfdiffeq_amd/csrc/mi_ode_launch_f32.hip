@@ -15,9 +15,9 @@ int launch_mlp_dims(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st) 
   const bool s6 = h->S == 6;
   if (mode == mi::MLP_F0) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_F0, 6, false>), grid, block, lds, st, M);
   else if (mode == mi::MLP_INITB) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_INITB, 6, false>), grid, block, lds, st, M);
-  else if (s6 && !h->allk) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 6, false>), grid, block, lds, st, M);
-  else if (s6 && h->allk) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 6, true>), grid, block, lds, st, M);
-  else if (!h->allk) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 3, false>), grid, block, lds, st, M);
+  else if (s6 && !h->ts_dense) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 6, false>), grid, block, lds, st, M);
+  else if (s6 && h->ts_dense) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 6, true>), grid, block, lds, st, M);
+  else if (!h->ts_dense) hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 3, false>), grid, block, lds, st, M);
   else hipLaunchKernelGGL((mi::k_mlp<DP, HP, mi::MLP_STEP, 3, true>), grid, block, lds, st, M);
   return 0;
 }

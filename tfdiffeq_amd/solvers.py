@@ -425,7 +425,10 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         _assert_increasing(t)
         eng = self._make_engine()
         if eng is None:
-            return super(_AdaptiveRKSolver, self).integrate(t)
+            out = super(_AdaptiveRKSolver, self).integrate(t)
+            self.stats = {'engine': 'plane kernels', 'n_attempts': getattr(self, '_n_attempts', 0),
+                          'n_accepted': getattr(self, '_n_accepted', 0), 'status': 0}
+            return out
         prof0 = eng.profile() if self._profile else None
         try:
             out = eng.integrate(t.to(torch.float64).numpy(), self.y0[0])
