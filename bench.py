@@ -121,9 +121,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     group = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'     # the latter: exercise the N>1 plumbing on one GPU
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group(backend='nccl', device_id=dev)
+        os.environ.setdefault('MASTER_PORT', '29511')
+        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
     n_gpus = world
     if args.gpus != n_gpus and rank == 0:
@@ -144,7 +146,7 @@ def main():
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -158,10 +160,10 @@ def main():
         prof_all_ms += p[2]
         prof_n += int(p[1])
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
@@ -216,7 +218,7 @@ def main():
         else:
             res['cpu_baseline'] = None
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,0 +1,138 @@
+// Standalone user of the C ABI (include/mi_ode.h): no Python, no torch - hipMalloc'ed buffers, plain C calls.
+//   1. fixed grid RK4 (3/8 rule) on a Lorenz batch vs a scalar host loop written here   (bit-exact expected)
+//   2. adaptive Dopri5 on the same batch vs the fine RK4 solution                        (1e-6)
+//   3. the stateless plane kernel mi_ode_lincomb vs a host loop                          (bit-exact expected)
+// Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -I include tests/c_abi/c_abi_smoke.cpp -L tfdiffeq_amd -lmi_ode
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "mi_ode.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
+#define MI(x) do { int r_ = (x); if (r_ < 0) { printf("mi_ode error %d: %s (%s)\n", r_, mi_ode_last_error(), #x); return 3; } } while (0)
+
+static void lorenz(const double* y, double* f) {
+  f[0] = 10.0 * (y[1] - y[0]);
+  f[1] = y[0] * (28.0 - y[2]) - y[1];
+  f[2] = y[0] * y[1] - (8.0 / 3.0) * y[2];
+}
+
+int main() {
+  const int B = 1000, D = 3, T = 41;
+  const long long n = (long long)B * D;
+  std::vector<double> y0(n), t(T);
+  for (int b = 0; b < B; ++b) { y0[3 * b] = 1.0 + 1e-3 * sin(b); y0[3 * b + 1] = 1.0 + 1e-3 * cos(b); y0[3 * b + 2] = 1.0 + 1e-4 * b / B; }
+  for (int i = 0; i < T; ++i) t[i] = 0.0125 * i;
+  // host reference: rk_common.rk4_alt_step_func arithmetic
+  std::vector<double> ref((size_t)T * n);
+  memcpy(ref.data(), y0.data(), n * sizeof(double));
+  for (int b = 0; b < B; ++b) {
+    double y[3] = {y0[3 * b], y0[3 * b + 1], y0[3 * b + 2]};
+    for (int i = 0; i + 1 < T; ++i) {
+      const double dt = t[i + 1] - t[i];
+      double k1[3], k2[3], k3[3], k4[3], ys[3];
+      lorenz(y, k1);
+      for (int d = 0; d < 3; ++d) ys[d] = y[d] + dt * k1[d] / 3;
+      lorenz(ys, k2);
+      for (int d = 0; d < 3; ++d) ys[d] = y[d] + dt * (k1[d] / -3 + k2[d]);
+      lorenz(ys, k3);
+      for (int d = 0; d < 3; ++d) ys[d] = y[d] + dt * (k1[d] - k2[d] + k3[d]);
+      lorenz(ys, k4);
+      for (int d = 0; d < 3; ++d) y[d] = y[d] + (k1[d] + 3 * k2[d] + 3 * k3[d] + k4[d]) * (dt / 8);
+      for (int d = 0; d < 3; ++d) ref[(size_t)(i + 1) * n + 3 * b + d] = y[d];
+    }
+  }
+  double *d_y0, *d_out;
+  CK(hipMalloc(&d_y0, n * sizeof(double)));
+  CK(hipMalloc(&d_out, (size_t)T * n * sizeof(double)));
+  CK(hipMemcpy(d_y0, y0.data(), n * sizeof(double), hipMemcpyHostToDevice));
+
+  // ---- 1. fixed grid RK4 -------------------------------------------------------------------------
+  mi_ode_desc d;
+  memset(&d, 0, sizeof(d));
+  d.dtype = MI_ODE_F64; d.adaptive = 0; d.batch = B; d.dim = D;
+  d.tableau.n_stages = 3;
+  d.rhs.kind = MI_ODE_RHS_LORENZ; d.rhs.sign = 1.0; d.rhs.scalars[0] = 10.0; d.rhs.scalars[1] = 8.0 / 3.0; d.rhs.scalars[2] = 28.0;
+  d.first_step = NAN;
+  mi_ode_handle h = nullptr;
+  MI(mi_ode_create(&d, &h));
+  mi_ode_stats st;
+  MI(mi_ode_fixed_grid_integrate(h, d_y0, t.data(), T, d_out, &st, nullptr));
+  std::vector<double> out((size_t)T * n);
+  CK(hipMemcpy(out.data(), d_out, (size_t)T * n * sizeof(double), hipMemcpyDeviceToHost));
+  double maxdiff = 0;
+  for (size_t i = 0; i < out.size(); ++i) maxdiff = fmax(maxdiff, fabs(out[i] - ref[i]));
+  printf("rk4 fixed grid: max |gpu - host| = %.3e, nfe %lld, launches %lld\n", maxdiff, (long long)st.nfe, (long long)st.n_launches);
+  if (maxdiff != 0.0) { printf("FAIL rk4 not bit-exact\n"); return 1; }
+  MI(mi_ode_destroy(h));
+
+  // ---- 2. adaptive dopri5 --------------------------------------------------------------------------
+  const double alpha[6] = {1 / 5., 3 / 10., 4 / 5., 8 / 9., 1., 1.};
+  const double beta[6][6] = {{1 / 5.}, {3 / 40., 9 / 40.}, {44 / 45., -56 / 15., 32 / 9.},
+                             {19372 / 6561., -25360 / 2187., 64448 / 6561., -212 / 729.},
+                             {9017 / 3168., -355 / 33., 46732 / 5247., 49 / 176., -5103 / 18656.},
+                             {35 / 384., 0, 500 / 1113., 125 / 192., -2187 / 6784., 11 / 84.}};
+  const double c_sol[7] = {35 / 384., 0, 500 / 1113., 125 / 192., -2187 / 6784., 11 / 84., 0};
+  const double c_err[7] = {35 / 384. - 1951 / 21600., 0, 500 / 1113. - 22642 / 50085., 125 / 192. - 451 / 720.,
+                           -2187 / 6784. - -12231 / 42400., 11 / 84. - 649 / 6300., -1. / 60.};
+  const double c_mid[7] = {6025192743 / 30085553152. / 2, 0, 51252292925 / 65400821598. / 2, -2691868925 / 45128329728. / 2,
+                           187940372067 / 1594534317056. / 2, -1776094331 / 19743644256. / 2, 11237099 / 235043384. / 2};
+  d.adaptive = 1;
+  d.tableau.n_stages = 6; d.tableau.fsal = 1;
+  for (int i = 0; i < 6; ++i) { d.tableau.alpha[i] = alpha[i]; for (int j = 0; j < 6; ++j) d.tableau.beta[i][j] = beta[i][j]; }
+  for (int j = 0; j < 7; ++j) { d.tableau.c_sol[j] = c_sol[j]; d.tableau.c_error[j] = c_err[j]; d.tableau.c_mid[j] = c_mid[j]; }
+  d.controller = MI_ODE_CTRL_MISC; d.interp = MI_ODE_INTERP_QUARTIC_MID; d.order = 5; d.init_order = 4;
+  d.rtol = 1e-9; d.atol = 1e-11; d.safety = (double)0.9f; d.ifactor = 10.0; d.dfactor = (double)0.2f;
+  d.max_num_steps = 100000;
+  MI(mi_ode_create(&d, &h));
+  const double t2[3] = {0.0, 0.25, 0.5};
+  int bits = mi_ode_integrate(h, d_y0, t2, 3, d_out, &st, nullptr);
+  if (bits != 0) { printf("FAIL dopri5 status %d (%s) %s\n", bits, bits > 0 ? mi_ode_status_string(bits) : "", mi_ode_last_error()); return 1; }
+  CK(hipMemcpy(out.data(), d_out, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost));
+  // fine host reference: the same RK4 with 32 sub-steps per grid interval (error ~1e-10)
+  double md2 = 0;
+  for (int b = 0; b < B; ++b) {
+    double y[3] = {y0[3 * b], y0[3 * b + 1], y0[3 * b + 2]};
+    const int sub = 32;
+    for (int i = 0; i < 40 * sub; ++i) {
+      const double dt = 0.0125 / sub;
+      double k1[3], k2[3], k3[3], k4[3], ys[3];
+      lorenz(y, k1);
+      for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * k1[q] / 3;
+      lorenz(ys, k2);
+      for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * (k1[q] / -3 + k2[q]);
+      lorenz(ys, k3);
+      for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * (k1[q] - k2[q] + k3[q]);
+      lorenz(ys, k4);
+      for (int q = 0; q < 3; ++q) y[q] = y[q] + (k1[q] + 3 * k2[q] + 3 * k3[q] + k4[q]) * (dt / 8);
+      if (i + 1 == 20 * sub) for (int q = 0; q < 3; ++q) md2 = fmax(md2, fabs(out[n + 3 * b + q] - y[q]));
+      if (i + 1 == 40 * sub) for (int q = 0; q < 3; ++q) md2 = fmax(md2, fabs(out[2 * n + 3 * b + q] - y[q]));
+    }
+  }
+  printf("dopri5 adaptive: attempts %lld accepted %lld nfe %lld launches %lld polls %d, max |dopri5 - fine rk4| = %.3e\n",
+         (long long)st.n_attempts, (long long)st.n_accepted, (long long)st.nfe, (long long)st.n_launches, st.n_polls, md2);
+  if (!(md2 < 1e-6)) { printf("FAIL dopri5 accuracy\n"); return 1; }
+  MI(mi_ode_destroy(h));
+
+  // ---- 3. plane kernel ------------------------------------------------------------------------------
+  double* d_tmp;
+  CK(hipMalloc(&d_tmp, n * sizeof(double)));
+  const void* xs[2] = {d_y0, d_out};
+  const double coef[2] = {0.3, -1.25};
+  MI(mi_ode_lincomb(MI_ODE_F64, n, d_y0, xs, coef, 2, 0.0625, d_tmp, nullptr));
+  std::vector<double> lc(n), o0(n);
+  CK(hipMemcpy(lc.data(), d_tmp, n * sizeof(double), hipMemcpyDeviceToHost));
+  CK(hipMemcpy(o0.data(), d_out, n * sizeof(double), hipMemcpyDeviceToHost));
+  double md3 = 0;
+  for (long long i = 0; i < n; ++i) {
+    const double acc = (0.0625 * 0.3) * y0[i] + (0.0625 * -1.25) * o0[i];
+    md3 = fmax(md3, fabs(lc[i] - (y0[i] + acc)));
+  }
+  printf("lincomb: max diff %.3e\n", md3);
+  if (md3 != 0.0) { printf("FAIL lincomb not bit-exact\n"); return 1; }
+  printf("C-ABI OK (abi %d)\n", mi_ode_abi_version());
+  return 0;
+}

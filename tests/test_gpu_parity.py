@@ -637,3 +637,18 @@ def test_next_solvers_rk_step_contract():
         assert_band(torch.stack(k[0]).cpu(), d[name + '_k'], 1e-13, 1e-13, name + ' k')
         out = I._interp_eval_step(N.INTERP_QUARTIC_MID, (y0,), y1, k, cm, dt, t0, t0 + dt, t0 + 0.3 * dt)
         assert_band(out[0].cpu(), d[name + '_interp_eval'], 1e-11, 1e-11, name + ' dense output')
+
+
+def test_c_abi_standalone_harness():
+    """tests/c_abi/c_abi_smoke.cpp: a plain C++ program (no Python, no torch) drives libmi_ode.so through
+    include/mi_ode.h: fixed-grid RK4 bit-exact against a scalar host loop, adaptive Dopri5, mi_ode_lincomb."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, 'tests', 'c_abi', 'c_abi_smoke')
+    if not os.path.exists(exe):
+        pytest.skip('harness not built (python -c "import __graft_entry__ as g; g.build()")')
+    env = dict(os.environ)
+    env['LD_LIBRARY_PATH'] = os.path.join(root, 'tfdiffeq_amd') + ':/opt/rocm/lib:' + env.get('LD_LIBRARY_PATH', '')
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 0 and 'C-ABI OK' in res.stdout, res.stdout[-2000:] + res.stderr[-2000:]
