@@ -1,0 +1,124 @@
+"""Mirror of tfdiffeq/adjoint.py: `odeint_adjoint` - O(1)-memory gradients by solving the augmented ODE backwards
+(the main caller of the hot path in training).
+
+Same algorithm and argument contract as the reference (adjoint.py:35-224), re-stated for torch autograd:
+  * `func` must be a module (reference: tf.keras.Model; here torch.nn.Module) so its parameters can be found;
+  * forward = `odeint` (any engine); backward loops i = T-1 .. 1 over the output times, building the heterogeneous
+    tuple state (*y_i, *adj_y, adj_time, adj_params) (adjoint.py:148) and calling `odeint` on it over [t_i, t_{i-1}]
+    (reversed time, handled by `_check_inputs` as in the reference) - that runs on the plane-kernel engine;
+  * vector-Jacobian products of `func` come from torch.autograd.grad (reference: tf.GradientTape, adjoint.py:76-95).
+Unlike the reference there is no module-global `_arguments` (adjoint.py:32, 217): the call is re-entrant.
+"""
+import torch
+
+from .odeint import odeint
+
+
+def _flatten(seq):
+    flat = [p.reshape(-1) for p in seq]
+    return torch.cat(flat) if len(flat) > 0 else torch.tensor([])
+
+
+class _TupleModule(torch.nn.Module):
+    """adjoint.py:203-211."""
+
+    def __init__(self, base_func):
+        super(_TupleModule, self).__init__()
+        self.base_func = base_func
+
+    def forward(self, t, y):
+        return (self.base_func(t, y[0]),)
+
+
+class _OdeintAdjointMethod(torch.autograd.Function):
+
+    @staticmethod
+    def forward(ctx, func, n_tensors, cfg, t, flat_params, *y0):
+        ctx.func, ctx.cfg, ctx.n_tensors = func, cfg, n_tensors
+        with torch.no_grad():
+            ans = odeint(func, tuple(y0), t, rtol=cfg['rtol'], atol=cfg['atol'], method=cfg['method'], options=cfg['options'])
+        ctx.save_for_backward(t, flat_params, *ans)
+        return ans
+
+    @staticmethod
+    def backward(ctx, *grad_output):
+        func, cfg, n_tensors = ctx.func, ctx.cfg, ctx.n_tensors
+        t, flat_params, *ans = ctx.saved_tensors
+        f_params = tuple(p for p in func.parameters() if p.requires_grad)
+        like = ans[0]
+        grad_output = tuple(g if g is not None else torch.zeros_like(a) for g, a in zip(grad_output, ans))
+
+        def augmented_dynamics(tt, y_aug):
+            # dynamics of the original system augmented with the adjoint wrt y, t and the parameters (adjoint.py:69-105)
+            y, adj_y = y_aug[:n_tensors], y_aug[n_tensors:2 * n_tensors]
+            with torch.enable_grad():
+                tt_ = tt.detach().requires_grad_(True)
+                y_ = tuple(v.detach().requires_grad_(True) for v in y)
+                func_eval = func(tt_, y_)
+                vjp = torch.autograd.grad(func_eval, (tt_,) + y_ + f_params, tuple(-a for a in adj_y),
+                                          allow_unused=True, retain_graph=False)
+            vjp_t, vjp_y, vjp_params = vjp[0], vjp[1:1 + n_tensors], vjp[1 + n_tensors:]
+            vjp_t = torch.zeros_like(tt) if vjp_t is None else vjp_t
+            vjp_y = tuple(torch.zeros_like(v) if g is None else g for g, v in zip(vjp_y, y))
+            vjp_params = _flatten([torch.zeros_like(p) if g is None else g for g, p in zip(vjp_params, f_params)])
+            if len(f_params) == 0:
+                vjp_params = torch.zeros((), dtype=like.dtype, device=like.device)
+            return (*[f.detach() for f in func_eval], *vjp_y, vjp_t.to(like.dtype), vjp_params.to(like.dtype))
+
+        T = ans[0].shape[0]
+        with torch.no_grad():
+            adj_y = tuple(g[-1] for g in grad_output)
+            adj_params = torch.zeros_like(flat_params, dtype=like.dtype) if flat_params.numel() > 0 else \
+                torch.zeros((), dtype=like.dtype, device=like.device)
+            adj_time = torch.zeros((), dtype=like.dtype, device=like.device)
+            time_vjps = []
+            t_dev = t.to(device=like.device)
+            for i in range(T - 1, 0, -1):
+                ans_i = tuple(a[i] for a in ans)
+                grad_output_i = tuple(g[i] for g in grad_output)
+                func_i = func(t_dev[i].to(like.dtype), ans_i)
+                # effect of moving the current time measurement point (adjoint.py:134-140)
+                dLd_cur_t = sum(torch.dot(f_.reshape(-1), g_.reshape(-1)) for f_, g_ in zip(func_i, grad_output_i))
+                adj_time = adj_time - dLd_cur_t
+                time_vjps.append(dLd_cur_t.reshape(1))
+                aug_y0 = (*ans_i, *adj_y, adj_time, adj_params)
+                aug_ans = odeint(augmented_dynamics, aug_y0, torch.stack([t[i], t[i - 1]]).detach().cpu(),
+                                 rtol=cfg['adjoint_rtol'], atol=cfg['adjoint_atol'], method=cfg['adjoint_method'],
+                                 options=cfg['adjoint_options'])
+                adj_y = tuple(a[1] for a in aug_ans[n_tensors:2 * n_tensors])
+                adj_time = aug_ans[2 * n_tensors][1]
+                adj_params = aug_ans[2 * n_tensors + 1][1]
+                adj_y = tuple(a + g[i - 1] for a, g in zip(adj_y, grad_output))
+            time_vjps.append(adj_time.reshape(1))
+            time_vjps = torch.cat(time_vjps[::-1]).to(dtype=t.dtype, device=t.device)
+            grad_params = adj_params.to(flat_params.dtype) if flat_params.numel() > 0 else None
+        return (None, None, None, time_vjps, grad_params, *adj_y)
+
+
+def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None, adjoint_method=None,
+                   adjoint_rtol=None, adjoint_atol=None, adjoint_options=None):
+    """adjoint.py:183-224.  Gradients flow to y0, t and func's parameters."""
+    if not isinstance(func, torch.nn.Module):
+        raise ValueError('func is required to be an instance of torch.nn.Module')     # adjoint.py:187-188 (tf.keras.Model there)
+    if adjoint_method is None:
+        adjoint_method = method
+    if adjoint_rtol is None:
+        adjoint_rtol = rtol
+    if adjoint_atol is None:
+        adjoint_atol = atol
+    if adjoint_options is None:
+        adjoint_options = options
+    tensor_input = False
+    if isinstance(y0, torch.Tensor):
+        tensor_input = True
+        y0 = (y0,)
+        func = _TupleModule(func)
+    params = [p for p in func.parameters() if p.requires_grad]
+    flat_params = _flatten(params) if params else torch.zeros(0, device=y0[0].device, dtype=y0[0].dtype)
+    cfg = dict(rtol=rtol, atol=atol, method=method, options=options, adjoint_method=adjoint_method,
+               adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol, adjoint_options=adjoint_options)
+    t = torch.as_tensor(t)
+    ys = _OdeintAdjointMethod.apply(func, len(y0), cfg, t, flat_params, *y0)
+    if tensor_input:
+        ys = ys[0]
+    return ys

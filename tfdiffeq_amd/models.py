@@ -1,0 +1,120 @@
+"""Mirror of tfdiffeq/models/dense_odenet.py for torch: ODEFunc, ODEBlock, ODENet.
+
+`ODEBlock` is config 5's real caller: t = [0, 1], rtol = atol = tol (1e-3), `max_num_steps = 1000`, optional zero
+augmentation, returns the state at t = 1 (dense_odenet.py:131-191).  When the ODEFunc is the plain
+(time-independent) tanh MLP and no gradient is being recorded, the integration runs on the fused MFMA kernel
+(`rhs.MLPTanh`, csrc/mi_ode_mlp.h); otherwise it goes through the plane-kernel engine (or `odeint_adjoint`).
+"""
+import torch
+from torch import nn
+
+from . import rhs as _rhs
+from .adjoint import odeint_adjoint
+from .odeint import odeint
+
+MAX_NUM_STEPS = 1000          # dense_odenet.py:14
+
+
+class ODEFunc(nn.Module):
+    """MLP modelling the derivative of the ODE system (dense_odenet.py:17-92): fc1 -> act -> fc2 -> act -> fc3."""
+
+    def __init__(self, input_dim, hidden_dim, augment_dim=0, time_dependent=False, non_linearity='relu'):
+        super(ODEFunc, self).__init__()
+        self.augment_dim = augment_dim
+        self.input_dim = input_dim + augment_dim
+        self.hidden_dim = hidden_dim
+        self.nfe = 0                                             # number of function evaluations (:38)
+        self.time_dependent = time_dependent
+        self.fc1 = nn.Linear(self.input_dim + (1 if time_dependent else 0), hidden_dim)
+        self.fc2 = nn.Linear(hidden_dim, hidden_dim)
+        self.fc3 = nn.Linear(hidden_dim, self.input_dim)
+        self.non_linearity_name = non_linearity
+        self.non_linearity = {'relu': nn.ReLU(), 'softplus': nn.Softplus(), 'tanh': nn.Tanh()}.get(non_linearity)
+        if self.non_linearity is None:
+            self.non_linearity = getattr(nn, non_linearity)()
+
+    def forward(self, t, x):
+        self.nfe += 1                                            # :78
+        if self.time_dependent:
+            t_vec = torch.ones(x.shape[0], 1, dtype=x.dtype, device=x.device) * t
+            out = self.fc1(torch.cat([t_vec, x], dim=-1))
+        else:
+            out = self.fc1(x)
+        out = self.non_linearity(out)
+        out = self.fc2(out)
+        out = self.non_linearity(out)
+        return self.fc3(out)
+
+    def device_rhs(self):
+        """The fused-kernel descriptor of this network, or None if the fused MLP kernel does not cover it."""
+        if self.time_dependent or self.non_linearity_name != 'tanh':
+            return None
+        return _rhs.MLPTanh(self.fc1.weight.detach().t().contiguous(), self.fc1.bias.detach(),
+                            self.fc2.weight.detach().t().contiguous(), self.fc2.bias.detach(),
+                            self.fc3.weight.detach().t().contiguous(), self.fc3.bias.detach())
+
+
+class ODEBlock(nn.Module):
+    """Solves the ODE defined by odefunc (dense_odenet.py:95-191)."""
+
+    def __init__(self, odefunc, is_conv=False, tol=1e-3, adjoint=False, solver='dopri5'):
+        super(ODEBlock, self).__init__()
+        if is_conv:
+            raise NotImplementedError('convolutional ODE functions are out of scope (SURVEY.md section 2)')
+        self.adjoint = adjoint
+        self.odefunc = odefunc
+        self.tol = tol
+        self.method = solver
+        self.channel_axis = -1
+        if solver == 'dopri5':
+            self.options = {'max_num_steps': MAX_NUM_STEPS}      # :126-127
+        else:
+            self.options = None
+
+    def forward(self, x, eval_times=None):
+        self.odefunc.nfe = 0                                     # :147
+        if eval_times is None:
+            integration_time = torch.tensor([0., 1.], dtype=x.dtype)     # :150
+        else:
+            integration_time = torch.as_tensor(eval_times, dtype=x.dtype)
+        if self.odefunc.augment_dim > 0:                         # :154-176 zero augmentation
+            aug = torch.zeros(x.shape[0], self.odefunc.augment_dim, dtype=x.dtype, device=x.device)
+            x_aug = torch.cat([x, aug], dim=-1)
+        else:
+            x_aug = x
+        needs_grad = torch.is_grad_enabled() and (x_aug.requires_grad or any(p.requires_grad for p in self.odefunc.parameters()))
+        kw = dict(rtol=self.tol, atol=self.tol, method=self.method, options=self.options)
+        if self.adjoint and needs_grad:
+            out = odeint_adjoint(self.odefunc, x_aug, integration_time, **kw)           # :178-181
+        else:
+            fused = None if needs_grad else self.odefunc.device_rhs()
+            func = fused if (fused is not None and fused.supports(x_aug)) else self.odefunc
+            with torch.no_grad():
+                out = odeint(func, x_aug, integration_time, **kw)                           # :184-186
+        if eval_times is None:
+            return out[1]                                        # :188-189
+        return out
+
+    def trajectory(self, x, timesteps):
+        """dense_odenet.py:193-205."""
+        return self.forward(x, eval_times=torch.linspace(0., 1., timesteps))
+
+
+class ODENet(nn.Module):
+    """An ODEBlock followed by a linear layer (dense_odenet.py:208-259)."""
+
+    def __init__(self, input_dim, hidden_dim, output_dim, augment_dim=0, time_dependent=False, non_linearity='relu',
+                 tol=1e-3, adjoint=False, solver='dopri5'):
+        super(ODENet, self).__init__()
+        self.input_dim, self.hidden_dim, self.output_dim = input_dim, hidden_dim, output_dim
+        self.augment_dim = augment_dim
+        odefunc = ODEFunc(input_dim, hidden_dim, augment_dim, time_dependent, non_linearity)
+        self.odeblock = ODEBlock(odefunc, tol=tol, adjoint=adjoint, solver=solver)
+        self.linear_layer = nn.Linear(odefunc.input_dim, output_dim)
+
+    def forward(self, x, return_features=False):
+        features = self.odeblock(x)
+        pred = self.linear_layer(features)
+        if return_features:
+            return features, pred
+        return pred
