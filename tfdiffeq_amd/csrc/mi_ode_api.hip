@@ -499,7 +499,10 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
   hipLaunchKernelGGL(k_set_outputs, dim3(1), dim3(64), 0, st, h->ctl, (int)n_out);
   h->n_launches += 1;
   const double t_end = t_out_host[n_out - 1];
-  int chunk = h->d.chunk_attempts > 0 ? h->d.chunk_attempts : 4;
+  // first chunk: what the previous call on this handle needed (ODEBlock-style callers repeat the same problem), else 4
+  int chunk = h->d.chunk_attempts > 0 ? h->d.chunk_attempts
+                                      : (h->last_call_attempts > 0 && h->last_call_attempts <= 64 ? (int)h->last_call_attempts : 4);
+  const long long attempts_before = h->ctl_host->n_attempt;
   for (;;) {
     if (chunk > 64) chunk = 64;
     for (int a = 0; a < chunk; ++a) {
@@ -529,6 +532,7 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
       chunk = (int)est;
     }
   }
+  h->last_call_attempts = h->ctl_host->n_attempt - attempts_before;
   return (int)h->ctl_host->status;
 }
 

@@ -61,6 +61,7 @@ struct mi_ode_solver {
   long long n_launches;
   int n_polls;
   int begun;
+  long long last_call_attempts;  // attempts the previous advance() needed: first-chunk estimate for repeated calls
   int own_exchange;
   // optional event profiling (desc.profile)
   hipEvent_t ev_a[64], ev_b[64], ev_c[64];
