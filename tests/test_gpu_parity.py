@@ -724,3 +724,17 @@ def test_odeblock_and_odenet_modules():
     traj = blk.trajectory(x, 5)
     assert traj.shape == (5, 96, 8)
     assert ODEFunc(4, 8, time_dependent=True)(torch.tensor(0.5), torch.randn(3, 4)).shape == (3, 4)
+
+
+def test_fused_engine_accepts_leading_batch_axes():
+    """Any [..., dim] state is a batch of trajectories for the fused kernels (the reference accepts any-rank tensors)."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(2)
+    y0 = to_dev(np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((7, 5, 11, 3)))
+    t = torch.tensor([0., 0.2, 0.4])
+    a = odeint(rhs.Lorenz(), y0, t, rtol=1e-8, atol=1e-10)
+    assert a.shape == (3, 7, 5, 11, 3) and odeint.last_stats.get('n_launches', 0) > 0
+    b = odeint(rhs.Lorenz(), y0.reshape(-1, 3), t, rtol=1e-8, atol=1e-10)
+    assert torch.equal(a.reshape(3, -1, 3), b)
+    c = odeint(rhs.Lorenz(), y0, t, method='rk4')
+    assert c.shape == (3, 7, 5, 11, 3)

@@ -490,7 +490,9 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
     if (!(t_out_host[i] > t_out_host[i - 1])) { mi_set_error("output times must increase"); return MI_ODE_ST_BAD_T; }
   int rc = ensure_t_out(h, n_out);
   if (rc != 0) return rc;
-  MI_HIP(hipStreamSynchronize(st));
+  // every advance() ends with a poll (stream idle), so the pinned staging buffer is free unless a fixed-grid call
+  // left a copy in flight - no need to wait for the init kernels of mi_ode_begin here
+  if (h->t_out_busy) { MI_HIP(hipStreamSynchronize(st)); h->t_out_busy = 0; }
   memcpy(h->t_out_host, t_out_host, (size_t)n_out * sizeof(double));
   MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)n_out * sizeof(double), hipMemcpyHostToDevice, st));
   h->cp.t_out = h->t_out_dev;
@@ -609,6 +611,7 @@ extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, 
     MI_HIP(hipStreamSynchronize(st));
     memcpy(h->t_out_host, t_host, (size_t)T * sizeof(double));
     MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)T * sizeof(double), hipMemcpyHostToDevice, st));
+    h->t_out_busy = 1;
     FixedArgs F;
     memset(&F, 0, sizeof(F));
     F.y0 = y0_dev; F.out = out_dev; F.t = h->t_out_dev; F.batch = h->d.batch; F.T = T; F.rk4 = euler ? 0 : 1; F.rhs = h->rhs;

@@ -51,6 +51,7 @@ struct mi_ode_solver {
   mi::Ctl* ctl_host;
   double* t_out_host;
   int t_out_host_cap;
+  int t_out_busy;             // an un-synchronised H2D copy out of t_out_host may still be in flight
   // launch geometry of the stage kernels
   int stage_grid, stage_block;
   int step_fused;             // 1: whole-attempt kernel in use

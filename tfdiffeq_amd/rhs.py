@@ -198,7 +198,7 @@ class MLPTanh(DeviceRHS):
     fixed_grid_fused = False     # the fused MLP kernel is the whole-attempt (adaptive) kernel only
 
     def supports(self, y0):
-        return (y0.dim() == 2 and y0.shape[-1] == self.dim and y0.dtype == torch.float32
+        return (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype == torch.float32
                 and self.dim <= 64 and self.hidden <= 128)
 
     def fill(self, rhs, dtype, device):

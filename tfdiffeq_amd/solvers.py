@@ -49,7 +49,7 @@ def _fill_tableau(tb_struct, tableau, c_mid):
 
 
 class _FusedEngine(object):
-    """Owns one mi_ode_handle.  y0: a contiguous [batch, dim] (or [dim]) device tensor."""
+    """Owns one mi_ode_handle.  y0: a device tensor [..., dim]; all leading axes are batch (trajectories)."""
 
     def __init__(self, device_rhs, y0, adaptive, tableau, c_mid=None, rtol=1e-7, atol=1e-9, controller=N.CTRL_MISC,
                  interp=N.INTERP_QUARTIC_MID, order=5, init_order=4, safety=0.9, ifactor=10.0, dfactor=0.2,
@@ -235,7 +235,7 @@ def _fusable(func, y0):
     if rhs is None or len(y0) != 1:
         return None
     y = y0[0]
-    if not (isinstance(y, torch.Tensor) and y.is_cuda and y.dim() in (1, 2) and rhs.supports(y)):
+    if not (isinstance(y, torch.Tensor) and y.is_cuda and y.dim() >= 1 and y.numel() > 0 and rhs.supports(y)):
         return None
     return rhs
 
