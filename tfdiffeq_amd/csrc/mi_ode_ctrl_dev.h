@@ -5,10 +5,9 @@
 
 namespace mi {
 
-// Reduce per-block records: slot s (0..255) takes blocks s, s+256, ...; then an LDS tree over the occupied slots.
-// The order does not depend on blockDim, so every caller (any workgroup size) produces the same bits.  All threads of
-// the workgroup must call it; the result is valid in thread 0.  SC1: read the records with agent-scope (sc1) loads -
-// the consumer side of the write-through hand-off used by the whole-attempt kernels' last workgroup.
+// Reduce per-block records in a fixed order (same bits for every caller).  The result is valid in thread 0 (which
+// is also the only thread that reads it afterwards).  SC1: read the records with agent-scope (sc1) loads - the
+// consumer side of the write-through hand-off used by the whole-attempt kernels' last workgroup.
 template <bool SC1>
 __device__ __forceinline__ double rec_load(const double* p) {
   if constexpr (SC1) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -17,33 +16,20 @@ __device__ __forceinline__ double rec_load(const double* p) {
 
 template <bool SC1 = false>
 __device__ __forceinline__ void reduce_block_records(const double* part, int nblocks, double* out /*[kRec]*/) {
-  __shared__ double s[5][256];
-  const int nt = (int)blockDim.x;
-  int width = 1;                                   // occupied slots, rounded up to a power of two (<= 256)
-  while (width < nblocks && width < 256) width <<= 1;
-  for (int slot = threadIdx.x; slot < width; slot += nt) {
+  // ONE wavefront does it: lane l folds records l, l+64, ... in order, then a fixed-order __shfl_down tree.  No LDS,
+  // no workgroup barriers on the per-attempt critical path; the order does not depend on the caller's workgroup size.
+  if (threadIdx.x < 64) {
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
-    for (int b = slot; b < nblocks; b += 256) {
+    for (int b = threadIdx.x; b < nblocks; b += 64) {
       const double* p = part + (long long)b * kRec;
       v0 = fmax(v0, rec_load<SC1>(p + R_MAXA)); v1 = fmax(v1, rec_load<SC1>(p + R_MAXB));
       v2 += rec_load<SC1>(p + R_SUMA); v3 += rec_load<SC1>(p + R_SUMB); v4 = fmax(v4, rec_load<SC1>(p + R_FLAG));
     }
-    s[0][slot] = v0; s[1][slot] = v1; s[2][slot] = v2; s[3][slot] = v3; s[4][slot] = v4;
-  }
-  __syncthreads();
-  for (int off = width >> 1; off > 0; off >>= 1) {
-    for (int slot = threadIdx.x; slot < off; slot += nt) {
-      s[0][slot] = fmax(s[0][slot], s[0][slot + off]);
-      s[1][slot] = fmax(s[1][slot], s[1][slot + off]);
-      s[2][slot] += s[2][slot + off];
-      s[3][slot] += s[3][slot + off];
-      s[4][slot] = fmax(s[4][slot], s[4][slot + off]);
+    v0 = wave_max(v0); v1 = wave_max(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_max(v4);
+    if (threadIdx.x == 0) {
+      out[R_MAXA] = v0; out[R_MAXB] = v1; out[R_SUMA] = v2; out[R_SUMB] = v3; out[R_FLAG] = v4;
+      out[R_N] = 0; out[6] = 0; out[7] = 0;
     }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    out[R_MAXA] = s[0][0]; out[R_MAXB] = s[1][0]; out[R_SUMA] = s[2][0]; out[R_SUMB] = s[3][0]; out[R_FLAG] = s[4][0];
-    out[R_N] = 0; out[6] = 0; out[7] = 0;
   }
 }
 
