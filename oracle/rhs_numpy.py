@@ -16,11 +16,21 @@ import numpy as np
 def make_rhs(name, params=None, dtype=np.float64, weights=None):
     p = params or {}
     dt = np.dtype(dtype)
+    # scalar states: evaluate through 0-d ARRAYS (np.asarray), not numpy scalars - numpy's scalar `**` goes through libm
+    # pow while the array path (which the fixture generator's stand-in takes) may use a SIMD pow: 1-ulp differences
+    # that the multistep divided differences amplify into different step sequences
     if name == 'sine':
-        return lambda t, y: 2 * y / t + t ** 4 * np.sin(2 * t) - t ** 2 + 4 * t ** 3
+        def sine(t, y):
+            t, y = np.asarray(t), np.asarray(y)
+            return 2 * y / t + t ** 4 * np.sin(2 * t) - t ** 2 + 4 * t ** 3
+        return sine
     if name == 'constant':
         a, b = p.get('a', 0.2), p.get('b', 3.0)
-        return lambda t, y: a + (y - (a * t + b)) ** 5
+
+        def constant(t, y):
+            t, y = np.asarray(t), np.asarray(y)
+            return a + (y - (a * t + b)) ** 5
+        return constant
     if name == 'cubic_linear':
         W = np.asarray(p['W'], dtype=dt)
         return lambda t, y: (y ** 3) @ W

@@ -457,9 +457,73 @@ def gen_next_solvers():
     run_case('run_spiral_b64_adaptive_heun', rhs_cubic(A), y0b, np.array([0., 0.5, 1.0]), 'adaptive_heun', rtol=1e-5, atol=1e-7)
 
 
+def gen_adams():
+    """the multistep family (fixed_adams.py, adams.py)."""
+    from tfdiffeq import adams, fixed_adams
+    import json as _json
+    tables = {'bashforth': fixed_adams._BASHFORTH_COEFFICIENTS, 'moulton': fixed_adams._MOULTON_COEFFICIENTS,
+              'divisor': fixed_adams._DIVISOR, 'min_order': fixed_adams._MIN_ORDER, 'max_order': fixed_adams._MAX_ORDER,
+              'max_iters': fixed_adams._MAX_ITERS, 'gamma_star': list(adams.gamma_star),
+              'source': 'integer Adams-Bashforth / Adams-Moulton coefficient tables and divisors (fixed_adams.py:8-90), '
+                        'gamma_star (adams.py:15-18), as values'}
+    path = os.path.join(os.path.dirname(os.path.dirname(HERE)), 'tfdiffeq_amd', 'tableaus', 'adams.json')
+    with open(path, 'w') as fh:
+        _json.dump(tables, fh)
+    save('fn_adams_tables', {'what': 'fixed_adams.py:8-90 tables (as float64 quotients coeff/divisor) and adams.py gamma_star'},
+         bashforth_over_div=np.asarray([[c / fixed_adams._DIVISOR[o] for c in row] + [0.0] * (20 - len(row))
+                                        for o, row in enumerate(fixed_adams._BASHFORTH_COEFFICIENTS)]),
+         moulton_over_div=np.asarray([[c / fixed_adams._DIVISOR[o] for c in row] + [0.0] * (20 - len(row))
+                                      for o, row in enumerate(fixed_adams._MOULTON_COEFFICIENTS)]),
+         gamma_star=np.asarray(adams.gamma_star, dtype=np.float64))
+    # trace of the variable-coefficient solver: (prev_t[0], next_t, order, accepted)
+    orig = adams.VariableCoefficientAdamsBashforth._adaptive_adams_step
+    log = []
+
+    def wrapped(self, st, final_t):
+        t_before = float(st.prev_t[0]._a)                      # the reference mutates its deques in place: read first
+        nt = float(np.asarray(st.next_t._a, dtype=np.float64))
+        nt = min(nt, float(np.asarray(final_t._a if hasattr(final_t, '_a') else final_t, dtype=np.float64)))
+        order = float(st.order)
+        new = orig(self, st, final_t)
+        log.append((t_before, nt, order, 1.0 if float(new.prev_t[0]._a) > t_before else 0.0))
+        return new
+    adams.VariableCoefficientAdamsBashforth._adaptive_adams_step = wrapped
+    f32t = np.linspace(1., 8., 10).astype(np.float32)
+    const, sine = rhs_constant(), rhs_sine()
+    y_exact_sine = lambda t: (-0.5 * t ** 4 * np.cos(2 * t) + 0.5 * t ** 3 * np.sin(2 * t)  # noqa: E731
+                              + 0.25 * t ** 2 * np.cos(2 * t) - t ** 3 + 2 * t ** 4 + (np.pi - 0.25) * t ** 2)
+    y0_c = np.float64(0.2 * np.float64(f32t[0]) + 3.0)
+    y0_s = np.float64(y_exact_sine(np.float64(f32t[0])))
+    A = np.array([[-0.1, 2.0], [-2.0, -0.1]])
+    y0b = np.random.default_rng(0).uniform(-2, 2, size=(64, 2))
+    cases = [('run_constant_adams', const, y0_c, f32t, 'adams', {}),
+             ('run_sine_adams', sine, y0_s, f32t, 'adams', {}),
+             ('run_linear0_adams', rhs_linear(np.zeros((10, 10))), np.ones((1, 10)), f32t, 'adams', {}),
+             ('run_spiral_b64_adams', rhs_cubic(A), y0b, np.linspace(0., 3., 4), 'adams', dict(rtol=1e-6, atol=1e-8)),
+             ('run_constant_explicit_adams', const, y0_c, f32t, 'explicit_adams', {}),
+             ('run_constant_fixed_adams', const, y0_c, f32t, 'fixed_adams', {}),
+             ('run_spiral_b64_explicit_adams', rhs_cubic(A), y0b, np.linspace(0., 0.4, 41), 'explicit_adams', dict(options={'max_order': 4})),
+             ('run_spiral_b64_fixed_adams', rhs_cubic(A), y0b, np.linspace(0., 0.4, 41), 'fixed_adams', {}),
+             ('run_sine_fixed_adams', sine, y0_s, np.linspace(1., 2., 41).astype(np.float32), 'fixed_adams', {})]
+    for name, rhs, y0, t, method, kw in cases:
+        del log[:]
+        arr = run_case(name, rhs, y0, t, method, **kw)
+        if method == 'adams':
+            d = dict(np.load(os.path.join(HERE, name + '.npz')))
+            d['trace'] = np.asarray(log, dtype=np.float64).reshape(-1, 4)
+            meta = json.loads(str(d['meta']))
+            meta['trace_columns'] = ['prev_t', 'next_t', 'order', 'accepted']
+            d['meta'] = np.asarray(json.dumps(meta, sort_keys=True))
+            np.savez_compressed(os.path.join(HERE, name + '.npz'), **d)
+        del arr
+    adams.VariableCoefficientAdamsBashforth._adaptive_adams_step = orig
+
+
 if __name__ == '__main__':
     np.random.seed(0)
-    if '--next-only' not in sys.argv:
+    if '--next-only' not in sys.argv and '--adams-only' not in sys.argv:
         gen_function_vectors()
         gen_runs()
-    gen_next_solvers()
+    if '--adams-only' not in sys.argv:
+        gen_next_solvers()
+    gen_adams()

@@ -92,7 +92,13 @@ class Tensor(object):
     def __getitem__(self, idx):
         if isinstance(idx, Tensor):
             idx = idx._a
+        if isinstance(idx, (int, np.integer)) and self._a.ndim >= 1:
+            return Tensor(self._a[idx, ...])      # a writable VIEW: TF lets you `var[j].assign(v)` (sliced assign)
         return Tensor(self._a[idx])
+
+    def assign(self, value):
+        self._a[...] = _np_of(value, like=self._a.dtype)
+        return self
 
     def __repr__(self):
         return 'standin.Tensor(%r, dtype=%s)' % (self._a, self._a.dtype)
@@ -367,6 +373,10 @@ class _Module(object):
         pass
 
 
+def _v1_assign(ref, value, **_):
+    return ref.assign(value)
+
+
 def install():
     """Install the stand-in as sys.modules['tensorflow'] (idempotent)."""
     me = sys.modules[__name__]
@@ -398,6 +408,8 @@ def install():
     tf.keras = keras
     tf.Module = _Module
     tf.UnconnectedGradients = types.SimpleNamespace(ZERO='zero')
+    tf.compat = types.SimpleNamespace(v1=types.SimpleNamespace(assign=_v1_assign))
+    tf.assign = _v1_assign
     sys.modules['tensorflow'] = tf
     sys.modules['tensorflow.math'] = math
     sys.modules['tensorflow.keras'] = keras

@@ -110,8 +110,12 @@ def _run_oracle(name):
         func = lambda t, ys: tuple(f(t, y_) for y_ in ys)  # noqa: E731
     else:
         y0, func = d['y0'], f
-    sol, stats = O.odeint(func, y0, d['t'], method=meta['method'], return_stats=True,
-                          max_attempts=meta['max_attempts'], **kw)
+    if meta['method'] in ('adams', 'fixed_adams', 'explicit_adams'):
+        from oracle import adams_numpy as AD
+        sol, stats = AD.odeint(func, y0, d['t'], method=meta['method'], return_stats=True, **kw)
+    else:
+        sol, stats = O.odeint(func, y0, d['t'], method=meta['method'], return_stats=True,
+                              max_attempts=meta['max_attempts'], **kw)
     return d, meta, sol, stats
 
 
@@ -122,7 +126,13 @@ def test_whole_runs_match_reference(name):
     vtol = 1e-5 if f32 else 1e-12
     if meta['rtol'] is not None and meta['rtol'] <= 1e-9:
         vtol = 1e-9                       # step sizes differ in the roundoff regime (below), so do the last digits
-    if 'trace' in d.files:
+    if 'trace' in d.files and meta['method'] == 'adams':
+        tr = np.asarray(stats.trace, dtype=np.float64).reshape(-1, 4)
+        ref = d['trace']                                  # (prev_t, next_t, order, accepted)
+        assert tr.shape == ref.shape, 'attempt count %d vs reference %d' % (len(tr), len(ref))
+        assert np.array_equal(tr[:, 2:], ref[:, 2:]), 'order / accept sequence differs'
+        np.testing.assert_allclose(tr[:, :2], ref[:, :2], rtol=1e-9, atol=0)
+    elif 'trace' in d.files:
         tr = np.asarray(stats.trace, dtype=np.float64).reshape(-1, 4)
         ref = d['trace']
         assert tr.shape == ref.shape, 'attempt count %d vs reference %d' % (len(tr), len(ref))
