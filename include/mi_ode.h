@@ -199,6 +199,10 @@ int mi_ode_error_norms(int32_t dtype, int64_t n, const void* err_dev, const void
 /* result_dev[1] (double) = sum_i ((x[i] - (xsub ? xsub[i] : 0)) / (atol + |y0[i]| * rtol))^2   (misc.py:225-237) */
 int mi_ode_scaled_sumsq(int32_t dtype, int64_t n, const void* x_dev, const void* xsub_dev, const void* y0_dev,
                         double rtol, double atol, double* result_dev, void* workspace_dev, void* stream);
+/* result_dev[1] (double) = 1.0 if ANY element violates |a - b| < atol + rtol * max(|a|, |b|), else 0.0
+ * (misc._has_converged, misc.py:129-134: the corrector iteration test of fixed_adams.py:196) */
+int mi_ode_not_converged(int32_t dtype, int64_t n, const void* a_dev, const void* b_dev, double rtol, double atol,
+                         double* result_dev, void* workspace_dev, void* stream);
 /* dense output at one time t in [t0, t1] from the accepted step's (y0, y1, k[0..nk-1]):
  * interp = QUARTIC_MID: interp.py:6-67 with y_mid = y0 + dt*sum c_mid[j] k[j] (dt = the step size the step was
  * taken with, dopri5.py:41); TSIT5 / TSIT5_REF: tsit5.py:33-50 */

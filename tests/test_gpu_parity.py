@@ -235,7 +235,7 @@ def _cases(engine):
         _, meta = load(n)
         if meta['max_attempts'] is not None:
             continue
-        if engine == 'fused' and (meta['rhs'] not in FUSED_RHS or meta['tuple_state']):
+        if engine == 'fused' and (meta['rhs'] not in FUSED_RHS or meta['tuple_state'] or 'adams' in meta['method']):
             continue
         if engine == 'planes' and n in ('run_lorenz_b64_tsit5_tiny', 'run_constant_bosh3', 'run_lv_rk4_1000',
                                         'run_lv_euler_1000'):
@@ -283,8 +283,16 @@ def test_plane_kernel_engine_reproduces_reference_runs(name):
     assert tuple(sol.shape) == d['y'].shape
     if f32:
         assert_band(sol.cpu(), d['y'], 2e-3, 2e-4, name)
+    elif name == 'run_sine_adams':
+        # the reference's own run is 6.7e-5 off the exact solution here (its test bar is 1e-4, odeint_tests.py:86-92):
+        # a step sequence that forks on a 1-ulp pow() difference moves the answer by that much
+        assert_band(sol.cpu(), d['y'], 1e-4, 1e-6, name)
     else:
         assert_band(sol.cpu(), d['y'], RTOL, ATOL, name)
+    if meta['method'] == 'adams' and 'trace' in d.files:
+        ref_att, ref_acc = len(d['trace']), int(d['trace'][:, 3].sum())
+        assert abs(stats['n_attempts'] - ref_att) <= max(2, ref_att // 20), (stats, ref_att)
+        assert abs(stats['n_accepted'] - ref_acc) <= max(2, ref_acc // 20), (stats, ref_acc)
 
 
 def test_tsit5_refcompat_first_attempts_match_reference_trace():
@@ -337,7 +345,9 @@ def _problem(ode, reverse=False):
 
 
 @pytest.mark.parametrize('method,odes', [('euler', ['constant']), ('midpoint', ['constant']), ('huen', ['constant']),
-                                         ('rk4', ['constant']), ('bosh3', ['constant']), ('dopri5', ['constant', 'sine'])])
+                                         ('rk4', ['constant']), ('bosh3', ['constant']), ('dopri5', ['constant', 'sine']),
+                                         ('explicit_adams', ['constant']), ('fixed_adams', ['constant']),
+                                         ('adams', ['constant', 'sine'])])
 @pytest.mark.parametrize('reverse', [False, True])
 def test_reference_unit_tests(method, odes, reverse):
     """TestSolverError / TestSolverBackwardsInTimeError (tests/odeint_tests.py:25-171): rel error < 1e-4."""
@@ -345,12 +355,16 @@ def test_reference_unit_tests(method, odes, reverse):
     for ode in odes:
         if method == 'bosh3' and reverse:
             continue
+        if method == 'adams' and reverse and ode == 'sine':
+            # the reference's backward test never passes ode= (odeint_tests.py:138-145): it only runs 'constant'.  On the
+            # reversed sine problem the reference itself (pinned oracle) is 8.7e-4 off - the p_next quirk, adams.py:210
+            continue
         f, y0, t, sol = _problem(ode, reverse)
         y = odeint(f, y0, t, method=method)
         assert float(np.max(np.abs((sol - y.cpu().numpy()) / sol))) < 1e-4
 
 
-@pytest.mark.parametrize('method', ['rk4', 'dopri5', 'euler', 'bosh3'])
+@pytest.mark.parametrize('method', ['rk4', 'dopri5', 'euler', 'bosh3', 'adams', 'explicit_adams', 'fixed_adams'])
 def test_no_integration(method):
     """TestNoIntegration (tests/odeint_tests.py:174-210): t_points[0:1] -> y0."""
     from tfdiffeq_amd import odeint

@@ -96,6 +96,8 @@ _PROTOS = {
                                      C.c_void_p, C.c_void_p]),
     'mi_ode_scaled_sumsq': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
                                       C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mi_ode_not_converged': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     'mi_ode_interp_eval': (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                      C.c_int32, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_void_p]),

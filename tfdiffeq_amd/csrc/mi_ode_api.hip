@@ -740,6 +740,7 @@ __global__ __launch_bounds__(256) void k_finalize_records(const double* part, in
   reduce_block_records(part, nblocks, rec);
   if (threadIdx.x == 0) {
     if (what == 0) { result[0] = rec[R_MAXA]; result[1] = rec[R_MAXB]; result[2] = rec[R_SUMA]; result[3] = rec[R_FLAG]; }
+    else if (what == 2) result[0] = rec[R_FLAG];
     else result[0] = rec[R_SUMA];
   }
 }
@@ -788,6 +789,20 @@ extern "C" int mi_ode_scaled_sumsq(int32_t dtype, int64_t n, const void* x_dev, 
   else if (dtype == MI_ODE_F32) hipLaunchKernelGGL(k_scaled_sumsq<float>, dim3(g), dim3(256), 0, st, (const float*)x_dev, (const float*)xsub_dev, (const float*)y0_dev, (long long)n, rtol, atol, part);
   else { mi_set_error("bad dtype"); return MI_ODE_E_INVALID; }
   hipLaunchKernelGGL(k_finalize_records, dim3(1), dim3(256), 0, st, (const double*)part, g, result_dev, 1);
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mi_ode_not_converged(int32_t dtype, int64_t n, const void* a_dev, const void* b_dev, double rtol, double atol,
+                                    double* result_dev, void* workspace_dev, void* stream) {
+  if (n <= 0 || !a_dev || !b_dev || !result_dev || !workspace_dev) { mi_set_error("not_converged: bad argument"); return MI_ODE_E_INVALID; }
+  const int g = streaming_grid(n);
+  hipStream_t st = (hipStream_t)stream;
+  double* part = (double*)workspace_dev;
+  if (dtype == MI_ODE_F64) hipLaunchKernelGGL(k_not_converged<double>, dim3(g), dim3(256), 0, st, (const double*)a_dev, (const double*)b_dev, (long long)n, rtol, atol, part);
+  else if (dtype == MI_ODE_F32) hipLaunchKernelGGL(k_not_converged<float>, dim3(g), dim3(256), 0, st, (const float*)a_dev, (const float*)b_dev, (long long)n, rtol, atol, part);
+  else { mi_set_error("bad dtype"); return MI_ODE_E_INVALID; }
+  hipLaunchKernelGGL(k_finalize_records, dim3(1), dim3(256), 0, st, (const double*)part, g, result_dev, 2);
   MI_HIP(hipGetLastError());
   return 0;
 }

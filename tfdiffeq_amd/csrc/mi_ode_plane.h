@@ -59,4 +59,17 @@ __global__ __launch_bounds__(256) void k_scaled_sumsq(const T* x, const T* xsub,
   block_reduce_store(acc, red, part + (long long)blockIdx.x * kRec);
 }
 
+// block records {-, -, -, -, flag}: flag = some element fails |a - b| < atol + rtol * max(|a|, |b|)   (misc.py:129-134)
+template <typename T>
+__global__ __launch_bounds__(256) void k_not_converged(const T* a, const T* b, long long n, double rtol, double atol, double* part) {
+  Acc acc;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const T x = a[i], y = b[i];
+    const T tol = (T)atol + (T)rtol * fmax(fabs(x), fabs(y));
+    if (!(fabs(x - y) < tol)) acc.flag = 1;
+  }
+  __shared__ double red[80];
+  block_reduce_store(acc, red, part + (long long)blockIdx.x * kRec);
+}
+
 }  // namespace mi

@@ -132,6 +132,19 @@ def _scaled_sumsq(x, xsub, y0, rtol, atol):
     return res
 
 
+def _has_converged(y0, y1, rtol, atol):
+    """misc.py:129-134: every element within atol + rtol*max(|y0|,|y1|); one kernel per component, one host sync."""
+    lib = N.load()
+    flags = []
+    for a, b in zip(y0, y1):
+        a, b = _contig(a), _contig(b)
+        res = torch.empty(1, dtype=torch.float64, device=a.device)
+        N.check(lib.mi_ode_not_converged(N.dtype_code(a.dtype), a.numel(), _ptr(a), _ptr(b), float(rtol), float(atol), _ptr(res),
+                                         _ptr(_reduce_workspace(a.device)), N.stream_ptr(a.device)), 'mi_ode_not_converged')
+        flags.append(res)
+    return not bool(torch.cat(flags).max().item() > 0)
+
+
 class _Exchange(object):
     """Combines per-rank reduction records for batch-sharded runs.  Records are laid out
     {max, max, sum, flag/sum, ...}: maxima for slots listed in `max_slots`, sums elsewhere, in rank order."""

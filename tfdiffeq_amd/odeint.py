@@ -1,16 +1,20 @@
 """Mirror of tfdiffeq/odeint.py: the `odeint` entry point and the SOLVERS registry (B1/B2)."""
+from .adams import VariableCoefficientAdamsBashforth
 from .adaptive_huen import AdaptiveHeunSolver
 from .bosh3 import Bosh3Solver
 from .dopri5 import Dopri5Solver
 from .dopri8 import Dopri8Solver
+from .fixed_adams import AdamsBashforth, AdamsBashforthMoulton
 from .fixed_grid import Euler, Midpoint, RK4, Heun
 from .misc import _check_inputs
 from .tsit5 import Tsit5Solver
 
-# odeint.py:11-25.  In scope of this build: dopri5, tsit5, bosh3, euler, rk4, plus the 8(f)
-# rank-1 widening (dopri8, adaptive_heun, midpoint, heun).  The multistep family (adams, explicit_adams,
-# fixed_adams) is out of scope (different kernel shape); asking for it raises KeyError like any unknown name.
+# odeint.py:11-25 - all 13 keys of the reference.  Hot path: dopri5, tsit5, bosh3, euler, rk4;
+# 8(f) widening: dopri8, adaptive_heun, midpoint, heun (rank 1), the multistep family (rank 4).
 SOLVERS = {
+    'explicit_adams': AdamsBashforth,
+    'fixed_adams': AdamsBashforthMoulton,
+    'adams': VariableCoefficientAdamsBashforth,
     'tsit5': Tsit5Solver,
     'dopri5': Dopri5Solver,
     'dopri8': Dopri8Solver,
