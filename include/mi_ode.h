@@ -53,6 +53,7 @@ extern "C" {
 #define MI_ODE_ST_DT_UNDERFLOW 0x1u    /* assert t0 + dt > t0            (dopri5.py:98)      */
 #define MI_ODE_ST_NONFINITE 0x2u       /* assert _is_finite(abs(y0))     (dopri5.py:99-100)  */
 #define MI_ODE_ST_MAX_STEPS 0x4u       /* assert n_steps < max_num_steps (dopri5.py:85-86)   */
+#define MI_ODE_ST_SYNC_TIMEOUT 0x10u   /* engine: the in-kernel grid hand-off of the whole-integration kernel timed out */
 #define MI_ODE_ST_BAD_T 0x8u           /* _assert_increasing / interpolation range (misc.py:158, interp.py:59) */
 /* negative returns: API errors */
 #define MI_ODE_E_INVALID (-1)          /* bad argument / unsupported combination */
@@ -136,7 +137,9 @@ typedef struct mi_ode_desc {
   int32_t profile;            /* 1: bracket the stage kernels of every attempt with HIP events (mi_ode_get_profile) */
   int32_t fusion;             /* 0 auto, 1 one kernel per RK stage (34 planes/attempt), 2 whole attempt in one kernel
                                  (4 planes/attempt; row-local RHS keep k_2..k_S on chip; single rank: the controller
-                                 runs in the kernel's last workgroup), 3 as 2 but with the controller as its own launch */
+                                 runs in the kernel's last workgroup), 3 as 2 but with the controller as its own launch,
+                                 4 whole integration in ONE launch (tiny row-local systems, single rank; auto picks it
+                                 when every workgroup can be co-resident; mi_ode_integrate only) */
   int32_t reserved;
 } mi_ode_desc;
 

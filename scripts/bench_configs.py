@@ -35,17 +35,21 @@ def run(name, f, y0, t, reps=10, **kw):
 rng = np.random.default_rng(0)
 A2 = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64)
 y2 = torch.tensor(rng.uniform(-2, 2, size=(4096, 2)), device=dev)
-for fusion in ('step', 'stage'):
+for fusion in ('whole', 'step', 'stage'):
     run('C2 spiral b4096 dopri5 T=10 fusion=%s' % fusion, rhs.CubicLinear(A2), y2, torch.linspace(0., 25., 10, dtype=torch.float64),
         method='dopri5', options={'fusion': fusion})
 run('C2 spiral b4096 dopri5 T=2', rhs.CubicLinear(A2), y2, torch.tensor([0., 25.]), method='dopri5')
 rng1 = np.random.default_rng(1)
 y3 = torch.tensor(np.array([1., 1., 1.]) + 1e-3 * rng1.standard_normal((65536, 3)), device=dev)
-for fusion in ('step', 'stage'):
+for fusion in ('whole', 'step', 'stage'):
     run('C3 lorenz b65536 tsit5 t=[0,1] fusion=%s' % fusion, rhs.Lorenz(), y3, torch.tensor([0., 1.]), rtol=1e-6, atol=1e-9,
         method='tsit5', options={'fusion': fusion})
 run('C3 lorenz b65536 tsit5 t=[0,10]', rhs.Lorenz(), y3, torch.tensor([0., 10.]), reps=3, rtol=1e-6, atol=1e-9, method='tsit5')
 run('C3 lorenz b65536 dopri5 t=[0,10]', rhs.Lorenz(), y3, torch.tensor([0., 10.]), reps=3, rtol=1e-6, atol=1e-9, method='dopri5')
+y1 = torch.tensor([[2., 0.]], dtype=torch.float64, device=dev)
+for fusion in ('whole', 'step'):
+    run('ode_demo spiral single trajectory dopri5 T=1000 fusion=%s' % fusion, rhs.CubicLinear(A2), y1,
+        torch.linspace(0., 25., 1000, dtype=torch.float64), method='dopri5', options={'fusion': fusion})
 run('C1 LV rk4 1000 steps (single trajectory)', rhs.LotkaVolterra(), torch.tensor([1., 1.], dtype=torch.float64, device=dev),
     torch.linspace(0., 10., 1001, dtype=torch.float64), reps=3, method='rk4')
 run('LV b65536 rk4 100 steps', rhs.LotkaVolterra(), torch.tensor(1 + rng.uniform(size=(65536, 2)), device=dev),

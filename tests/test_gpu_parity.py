@@ -244,11 +244,16 @@ def _cases(engine):
     return out
 
 
-@pytest.mark.parametrize('fusion', ['step', 'stage'])
+@pytest.mark.parametrize('fusion', ['step', 'stage', 'whole'])
 @pytest.mark.parametrize('name', _cases('fused'))
 def test_fused_engine_reproduces_reference_runs(name, fusion):
-    """fusion='stage': one kernel per RK stage (34 planes per attempt); 'step': whole attempt in one kernel."""
+    """fusion='stage': one kernel per RK stage (34 planes per attempt); 'step': whole attempt in one kernel;
+    'whole': the whole adaptive integration in one launch (tiny row-local systems)."""
     _, meta0 = load(name)
+    if fusion == 'whole' and (meta0['rhs'] not in ('cubic_linear', 'lotka_volterra', 'lorenz') or
+                              meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') or
+                              (meta0['rhs'] == 'cubic_linear' and len(meta0['rhs_params']['W']) != 2)):
+        pytest.skip('whole-integration kernel: adaptive solvers on the row-local catalogue systems')
     if fusion == 'step' and meta0['rhs'] == 'linear' and len(meta0['rhs_params']['W']) not in (2, 16, 32, 64, 128):
         fusion = 'auto'                                 # no whole-attempt kernel for the VALU fallback family
     if meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') and meta0['rhs'] == 'linear':
@@ -515,6 +520,65 @@ def test_exchange_hook_path_on_one_gpu():
     out = json.loads(lines[-1])
     assert out['diff'] == 0.0 and out['diff4'] == 0.0, out
     assert out['att_a'] == out['att_b'] and out['launch_b'] > out['launch_a'], out
+
+
+# ---------------------------------------------------------------------------------------------
+# whole integration in ONE launch (tiny row-local systems) vs one launch per attempt: identical bits
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('method', ['dopri5', 'bosh3', 'tsit5'])
+@pytest.mark.parametrize('problem,batch', [('lorenz', 1), ('lorenz', 300), ('lorenz', 65536), ('lv', 256), ('lv', 5000),
+                                           ('spiral', 4096), ('spiral', 77), ('linear2', 1000)])
+def test_whole_integration_kernel_equals_launch_per_attempt(problem, batch, method):
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(11)
+    if problem == 'lorenz':
+        f, y0, t = rhs.Lorenz(), np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((batch, 3)), np.linspace(0., 0.5, 11)
+    elif problem == 'lv':
+        f, y0, t = rhs.LotkaVolterra(), 1 + 0.5 * rng.uniform(size=(batch, 2)), np.linspace(0., 2.0, 5)
+    elif problem == 'spiral':
+        f = rhs.CubicLinear(torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64))
+        y0, t = rng.uniform(-2, 2, size=(batch, 2)), np.linspace(0., 2.0, 21)
+    else:
+        f = rhs.Linear.from_matrix(torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64))
+        y0, t = rng.uniform(-2, 2, size=(batch, 2)), np.array([0., 1.0, 1.5, 4.0])
+    if method == 'bosh3':
+        t = t[0] + 0.05 * (t - t[0])                    # the typo tableau is ~25x more expensive
+    y0 = to_dev(y0, torch.float64)
+    tt = torch.tensor(t, dtype=torch.float64)
+    tol = dict(rtol=1e-6, atol=1e-9)
+    a = odeint(f, y0, tt, method=method, options={'fusion': 'step'}, **tol)
+    sa = dict(odeint.last_stats)
+    b = odeint(f, y0, tt, method=method, options={'fusion': 'whole'}, **tol)
+    sb = dict(odeint.last_stats)
+    c = odeint(f, y0, tt, method=method, **tol)          # auto picks the one-launch kernel for these sizes
+    sc = dict(odeint.last_stats)
+    assert sb['n_launches'] == 1 and sc['n_launches'] == 1 and sa['n_launches'] > 1, (sa, sb, sc)
+    for k_ in ('n_attempts', 'n_accepted', 'nfe', 'status'):
+        assert sa[k_] == sb[k_] == sc[k_], (k_, sa, sb, sc)
+    assert torch.equal(a, b) and torch.equal(b, c)
+    # reversed time and float32 state go through the same kernel
+    if problem != 'spiral':                              # the cubic spiral blows up in finite time backwards
+        tr = torch.tensor(t[::-1].copy(), dtype=torch.float64)
+        ar = odeint(f, y0, tr, method=method, options={'fusion': 'step'}, **tol)
+        br = odeint(f, y0, tr, method=method, options={'fusion': 'whole'}, **tol)
+        assert torch.equal(ar, br)
+    y32 = y0.float()
+    a32 = odeint(f, y32, tt, method=method, options={'fusion': 'step'}, rtol=1e-4, atol=1e-6)
+    b32 = odeint(f, y32, tt, method=method, options={'fusion': 'whole'}, rtol=1e-4, atol=1e-6)
+    assert torch.equal(a32, b32)
+
+
+def test_whole_integration_kernel_status_paths():
+    from tfdiffeq_amd import odeint, rhs
+    y0 = to_dev(np.array([[1., 1., 1.]]), torch.float64)
+    tt = torch.tensor([0., 5.0], dtype=torch.float64)
+    with pytest.raises(AssertionError, match='max_num_steps'):
+        odeint(rhs.Lorenz(), y0, tt, method='dopri5', options={'fusion': 'whole', 'max_num_steps': 5})
+    bad = to_dev(np.array([[1., float('nan'), 1.]]), torch.float64)
+    with pytest.raises(AssertionError, match='non-finite'):
+        odeint(rhs.Lorenz(), bad, tt, method='dopri5', options={'fusion': 'whole'})
+    with pytest.raises(Exception):
+        odeint(rhs.Lorenz(), to_dev(np.ones((600000, 3)), torch.float64), tt, method='dopri5', options={'fusion': 'whole'})
 
 
 # ---------------------------------------------------------------------------------------------

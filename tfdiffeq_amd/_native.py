@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH = 1, 2, 3, 4, 5
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
-ST_DT_UNDERFLOW, ST_NONFINITE, ST_MAX_STEPS, ST_BAD_T = 1, 2, 4, 8
+ST_DT_UNDERFLOW, ST_NONFINITE, ST_MAX_STEPS, ST_BAD_T, ST_SYNC_TIMEOUT = 1, 2, 4, 8, 16
 
 
 class Tableau(C.Structure):

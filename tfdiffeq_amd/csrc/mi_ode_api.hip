@@ -10,6 +10,7 @@
 #include "mi_ode_host.h"
 #include "mi_ode_plane.h"
 #include "mi_ode_step_fused.h"
+#include "mi_ode_persist.h"
 #include "mi_ode_mlp.h"
 
 using namespace mi;
@@ -34,6 +35,7 @@ extern "C" const char* mi_ode_status_string(uint32_t s) {
   if (s & MI_ODE_ST_NONFINITE) return "non-finite values in state `y`";               // dopri5.py:100
   if (s & MI_ODE_ST_MAX_STEPS) return "max_num_steps exceeded";                       // dopri5.py:85
   if (s & MI_ODE_ST_DT_UNDERFLOW) return "underflow in dt";                           // dopri5.py:98
+  if (s & MI_ODE_ST_SYNC_TIMEOUT) return "engine: grid hand-off timed out (whole-integration kernel)";
   return "ok";
 }
 
@@ -346,6 +348,19 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     h->fused_ctl = (h->step_fused && h->d.world_size <= 1 && desc->allgather == nullptr && desc->fusion != 3 &&
                     !(light_many && desc->fusion == 0)) ? 1 : 0;
   }
+  {   // whole integration in one launch: tiny row-local systems, single rank, one trajectory per thread, every
+      // workgroup co-resident (the in-kernel hand-off spins)
+    const bool rowlocal = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ;
+    const long long g = (desc->batch + 255) / 256;
+    bool can = desc->adaptive && rowlocal && h->d.world_size <= 1 && desc->allgather == nullptr && g <= kPersistMaxGrid;
+    if (can) {
+      const int cap = h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h);
+      can = cap > 0 && g <= cap;
+    }
+    if (desc->fusion == 4 && !can) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local RHS, single rank, batch <= co-resident threads)"); delete h; return MI_ODE_E_INVALID; }
+    h->persist = (can && (desc->fusion == 4 || (desc->fusion == 0 && !desc->profile))) ? 1 : 0;
+    h->persist_grid = (int)g;
+  }
   // controller / dense-output parameters
   h->cp.rtol = desc->rtol; h->cp.atol = desc->atol;
   h->cp.safety = desc->safety; h->cp.ifactor = desc->ifactor; h->cp.dfactor = desc->dfactor;
@@ -363,6 +378,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   hipError_t e = hipSuccess;
   e = hipMalloc((void**)&h->planes, (size_t)h->stride * kNumPlanes);
   if (e == hipSuccess) e = hipMalloc((void**)&h->partials, (size_t)kMaxBlocks * kRec * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->partials, 0, (size_t)kMaxBlocks * kRec * sizeof(double));   // no stale stamps
   if (desc->exchange_send_dev != nullptr && desc->exchange_recv_dev != nullptr) {
     h->rank_rec = desc->exchange_send_dev;
     h->gathered = desc->exchange_recv_dev;
@@ -538,6 +554,50 @@ extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t
   return (int)h->ctl_host->status;
 }
 
+// One launch for the whole call (mi_ode_persist.h): upload the scalar state and the output times, run, read back.
+static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double* t_host, int32_t T, void* out_dev,
+                             mi_ode_stats* stats, hipStream_t st) {
+  MI_HIP(hipStreamSynchronize(st));            // pinned staging buffers may still be in flight from a previous call
+  int rc = ensure_t_out(h, T - 1);
+  if (rc != 0) return rc;
+  Ctl* c = h->ctl_host;
+  memset(c, 0, sizeof(Ctl));
+  c->t0 = c->t1 = t_host[0];
+  c->dt = h->cp.auto_first_step ? 0.0 : h->d.first_step;
+  c->idx_y0 = 0; c->idx_y1 = 1;
+  for (int j = 0; j < kMaxK; ++j) c->idx_k[j] = 2 + j;
+  h->n_launches = 0; h->n_polls = 0; h->enq_attempts = 0; h->prof_done = 0;
+  memcpy(h->t_out_host, t_host + 1, (size_t)(T - 1) * sizeof(double));
+  MI_HIP(hipMemcpyAsync(h->ctl, c, sizeof(Ctl), hipMemcpyHostToDevice, st));
+  MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)(T - 1) * sizeof(double), hipMemcpyHostToDevice, st));
+  h->cp.t_out = h->t_out_dev;
+  h->cur_out = (char*)out_dev + (size_t)h->n * h->elt;
+  PersistArgs A;
+  memset(&A, 0, sizeof(A));
+  fill_step_args(h, A.s);
+  A.s.ticket = nullptr;
+  A.y0 = y0_dev; A.out0 = out_dev; A.n_out = T - 1;
+  A.stamp_base = h->stamp_base;
+  A.spin_limit = 1 << 21;
+  rc = h->is_f32 ? mi_launch_persist_f32(h, A, h->persist_grid, st) : mi_launch_persist_f64(h, A, h->persist_grid, st);
+  if (rc != 0) return rc;
+  rc = poll_ctl(h, st);
+  if (rc != 0) return rc;
+  h->begun = 1;
+  h->last_call_attempts = h->ctl_host->n_attempt;
+#ifdef MI_PERSIST_PROF
+  {
+    const Ctl* cc = h->ctl_host;
+    const double na = cc->n_attempt > 0 ? (double)cc->n_attempt : 1.0;
+    fprintf(stderr, "[persist prof] attempts %lld  ns/attempt: stages %.0f  reduce+handoff %.0f  controller %.0f  emit %.0f\n",
+            cc->n_attempt, 10.0 * cc->prof[0] / na, 10.0 * cc->prof[1] / na, 10.0 * cc->prof[2] / na, 10.0 * cc->prof[3] / na);
+  }
+#endif
+  h->stamp_base += (double)h->ctl_host->n_attempt + 16.0;      // hand-offs of this call: attempts + 2 (+ margin)
+  if (stats) fill_stats(h, stats);
+  return (int)h->ctl_host->status;
+}
+
 extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const double* t_host, int32_t T, void* out_dev,
                                 mi_ode_stats* stats, void* stream) {
   if (h == nullptr || y0_dev == nullptr || t_host == nullptr || out_dev == nullptr || T < 1) { mi_set_error("bad argument"); return MI_ODE_E_INVALID; }
@@ -547,6 +607,11 @@ extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const doubl
       if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = MI_ODE_ST_BAD_T; }
       return MI_ODE_ST_BAD_T;                  // _assert_increasing (misc.py:158-159)
     }
+  if (h->persist && T > 1 && h->d.adaptive) {
+    const int prc = integrate_persist(h, y0_dev, t_host, T, out_dev, stats, st);
+    if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4) return prc;
+    h->persist = 0;        // the grid hand-off timed out (co-residency lost to another persistent kernel?): this
+  }                        // handle goes back to one launch per attempt, starting with this call
   int rc = begin_impl(h, y0_dev, t_host[0], out_dev, stream);   // before_integrate runs even when T == 1 (solvers.py:31);
   if (rc != 0) return rc;                                        // solution = [y0] is written by the same kernel
   int status = 0;

@@ -37,6 +37,7 @@ struct Ctl {
   unsigned status;          // MI_ODE_ST_*
   int y0_nonfinite;
   int accepted;             // result of the last attempt
+  long long prof[4];        // -DMI_PERSIST_PROF: wall_clock64 ticks (10 ns) in stages / reduce+hand-off / controller / emit
 };
 
 // Stage kernel flavours.  STAGE / LAST_FSAL follow rk_common.py:49-60 literally (operation
@@ -228,11 +229,9 @@ __device__ __forceinline__ double wave_max(double v) {
   return v;
 }
 
-// Block-reduce an Acc and let thread 0 write one record.  `red` is >= 5*16 doubles of LDS.
-// SC1: store the record write-through with agent-scope (sc1) stores - the producer side of the in-kernel hand-off
-// to the last workgroup (no release fence needed; the caller drains vmcnt before taking its ticket).
-template <bool SC1 = false>
-__device__ __forceinline__ void block_reduce_store(const Acc& a, double* red, double* rec_out) {
+// Block-reduce an Acc.  `red` is >= 5*16 doubles of LDS.
+// Core: after the call thread 0 holds the block's {max a, max b, sum a, sum b, flag} in r[0..4].
+__device__ __forceinline__ void block_reduce_thread0(const Acc& a, double* red, double (&r)[5]) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
   double v0 = wave_max(a.maxa), v1 = wave_max(a.maxb), v2 = wave_sum(a.suma), v3 = wave_sum(a.sumb);
   double v4 = wave_max((double)a.flag);
@@ -241,21 +240,32 @@ __device__ __forceinline__ void block_reduce_store(const Acc& a, double* red, do
     red[wave] = v0; red[16 + wave] = v1; red[32 + wave] = v2; red[48 + wave] = v3; red[64 + wave] = v4;
   }
   __syncthreads();
+  r[0] = r[1] = r[2] = r[3] = r[4] = 0;
   if (threadIdx.x == 0) {
-    double r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0;
     for (int w = 0; w < nw; ++w) {
-      r0 = fmax(r0, red[w]); r1 = fmax(r1, red[16 + w]); r2 += red[32 + w]; r3 += red[48 + w];
-      r4 = fmax(r4, red[64 + w]);
+      r[0] = fmax(r[0], red[w]); r[1] = fmax(r[1], red[16 + w]); r[2] += red[32 + w]; r[3] += red[48 + w];
+      r[4] = fmax(r[4], red[64 + w]);
     }
+  }
+}
+
+// ... and let thread 0 write one record.
+// SC1: store the record write-through with agent-scope (sc1) stores - the producer side of the in-kernel hand-off
+// to the last workgroup (no release fence needed; the caller drains vmcnt before taking its ticket).
+template <bool SC1 = false>
+__device__ __forceinline__ void block_reduce_store(const Acc& a, double* red, double* rec_out) {
+  double r[5];
+  block_reduce_thread0(a, red, r);
+  if (threadIdx.x == 0) {
     if constexpr (SC1) {
-      __hip_atomic_store(rec_out + R_MAXA, r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(rec_out + R_MAXB, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(rec_out + R_SUMA, r2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(rec_out + R_SUMB, r3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(rec_out + R_FLAG, r4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rec_out + R_MAXA, r[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rec_out + R_MAXB, r[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rec_out + R_SUMA, r[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rec_out + R_SUMB, r[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(rec_out + R_FLAG, r[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
-      rec_out[R_MAXA] = r0; rec_out[R_MAXB] = r1; rec_out[R_SUMA] = r2; rec_out[R_SUMB] = r3;
-      rec_out[R_FLAG] = r4; rec_out[R_N] = 0; rec_out[6] = 0; rec_out[7] = 0;
+      rec_out[R_MAXA] = r[0]; rec_out[R_MAXB] = r[1]; rec_out[R_SUMA] = r[2]; rec_out[R_SUMB] = r[3];
+      rec_out[R_FLAG] = r[4]; rec_out[R_N] = 0; rec_out[6] = 0; rec_out[7] = 0;
     }
   }
 }

@@ -7,6 +7,7 @@ namespace mi {
 struct StepArgs;
 struct MlpArgs;
 struct FixedArgs;
+struct PersistArgs;
 
 enum Family {
   FAM_NONE = 0,
@@ -56,6 +57,9 @@ struct mi_ode_solver {
   int stage_grid, stage_block;
   int step_fused;             // 1: whole-attempt kernel in use
   int step_grid, step_block;
+  int persist;                // 1: whole integration in one launch (mi_ode_persist.h)
+  int persist_grid;
+  double stamp_base;          // hand-off stamps already used on this handle's record buffer
   int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)
   int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation
   // bookkeeping
@@ -83,6 +87,10 @@ int mi_launch_step_f64(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
 int mi_launch_step_f32(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
 int mi_launch_fixed_f64(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
 int mi_launch_fixed_f32(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
+int mi_launch_persist_f64(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);
+int mi_launch_persist_f32(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);
+int mi_persist_capacity_f64(mi_ode_solver* h);
+int mi_persist_capacity_f32(mi_ode_solver* h);
 int mi_launch_mlp_f32(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st);
 int mi_stage_geometry_f64(mi_ode_solver* h);
 int mi_stage_geometry_f32(mi_ode_solver* h);

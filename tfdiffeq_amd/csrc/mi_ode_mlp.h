@@ -259,7 +259,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
         const long long idx = row * d + col;
         P.y1[idx] = ys[i];
         P.f1[idx] = k[S][i];
-        step_emit<float, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx);
+        step_emit<float, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, A.t_out);
         acc.maxa = fmax(acc.maxa, (double)fabsf(y0e[i]));
         acc.maxb = fmax(acc.maxb, (double)fabsf(ys[i]));
         acc.suma += (double)err * (double)err;

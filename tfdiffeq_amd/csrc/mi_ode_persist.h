@@ -1,0 +1,321 @@
+// Whole-integration kernel for the tiny row-local systems: ONE launch per odeint() call.
+//
+// Small problems (the reference's own demos and tests: 1 .. 65536 trajectories of dim 2-3) are bound by launch
+// latency, not by bytes: a whole-attempt kernel lasts ~5 us and the gap to the next launch another ~5 us.  Here the
+// adaptive loop of AdaptiveStepsizeODESolver.integrate (solvers.py:28-41, dopri5.py:82-121) runs INSIDE one kernel:
+//   * a thread owns one trajectory; y, f0 and the stage derivatives k_1..k_{S+1} never leave its registers;
+//   * before_integrate (f0, misc._select_initial_step) is the kernel's prologue (two grid reductions);
+//   * per attempt: stages -> block reduction -> grid hand-off -> EVERY workgroup reduces the same records in the same
+//     fixed order and applies the controller to its own copy of the scalar state (same bits everywhere, no broadcast
+//     phase); accepted steps write the requested outputs from registers (dense output, dopri5.py:87/interp.py);
+//   * HBM traffic = y0 in + solution rows out.
+// Grid hand-off: every workgroup publishes its record as stamped 16-byte {value, stamp} pairs (sc1 write-through
+// stores), polls everybody's pairs with sc1 loads until the stamps match, and folds (no atomics, no fences - see
+// below).  Records are double-buffered by hand-off parity: a workgroup can be at most one hand-off ahead of the
+// slowest one.
+// All workgroups must be co-resident: the host only picks this kernel when gridDim.x <= CUs x occupancy, and the
+// spin is bounded (MI_ODE_ST_SYNC_TIMEOUT) so that a scheduling surprise ends in an error, not a hang.
+// The arithmetic is that of k_stage_rowlocal<M_F0 / M_INITB> and k_step_rowlocal, operation for operation, and the
+// records are reduced in the same order (same grid, same row -> thread map): results are bit-identical to the
+// launch-per-attempt path.
+#pragma once
+#include "mi_ode_step_fused.h"
+
+namespace mi {
+
+#ifdef MI_PERSIST_PROF
+#define MI_TICK(var) const long long var = (long long)wall_clock64()
+#define MI_TOCK(slot, a, b) do { if (threadIdx.x == 0 && blockIdx.x == 0) s_c.prof[slot] += (b) - (a); } while (0)
+#else
+#define MI_TICK(var)
+#define MI_TOCK(slot, a, b)
+#endif
+
+struct PersistArgs {
+  StepArgs s;                  // tableau, RHS, controller parameters; out = solution[1:], t_out = t[1:] (device);
+                               // partials = 2 x gridDim.x records; ctl = initial scalar state in, final state out
+  const void* y0;              // caller's initial state [batch, D]
+  void* out0;                  // solution[0]
+  double stamp_base;           // stamps of this call are stamp_base + 1, + 2, ... (above every earlier call's)
+  int n_out;                   // T - 1
+  int spin_limit;              // bound on the spin iterations of one hand-off
+};
+
+// k_set_outputs as a device function (solvers.py:33-34 + the entry assertions of dopri5.py:98-100)
+__device__ __forceinline__ void set_outputs_apply(Ctl* c, int n_out) {
+  c->next_out = 0; c->n_out = n_out; c->n_steps_out = 0; c->emit_lo = c->emit_hi = 0;
+  c->done = 0;
+  if (c->status != 0) { c->done = 1; return; }
+  if (n_out <= 0) { c->done = 1; return; }
+  if (c->y0_nonfinite && c->n_attempt == 0) { c->status |= MI_ODE_ST_NONFINITE; c->done = 1; return; }
+  if (!(c->t1 + c->dt > c->t1)) { c->status |= MI_ODE_ST_DT_UNDERFLOW; c->done = 1; }
+}
+
+// ---- grid hand-off records -------------------------------------------------------------------------------------
+// A record is 5 x {value, stamp} pairs (16 bytes each, 128-byte stride).  A pair travels in ONE 16-byte sc1
+// (agent-scope, write-through) store and is read back with ONE 16-byte sc1 load, so a value and its stamp are always
+// seen together: no "drain, then publish a flag" round trip, no atomics, no fences.  Stamps of a call are
+// stamp_base + 1, + 2, ...; the host raises stamp_base past every stamp of the previous call on the handle.
+typedef double d2_t __attribute__((ext_vector_type(2)));
+constexpr int kPersistTout = 1024;
+constexpr int kPRec = 16;                                     // doubles per hand-off record (5 pairs + padding)
+constexpr int kPersistMaxGrid = kMaxBlocks * kRec / (2 * kPRec);   // two parity buffers inside the `partials` allocation
+
+__device__ __forceinline__ void store_pair_sc1(double* p, double value, double stamp) {
+  d2_t v = {value, stamp};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// all five pairs of one record: five loads in flight, one wait
+__device__ __forceinline__ void load_record_sc1(const double* p, d2_t (&v)[5]) {
+  asm volatile(
+      "global_load_dwordx4 %0, %5, off sc1\n\t"
+      "global_load_dwordx4 %1, %5, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %5, off offset:32 sc1\n\t"
+      "global_load_dwordx4 %3, %5, off offset:48 sc1\n\t"
+      "global_load_dwordx4 %4, %5, off offset:64 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
+      : "v"(p)
+      : "memory");
+}
+
+struct PersistShared {
+  Ctl c;
+  double red[80];
+  double rec[kRec];
+  double vals[5][kPersistMaxGrid];                            // every workgroup's record, staged for the fixed-order fold
+  double tout[kPersistTout];                                  // the requested output times, when they fit
+  int ok;
+};
+
+// Block record -> (grid hand-off) -> combined record in sh.rec (valid for thread 0 after the trailing barrier).
+// Returns false on a hand-off timeout.  `gen` counts hand-offs (uniform over the grid).  Thread i polls record i
+// (one round trip once the slowest workgroup has published), wavefront 0 folds in reduce_block_records' fixed order.
+__device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc, PersistShared& sh, unsigned gen) {
+  const int G = (int)gridDim.x;
+  if (G == 1) {
+    block_reduce_store<false>(acc, sh.red, sh.rec);          // one record: folding it with zeros is exact
+    __syncthreads();
+    return true;
+  }
+  double* buf = A.s.partials + (long long)(gen & 1u) * G * kPRec;
+  const double stamp = A.stamp_base + (double)(gen + 1u);
+  double r[5];
+  block_reduce_thread0(acc, sh.red, r);
+  if (threadIdx.x == 0) {
+    sh.ok = 1;
+    double* mine = buf + (long long)blockIdx.x * kPRec;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) store_pair_sc1(mine + 2 * i, r[i], stamp);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < G; b += blockDim.x) {
+    const double* p = buf + (long long)b * kPRec;
+    d2_t v[5];
+    int spins = 0;
+    for (;;) {
+      load_record_sc1(p, v);
+      if (v[0].y == stamp && v[1].y == stamp && v[2].y == stamp && v[3].y == stamp && v[4].y == stamp) break;
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > A.spin_limit) { sh.ok = 0; break; }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) sh.vals[i][b] = v[i].x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 64 && sh.ok) {
+    double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+    for (int b = threadIdx.x; b < G; b += 64) {
+      v0 = fmax(v0, sh.vals[R_MAXA][b]); v1 = fmax(v1, sh.vals[R_MAXB][b]);
+      v2 += sh.vals[R_SUMA][b]; v3 += sh.vals[R_SUMB][b]; v4 = fmax(v4, sh.vals[R_FLAG][b]);
+    }
+    v0 = wave_max(v0); v1 = wave_max(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_max(v4);
+    if (threadIdx.x == 0) {
+      sh.rec[R_MAXA] = v0; sh.rec[R_MAXB] = v1; sh.rec[R_SUMA] = v2; sh.rec[R_SUMB] = v3; sh.rec[R_FLAG] = v4;
+      sh.rec[R_N] = 0; sh.rec[6] = 0; sh.rec[7] = 0;
+    }
+  }
+  __syncthreads();
+  return sh.ok != 0;
+}
+
+template <typename T, int S, bool TS, class RHS>
+__global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
+  constexpr int D = RHS::D;
+  using Row = RowVec<T, D>;
+  __shared__ PersistShared sh;
+  Ctl& s_c = sh.c;
+  double* rec = sh.rec;
+
+  const RHS rhs(A.s.rhs);
+  const T sign = (T)A.s.rhs.sign;
+  CtrlParams cp = A.s.cp;
+  if (A.n_out <= kPersistTout) {                              // the output cursor and the dense output read t from LDS
+    for (int i = threadIdx.x; i < A.n_out; i += blockDim.x) sh.tout[i] = A.s.t_out[i];
+    cp.t_out = sh.tout;
+  }
+  const double* t_out = cp.t_out;
+  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = row < A.s.batch;
+  unsigned gen = 0;
+
+  if (threadIdx.x == 0) s_c = *A.s.ctl;                       // uploaded by the host before the launch
+  Row y;
+#pragma unroll
+  for (int d = 0; d < D; ++d) y.v[d] = (T)0;
+  if (live) {
+    y = *(const Row*)((const T*)A.y0 + row * D);
+    *(Row*)((T*)A.out0 + row * D) = y;                        // solution[0] = y0 (solvers.py:30)
+  }
+  __syncthreads();
+  const T t_first = (T)s_c.t1;
+
+  // ---- before_integrate: f0 and the norms of misc._select_initial_step (k_stage_rowlocal<M_F0>) ----
+  T f0[D];
+  {
+    Acc acc;
+    T ys[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ys[d] = y.v[d];
+    rhs(sign * t_first, ys, f0);
+#pragma unroll
+    for (int d = 0; d < D; ++d) f0[d] = sign * f0[d];
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const T sc = (T)cp.atol + fabs(y.v[d]) * (T)cp.rtol;  // misc.py:225
+        const double q0 = (double)(y.v[d] / sc);
+        acc.suma += q0 * q0;
+        if (!finite_(y.v[d])) acc.flag = 1;
+      }
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const T sc = (T)cp.atol + fabs(y.v[d]) * (T)cp.rtol;
+        const double q1 = (double)(f0[d] / sc);
+        acc.sumb += q1 * q1;                                  // misc.py:228
+      }
+    }
+    const bool ok = grid_reduce(A, acc, sh, gen++);
+    if (threadIdx.x == 0) {
+      if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
+      else { rec[R_N] = (double)cp.n_local; controller_apply(&s_c, rec, PH_F0, cp); }
+    }
+    __syncthreads();
+  }
+  if (cp.auto_first_step && !(s_c.status & MI_ODE_ST_SYNC_TIMEOUT)) {   // k_stage_rowlocal<M_INITB> (misc.py:235-245)
+    Acc acc;
+    const T h0 = (T)s_c.h0;
+    T ys[D], f1[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) ys[d] = y.v[d] + h0 * f0[d];
+    rhs(sign * (t_first + (T)1.0 * h0), ys, f1);
+    if (live) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const T kn = sign * f1[d];
+        const T sc = (T)cp.atol + fabs(y.v[d]) * (T)cp.rtol;
+        const double q = (double)((kn - f0[d]) / sc);         // misc.py:237
+        acc.suma += q * q;
+      }
+    }
+    const bool ok = grid_reduce(A, acc, sh, gen++);
+    if (threadIdx.x == 0) {
+      if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
+      else { rec[R_N] = (double)cp.n_local; controller_apply(&s_c, rec, PH_INITB, cp); }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && !(s_c.status & MI_ODE_ST_SYNC_TIMEOUT)) set_outputs_apply(&s_c, A.n_out);
+  __syncthreads();
+
+  // ---- the adaptive loop (dopri5.py:82-121); the attempt is k_step_rowlocal's ----
+  T k[S + 1][D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) k[0][d] = f0[d];
+  while (!s_c.done) {
+    MI_TICK(tk0);
+    T hs = (T)s_c.dt;                                         // rk_common.py:46
+    asm volatile("" : "+v"(hs));                              // keep the dt*coefficient products out of the loop-invariant set
+    const T t0 = (T)s_c.t1;                                   // rk_common.py:45
+    T ys[D];
+    auto stage = [&](auto sg_c) {
+      constexpr int SG = decltype(sg_c)::value;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        T kk[SG];
+#pragma unroll
+        for (int j = 0; j < SG; ++j) kk[j] = k[j][d];
+        ys[d] = step_combine<T, SG>(y.v[d], kk, hs, A.s);
+      }
+      T kn[D];
+      rhs(sign * (t0 + (T)A.s.alpha[SG - 1] * hs), ys, kn);
+#pragma unroll
+      for (int d = 0; d < D; ++d) k[SG][d] = sign * kn[d];
+    };
+    stage(std::integral_constant<int, 1>{});
+    stage(std::integral_constant<int, 2>{});
+    stage(std::integral_constant<int, 3>{});
+    if constexpr (S == 6) {
+      stage(std::integral_constant<int, 4>{});
+      stage(std::integral_constant<int, 5>{});
+      stage(std::integral_constant<int, 6>{});
+    }
+    Acc acc;
+    T ymid[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      T kk[S + 1];
+#pragma unroll
+      for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
+      T err;
+      step_finish<T, S>(y.v[d], kk, hs, A.s, err, ymid[d]);
+      if (live) {
+        acc.maxa = fmax(acc.maxa, (double)fabs(y.v[d]));
+        acc.maxb = fmax(acc.maxb, (double)fabs(ys[d]));
+        acc.suma += (double)err * (double)err;
+      }
+    }
+    MI_TICK(tk1);
+    const bool ok = grid_reduce(A, acc, sh, gen++);
+    MI_TICK(tk2);
+    if (threadIdx.x == 0) {
+      if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; s_c.accepted = 0; }
+      else { rec[R_N] = (double)cp.n_local; controller_apply(&s_c, rec, PH_ATTEMPT, cp); }
+    }
+    MI_TICK(tk3);
+    MI_TOCK(0, tk0, tk1); MI_TOCK(1, tk1, tk2); MI_TOCK(2, tk2, tk3);
+    __syncthreads();
+    if (s_c.accepted) {
+      if (live && s_c.emit_hi > s_c.emit_lo) {
+        StepPlanes<T, S> P;
+        P.j_lo = s_c.emit_lo; P.j_hi = s_c.emit_hi;
+        P.t_start = s_c.emit_t0; P.t_new = s_c.emit_t1; P.dt64 = s_c.emit_dt;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          T kk[S + 1];
+#pragma unroll
+          for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
+          step_emit<T, S, TS>(A.s, P, y.v[d], ys[d], kk, ymid[d], row * D + d, t_out);
+        }
+      }
+#pragma unroll
+      for (int d = 0; d < D; ++d) { y.v[d] = ys[d]; k[0][d] = k[S][d]; }     // FSAL (rk_common.py:58)
+    }
+    MI_TICK(tk4);
+    MI_TOCK(3, tk3, tk4);
+    __syncthreads();                                          // s_c is rewritten by the next attempt's controller
+  }
+
+  // ---- hand the final state back: planes idx_y0 / idx_k[0] (mi_ode_get_state), scalar state to the host ----
+  if (live) {
+    *(Row*)((T*)(A.s.planes + (long long)s_c.idx_y0 * A.s.stride) + row * D) = y;
+    Row f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) f.v[d] = k[0][d];
+    *(Row*)((T*)(A.s.planes + (long long)s_c.idx_k[0] * A.s.stride) + row * D) = f;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) *A.s.ctl = s_c;
+}
+
+}  // namespace mi

@@ -130,17 +130,17 @@ __device__ __forceinline__ void step_finish(T y0, const T* k, T hs, const StepAr
 // speculative dense output of one element for every requested time inside the attempt
 template <typename T, int S, bool TS>
 __device__ __forceinline__ void step_emit(const StepArgs& A, const StepPlanes<T, S>& P, T y0, T y1, const T* k, T ymid,
-                                          long long idx) {
+                                          long long idx, const double* t_out) {
   if (P.j_hi <= P.j_lo) return;
   T* out = (T*)A.out;
   if constexpr (TS) {
     for (int j = P.j_lo; j < P.j_hi; ++j)
-      out[(long long)j * A.n_plane + idx] = tsit5_dense<T, S + 1>(y0, k, P.t_start, P.t_new, A.t_out[j], A.interp);
+      out[(long long)j * A.n_plane + idx] = tsit5_dense<T, S + 1>(y0, k, P.t_start, P.t_new, t_out[j], A.interp);
   } else {
     T co[5];
     quartic_from_mid<T>(y0, y1, ymid, k[0], k[S], (T)P.dt64, co);
     for (int j = P.j_lo; j < P.j_hi; ++j)
-      out[(long long)j * A.n_plane + idx] = quartic_eval<T>(co, interp_x<T>(P.t_start, P.t_new, A.t_out[j]));
+      out[(long long)j * A.n_plane + idx] = quartic_eval<T>(co, interp_x<T>(P.t_start, P.t_new, t_out[j]));
   }
 }
 
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
       acc.maxa = fmax(acc.maxa, (double)fabs(y0.v[d]));
       acc.maxb = fmax(acc.maxb, (double)fabs(ys[d]));
       acc.suma += (double)err * (double)err;
-      step_emit<T, S, TS>(A, P, y0.v[d], ys[d], kk, ymid, row * D + d);
+      step_emit<T, S, TS>(A, P, y0.v[d], ys[d], kk, ymid, row * D + d, A.t_out);
     }
     *(Row*)(P.y1 + row * D) = y1;
     *(Row*)(P.f1 + row * D) = f1;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
         const long long idx = row * D + col;
         P.y1[idx] = ys[i];
         P.f1[idx] = k[S][i];
-        step_emit<T, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx);
+        step_emit<T, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, A.t_out);
         acc.maxa = fmax(acc.maxa, (double)fabs(y0e[i]));
         acc.maxb = fmax(acc.maxb, (double)fabs(ys[i]));
         acc.suma += (double)err * (double)err;

@@ -77,7 +77,7 @@ class _FusedEngine(object):
         d.linear_variant = int(linear_variant)
         d.chunk_attempts = int(chunk_attempts)
         d.profile = 1 if profile else 0
-        d.fusion = {'auto': 0, 'stage': 1, 'step': 2, 'step_split': 3}.get(fusion, fusion)
+        d.fusion = {'auto': 0, 'stage': 1, 'step': 2, 'step_split': 3, 'whole': 4}.get(fusion, fusion)
         self._hook = None
         if process_group is not None:
             import torch.distributed as dist
@@ -131,6 +131,8 @@ class _FusedEngine(object):
         if bits == 0:
             return
         msg = N.status_message(bits)
+        if bits & N.ST_SYNC_TIMEOUT:       # engine fault, not one of the reference's assertions
+            raise RuntimeError(msg + " - retry with options={'fusion': 'step'}")
         if bits & N.ST_MAX_STEPS:
             msg = 'max_num_steps exceeded ({}>={})'.format(self.desc.max_num_steps, self.desc.max_num_steps)
         if bits & N.ST_DT_UNDERFLOW:
