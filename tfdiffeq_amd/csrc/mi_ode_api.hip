@@ -364,6 +364,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   // controller / dense-output parameters
   h->cp.rtol = desc->rtol; h->cp.atol = desc->atol;
   h->cp.safety = desc->safety; h->cp.ifactor = desc->ifactor; h->cp.dfactor = desc->dfactor;
+  h->cp.inv_ifactor = 1.0 / desc->ifactor; h->cp.inv_dfactor = 1.0 / desc->dfactor;   // same IEEE quotients as on the device
   h->cp.max_num_steps = desc->max_num_steps > 0 ? desc->max_num_steps : 2147483647LL;
   h->cp.n_local = h->n;
   h->cp.order = desc->order; h->cp.init_order = desc->init_order;
@@ -579,6 +580,11 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   A.y0 = y0_dev; A.out0 = out_dev; A.n_out = T - 1;
   A.stamp_base = h->stamp_base;
   A.spin_limit = 1 << 21;
+  // back-off before the first poll (units of 64 clocks): a failed poll round costs G x G record loads on the fabric, so
+  // wait about as long as the publish needs to become visible (measured: G=16 best at <= 24, G=256 best at 32)
+  A.sleep_first = h->persist_grid <= 32 ? 16 : 32; A.sleep_poll = 2;
+  if (const char* e0 = getenv("MI_ODE_PERSIST_SLEEP0")) A.sleep_first = atoi(e0);
+  if (const char* e1 = getenv("MI_ODE_PERSIST_SLEEP1")) A.sleep_poll = atoi(e1);
   rc = h->is_f32 ? mi_launch_persist_f32(h, A, h->persist_grid, st) : mi_launch_persist_f64(h, A, h->persist_grid, st);
   if (rc != 0) return rc;
   rc = poll_ctl(h, st);

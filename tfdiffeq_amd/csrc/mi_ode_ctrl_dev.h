@@ -40,7 +40,7 @@ __device__ __forceinline__ double nan_max(double a, double b) { return (isnan(a)
 // misc._optimal_step_size (misc.py:267-287) / tsit5._optimal_step_size (tsit5.py:53-62)
 __device__ __forceinline__ double optimal_step(double last_step, double ratio, const CtrlParams& P) {
   if (ratio == 0.0) return last_step * P.ifactor;
-  const double dfac = (ratio < 1.0) ? 1.0 : P.dfactor;
+  const double inv_dfac = (ratio < 1.0) ? 1.0 : P.inv_dfactor;      // 1 / dfactor, dfactor = 1 when ratio < 1 (misc.py:275-276)
   double er, expo;
   if (P.controller == MI_ODE_CTRL_TSIT5) {
     er = ratio;                                            // no sqrt (tsit5.py:59)
@@ -49,8 +49,69 @@ __device__ __forceinline__ double optimal_step(double last_step, double ratio, c
     er = P.is_f32 ? (double)sqrtf((float)ratio) : sqrt(ratio);   // sqrt in the ratio's dtype (misc.py:277-278)
     expo = (double)(float)(1.0 / (double)P.order);         // float32 detour, F4 (misc.py:281-282)
   }
-  const double factor = nan_max(1.0 / P.ifactor, nan_min(pow(er, expo) / P.safety, 1.0 / dfac));
+  const double factor = nan_max(P.inv_ifactor, nan_min(pow(er, expo) / P.safety, inv_dfac));
   return last_step / factor;
+}
+
+// The scalars one attempt reads and writes (a plain value type: a caller that keeps it in registers pays no memory
+// traffic for the controller - the whole-integration kernel does).
+struct AttemptState {
+  double t0, t1, dt, ratio, emit_t0, emit_t1, emit_dt;
+  long long n_attempt, n_accept, n_reject, nfe, n_steps_out;
+  int next_out, n_out, emit_lo, emit_hi, done, accepted;
+  unsigned status;
+  __device__ __forceinline__ void load(const Ctl& c) {
+    t0 = c.t0; t1 = c.t1; dt = c.dt; ratio = c.ratio; emit_t0 = c.emit_t0; emit_t1 = c.emit_t1; emit_dt = c.emit_dt;
+    n_attempt = c.n_attempt; n_accept = c.n_accept; n_reject = c.n_reject; nfe = c.nfe; n_steps_out = c.n_steps_out;
+    next_out = c.next_out; n_out = c.n_out; emit_lo = c.emit_lo; emit_hi = c.emit_hi; done = c.done; accepted = c.accepted;
+    status = c.status;
+  }
+  __device__ __forceinline__ void store(Ctl& c) const {
+    c.t0 = t0; c.t1 = t1; c.dt = dt; c.ratio = ratio; c.emit_t0 = emit_t0; c.emit_t1 = emit_t1; c.emit_dt = emit_dt;
+    c.n_attempt = n_attempt; c.n_accept = n_accept; c.n_reject = n_reject; c.nfe = nfe; c.n_steps_out = n_steps_out;
+    c.next_out = next_out; c.n_out = n_out; c.emit_lo = emit_lo; c.emit_hi = emit_hi; c.done = done; c.accepted = accepted;
+    c.status = status;
+  }
+};
+
+// dopri5.py:103-121 on the combined record of one attempt: error ratio, accept test, next step size, output cursor,
+// termination checks.  Shared by k_controller, the whole-attempt kernels' last workgroup and the whole-integration kernel.
+__device__ __forceinline__ void attempt_core(AttemptState& c, const double* rec, const CtrlParams& P) {
+  const double N = rec[R_N];
+  c.n_attempt += 1;
+  c.nfe += P.n_stages;
+  c.n_steps_out += 1;
+  const double dt = c.dt, t_start = c.t1;
+  double ratio;
+  if (P.is_f32) {                                          // misc.py:256-263 in the state dtype
+    const float tol = (float)P.atol + (float)P.rtol * (float)fmax(rec[R_MAXA], rec[R_MAXB]);
+    ratio = (double)(float)(rec[R_SUMA] / (N * (double)tol * (double)tol));
+  } else {
+    const double tol = P.atol + P.rtol * fmax(rec[R_MAXA], rec[R_MAXB]);
+    ratio = rec[R_SUMA] / (N * tol * tol);
+  }
+  c.ratio = ratio;
+  const bool accept = ratio <= 1.0;                        // NaN -> rejected (dopri5.py:108)
+  const double dt_next = optimal_step(dt, ratio, P);
+  c.accepted = accept ? 1 : 0;
+  c.emit_lo = c.emit_hi = c.next_out;
+  if (accept) {
+    c.n_accept += 1;
+    const double t_new = t_start + dt;
+    c.emit_t0 = t_start; c.emit_t1 = t_new; c.emit_dt = dt;
+    c.t0 = t_start; c.t1 = t_new;
+    // outputs that fall into (t_start, t_new]   (`while next_t > t1` exits, dopri5.py:84)
+    int nx = c.next_out;
+    while (nx < c.n_out && !(P.t_out[nx] > t_new)) ++nx;
+    if (nx > c.next_out) { c.emit_hi = nx; c.next_out = nx; c.n_steps_out = 0; }
+  } else {
+    c.n_reject += 1;
+    c.t0 = t_start;                                        // rejected: rk_state.t0 == rk_state.t1
+  }
+  c.dt = dt_next;
+  if (c.next_out >= c.n_out) { c.done = 1; return; }
+  if (c.n_steps_out >= P.max_num_steps) { c.status |= MI_ODE_ST_MAX_STEPS; c.done = 1; return; }   // dopri5.py:85
+  if (!(c.t1 + dt_next > c.t1)) { c.status |= MI_ODE_ST_DT_UNDERFLOW; c.done = 1; }               // dopri5.py:98
 }
 
 // One thread: apply the phase logic to the combined record `rec` with exactly the reference's scalar arithmetic.
@@ -97,46 +158,18 @@ __device__ __forceinline__ void controller_apply(Ctl* c, const double* rec, int 
   }
 
   // ---- PH_ATTEMPT: dopri5.py:103-121 -------------------------------------------------------
-  c->n_attempt += 1;
-  c->nfe += P.n_stages;
-  c->n_steps_out += 1;
-  const double dt = c->dt, t_start = c->t1;
-  double ratio;
-  if (P.is_f32) {                                          // misc.py:256-263 in the state dtype
-    const float tol = (float)P.atol + (float)P.rtol * (float)fmax(rec[R_MAXA], rec[R_MAXB]);
-    ratio = (double)(float)(rec[R_SUMA] / (N * (double)tol * (double)tol));
-  } else {
-    const double tol = P.atol + P.rtol * fmax(rec[R_MAXA], rec[R_MAXB]);
-    ratio = rec[R_SUMA] / (N * tol * tol);
-  }
-  c->ratio = ratio;
-  const bool accept = ratio <= 1.0;                        // NaN -> rejected (dopri5.py:108)
-  const double dt_next = optimal_step(dt, ratio, P);
-  c->accepted = accept ? 1 : 0;
-  c->emit_lo = c->emit_hi = c->next_out;
-  if (accept) {
-    c->n_accept += 1;
-    const double t_new = t_start + dt;
+  AttemptState a;
+  a.load(*c);
+  attempt_core(a, rec, P);
+  if (a.accepted) {
     // the step's planes, for dense output
     c->emit_y0 = c->idx_y0; c->emit_y1 = c->idx_y1;
     for (int j = 0; j <= P.n_stages; ++j) c->emit_k[j] = c->idx_k[j];
-    c->emit_t0 = t_start; c->emit_t1 = t_new; c->emit_dt = dt;
     // rotate: y1 becomes the state, k_S (= f1, FSAL) becomes f0
     const int iy = c->idx_y0; c->idx_y0 = c->idx_y1; c->idx_y1 = iy;
     const int ik = c->idx_k[0]; c->idx_k[0] = c->idx_k[P.n_stages]; c->idx_k[P.n_stages] = ik;
-    c->t0 = t_start; c->t1 = t_new;
-    // outputs that fall into (t_start, t_new]   (`while next_t > t1` exits, dopri5.py:84)
-    int nx = c->next_out;
-    while (nx < c->n_out && !(P.t_out[nx] > t_new)) ++nx;
-    if (nx > c->next_out) { c->emit_hi = nx; c->next_out = nx; c->n_steps_out = 0; }
-  } else {
-    c->n_reject += 1;
-    c->t0 = t_start;                                       // rejected: rk_state.t0 == rk_state.t1
   }
-  c->dt = dt_next;
-  if (c->next_out >= c->n_out) { c->done = 1; return; }
-  if (c->n_steps_out >= P.max_num_steps) { c->status |= MI_ODE_ST_MAX_STEPS; c->done = 1; return; }   // dopri5.py:85
-  if (!(c->t1 + dt_next > c->t1)) { c->status |= MI_ODE_ST_DT_UNDERFLOW; c->done = 1; }               // dopri5.py:98
+  a.store(*c);
 }
 
 }  // namespace mi

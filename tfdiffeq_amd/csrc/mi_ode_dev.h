@@ -275,6 +275,7 @@ enum Phase { PH_F0 = 0, PH_INITB = 1, PH_ATTEMPT = 2 };
 
 struct CtrlParams {
   double rtol, atol, safety, ifactor, dfactor;
+  double inv_ifactor, inv_dfactor;   // 1.0 / ifactor, 1.0 / dfactor (host-computed: the same IEEE quotients)
   long long max_num_steps;
   long long n_local;          // elements held by this rank
   int order, init_order;

@@ -25,7 +25,7 @@ namespace mi {
 
 #ifdef MI_PERSIST_PROF
 #define MI_TICK(var) const long long var = (long long)wall_clock64()
-#define MI_TOCK(slot, a, b) do { if (threadIdx.x == 0 && blockIdx.x == 0) s_c.prof[slot] += (b) - (a); } while (0)
+#define MI_TOCK(slot, a, b) do { if (threadIdx.x == 0 && blockIdx.x == 0) s_c.prof[slot] += (b) - (a); } while (0)   /* s_c: LDS */
 #else
 #define MI_TICK(var)
 #define MI_TOCK(slot, a, b)
@@ -39,6 +39,7 @@ struct PersistArgs {
   double stamp_base;           // stamps of this call are stamp_base + 1, + 2, ... (above every earlier call's)
   int n_out;                   // T - 1
   int spin_limit;              // bound on the spin iterations of one hand-off
+  int sleep_first, sleep_poll; // back-off (units of 64 clocks): before the first poll / between polls
 };
 
 // k_set_outputs as a device function (solvers.py:33-34 + the entry assertions of dopri5.py:98-100)
@@ -80,64 +81,67 @@ __device__ __forceinline__ void load_record_sc1(const double* p, d2_t (&v)[5]) {
       : "memory");
 }
 
-struct PersistShared {
-  Ctl c;
-  double red[80];
-  double rec[kRec];
-  double vals[5][kPersistMaxGrid];                            // every workgroup's record, staged for the fixed-order fold
-  double tout[kPersistTout];                                  // the requested output times, when they fit
-  int ok;
+// what the controller (thread 0, registers) tells the rest of the workgroup after an attempt
+struct PersistPub {
+  double dt, t1, emit_t0, emit_t1, emit_dt;
+  int accepted, emit_lo, emit_hi, done;
 };
 
-// Block record -> (grid hand-off) -> combined record in sh.rec (valid for thread 0 after the trailing barrier).
-// Returns false on a hand-off timeout.  `gen` counts hand-offs (uniform over the grid).  Thread i polls record i
-// (one round trip once the slowest workgroup has published), wavefront 0 folds in reduce_block_records' fixed order.
-__device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc, PersistShared& sh, unsigned gen) {
+struct PersistShared {
+  Ctl c;                                                      // prologue (before_integrate) and the final write-back
+  PersistPub pub;
+  double red[80];
+  double vals[5][kPersistMaxGrid];                            // every workgroup's record, staged for the fixed-order fold
+  double tout[kPersistTout];                                  // the requested output times, when they fit
+  int ok;                                                     // 1 until a hand-off times out
+};
+
+// Block record -> (grid hand-off) -> combined record {max a, max b, sum a, sum b, flag} in THREAD 0's registers.
+// Returns false (to every thread) on a hand-off timeout.  `gen` counts hand-offs (uniform over the grid).  Thread i
+// polls record i (one round trip once the slowest workgroup has published), wavefront 0 folds in
+// reduce_block_records' fixed order.
+__device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc, PersistShared& sh, unsigned gen,
+                                            double (&r)[5]) {
   const int G = (int)gridDim.x;
-  if (G == 1) {
-    block_reduce_store<false>(acc, sh.red, sh.rec);          // one record: folding it with zeros is exact
-    __syncthreads();
-    return true;
-  }
+  block_reduce_thread0(acc, sh.red, r);
+  if (G == 1) return true;                                    // one record: folding it with zeros is exact
   double* buf = A.s.partials + (long long)(gen & 1u) * G * kPRec;
   const double stamp = A.stamp_base + (double)(gen + 1u);
-  double r[5];
-  block_reduce_thread0(acc, sh.red, r);
   if (threadIdx.x == 0) {
-    sh.ok = 1;
     double* mine = buf + (long long)blockIdx.x * kPRec;
 #pragma unroll
     for (int i = 0; i < 5; ++i) store_pair_sc1(mine + 2 * i, r[i], stamp);
   }
-  __syncthreads();
   for (int b = threadIdx.x; b < G; b += blockDim.x) {
     const double* p = buf + (long long)b * kPRec;
     d2_t v[5];
     int spins = 0;
+    for (int i = 0; i < A.sleep_first; ++i) __builtin_amdgcn_s_sleep(1);
     for (;;) {
       load_record_sc1(p, v);
       if (v[0].y == stamp && v[1].y == stamp && v[2].y == stamp && v[3].y == stamp && v[4].y == stamp) break;
-      __builtin_amdgcn_s_sleep(1);
+      for (int i = 0; i < A.sleep_poll; ++i) __builtin_amdgcn_s_sleep(1);
       if (++spins > A.spin_limit) { sh.ok = 0; break; }
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) sh.vals[i][b] = v[i].x;
   }
   __syncthreads();
-  if (threadIdx.x < 64 && sh.ok) {
+  const bool ok = sh.ok != 0;
+  if (threadIdx.x < 64 && ok) {
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
     for (int b = threadIdx.x; b < G; b += 64) {
       v0 = fmax(v0, sh.vals[R_MAXA][b]); v1 = fmax(v1, sh.vals[R_MAXB][b]);
       v2 += sh.vals[R_SUMA][b]; v3 += sh.vals[R_SUMB][b]; v4 = fmax(v4, sh.vals[R_FLAG][b]);
     }
-    v0 = wave_max(v0); v1 = wave_max(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_max(v4);
-    if (threadIdx.x == 0) {
-      sh.rec[R_MAXA] = v0; sh.rec[R_MAXB] = v1; sh.rec[R_SUMA] = v2; sh.rec[R_SUMB] = v3; sh.rec[R_FLAG] = v4;
-      sh.rec[R_N] = 0; sh.rec[6] = 0; sh.rec[7] = 0;
-    }
+    r[0] = wave_max(v0); r[1] = wave_max(v1); r[2] = wave_sum(v2); r[3] = wave_sum(v3); r[4] = wave_max(v4);
   }
-  __syncthreads();
-  return sh.ok != 0;
+  return ok;
+}
+
+__device__ __forceinline__ void fill_record(double (&rec)[kRec], const double (&r)[5], double n) {
+  rec[R_MAXA] = r[0]; rec[R_MAXB] = r[1]; rec[R_SUMA] = r[2]; rec[R_SUMB] = r[3]; rec[R_FLAG] = r[4];
+  rec[R_N] = n; rec[6] = 0; rec[7] = 0;
 }
 
 template <typename T, int S, bool TS, class RHS>
@@ -146,7 +150,6 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
   using Row = RowVec<T, D>;
   __shared__ PersistShared sh;
   Ctl& s_c = sh.c;
-  double* rec = sh.rec;
 
   const RHS rhs(A.s.rhs);
   const T sign = (T)A.s.rhs.sign;
@@ -159,8 +162,9 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = row < A.s.batch;
   unsigned gen = 0;
+  double r[5], rec[kRec];
 
-  if (threadIdx.x == 0) s_c = *A.s.ctl;                       // uploaded by the host before the launch
+  if (threadIdx.x == 0) { s_c = *A.s.ctl; sh.ok = 1; }        // the scalar state was uploaded before the launch
   Row y;
 #pragma unroll
   for (int d = 0; d < D; ++d) y.v[d] = (T)0;
@@ -173,6 +177,7 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
 
   // ---- before_integrate: f0 and the norms of misc._select_initial_step (k_stage_rowlocal<M_F0>) ----
   T f0[D];
+  bool ok;
   {
     Acc acc;
     T ys[D];
@@ -196,14 +201,11 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
         acc.sumb += q1 * q1;                                  // misc.py:228
       }
     }
-    const bool ok = grid_reduce(A, acc, sh, gen++);
-    if (threadIdx.x == 0) {
-      if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
-      else { rec[R_N] = (double)cp.n_local; controller_apply(&s_c, rec, PH_F0, cp); }
-    }
+    ok = grid_reduce(A, acc, sh, gen++, r);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_F0, cp); }
     __syncthreads();
   }
-  if (cp.auto_first_step && !(s_c.status & MI_ODE_ST_SYNC_TIMEOUT)) {   // k_stage_rowlocal<M_INITB> (misc.py:235-245)
+  if (cp.auto_first_step && ok) {                             // k_stage_rowlocal<M_INITB> (misc.py:235-245)
     Acc acc;
     const T h0 = (T)s_c.h0;
     T ys[D], f1[D];
@@ -219,25 +221,28 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
         acc.suma += q * q;
       }
     }
-    const bool ok = grid_reduce(A, acc, sh, gen++);
-    if (threadIdx.x == 0) {
-      if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
-      else { rec[R_N] = (double)cp.n_local; controller_apply(&s_c, rec, PH_INITB, cp); }
-    }
-    __syncthreads();
+    ok = grid_reduce(A, acc, sh, gen++, r);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_INITB, cp); }
   }
-  if (threadIdx.x == 0 && !(s_c.status & MI_ODE_ST_SYNC_TIMEOUT)) set_outputs_apply(&s_c, A.n_out);
+  // thread 0 keeps the scalar state of the loop in registers from here on and publishes what the others need
+  AttemptState st;
+  if (threadIdx.x == 0) {
+    if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
+    else set_outputs_apply(&s_c, A.n_out);
+    st.load(s_c);
+    sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.done = st.done; sh.pub.accepted = 0;
+  }
   __syncthreads();
 
   // ---- the adaptive loop (dopri5.py:82-121); the attempt is k_step_rowlocal's ----
   T k[S + 1][D];
 #pragma unroll
   for (int d = 0; d < D; ++d) k[0][d] = f0[d];
-  while (!s_c.done) {
+  while (!sh.pub.done) {
     MI_TICK(tk0);
-    T hs = (T)s_c.dt;                                         // rk_common.py:46
+    T hs = (T)sh.pub.dt;                                      // rk_common.py:46
     asm volatile("" : "+v"(hs));                              // keep the dt*coefficient products out of the loop-invariant set
-    const T t0 = (T)s_c.t1;                                   // rk_common.py:45
+    const T t0 = (T)sh.pub.t1;                                // rk_common.py:45
     T ys[D];
     auto stage = [&](auto sg_c) {
       constexpr int SG = decltype(sg_c)::value;
@@ -277,20 +282,23 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
       }
     }
     MI_TICK(tk1);
-    const bool ok = grid_reduce(A, acc, sh, gen++);
+    ok = grid_reduce(A, acc, sh, gen++, r);                   // (its barriers also fence the reads of sh.pub above)
     MI_TICK(tk2);
     if (threadIdx.x == 0) {
-      if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; s_c.accepted = 0; }
-      else { rec[R_N] = (double)cp.n_local; controller_apply(&s_c, rec, PH_ATTEMPT, cp); }
+      if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
+      else { fill_record(rec, r, (double)cp.n_local); attempt_core(st, rec, cp); }
+      sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.emit_t0 = st.emit_t0; sh.pub.emit_t1 = st.emit_t1;
+      sh.pub.emit_dt = st.emit_dt; sh.pub.accepted = st.accepted; sh.pub.emit_lo = st.emit_lo;
+      sh.pub.emit_hi = st.emit_hi; sh.pub.done = st.done;
     }
     MI_TICK(tk3);
     MI_TOCK(0, tk0, tk1); MI_TOCK(1, tk1, tk2); MI_TOCK(2, tk2, tk3);
     __syncthreads();
-    if (s_c.accepted) {
-      if (live && s_c.emit_hi > s_c.emit_lo) {
+    if (sh.pub.accepted) {
+      if (live && sh.pub.emit_hi > sh.pub.emit_lo) {
         StepPlanes<T, S> P;
-        P.j_lo = s_c.emit_lo; P.j_hi = s_c.emit_hi;
-        P.t_start = s_c.emit_t0; P.t_new = s_c.emit_t1; P.dt64 = s_c.emit_dt;
+        P.j_lo = sh.pub.emit_lo; P.j_hi = sh.pub.emit_hi;
+        P.t_start = sh.pub.emit_t0; P.t_new = sh.pub.emit_t1; P.dt64 = sh.pub.emit_dt;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
           T kk[S + 1];
@@ -304,10 +312,9 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
     }
     MI_TICK(tk4);
     MI_TOCK(3, tk3, tk4);
-    __syncthreads();                                          // s_c is rewritten by the next attempt's controller
   }
 
-  // ---- hand the final state back: planes idx_y0 / idx_k[0] (mi_ode_get_state), scalar state to the host ----
+  // ---- hand the final state back: planes idx_y0 / idx_k[0] (mi_ode_get_state; never rotated here), scalars to the host ----
   if (live) {
     *(Row*)((T*)(A.s.planes + (long long)s_c.idx_y0 * A.s.stride) + row * D) = y;
     Row f;
@@ -315,7 +322,10 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
     for (int d = 0; d < D; ++d) f.v[d] = k[0][d];
     *(Row*)((T*)(A.s.planes + (long long)s_c.idx_k[0] * A.s.stride) + row * D) = f;
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) *A.s.ctl = s_c;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st.store(s_c);
+    *A.s.ctl = s_c;
+  }
 }
 
 }  // namespace mi
