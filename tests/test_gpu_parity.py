@@ -568,6 +568,41 @@ def test_whole_integration_kernel_equals_launch_per_attempt(problem, batch, meth
     assert torch.equal(a32, b32)
 
 
+@pytest.mark.parametrize('method', ['dopri5', 'bosh3', 'tsit5'])
+@pytest.mark.parametrize('problem', ['linear16', 'linear32_bias', 'linear128', 'linear64_f32', 'linear128_big'])
+def test_whole_integration_mfma_kernel_equals_launch_per_attempt(problem, method):
+    """Linear RHS on the persistent MFMA grid: one launch for the whole call, same bits as one launch per attempt."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(13)
+    D = int(''.join(ch for ch in problem.split('_')[0] if ch.isdigit()))
+    batch = {'linear16': 1000, 'linear32_bias': 37, 'linear128': 3000, 'linear64_f32': 5000, 'linear128_big': 20000}[problem]
+    dtype = torch.float32 if problem.endswith('f32') else torch.float64
+    S_ = rng.standard_normal((D, D))
+    A = -0.5 * np.eye(D) + 0.5 * (S_ - S_.T) / np.sqrt(D)
+    bias = torch.tensor(0.1 * rng.standard_normal(D)) if problem.endswith('bias') else None
+    f = rhs.Linear(torch.tensor(A.T.copy()), bias) if bias is not None else rhs.Linear.from_matrix(torch.tensor(A))
+    y0 = to_dev(rng.standard_normal((batch, D)), dtype)
+    t = np.array([0., 0.3, 0.35, 1.0])
+    if method == 'bosh3':
+        t = 0.05 * t
+    tol = dict(rtol=1e-6, atol=1e-9) if dtype == torch.float64 else dict(rtol=1e-4, atol=1e-6)
+    for tt in (torch.tensor(t), torch.tensor(-t)):             # forward and reversed time
+        a = odeint(f, y0, tt, method=method, options={'fusion': 'step'}, **tol)
+        sa = dict(odeint.last_stats)
+        b = odeint(f, y0, tt, method=method, options={'fusion': 'whole'}, **tol)
+        sb = dict(odeint.last_stats)
+        c = odeint(f, y0, tt, method=method, **tol)
+        sc = dict(odeint.last_stats)
+        assert sb['n_launches'] == 1 and sc['n_launches'] == 1 and sa['n_launches'] > 1, (sa, sb, sc)
+        for k_ in ('n_attempts', 'n_accepted', 'nfe', 'status'):
+            assert sa[k_] == sb[k_] == sc[k_], (k_, sa, sb, sc)
+        assert torch.equal(a, b) and torch.equal(b, c)
+    # the engine is cached: a second call on the same handle must not see the first call's hand-off stamps
+    b2 = odeint(f, y0, torch.tensor(t), method=method, options={'fusion': 'whole'}, **tol)
+    a2 = odeint(f, y0, torch.tensor(t), method=method, options={'fusion': 'step'}, **tol)
+    assert torch.equal(a2, b2)
+
+
 def test_whole_integration_kernel_status_paths():
     from tfdiffeq_amd import odeint, rhs
     y0 = to_dev(np.array([[1., 1., 1.]]), torch.float64)

@@ -8,6 +8,7 @@ struct StepArgs;
 struct MlpArgs;
 struct FixedArgs;
 struct PersistArgs;
+struct InitArgs;
 
 enum Family {
   FAM_NONE = 0,
@@ -59,6 +60,7 @@ struct mi_ode_solver {
   int step_grid, step_block;
   int persist;                // 1: whole integration in one launch (mi_ode_persist.h)
   int persist_grid;
+  int init_tiles16;           // 1: before_integrate runs on the 16-row tile kernels (k_init_linear_mfma), grid = step_grid
   double stamp_base;          // hand-off stamps already used on this handle's record buffer
   int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)
   int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation
@@ -89,6 +91,8 @@ int mi_launch_fixed_f64(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
 int mi_launch_fixed_f32(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
 int mi_launch_persist_f64(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);
 int mi_launch_persist_f32(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);
+int mi_launch_init_linear_f64(mi_ode_solver* h, int phase, mi::InitArgs& I, hipStream_t st);
+int mi_launch_init_linear_f32(mi_ode_solver* h, int phase, mi::InitArgs& I, hipStream_t st);
 int mi_persist_capacity_f64(mi_ode_solver* h);
 int mi_persist_capacity_f32(mi_ode_solver* h);
 int mi_launch_mlp_f32(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st);

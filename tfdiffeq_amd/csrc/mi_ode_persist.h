@@ -31,16 +31,55 @@ namespace mi {
 #define MI_TOCK(slot, a, b)
 #endif
 
+constexpr int kPersistTSmall = 8;      // output times that travel as kernel arguments
+constexpr int kPersistTout = 1024;     // output times cached in LDS
+
 struct PersistArgs {
   StepArgs s;                  // tableau, RHS, controller parameters; out = solution[1:], t_out = t[1:] (device);
                                // partials = 2 x gridDim.x records; ctl = initial scalar state in, final state out
   const void* y0;              // caller's initial state [batch, D]
   void* out0;                  // solution[0]
+  Ctl* ctl_host;               // pinned host copy of the final scalar state (zero-copy store: the host only synchronises)
+  double t0, first_dt;         // scalar state at entry (the kernel builds its Ctl itself: no upload)
+  double t_small[kPersistTSmall];   // the output times when n_out <= kPersistTSmall (else s.t_out, device)
   double stamp_base;           // stamps of this call are stamp_base + 1, + 2, ... (above every earlier call's)
   int n_out;                   // T - 1
   int spin_limit;              // bound on the spin iterations of one hand-off
   int sleep_first, sleep_poll; // back-off (units of 64 clocks): before the first poll / between polls
 };
+
+// thread 0: the scalar state mi_ode_begin would have uploaded
+__device__ __forceinline__ void persist_init_ctl(Ctl& c, const PersistArgs& A) {
+  int* w = (int*)&c;
+  for (int i = 0; i < (int)(sizeof(Ctl) / sizeof(int)); ++i) w[i] = 0;
+  c.t0 = c.t1 = A.t0;
+  c.dt = A.s.cp.auto_first_step ? 0.0 : A.first_dt;
+  c.idx_y0 = 0; c.idx_y1 = 1;
+  for (int j = 0; j < kMaxK; ++j) c.idx_k[j] = 2 + j;
+}
+
+// every thread: output times into LDS when they fit (kernel arguments for tiny T, else the uploaded array)
+__device__ __forceinline__ const double* persist_stage_tout(const PersistArgs& A, double* lds_tout) {
+  if (A.n_out <= kPersistTSmall) {
+    if ((int)threadIdx.x < A.n_out) lds_tout[threadIdx.x] = A.t_small[threadIdx.x];
+    return lds_tout;
+  }
+  if (A.n_out <= kPersistTout) {
+    for (int i = threadIdx.x; i < A.n_out; i += blockDim.x) lds_tout[i] = A.s.t_out[i];
+    return lds_tout;
+  }
+  return A.s.t_out;
+}
+
+__device__ __forceinline__ void persist_write_back(const PersistArgs& A, const Ctl& c) {
+  *A.s.ctl = c;                                               // device copy (mi_ode_get_state / get_stats)
+  if (A.ctl_host != nullptr) {
+    const long long* src = (const long long*)&c;
+    long long* dst = (long long*)A.ctl_host;
+    for (int i = 0; i < (int)(sizeof(Ctl) / sizeof(long long)); ++i)
+      __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 
 // k_set_outputs as a device function (solvers.py:33-34 + the entry assertions of dopri5.py:98-100)
 __device__ __forceinline__ void set_outputs_apply(Ctl* c, int n_out) {
@@ -58,7 +97,6 @@ __device__ __forceinline__ void set_outputs_apply(Ctl* c, int n_out) {
 // seen together: no "drain, then publish a flag" round trip, no atomics, no fences.  Stamps of a call are
 // stamp_base + 1, + 2, ...; the host raises stamp_base past every stamp of the previous call on the handle.
 typedef double d2_t __attribute__((ext_vector_type(2)));
-constexpr int kPersistTout = 1024;
 constexpr int kPRec = 16;                                     // doubles per hand-off record (5 pairs + padding)
 constexpr int kPersistMaxGrid = kMaxBlocks * kRec / (2 * kPRec);   // two parity buffers inside the `partials` allocation
 
@@ -81,6 +119,23 @@ __device__ __forceinline__ void load_record_sc1(const double* p, d2_t (&v)[5]) {
       : "memory");
 }
 
+// Values read from LDS land in VGPRs even when every lane reads the same word; the tile passes have no VGPRs to
+// spare, so wave-uniform scalars are moved to SGPRs explicitly.
+__device__ __forceinline__ int uniform_i(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ double uniform_d(double v) {
+  const long long b = __double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)b >> 32));
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <typename P>
+__device__ __forceinline__ P* uniform_p(P* p) {
+  const unsigned long long b = (unsigned long long)p;
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b);
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+  return (P*)(((unsigned long long)hi << 32) | lo);
+}
+
 // what the controller (thread 0, registers) tells the rest of the workgroup after an attempt
 struct PersistPub {
   double dt, t1, emit_t0, emit_t1, emit_dt;
@@ -90,6 +145,7 @@ struct PersistPub {
 struct PersistShared {
   Ctl c;                                                      // prologue (before_integrate) and the final write-back
   PersistPub pub;
+  AttemptState st;                                            // MFMA kernel: the loop's scalar state rests here between attempts
   double red[80];
   double vals[5][kPersistMaxGrid];                            // every workgroup's record, staged for the fixed-order fold
   double tout[kPersistTout];                                  // the requested output times, when they fit
@@ -154,17 +210,14 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
   const RHS rhs(A.s.rhs);
   const T sign = (T)A.s.rhs.sign;
   CtrlParams cp = A.s.cp;
-  if (A.n_out <= kPersistTout) {                              // the output cursor and the dense output read t from LDS
-    for (int i = threadIdx.x; i < A.n_out; i += blockDim.x) sh.tout[i] = A.s.t_out[i];
-    cp.t_out = sh.tout;
-  }
+  cp.t_out = persist_stage_tout(A, sh.tout);                  // the output cursor and the dense output read t from LDS
   const double* t_out = cp.t_out;
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = row < A.s.batch;
   unsigned gen = 0;
   double r[5], rec[kRec];
 
-  if (threadIdx.x == 0) { s_c = *A.s.ctl; sh.ok = 1; }        // the scalar state was uploaded before the launch
+  if (threadIdx.x == 0) { persist_init_ctl(s_c, A); sh.ok = 1; }
   Row y;
 #pragma unroll
   for (int d = 0; d < D; ++d) y.v[d] = (T)0;
@@ -324,8 +377,114 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st.store(s_c);
-    *A.s.ctl = s_c;
+    persist_write_back(A, s_c);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Linear RHS, dim in {16, 32, 64, 128}: the whole call in one launch on the persistent MFMA grid.
+// Same hand-off and redundant controller as above; the state stays in HBM planes (a workgroup only ever touches its own
+// tiles, so planes written in one attempt are re-read by the SAME workgroup in the next - sc0 loads skip its L1),
+// the W slices are loaded once per call, before_integrate uses the same 16-row tile passes as k_init_linear_mfma.
+// The first attempt reads y0 straight from the caller's buffer (no seed copy); y planes 0/1 and f planes 2 / 2+S
+// alternate on accept exactly like the plane rotation of controller_apply.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int D, int S, bool TS>
+__global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ PersistShared sh;
+  Ctl& s_c = sh.c;
+  LinCtx<T, D> cx;
+  cx.init(A.s.rhs, (T*)smem_raw);
+  CtrlParams cp = A.s.cp;
+  cp.t_out = persist_stage_tout(A, sh.tout);
+  const double* t_out = cp.t_out;
+  unsigned gen = 0;
+  double r[5], rec[kRec];
+  if (threadIdx.x == 0) { persist_init_ctl(s_c, A); sh.ok = 1; }
+  __syncthreads();
+
+  T* const ya = (T*)(A.s.planes);
+  T* const yb = (T*)(A.s.planes + A.s.stride);
+  T* const fa = (T*)(A.s.planes + 2 * A.s.stride);
+  T* const fb = (T*)(A.s.planes + (long long)(2 + S) * A.s.stride);
+  const T* const y_user = (const T*)A.y0;
+
+  bool ok;
+  {
+    Acc acc;
+    lin_f0_pass<T, D, true>(A.s, y_user, fa, (T*)nullptr, (T*)A.out0, cx, acc);
+    ok = grid_reduce(A, acc, sh, gen++, r);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_F0, cp); }
+    __syncthreads();
+  }
+  if (cp.auto_first_step && ok) {
+    Acc acc;
+    lin_initb_pass<T, D, true>(A.s, y_user, fa, (T)uniform_d(s_c.h0), cx, acc);
+    ok = grid_reduce(A, acc, sh, gen++, r);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_INITB, cp); }
+  }
+  // The scalar state of the loop rests in LDS between attempts (thread 0 pulls it into registers only around
+  // attempt_core): the tile passes need the whole register file.
+  auto publish = [&](const AttemptState& st) {                // thread 0: what the next attempt needs
+    sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.accepted = st.accepted; sh.pub.done = st.done;
+    int j = st.next_out;                                      // speculative output range of the NEXT attempt (resolve_step)
+    const double t_new = st.t1 + st.dt;
+    while (j < st.n_out && !(t_out[j] > t_new)) ++j;
+    sh.pub.emit_lo = st.next_out; sh.pub.emit_hi = j;
+  };
+  if (threadIdx.x == 0) {
+    if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
+    else set_outputs_apply(&s_c, A.n_out);
+    AttemptState st;
+    st.load(s_c);
+    st.accepted = 0;
+    publish(st);
+    sh.st = st;
+  }
+  __syncthreads();
+
+  const T* cur_y = y_user;
+  T* cur_f = fa;
+  while (!uniform_i(sh.pub.done)) {
+    StepPlanes<T, S> P;
+    const double dt_u = uniform_d(sh.pub.dt), t1_u = uniform_d(sh.pub.t1);
+    P.y0 = cur_y; P.f0 = cur_f;
+    P.y1 = (cur_y == ya) ? yb : ya;
+    P.f1 = (cur_f == fa) ? fb : fa;
+    P.hs = (T)dt_u; P.t0 = (T)t1_u;
+    P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
+    P.j_lo = uniform_i(sh.pub.emit_lo); P.j_hi = uniform_i(sh.pub.emit_hi);
+    Acc acc;
+    lin_attempt_pass<T, D, S, TS, true>(A.s, P, cx, acc, t_out);
+    ok = grid_reduce(A, acc, sh, gen++, r);                   // (its barriers also fence the reads of sh.pub above)
+    if (threadIdx.x == 0) {
+      AttemptState st = sh.st;
+      if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
+      else { fill_record(rec, r, (double)cp.n_local); attempt_core(st, rec, cp); }
+      publish(st);
+      sh.st = st;
+    }
+    __syncthreads();
+    if (uniform_i(sh.pub.accepted)) { cur_y = P.y1; cur_f = P.f1; }
+  }
+
+  // final state for mi_ode_get_state: plane indices as controller_apply's rotation would have left them
+  if (cur_y == y_user) {                                      // no accepted step (error exit): seed plane 0 with y0
+    const long long n = A.s.batch * D;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) ya[i] = y_user[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sh.st.store(s_c);
+    s_c.idx_y0 = (cur_y == yb) ? 1 : 0; s_c.idx_y1 = (cur_y == yb) ? 0 : 1;
+    s_c.idx_k[0] = (cur_f == fa) ? 2 : 2 + S; s_c.idx_k[S] = (cur_f == fa) ? 2 + S : 2;
+    persist_write_back(A, s_c);
+  }
+}
+
+template <typename T, int D>
+constexpr size_t persist_linear_lds_bytes() {
+  return (size_t)16 * (D + MfmaTraits<T>::VEC) * sizeof(T);
 }
 
 }  // namespace mi

@@ -278,45 +278,83 @@ __global__ __launch_bounds__(256) void k_fixed_rowlocal(FixedArgs A) {
 //     barrier -> 32 MFMA steps against the wave's resident W slice -> k_{sigma+1} (registers) -> barrier.
 //     y0 / f0 of the NEXT tile are prefetched into registers during the stages of the current one.
 // ------------------------------------------------------------------------------------------------
-template <typename T, int D, int S, bool TS>
-__global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
+// Per-thread context of the 16-row-tile linear kernels: the wavefront's W slice (resident in VGPRs), bias, LDS tile.
+template <typename T, int D>
+struct LinCtx {
   using TR = MfmaTraits<T>;
   using acc_t = typename TR::acc_t;
-  constexpr int VEC = TR::VEC;
-  constexpr int R_ = 16;
-  constexpr int LD = D + VEC;
-  constexpr int KS = D / 4;
+  static constexpr int VEC = TR::VEC;
+  static constexpr int R_ = 16;
+  static constexpr int LD = D + VEC;
+  static constexpr int KS = D / 4;
   using CH = Chunk<T, VEC>;
-
-  StepPlanes<T, S> P;
-  if (!resolve_step<T, S>(A, P)) return;
-
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* s_ys = (T*)smem_raw;                                   // [R_][LD]
-  double* red = (double*)(s_ys + R_ * LD);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const T* W = (const T*)A.rhs.w[0];
-  const T* bias = (const T*)A.rhs.b[0];
-  const T sign = (T)A.rhs.sign;
-  const int col = 16 * wave + li;
-
+  int lane, wave, li, lg, col;
   T bf[KS];
-#pragma unroll
-  for (int s = 0; s < KS; ++s) bf[s] = W[(long long)(lg * KS + s) * D + col];
-  const T bias_v = bias != nullptr ? bias[col] : (T)0;
+  T bias_v, sign;
+  bool has_bias;
+  T* s_ys;                                                   // [R_][LD]
 
-  Acc acc;
+  __device__ __forceinline__ void init(const RhsParams& rhs, T* lds) {
+    const int tid = threadIdx.x;
+    lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
+    col = 16 * wave + li;
+    const T* W = (const T*)rhs.w[0];
+    const T* bias = (const T*)rhs.b[0];
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bf[s] = W[(long long)(lg * KS + s) * D + col];
+    has_bias = bias != nullptr;
+    bias_v = has_bias ? bias[col] : (T)0;
+    sign = (T)rhs.sign;
+    s_ys = lds;
+  }
+  __device__ __forceinline__ int row_of(int i) const { return TR::acc_row(lane, i); }
+
+  // f(ys) for the tile: ys (this thread's 4 accumulator-layout elements) -> LDS -> barrier -> KS MFMA steps against
+  // the resident W slice -> k (same layout, reversed-time sign applied) -> barrier (every wave is done with the tile)
+  __device__ __forceinline__ void rhs_eval(const T (&ys)[4], T (&kn)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s_ys[TR::acc_row(lane, i) * LD + col] = ys[i];
+    __syncthreads();
+    acc_t c0 = {0, 0, 0, 0};
+    const T* ap = s_ys + li * LD + lg * KS;
+#pragma unroll
+    for (int m = 0; m < KS / VEC; ++m) {
+      const CH a0 = *(const CH*)(ap + m * VEC);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], bf[m * VEC + v], c0);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      T k_ = c0[i];
+      if (has_bias) k_ = k_ + bias_v;
+      kn[i] = sign * k_;
+    }
+    __syncthreads();
+  }
+};
+
+// SC0: read the streamed state with workgroup-scope (sc0, L1-bypassing) loads - needed when the kernel outlives an
+// attempt (whole-integration kernel: a plane is rewritten and re-read inside one launch)
+template <bool SC0, typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+  if constexpr (SC0) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else return *p;
+}
+
+// One adaptive attempt over this workgroup's tiles (tile = blockIdx.x, + gridDim.x, ...).
+template <typename T, int D, int S, bool TS, bool SC0>
+__device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPlanes<T, S>& P, LinCtx<T, D>& cx, Acc& acc,
+                                                 const double* t_out) {
+  constexpr int R_ = LinCtx<T, D>::R_;
   const long long ntiles = (A.batch + R_ - 1) / R_;
   T y0n[4], f0n[4];                                          // prefetched next tile (accumulator layout)
   auto fetch = [&](long long t_i) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long row = t_i * R_ + TR::acc_row(lane, i);
+      const long long row = t_i * R_ + cx.row_of(i);
       const bool ok = row < A.batch;
-      y0n[i] = ok ? P.y0[row * D + col] : (T)0;
-      f0n[i] = ok ? P.f0[row * D + col] : (T)0;
+      y0n[i] = ok ? stream_load<SC0>(P.y0 + row * D + cx.col) : (T)0;
+      f0n[i] = ok ? stream_load<SC0>(P.f0 + row * D + cx.col) : (T)0;
     }
   };
   if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -340,24 +378,8 @@ __global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
 #pragma unroll
         for (int j = 0; j < SG; ++j) kk[j] = k[j][i];
         ys[i] = step_combine<T, SG>(y0e[i], kk, hs, A);
-        s_ys[TR::acc_row(lane, i) * LD + col] = ys[i];
       }
-      __syncthreads();
-      acc_t c0 = {0, 0, 0, 0};
-      const T* ap = s_ys + li * LD + lg * KS;
-#pragma unroll
-      for (int m = 0; m < KS / VEC; ++m) {
-        const CH a0 = *(const CH*)(ap + m * VEC);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], bf[m * VEC + v], c0);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        T kn = c0[i];
-        if (bias != nullptr) kn = kn + bias_v;
-        k[SG][i] = sign * kn;
-      }
-      __syncthreads();                                       // every wave is done reading the tile
+      cx.rhs_eval(ys, k[SG]);
     };
     stage(std::integral_constant<int, 1>{});
     stage(std::integral_constant<int, 2>{});
@@ -369,24 +391,137 @@ __global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long row = row0 + TR::acc_row(lane, i);
+      const long long row = row0 + cx.row_of(i);
       if (row < A.batch) {
         T kk[S + 1];
 #pragma unroll
         for (int j = 0; j <= S; ++j) kk[j] = k[j][i];
         T err, ymid;
         step_finish<T, S>(y0e[i], kk, hs, A, err, ymid);
-        const long long idx = row * D + col;
+        const long long idx = row * D + cx.col;
         P.y1[idx] = ys[i];
         P.f1[idx] = k[S][i];
-        step_emit<T, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, A.t_out);
+        step_emit<T, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, t_out);
         acc.maxa = fmax(acc.maxa, (double)fabs(y0e[i]));
         acc.maxb = fmax(acc.maxb, (double)fabs(ys[i]));
         acc.suma += (double)err * (double)err;
       }
     }
   }
+}
+
+// before_integrate, first half (dopri5.py:71 + misc.py:225-233): f0 = f(t0, y0), sums of (y0/sc)^2 and (f0/sc)^2, the
+// non-finite flag; optionally seeds a state plane and solution[0] with y0 in the same pass.
+template <typename T, int D, bool SC0>
+__device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f0_out, T* copy_a, T* copy_b, LinCtx<T, D>& cx,
+                                            Acc& acc) {
+  constexpr int R_ = LinCtx<T, D>::R_;
+  const long long ntiles = (A.batch + R_ - 1) / R_;
+  T y0n[4];
+  auto fetch = [&](long long t_i) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long row = t_i * R_ + cx.row_of(i);
+      y0n[i] = row < A.batch ? stream_load<SC0>(y0 + row * D + cx.col) : (T)0;
+    }
+  };
+  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+    T y0e[4], kn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y0e[i] = y0n[i];
+    if (tile_i + gridDim.x < ntiles) fetch(tile_i + gridDim.x);
+    cx.rhs_eval(y0e, kn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long row = tile_i * R_ + cx.row_of(i);
+      if (row < A.batch) {
+        const long long idx = row * D + cx.col;
+        f0_out[idx] = kn[i];
+        if (copy_a != nullptr) copy_a[idx] = y0e[i];
+        if (copy_b != nullptr) copy_b[idx] = y0e[i];
+        const T sc = (T)A.cp.atol + fabs(y0e[i]) * (T)A.cp.rtol;     // misc.py:225
+        const double q0 = (double)(y0e[i] / sc);
+        acc.suma += q0 * q0;
+        if (!finite_(y0e[i])) acc.flag = 1;
+        const double q1 = (double)(kn[i] / sc);
+        acc.sumb += q1 * q1;                                         // misc.py:228
+      }
+    }
+  }
+}
+
+// before_integrate, second half (misc.py:235-237): f1 = f(t0 + h0, y0 + h0 f0), sum of ((f1 - f0)/sc)^2
+template <typename T, int D, bool SC0>
+__device__ __forceinline__ void lin_initb_pass(const StepArgs& A, const T* y0, const T* f0, T h0, LinCtx<T, D>& cx, Acc& acc) {
+  constexpr int R_ = LinCtx<T, D>::R_;
+  const long long ntiles = (A.batch + R_ - 1) / R_;
+  T y0n[4], f0n[4];
+  auto fetch = [&](long long t_i) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long row = t_i * R_ + cx.row_of(i);
+      const bool ok = row < A.batch;
+      y0n[i] = ok ? stream_load<SC0>(y0 + row * D + cx.col) : (T)0;
+      f0n[i] = ok ? stream_load<SC0>(f0 + row * D + cx.col) : (T)0;
+    }
+  };
+  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
+  for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+    T y0e[4], f0e[4], ys[4], kn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { y0e[i] = y0n[i]; f0e[i] = f0n[i]; ys[i] = y0e[i] + h0 * f0e[i]; }   // misc.py:235
+    if (tile_i + gridDim.x < ntiles) fetch(tile_i + gridDim.x);
+    cx.rhs_eval(ys, kn);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long row = tile_i * R_ + cx.row_of(i);
+      if (row < A.batch) {
+        const T sc = (T)A.cp.atol + fabs(y0e[i]) * (T)A.cp.rtol;
+        const double q = (double)((kn[i] - f0e[i]) / sc);            // misc.py:237
+        acc.suma += q * q;
+      }
+    }
+  }
+}
+
+template <typename T, int D, int S, bool TS>
+__global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
+  StepPlanes<T, S> P;
+  if (!resolve_step<T, S>(A, P)) return;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* s_ys = (T*)smem_raw;
+  double* red = (double*)(s_ys + LinCtx<T, D>::R_ * LinCtx<T, D>::LD);
+  LinCtx<T, D> cx;
+  cx.init(A.rhs, s_ys);
+  Acc acc;
+  lin_attempt_pass<T, D, S, TS, false>(A, P, cx, acc, A.t_out);
   finish_attempt(A, acc, red);
+}
+
+// before_integrate for the launch-per-attempt schedule: PHASE 0 = f0 pass (reads the caller's y0, seeds the state plane
+// and solution[0]), PHASE 1 = second half of misc._select_initial_step.  Each is followed by k_controller.
+struct InitArgs {
+  StepArgs s;
+  const void* y0;              // PHASE 0: the caller's initial state
+  void* copy_b;                // PHASE 0: solution[0] (may be null)
+};
+
+template <typename T, int D, int PHASE>
+__global__ __launch_bounds__(D * 4) void k_init_linear_mfma(InitArgs I) {
+  const StepArgs& A = I.s;
+  const Ctl* c = A.ctl;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* s_ys = (T*)smem_raw;
+  double* red = (double*)(s_ys + LinCtx<T, D>::R_ * LinCtx<T, D>::LD);
+  LinCtx<T, D> cx;
+  cx.init(A.rhs, s_ys);
+  Acc acc;
+  T* plane_y = (T*)(A.planes + (long long)c->idx_y0 * A.stride);
+  T* plane_f = (T*)(A.planes + (long long)c->idx_k[0] * A.stride);
+  if constexpr (PHASE == 0) lin_f0_pass<T, D, false>(A, (const T*)I.y0, plane_f, plane_y, (T*)I.copy_b, cx, acc);
+  else lin_initb_pass<T, D, false>(A, plane_y, plane_f, (T)c->h0, cx, acc);
+  block_reduce_store<false>(acc, red, A.partials + (long long)blockIdx.x * kRec);
 }
 
 template <typename T, int D>
