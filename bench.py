@@ -108,8 +108,9 @@ def main():
     ap.add_argument('--batch', type=int, default=BATCH_PER_GPU, help='rows per GPU (default: config 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--linear-variant', type=int, default=0)
-    ap.add_argument('--fusion', default='auto', choices=['auto', 'stage', 'step'],
-                    help="'stage': one kernel per RK stage (34 planes/attempt, HBM-bound); 'step'/'auto': whole attempt in one kernel")
+    ap.add_argument('--fusion', default='auto', choices=['auto', 'stage', 'step', 'whole'],
+                    help="'stage': one kernel per RK stage (34 planes/attempt, HBM-bound); 'step': whole attempt in one kernel; "
+                         "'whole'/'auto' (single GPU): the whole call in one launch")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -187,7 +188,26 @@ def main():
                'kernel_launches': int(stats.get('n_launches', 0)),
                'element_steps_per_s': n_elem_global * attempts * args.steps / elapsed,
                'attempt_kernels_ms': all_ms}
-        if step_fused:
+        whole = int(stats.get('n_launches', 0)) == 1          # the whole call ran in one launch (k_persist_linear_mfma)
+        if whole:
+            # One launch = before_integrate (2 RHS passes) + every attempt (6 stages each): nfe RHS evaluations of
+            # 2*dim flop per element on the fp64 matrix pipe, plus the in-kernel grid hand-offs and controllers.
+            # Algorithmic HBM bytes: f0 pass 3 planes (y0 in, f0 + solution[0] out), initial-step pass 2, each attempt 4
+            # (y0, f0 in; y1, f1 out), one plane per output row.
+            nfe = int(stats.get('nfe', 0))
+            flops = nfe * 2 * DIM * n_elem_rank
+            planes = 3 + 2 + 4 * attempts + (len(t) - 1)
+            ach = flops / (last_ms * 1e-3) / 1e12 if last_ms > 0 else 0.0
+            cfg['fusion'] = 'whole (the whole odeint call in one kernel launch)'
+            roof = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': ach / FP64_MFMA_PEAK_TFLOPS, 'traffic': pmc_traffic('k_persist_linear_mfma<double, 128, 6'),
+                    'kernel': 'k_persist_linear_mfma<double,128,6> (before_integrate + all attempts: %d RHS evaluations on '
+                              'v_mfma_f64_16x16x4_f64, error norms, in-kernel controller and dense output)' % nfe,
+                    'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': planes * n_elem_rank * 8,
+                    'hbm_GBps_at_algorithmic_bytes': (planes * n_elem_rank * 8) / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0,
+                    'avg_launch_ms': last_ms, 'launches_timed': prof_n,
+                    'peak_source': 'AMD MI355X datasheet FP64 matrix 78.6 TFLOP/s (not listed in MI355X_MICROARCH.md)'}
+        elif step_fused:
             # k_step_linear_mfma<double,128,6>: 6 stages x 2*dim flop per element on the fp64 matrix pipe;
             # HBM traffic is only 5 planes (y0,f0 in; y1,f1,y_mid out), so the bound is the fp64 MFMA rate.
             flops = 6 * 2 * DIM * n_elem_rank
