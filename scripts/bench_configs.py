@@ -54,6 +54,13 @@ run('C1 LV rk4 1000 steps (single trajectory)', rhs.LotkaVolterra(), torch.tenso
     torch.linspace(0., 10., 1001, dtype=torch.float64), reps=3, method='rk4')
 run('LV b65536 rk4 100 steps', rhs.LotkaVolterra(), torch.tensor(1 + rng.uniform(size=(65536, 2)), device=dev),
     torch.linspace(0., 1., 101, dtype=torch.float64), reps=3, method='rk4')
+rngl = np.random.default_rng(2)
+Sl = rngl.standard_normal((128, 128))
+Al = torch.tensor(-0.5 * np.eye(128) + 0.5 * (Sl - Sl.T) / np.sqrt(128))
+yl = torch.tensor(rngl.standard_normal((65536, 128)), device=dev)
+for fusion in ('auto', 'stage'):
+    run('linear b65536 d128 rk4 fp64, 10 steps, fusion=%s' % fusion, rhs.Linear.from_matrix(Al), yl,
+        torch.linspace(0., 1., 11, dtype=torch.float64), reps=5, method='rk4', options={'fusion': fusion})
 # config 5: MLP 64-128-128-64 tanh fp32, batch 32768, rtol=atol=1e-3 (plane-kernel engine + torch matmul)
 g = torch.Generator().manual_seed(4)
 

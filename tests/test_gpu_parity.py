@@ -256,10 +256,8 @@ def test_fused_engine_reproduces_reference_runs(name, fusion):
         pytest.skip('whole-integration kernel: adaptive solvers on the row-local catalogue systems')
     if fusion == 'step' and meta0['rhs'] == 'linear' and len(meta0['rhs_params']['W']) not in (2, 16, 32, 64, 128):
         fusion = 'auto'                                 # no whole-attempt kernel for the VALU fallback family
-    if meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') and meta0['rhs'] == 'linear':
-        if fusion == 'stage':
-            pytest.skip('fixed grid + linear RHS has one path (per-stage MFMA kernels)')
-        fusion = 'auto'
+    if meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') and meta0['rhs'] == 'linear' and fusion == 'whole':
+        pytest.skip("fixed grid: 'step' already is the one-launch kernel")
     if meta0['rhs'] == 'mlp_tanh' and fusion == 'stage':
         pytest.skip('the MLP family only has the whole-attempt kernel')
     d, meta, sol, stats = _run_product(name, 'fused', fusion)
@@ -601,6 +599,40 @@ def test_whole_integration_mfma_kernel_equals_launch_per_attempt(problem, method
     b2 = odeint(f, y0, torch.tensor(t), method=method, options={'fusion': 'whole'}, **tol)
     a2 = odeint(f, y0, torch.tensor(t), method=method, options={'fusion': 'step'}, **tol)
     assert torch.equal(a2, b2)
+
+
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+@pytest.mark.parametrize('problem', ['linear16', 'linear32_bias', 'linear128', 'linear64_f32'])
+def test_fixed_grid_linear_one_launch_equals_per_stage_kernels(problem, method):
+    """Fixed grid + linear RHS: the whole integration in one launch (k_fixed_linear_mfma) vs the FX_* stage kernels."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(17)
+    D = int(''.join(ch for ch in problem.split('_')[0] if ch.isdigit()))
+    batch = {'linear16': 1000, 'linear32_bias': 37, 'linear128': 3000, 'linear64_f32': 5000}[problem]
+    dtype = torch.float32 if problem.endswith('f32') else torch.float64
+    S_ = rng.standard_normal((D, D))
+    A = -0.5 * np.eye(D) + 0.5 * (S_ - S_.T) / np.sqrt(D)
+    bias = torch.tensor(0.1 * rng.standard_normal(D)) if problem.endswith('bias') else None
+    f = rhs.Linear(torch.tensor(A.T.copy()), bias) if bias is not None else rhs.Linear.from_matrix(torch.tensor(A))
+    y0 = to_dev(rng.standard_normal((batch, D)), dtype)
+    for t in (np.linspace(0., 1., 21), -np.linspace(0., 1., 21) ** 2):
+        tt = torch.tensor(t)
+        a = odeint(f, y0, tt, method=method, options={'fusion': 'stage'})
+        sa = dict(odeint.last_stats)
+        b = odeint(f, y0, tt, method=method)
+        sb = dict(odeint.last_stats)
+        assert sb['n_launches'] == 1 and sa['n_launches'] > 1, (sa, sb)
+        assert torch.equal(a, b)
+    # and against the numpy oracle (fp64 only; matmul accumulation order differs)
+    if dtype == torch.float64:
+        from oracle import ode_numpy as O
+        from oracle.rhs_numpy import make_rhs
+        Wn = A.T.copy()
+        fn = (lambda t_, y_: y_ @ Wn + bias.numpy()) if bias is not None else (lambda t_, y_: y_ @ Wn)
+        ref = O.odeint(fn, y0.cpu().numpy(), np.linspace(0., 1., 21), method=method)
+        ref = np.asarray(ref[0] if isinstance(ref, tuple) else ref)
+        got = odeint(f, y0, torch.tensor(np.linspace(0., 1., 21)), method=method).cpu().numpy()
+        assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
 
 
 def test_whole_integration_kernel_status_paths():

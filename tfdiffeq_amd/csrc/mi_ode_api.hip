@@ -337,7 +337,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
                                         h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP);
     if (h->family == FAM_MLP && desc->fusion == 1) { mi_set_error("the MLP family only has a whole-attempt kernel"); delete h; return MI_ODE_E_INVALID; }
     const bool can_fixed = !desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
-                                               h->family == FAM_LORENZ);
+                                               h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA);
     if (desc->fusion == 2 && !can && !can_fixed) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); delete h; return MI_ODE_E_INVALID; }
     h->step_fused = (can && desc->fusion != 1) ? 1 : 0;
     h->ts_dense = (desc->interp != MI_ODE_INTERP_QUARTIC_MID) ? 1 : 0;
@@ -704,9 +704,10 @@ extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, 
     }
   h->n_launches = 0; h->n_polls = 0;
   const size_t pbytes = (size_t)h->n * h->elt;
-  if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ) &&
-      h->d.fusion != 1) {
-    // tiny row-local systems: the whole integration is ONE launch (k_fixed_rowlocal)
+  if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
+       h->family == FAM_LINEAR_MFMA) && h->d.fusion != 1) {
+    // trajectories never interact on a fixed grid: the whole integration is ONE launch
+    // (k_fixed_rowlocal for the tiny row-local systems, k_fixed_linear_mfma for the linear RHS)
     int rcf = ensure_t_out(h, T);
     if (rcf != 0) return rcf;
     MI_HIP(hipStreamSynchronize(st));

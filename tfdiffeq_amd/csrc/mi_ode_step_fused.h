@@ -278,6 +278,14 @@ __global__ __launch_bounds__(256) void k_fixed_rowlocal(FixedArgs A) {
 //     barrier -> 32 MFMA steps against the wave's resident W slice -> k_{sigma+1} (registers) -> barrier.
 //     y0 / f0 of the NEXT tile are prefetched into registers during the stages of the current one.
 // ------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also carries a workgroup-scope fence, i.e. an
+// s_waitcnt vmcnt(0): every global load still in flight (the next tile's prefetch) and every store (the previous
+// tile's y1 / f1 / outputs) would have to land before the FIRST stage of a tile may start its MFMA phase - that exposed
+// ~2 us of HBM latency per tile.  The tile kernels only exchange data through LDS at these points.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // Per-thread context of the 16-row-tile linear kernels: the wavefront's W slice (resident in VGPRs), bias, LDS tile.
 template <typename T, int D>
 struct LinCtx {
@@ -314,7 +322,7 @@ struct LinCtx {
   __device__ __forceinline__ void rhs_eval(const T (&ys)[4], T (&kn)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_ys[TR::acc_row(lane, i) * LD + col] = ys[i];
-    __syncthreads();
+    lds_barrier();
     acc_t c0 = {0, 0, 0, 0};
     const T* ap = s_ys + li * LD + lg * KS;
 #pragma unroll
@@ -329,7 +337,7 @@ struct LinCtx {
       if (has_bias) k_ = k_ + bias_v;
       kn[i] = sign * k_;
     }
-    __syncthreads();
+    lds_barrier();
   }
 };
 
@@ -522,6 +530,62 @@ __global__ __launch_bounds__(D * 4) void k_init_linear_mfma(InitArgs I) {
   if constexpr (PHASE == 0) lin_f0_pass<T, D, false>(A, (const T*)I.y0, plane_f, plane_y, (T*)I.copy_b, cx, acc);
   else lin_initb_pass<T, D, false>(A, plane_y, plane_f, (T)c->h0, cx, acc);
   block_reduce_store<false>(acc, red, A.partials + (long long)blockIdx.x * kRec);
+}
+
+// Fixed grid (solvers.py:82-104) for the linear RHS, dim in {16, 32, 64, 128}: trajectories never interact on a fixed
+// grid, so a tile runs through EVERY grid interval with y and k_1..k_4 in registers (Euler: fixed_grid.py:6-7, RK4
+// 3/8 rule: rk_common.py:73-81, the arithmetic of the FX_* stage modes) and streams solution[i+1]; one launch per call.
+// Traffic = y0 in + T solution rows out; bound: fp64/fp32 MFMA.  Only W (64 VGPRs at D = 128) and a handful of state
+// registers are live.  (Forcing two workgroups per CU with a 128-VGPR cap brought nothing: the limit is not phase
+// serialisation - see DESIGN.md, "what limits the tile kernels".)
+template <typename T, int D>
+__global__ __launch_bounds__(D * 4) void k_fixed_linear_mfma(FixedArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  LinCtx<T, D> cx;
+  cx.init(A.rhs, (T*)smem_raw);
+  constexpr int R_ = LinCtx<T, D>::R_;
+  const long long ntiles = (A.batch + R_ - 1) / R_;
+  const long long n = A.batch * D;
+  const T* y0p = (const T*)A.y0;
+  T* out = (T*)A.out;
+  for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+    T y[4];
+    long long idx[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long row = tile_i * R_ + cx.row_of(i);
+      ok[i] = row < A.batch;
+      idx[i] = row * D + cx.col;
+      y[i] = ok[i] ? y0p[idx[i]] : (T)0;
+      if (ok[i]) out[idx[i]] = y[i];                          // solution = [y0]
+    }
+    for (int s = 0; s + 1 < A.T; ++s) {
+      const T t0 = (T)A.t[s];                                 // solvers.py:84: the grid is cast to the STATE dtype
+      const T dt = (T)A.t[s + 1] - t0;
+      T k1[4], k2[4], k3[4], k4[4], ys[4];
+      cx.rhs_eval(y, k1);
+      if (!A.rk4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = y[i] + dt * k1[i];                           // fixed_grid.py:7
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ys[i] = y[i] + dt * k1[i] / (T)3;                   // rk_common.py:77
+        cx.rhs_eval(ys, k2);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ys[i] = y[i] + dt * (k1[i] / (T)-3 + k2[i]);        // :78
+        cx.rhs_eval(ys, k3);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ys[i] = y[i] + dt * (k1[i] - k2[i] + k3[i]);        // :79
+        cx.rhs_eval(ys, k4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y[i] = y[i] + (k1[i] + (T)3 * k2[i] + (T)3 * k3[i] + k4[i]) * (dt / (T)8);   // :81
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (ok[i]) out[(long long)(s + 1) * n + idx[i]] = y[i];
+    }
+  }
 }
 
 template <typename T, int D>
