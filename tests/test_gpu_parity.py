@@ -635,6 +635,35 @@ def test_fixed_grid_linear_one_launch_equals_per_stage_kernels(problem, method):
         assert np.max(np.abs(got - ref)) <= 1e-12 * max(1.0, np.max(np.abs(ref)))
 
 
+@pytest.mark.parametrize('method', ['dopri5', 'bosh3', 'tsit5'])
+@pytest.mark.parametrize('shape', [(32768, 64, 128), (1000, 64, 128), (300, 10, 20), (4096, 16, 16)])
+def test_whole_integration_mlp_kernel_equals_launch_per_attempt(shape, method):
+    """ODEFunc-shaped tanh MLP (config 5): the whole call in one launch, same bits as one launch per attempt."""
+    from tfdiffeq_amd import odeint, rhs
+    batch, d_, h_ = shape
+    g = torch.Generator().manual_seed(21)
+
+    def glorot(i, o):
+        lim = (6.0 / (i + o)) ** 0.5
+        return (torch.rand(i, o, generator=g) * 2 - 1) * lim
+    f = rhs.MLPTanh(glorot(d_, h_).to(dev()), (0.1 * torch.randn(h_, generator=g)).to(dev()), glorot(h_, h_).to(dev()),
+                    (0.1 * torch.randn(h_, generator=g)).to(dev()), glorot(h_, d_).to(dev()), (0.1 * torch.randn(d_, generator=g)).to(dev()))
+    y0 = torch.randn(batch, d_, generator=g).to(dev())
+    t = torch.tensor([0., 0.25, 0.3, 1.0]) * (0.05 if method == 'bosh3' else 1.0)
+    tol = dict(rtol=1e-4, atol=1e-5)
+    for tt in (t, -t):
+        a = odeint(f, y0, tt, method=method, options={'fusion': 'step'}, **tol)
+        sa = dict(odeint.last_stats)
+        b = odeint(f, y0, tt, method=method, options={'fusion': 'whole'}, **tol)
+        sb = dict(odeint.last_stats)
+        c = odeint(f, y0, tt, method=method, **tol)
+        sc = dict(odeint.last_stats)
+        assert sb['n_launches'] == 1 and sc['n_launches'] == 1 and sa['n_launches'] > 1, (sa, sb, sc)
+        for k_ in ('n_attempts', 'n_accepted', 'nfe', 'status'):
+            assert sa[k_] == sb[k_] == sc[k_], (k_, sa, sb, sc)
+        assert torch.equal(a, b) and torch.equal(b, c)
+
+
 def test_whole_integration_kernel_status_paths():
     from tfdiffeq_amd import odeint, rhs
     y0 = to_dev(np.array([[1., 1., 1.]]), torch.float64)
@@ -705,7 +734,7 @@ def test_config5_mlp_fused_kernel_full_size():
     t = torch.tensor([0., 0.5, 1.0])
     a = odeint(f, y0, t, rtol=1e-3, atol=1e-3, method='dopri5')
     sa = dict(odeint.last_stats)
-    assert sa['status'] == 0 and sa['n_launches'] < 40            # one launch per attempt (+ controller, emit, init)
+    assert sa['status'] == 0 and sa['n_launches'] == 1           # the whole call is one launch
     b = odeint(f, y0, t, rtol=1e-3, atol=1e-3, method='dopri5', options={'force_plane_kernels': True})
     assert (a - b).abs().max().item() < 2e-4 * max(1.0, b.abs().max().item())
     # tight tolerance on a slice against the numpy oracle (fp32 arithmetic on both sides)

@@ -352,11 +352,12 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       // hand-off spins).  Row-local systems: one trajectory per thread; linear MFMA family: the persistent tile grid.
     const bool rowlocal = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ;
     const bool mfma = h->family == FAM_LINEAR_MFMA && h->step_fused;
+    const bool mlp = h->family == FAM_MLP;
     h->init_tiles16 = mfma ? 1 : 0;
-    const long long g = mfma ? (long long)h->step_grid : (desc->batch + 255) / 256;
-    bool can = desc->adaptive && (rowlocal || mfma) && h->d.world_size <= 1 && desc->allgather == nullptr && g <= kPersistMaxGrid;
+    const long long g = (mfma || mlp) ? (long long)h->step_grid : (desc->batch + 255) / 256;
+    bool can = desc->adaptive && (rowlocal || mfma || mlp) && h->d.world_size <= 1 && desc->allgather == nullptr && g <= kPersistMaxGrid;
     if (can) {
-      const int cap = h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h);
+      const int cap = mlp ? mi_persist_capacity_mlp_f32(h) : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
       can = cap > 0 && g <= cap;
     }
     if (desc->fusion == 4 && !can) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local or MFMA-linear RHS, single rank, every workgroup co-resident)"); delete h; return MI_ODE_E_INVALID; }
@@ -610,7 +611,8 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   if (const char* e1 = getenv("MI_ODE_PERSIST_SLEEP1")) A.sleep_poll = atoi(e1);
   const bool prof = h->d.profile && h->ev_ready;
   if (prof) (void)hipEventRecord(h->ev_a[0], st);
-  rc = h->is_f32 ? mi_launch_persist_f32(h, A, h->persist_grid, st) : mi_launch_persist_f64(h, A, h->persist_grid, st);
+  if (h->family == FAM_MLP) rc = mi_launch_persist_mlp_f32(h, A, h->persist_grid, st);
+  else rc = h->is_f32 ? mi_launch_persist_f32(h, A, h->persist_grid, st) : mi_launch_persist_f64(h, A, h->persist_grid, st);
   if (rc != 0) return rc;
   if (prof) (void)hipEventRecord(h->ev_c[0], st);
   MI_HIP(hipStreamSynchronize(st));            // the kernel's last act was the zero-copy store of the final state

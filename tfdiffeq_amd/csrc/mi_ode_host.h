@@ -95,6 +95,8 @@ int mi_launch_init_linear_f64(mi_ode_solver* h, int phase, mi::InitArgs& I, hipS
 int mi_launch_init_linear_f32(mi_ode_solver* h, int phase, mi::InitArgs& I, hipStream_t st);
 int mi_persist_capacity_f64(mi_ode_solver* h);
 int mi_persist_capacity_f32(mi_ode_solver* h);
+int mi_launch_persist_mlp_f32(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);
+int mi_persist_capacity_mlp_f32(mi_ode_solver* h);
 int mi_launch_mlp_f32(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st);
 int mi_stage_geometry_f64(mi_ode_solver* h);
 int mi_stage_geometry_f32(mi_ode_solver* h);

@@ -9,6 +9,7 @@
 // (weights are zero-padded in registers, state columns are masked).
 #pragma once
 #include <type_traits>
+#include "mi_ode_persist.h"
 #include "mi_ode_step_fused.h"
 
 namespace mi {
@@ -104,40 +105,31 @@ struct MlpArgs {
   int hidden;                // real hidden width
 };
 
-template <int DP, int HP, int MODE, int S, bool TS>
-__global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
+// Per-thread context of the MLP tile kernels: resident weight slices (zero padded), biases, LDS tiles, element map.
+template <int DP, int HP>
+struct MlpCtx {
   using G = MlpGeom<DP, HP>;
-  const StepArgs& A = M.step;
-  StepPlanes<float, S> P;
-  if (MODE == MLP_F0) {
-    P.y0 = (const float*)M.x_y0;
-    P.f0 = nullptr; P.y1 = nullptr; P.hs = 0.f; P.t0 = 0.f; P.j_lo = P.j_hi = 0;
-    P.f1 = (float*)(A.planes + 2 * A.stride);               // F0 writes f0 into idx_k[0] of a fresh handle
-  } else {
-    if (!resolve_step<float, S>(A, P)) return;
-    if (MODE == MLP_INITB) P.hs = (float)A.ctl->h0;
-  }
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* s_x = (float*)smem_raw;
-  float* s_h1 = s_x + G::R * G::LDX;
-  float* s_h2 = s_h1 + G::R * G::LDH;
-  double* red = (double*)(s_h2 + G::R * G::LDH);
-
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  const int d = A.dim, hd = M.hidden;
-  const float* W1 = (const float*)A.rhs.w[0];
-  const float* W2 = (const float*)A.rhs.w[1];
-  const float* W3 = (const float*)A.rhs.w[2];
-  const float* B1 = (const float*)A.rhs.b[0];
-  const float* B2 = (const float*)A.rhs.b[1];
-  const float* B3 = (const float*)A.rhs.b[2];
-  const float sign = (float)A.rhs.sign;
-  constexpr int KS1 = DP / 4, KS2 = HP / 4;
-
-  // resident weight slices, zero padded: lane (col = li, group lg) holds W[k = lg*KS + s][16*block + li]
+  static constexpr int KS1 = DP / 4, KS2 = HP / 4;
+  float *s_x, *s_h1, *s_h2;
   float w1f[KS1], w2f[KS2], w3f[KS2];
-  {
+  float b1v, b2v, b3v, sign;
+  int lane, wave, li, lg, d, hd, col, rbase;
+  bool owner;
+
+  __device__ __forceinline__ void init(const RhsParams& rhs, int dim, char* smem) {
+    s_x = (float*)smem;
+    s_h1 = s_x + G::R * G::LDX;
+    s_h2 = s_h1 + G::R * G::LDH;
+    lane = threadIdx.x & 63; wave = threadIdx.x >> 6; li = lane & 15; lg = lane >> 4;
+    d = dim; hd = rhs.hidden;
+    const float* W1 = (const float*)rhs.w[0];
+    const float* W2 = (const float*)rhs.w[1];
+    const float* W3 = (const float*)rhs.w[2];
+    const float* B1 = (const float*)rhs.b[0];
+    const float* B2 = (const float*)rhs.b[1];
+    const float* B3 = (const float*)rhs.b[2];
+    sign = (float)rhs.sign;
+    // resident weight slices, zero padded: lane (col = li, group lg) holds W[k = lg*KS + s][16*block + li]
     const int c12 = 16 * wave + li;
 #pragma unroll
     for (int s = 0; s < KS1; ++s) {
@@ -155,16 +147,34 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
       const int k = lg * KS2 + s;
       w3f[s] = (wave < G::NW3 && k < hd && c3 < d) ? W3[(long long)k * d + c3] : 0.f;
     }
+    b1v = (B1 != nullptr && wave < G::NW12 && c12 < hd) ? B1[c12] : 0.f;
+    b2v = (B2 != nullptr && wave < G::NW12 && c12 < hd) ? B2[c12] : 0.f;
+    col = 16 * (wave % G::CB3) + li;                          // this thread's state column (owner waves)
+    b3v = (B3 != nullptr && wave < G::NW3 && col < d) ? B3[col] : 0.f;
+    owner = wave < G::NW3 && col < d;
+    rbase = 16 * (wave / G::CB3) + 4 * lg;                    // + i : row inside the tile
   }
-  const int c12 = 16 * wave + li;
-  const float b1v = (B1 != nullptr && wave < G::NW12 && c12 < hd) ? B1[c12] : 0.f;
-  const float b2v = (B2 != nullptr && wave < G::NW12 && c12 < hd) ? B2[c12] : 0.f;
-  const int col = 16 * (wave % G::CB3) + li;                // this thread's state column (owner waves)
-  const float b3v = (B3 != nullptr && wave < G::NW3 && col < d) ? B3[col] : 0.f;
-  const bool owner = wave < G::NW3 && col < d;
-  const int rbase = 16 * (wave / G::CB3) + 4 * lg;          // + i : row inside the tile
+  // input tile -> LDS (owner threads write their elements; padded columns of s_x must read as zero)
+  __device__ __forceinline__ void put_x(const float* v4) {
+    if (wave < G::NW3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s_x[(rbase + i) * G::LDX + col] = (col < d) ? v4[i] : 0.f;
+    }
+  }
+  __device__ __forceinline__ void eval(float* out4) {
+    mlp_eval<DP, HP>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v, b2v, b3v, out4);
+  }
+};
 
-  Acc acc;
+// One pass over this workgroup's tiles: MODE F0 (f0 + the norms of misc._select_initial_step, seeds copy_a / copy_b),
+// INITB (second half of _select_initial_step), STEP (one adaptive attempt).  SC0 as in the linear kernels.
+template <int DP, int HP, int MODE, int S, bool TS, bool SC0>
+__device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<float, S>& P, void* copy_a, void* copy_b,
+                                         MlpCtx<DP, HP>& cx, Acc& acc, const double* t_out) {
+  using G = MlpGeom<DP, HP>;
+  const int d = cx.d, col = cx.col, rbase = cx.rbase;
+  const bool owner = cx.owner;
+  const float sign = cx.sign;
   const long long ntiles = (A.batch + G::R - 1) / G::R;
   for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
     const long long row0 = tile_i * G::R;
@@ -175,30 +185,23 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
     for (int i = 0; i < 4; ++i) {
       const long long row = row0 + rbase + i;
       const bool ok = owner && row < A.batch;
-      y0e[i] = ok ? P.y0[row * d + col] : 0.f;
-      k[0][i] = (ok && MODE != MLP_F0) ? P.f0[row * d + col] : 0.f;
+      y0e[i] = ok ? stream_load<SC0>(P.y0 + row * d + col) : 0.f;
+      k[0][i] = (ok && MODE != MLP_F0) ? stream_load<SC0>(P.f0 + row * d + col) : 0.f;
       if (MODE == MLP_F0 && ok) {
-        if (M.copy_a != nullptr) ((float*)M.copy_a)[row * d + col] = y0e[i];
-        if (M.copy_b != nullptr) ((float*)M.copy_b)[row * d + col] = y0e[i];
+        if (copy_a != nullptr) ((float*)copy_a)[row * d + col] = y0e[i];
+        if (copy_b != nullptr) ((float*)copy_b)[row * d + col] = y0e[i];
       }
     }
-    // input tile -> LDS (owner threads write their elements; padded columns of s_x must read as zero)
-    auto put_x = [&](const float* v4) {
-      if (wave < G::NW3) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s_x[(rbase + i) * G::LDX + col] = (col < d) ? v4[i] : 0.f;
-      }
-    };
     if (MODE == MLP_F0) {
-      put_x(y0e);
-      mlp_eval<DP, HP>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v, b2v, b3v, kn);
+      cx.put_x(y0e);
+      cx.eval(kn);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const long long row = row0 + rbase + i;
         if (owner && row < A.batch) {
           const float f0 = sign * kn[i];
           P.f1[row * d + col] = f0;
-          const float sc = (float)M.atol + fabsf(y0e[i]) * (float)M.rtol;      // misc.py:225
+          const float sc = (float)A.cp.atol + fabsf(y0e[i]) * (float)A.cp.rtol;      // misc.py:225
           const double q0 = (double)(y0e[i] / sc), q1 = (double)(f0 / sc);
           acc.suma += q0 * q0; acc.sumb += q1 * q1;
           if (!finite_(y0e[i])) acc.flag = 1;
@@ -210,13 +213,13 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
     if (MODE == MLP_INITB) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) ys[i] = y0e[i] + hs * k[0][i];               // misc.py:235
-      put_x(ys);
-      mlp_eval<DP, HP>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v, b2v, b3v, kn);
+      cx.put_x(ys);
+      cx.eval(kn);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const long long row = row0 + rbase + i;
         if (owner && row < A.batch) {
-          const float sc = (float)M.atol + fabsf(y0e[i]) * (float)M.rtol;
+          const float sc = (float)A.cp.atol + fabsf(y0e[i]) * (float)A.cp.rtol;
           const double q = (double)((sign * kn[i] - k[0][i]) / sc);            // misc.py:237
           acc.suma += q * q;
         }
@@ -234,8 +237,8 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
         for (int j = 0; j < SG; ++j) kk[j] = k[j][i];
         ys[i] = step_combine<float, SG>(y0e[i], kk, hs, A);
       }
-      put_x(ys);
-      mlp_eval<DP, HP>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v, b2v, b3v, kn);
+      cx.put_x(ys);
+      cx.eval(kn);
 #pragma unroll
       for (int i = 0; i < 4; ++i) k[SG][i] = sign * kn[i];
     };
@@ -259,7 +262,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
         const long long idx = row * d + col;
         P.y1[idx] = ys[i];
         P.f1[idx] = k[S][i];
-        step_emit<float, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, A.t_out);
+        step_emit<float, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, t_out);
         acc.maxa = fmax(acc.maxa, (double)fabsf(y0e[i]));
         acc.maxb = fmax(acc.maxb, (double)fabsf(ys[i]));
         acc.suma += (double)err * (double)err;
@@ -267,8 +270,126 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
     }
     __syncthreads();
   }
+}
+
+template <int DP, int HP, int MODE, int S, bool TS>
+__global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
+  using G = MlpGeom<DP, HP>;
+  const StepArgs& A = M.step;
+  StepPlanes<float, S> P;
+  if (MODE == MLP_F0) {
+    P.y0 = (const float*)M.x_y0;
+    P.f0 = nullptr; P.y1 = nullptr; P.hs = 0.f; P.t0 = 0.f; P.j_lo = P.j_hi = 0;
+    P.f1 = (float*)(A.planes + 2 * A.stride);               // F0 writes f0 into idx_k[0] of a fresh handle
+  } else {
+    if (!resolve_step<float, S>(A, P)) return;
+    if (MODE == MLP_INITB) P.hs = (float)A.ctl->h0;
+  }
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  MlpCtx<DP, HP> cx;
+  cx.init(A.rhs, A.dim, smem_raw);
+  double* red = (double*)(cx.s_h2 + G::R * G::LDH);
+  Acc acc;
+  mlp_pass<DP, HP, MODE, S, TS, false>(A, P, M.copy_a, M.copy_b, cx, acc, A.t_out);
   if constexpr (MODE == MLP_STEP) finish_attempt(A, acc, red);
   else block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
+}
+
+// The whole call in one launch (see mi_ode_persist.h): before_integrate, every attempt, controller and dense output on
+// the persistent tile grid; weights are loaded once per call.  Same planes / hand-off / redundant controller as
+// k_persist_linear_mfma.
+template <int DP, int HP, int S, bool TS>
+__global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(PersistArgs A) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ PersistShared sh;
+  Ctl& s_c = sh.c;
+  MlpCtx<DP, HP> cx;
+  cx.init(A.s.rhs, A.s.dim, smem_raw);
+  CtrlParams cp = A.s.cp;
+  cp.t_out = persist_stage_tout(A, sh.tout);
+  const double* t_out = cp.t_out;
+  unsigned gen = 0;
+  double r[5], rec[kRec];
+  if (threadIdx.x == 0) { persist_init_ctl(s_c, A); sh.ok = 1; }
+  __syncthreads();
+
+  float* const ya = (float*)(A.s.planes);
+  float* const yb = (float*)(A.s.planes + A.s.stride);
+  float* const fa = (float*)(A.s.planes + 2 * A.s.stride);
+  float* const fb = (float*)(A.s.planes + (long long)(2 + S) * A.s.stride);
+  const float* const y_user = (const float*)A.y0;
+
+  bool ok;
+  {
+    StepPlanes<float, S> P;
+    P.y0 = y_user; P.f0 = nullptr; P.y1 = nullptr; P.f1 = fa; P.hs = 0.f; P.t0 = 0.f; P.j_lo = P.j_hi = 0;
+    Acc acc;
+    mlp_pass<DP, HP, MLP_F0, S, TS, true>(A.s, P, nullptr, A.out0, cx, acc, t_out);
+    ok = grid_reduce(A, acc, sh, gen++, r);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_F0, cp); }
+    __syncthreads();
+  }
+  if (cp.auto_first_step && ok) {
+    StepPlanes<float, S> P;
+    P.y0 = y_user; P.f0 = fa; P.y1 = nullptr; P.f1 = nullptr; P.hs = (float)uniform_d(s_c.h0); P.t0 = 0.f; P.j_lo = P.j_hi = 0;
+    Acc acc;
+    mlp_pass<DP, HP, MLP_INITB, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
+    ok = grid_reduce(A, acc, sh, gen++, r);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_INITB, cp); }
+  }
+  auto publish = [&](const AttemptState& st) {                // thread 0: what the next attempt needs
+    sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.accepted = st.accepted; sh.pub.done = st.done;
+    int j = st.next_out;                                      // speculative output range of the NEXT attempt (resolve_step)
+    const double t_new = st.t1 + st.dt;
+    while (j < st.n_out && !(t_out[j] > t_new)) ++j;
+    sh.pub.emit_lo = st.next_out; sh.pub.emit_hi = j;
+  };
+  if (threadIdx.x == 0) {
+    if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
+    else set_outputs_apply(&s_c, A.n_out);
+    AttemptState st;
+    st.load(s_c);
+    st.accepted = 0;
+    publish(st);
+    sh.st = st;
+  }
+  __syncthreads();
+
+  const float* cur_y = y_user;
+  float* cur_f = fa;
+  while (!uniform_i(sh.pub.done)) {
+    StepPlanes<float, S> P;
+    const double dt_u = uniform_d(sh.pub.dt), t1_u = uniform_d(sh.pub.t1);
+    P.y0 = cur_y; P.f0 = cur_f;
+    P.y1 = (cur_y == ya) ? yb : ya;
+    P.f1 = (cur_f == fa) ? fb : fa;
+    P.hs = (float)dt_u; P.t0 = (float)t1_u;
+    P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
+    P.j_lo = uniform_i(sh.pub.emit_lo); P.j_hi = uniform_i(sh.pub.emit_hi);
+    Acc acc;
+    mlp_pass<DP, HP, MLP_STEP, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
+    ok = grid_reduce(A, acc, sh, gen++, r);
+    if (threadIdx.x == 0) {
+      AttemptState st = sh.st;
+      if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
+      else { fill_record(rec, r, (double)cp.n_local); attempt_core(st, rec, cp); }
+      publish(st);
+      sh.st = st;
+    }
+    __syncthreads();
+    if (uniform_i(sh.pub.accepted)) { cur_y = P.y1; cur_f = P.f1; }
+  }
+
+  if (cur_y == y_user) {                                      // no accepted step (error exit): seed plane 0 with y0
+    const long long n = A.s.batch * (long long)A.s.dim;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) ya[i] = y_user[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sh.st.store(s_c);
+    s_c.idx_y0 = (cur_y == yb) ? 1 : 0; s_c.idx_y1 = (cur_y == yb) ? 0 : 1;
+    s_c.idx_k[0] = (cur_f == fa) ? 2 : 2 + S; s_c.idx_k[S] = (cur_f == fa) ? 2 + S : 2;
+    persist_write_back(A, s_c);
+  }
 }
 
 }  // namespace mi
