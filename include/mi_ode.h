@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI_ODE_ABI_VERSION 1
+#define MI_ODE_ABI_VERSION 2
 #define MI_ODE_MAX_STAGES 6          /* rows of the tableau (dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -69,7 +69,9 @@ enum mi_ode_rhs_kind {
   MI_ODE_RHS_CUBIC_LINEAR = 2,   /* f = (y**3) @ W             examples/ode_demo.py:33-35 (spiral)          */
   MI_ODE_RHS_LOTKA_VOLTERRA = 3, /* dim 2: [a u - b u v, -c v + d u v]   scalars = {a,b,c,d}                */
   MI_ODE_RHS_LORENZ = 4,         /* dim 3: examples/lorenz_attractor.py:20-37, scalars = {sigma,beta,rho}   */
-  MI_ODE_RHS_MLP_TANH = 5        /* dim->hidden->hidden->dim, tanh; models/dense_odenet.py:41-92            */
+  MI_ODE_RHS_MLP_TANH = 5,       /* dim->hidden->hidden->dim, tanh; models/dense_odenet.py:41-92            */
+  MI_ODE_RHS_PLUGIN = 6          /* user device code for a trajectory-local system of small dim: mi_ode_rhs.plugin
+                                    (csrc/mi_ode_plugin.h); scalars[0..7] and w[]/b[] are passed through to it  */
 };
 
 enum mi_ode_controller {
@@ -101,6 +103,7 @@ typedef struct mi_ode_rhs {
   double scalars[8];          /* kind specific scalars */
   const void* w[3];           /* device pointers, state dtype: LINEAR/CUBIC {W}; MLP {W1,W2,W3} ([in,out] row-major) */
   const void* b[3];           /* device pointers (nullable): biases */
+  const void* plugin;         /* MI_ODE_RHS_PLUGIN: what the plugin's mi_ode_plugin_get(dtype) returned */
 } mi_ode_rhs;
 
 /* Exchange hook for batch-sharded runs: all-gather `count` doubles per rank.

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Cost of the generic path (arbitrary Python callable f(t, y) over torch ops + plane kernels) per RK attempt."""
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from tfdiffeq_amd import odeint, rhs  # noqa: E402
+
+dev = torch.device('cuda:0')
+
+
+def lorenz(t, y):
+    x, yy, z = y[..., 0], y[..., 1], y[..., 2]
+    return torch.stack([10.0 * (yy - x), x * (28.0 - z) - yy, x * yy - (8.0 / 3.0) * z], dim=-1)
+
+
+def run(name, f, y0, t, reps=5, **kw):
+    for _ in range(2):
+        odeint(f, y0, t, **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        odeint(f, y0, t, **kw)
+    torch.cuda.synchronize()
+    ms = 1e3 * (time.perf_counter() - t0) / reps
+    st = dict(odeint.last_stats)
+    print(json.dumps({'case': name, 'ms_per_call': round(ms, 3), 'attempts': st.get('n_attempts'),
+                      'us_per_attempt': round(1e3 * ms / max(st.get('n_attempts') or 1, 1), 1), 'engine': st.get('engine')}))
+
+
+y0 = torch.tensor([[1., 1., 1.]], dtype=torch.float64, device=dev).repeat(4096, 1) + 1e-3 * torch.randn(4096, 3, dtype=torch.float64, device=dev)
+t = torch.tensor([0., 1.0], dtype=torch.float64)
+for m in ('dopri5', 'tsit5', 'rk4'):
+    tt = t if m != 'rk4' else torch.linspace(0., 1., 51, dtype=torch.float64)
+    run('python callable lorenz b4096 %s' % m, lorenz, y0, tt, method=m, rtol=1e-6, atol=1e-9)
+    run('device RHS      lorenz b4096 %s' % m, rhs.Lorenz(), y0, tt, method=m, rtol=1e-6, atol=1e-9)

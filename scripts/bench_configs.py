@@ -54,6 +54,13 @@ run('C1 LV rk4 1000 steps (single trajectory)', rhs.LotkaVolterra(), torch.tenso
     torch.linspace(0., 10., 1001, dtype=torch.float64), reps=3, method='rk4')
 run('LV b65536 rk4 100 steps', rhs.LotkaVolterra(), torch.tensor(1 + rng.uniform(size=(65536, 2)), device=dev),
     torch.linspace(0., 1., 101, dtype=torch.float64), reps=3, method='rk4')
+from tfdiffeq_amd import plugin_examples  # noqa: E402
+yv = torch.tensor(rng.uniform(-2, 2, size=(4096, 2)), device=dev)
+vdp = plugin_examples.van_der_pol(5.0)
+run('plugin: van der Pol mu=5 b4096 dopri5 t=[0,10] (user device code, one launch)', vdp, yv, torch.tensor([0., 10.]), method='dopri5',
+    rtol=1e-6, atol=1e-9)
+run('same system as a Python callable (torch ops + plane kernels)', vdp, yv, torch.tensor([0., 10.]), reps=2, method='dopri5',
+    rtol=1e-6, atol=1e-9, options={'force_plane_kernels': True})
 rngl = np.random.default_rng(2)
 Sl = rngl.standard_normal((128, 128))
 Al = torch.tensor(-0.5 * np.eye(128) + 0.5 * (Sl - Sl.T) / np.sqrt(128))

@@ -664,6 +664,72 @@ def test_whole_integration_mlp_kernel_equals_launch_per_attempt(shape, method):
         assert torch.equal(a, b) and torch.equal(b, c)
 
 
+# ---------------------------------------------------------------------------------------------
+# user-defined device right-hand sides (RHS plugins, csrc/mi_ode_plugin.h)
+# ---------------------------------------------------------------------------------------------
+def test_custom_rhs_plugin_runs_the_catalogue_kernels_bit_for_bit():
+    """Lorenz written as a plugin == the built-in rhs.Lorenz on every schedule (same kernels, same arithmetic)."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(23)
+    from tfdiffeq_amd import plugin_examples
+    custom = plugin_examples.lorenz()
+    builtin = rhs.Lorenz()
+    for dtype, tol in ((torch.float64, dict(rtol=1e-6, atol=1e-9)), (torch.float32, dict(rtol=1e-4, atol=1e-6))):
+        for batch in (1, 5000):
+            y0 = to_dev(np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((batch, 3)), dtype)
+            tt = torch.tensor(np.linspace(0., 0.5, 6))
+            for method in ('dopri5', 'tsit5', 'bosh3'):
+                t_ = tt * (0.05 if method == 'bosh3' else 1.0)
+                for fusion in ('whole', 'step'):
+                    a = odeint(builtin, y0, t_, method=method, options={'fusion': fusion}, **tol)
+                    sa = dict(odeint.last_stats)
+                    b = odeint(custom, y0, t_, method=method, options={'fusion': fusion}, **tol)
+                    sb = dict(odeint.last_stats)
+                    assert torch.equal(a, b), (dtype, batch, method, fusion)
+                    assert sa['n_attempts'] == sb['n_attempts'] and sa['n_launches'] == sb['n_launches']
+                c = odeint(custom, y0, -t_, method=method, **tol)                  # reversed time
+                assert torch.equal(c, odeint(builtin, y0, -t_, method=method, **tol))
+            for method in ('euler', 'rk4'):
+                g_ = torch.tensor(np.linspace(0., 0.2, 21))
+                assert torch.equal(odeint(custom, y0, g_, method=method), odeint(builtin, y0, g_, method=method))
+                assert odeint.last_stats['n_launches'] == 1
+    # too many trajectories for the co-resident grid: one launch per attempt, still the plugin's kernels
+    big = to_dev(np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((200000, 3)), torch.float64)
+    tb = torch.tensor([0., 0.1])
+    assert torch.equal(odeint(custom, big, tb, method='dopri5'), odeint(builtin, big, tb, method='dopri5'))
+    assert odeint.last_stats['n_launches'] > 1
+    with pytest.raises(Exception, match='per-stage'):
+        odeint(custom, big[:10], tb, method='dopri5', options={'fusion': 'stage'})
+
+
+def test_custom_rhs_plugin_time_dependent_system_against_oracle():
+    """A forced oscillator (uses t and parameters) through the one-launch kernel vs the numpy oracle and the exact solution."""
+    from tfdiffeq_amd import odeint, rhs
+    from tfdiffeq_amd import plugin_examples
+    w, amp = 2.0, 0.7
+    f = plugin_examples.forced_oscillator(amp, w)
+    rng = np.random.default_rng(29)
+    y0n = rng.standard_normal((300, 2))
+    y0 = to_dev(y0n, torch.float64)
+    t = np.linspace(0., 3.0, 13)
+    sol = odeint(f, y0, torch.tensor(t), rtol=1e-9, atol=1e-11, method='dopri5')
+    assert odeint.last_stats['n_launches'] == 1
+    # exact: particular A cos(w t), A = amp / (1 - w^2), plus the homogeneous part fitted to y0
+    A_ = amp / (1.0 - w * w)
+    c1, c2 = y0n[:, 0] - A_, y0n[:, 1]
+    exact0 = c1[None, :] * np.cos(t)[:, None] + c2[None, :] * np.sin(t)[:, None] + A_ * np.cos(w * t)[:, None]
+    assert np.max(np.abs(sol[..., 0].cpu().numpy() - exact0)) < 1e-7
+    ref = O.odeint(lambda t_, y_: np.stack([y_[..., 1], amp * np.cos(w * t_) - y_[..., 0]], axis=-1), y0n, t,
+                   rtol=1e-9, atol=1e-11, method='dopri5')
+    assert_band(sol.cpu(), np.asarray(ref), 1e-8, 1e-10, 'plugin vs oracle')
+    # the same system through the generic path (torch_fn + plane kernels)
+    gen = odeint(f, y0, torch.tensor(t), rtol=1e-9, atol=1e-11, method='dopri5', options={'force_plane_kernels': True})
+    assert (gen - sol).abs().max().item() < 1e-8
+    # reversed time: f <- -f(-t, y) (misc.py:318-321) needs the stage time with the right sign
+    back = odeint(f, sol[-1], torch.tensor(t[::-1].copy()), rtol=1e-9, atol=1e-11, method='dopri5')
+    assert (back[-1] - y0).abs().max().item() < 1e-6
+
+
 def test_whole_integration_kernel_status_paths():
     from tfdiffeq_amd import odeint, rhs
     y0 = to_dev(np.array([[1., 1., 1.]]), torch.float64)

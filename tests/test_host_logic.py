@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol_and_layout_matches():
     assert declared == list(N.EXPORTED_SYMBOLS), (declared, N.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mi_ode_abi_version() == 1
+    assert lib.mi_ode_abi_version() == N.ABI_VERSION == 2
     assert lib.mi_ode_sizeof(0) == C.sizeof(N.Desc) and lib.mi_ode_sizeof(1) == C.sizeof(N.Stats)
     assert lib.mi_ode_status_string(N.ST_MAX_STEPS).decode().startswith('max_num_steps exceeded')
     assert lib.mi_ode_status_string(N.ST_DT_UNDERFLOW).decode().startswith('underflow in dt')
@@ -158,3 +158,31 @@ def test_device_rhs_python_paths_match_numpy():
     np.testing.assert_allclose(rhs.CubicLinear(torch.tensor(A))(None, torch.tensor(y4)).numpy(), (y4 ** 3) @ A, rtol=1e-13)
     rev = rhs.Lorenz().reversed()
     np.testing.assert_allclose(rev(torch.tensor(1.0), torch.tensor(y)).numpy(), -rhs.Lorenz()(None, torch.tensor(y)).numpy())
+
+
+def test_rhs_plugin_builds_and_exports_its_table():
+    """rhs.CustomRowLocal: generated source, hipcc cross-compile, cache hit, table layout (no GPU needed)."""
+    import ctypes as C
+    import os
+    import torch
+    from tfdiffeq_amd import _plugin_build, rhs
+    from tfdiffeq_amd import plugin_examples
+    f = plugin_examples.van_der_pol(5.0)
+    src = f.source(torch.float64)
+    assert 'static constexpr int D = 2;' in src and 'MI_ODE_PLUGIN_F64' in src and 'k[1] = p[0]' in src
+    path = _plugin_build.build(src)
+    mtime = os.path.getmtime(path)
+    assert _plugin_build.build(src) == path and os.path.getmtime(path) == mtime        # cache hit, no recompile
+    lib, table = f._plugin(torch.float64)
+
+    class Table(C.Structure):
+        _fields_ = [('abi', C.c_int), ('dtype', C.c_int), ('dim', C.c_int), ('reserved', C.c_int), ('solver_size', C.c_size_t),
+                    ('launch_init', C.c_void_p), ('launch_step', C.c_void_p), ('launch_fixed', C.c_void_p), ('persist_fn', C.c_void_p)]
+    tb = Table.from_address(table)
+    core = N.load()
+    assert tb.abi == 1 and tb.dtype == N.dtype_code(torch.float64) and tb.dim == 2
+    assert tb.solver_size == core.mi_ode_sizeof(4)
+    assert tb.launch_init and tb.launch_step and tb.launch_fixed and tb.persist_fn
+    assert not lib.mi_ode_plugin_get(N.dtype_code(torch.float32))                      # built for one dtype only
+    with pytest.raises(ValueError):
+        rhs.CustomRowLocal(9, "k[0] = 0;")

@@ -18,9 +18,10 @@ MAX_LINCOMB = 14
 REC = 8
 
 F32, F64 = 0, 1
-RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH = 1, 2, 3, 4, 5
+RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH, RHS_PLUGIN = 1, 2, 3, 4, 5, 6
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
+ABI_VERSION = 2
 ST_DT_UNDERFLOW, ST_NONFINITE, ST_MAX_STEPS, ST_BAD_T, ST_SYNC_TIMEOUT = 1, 2, 4, 8, 16
 
 
@@ -36,7 +37,7 @@ class Tableau(C.Structure):
 class Rhs(C.Structure):
     _fields_ = [('kind', C.c_int32), ('hidden', C.c_int32), ('sign', C.c_double),
                 ('scalars', C.c_double * 8),
-                ('w', C.c_void_p * 3), ('b', C.c_void_p * 3)]
+                ('w', C.c_void_p * 3), ('b', C.c_void_p * 3), ('plugin', C.c_void_p)]
 
 
 ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
@@ -137,7 +138,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError here = the .so does not export what mi_ode.h declares
         fn.restype = res
         fn.argtypes = args
-    if lib.mi_ode_abi_version() != 1:
+    if lib.mi_ode_abi_version() != ABI_VERSION:
         raise NativeError('libmi_ode.so ABI version mismatch')
     for which, st in ((0, Desc), (1, Stats), (2, Tableau), (3, Rhs)):
         if lib.mi_ode_sizeof(which) != C.sizeof(st):

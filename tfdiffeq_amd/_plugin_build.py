@@ -1,0 +1,69 @@
+"""Compile and load right-hand-side plugins (csrc/mi_ode_plugin.h): hipcc, gfx950, cached by source hash."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import tempfile
+
+from . import _native as N
+
+HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=off', '-shared',
+         '-I', N.CSRC, '-I', os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'include')]
+_loaded = {}
+
+
+def plugin_dir():
+    d = os.environ.get('TFDIFFEQ_AMD_PLUGIN_DIR')
+    if not d:
+        d = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_plugins')      # in-tree: travels with the checkout
+    try:
+        os.makedirs(d, exist_ok=True)
+        if os.access(d, os.W_OK):
+            return d
+    except OSError:
+        pass
+    d = os.path.join(tempfile.gettempdir(), 'tfdiffeq_amd_plugins')
+    os.makedirs(d, exist_ok=True)
+    return d
+
+
+def _headers_digest():
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(N.CSRC)):
+        if name.endswith('.h'):
+            with open(os.path.join(N.CSRC, name), 'rb') as fh:
+                h.update(fh.read())
+    return h.hexdigest()
+
+
+def build(source, verbose=False):
+    """Path of the compiled plugin for `source` (compiles on a cache miss; the key covers the kernel headers too)."""
+    key = hashlib.sha256((source + _headers_digest() + ' '.join(FLAGS)).encode()).hexdigest()[:24]
+    out = os.path.join(plugin_dir(), 'rhs_%s.so' % key)
+    if os.path.exists(out):
+        return out
+    src = out[:-3] + '.hip'
+    with open(src, 'w') as fh:
+        fh.write(source)
+    tmp = out + '.tmp%d' % os.getpid()
+    res = subprocess.run([HIPCC] + FLAGS + [src, '-o', tmp], capture_output=True, text=True)
+    if verbose or res.returncode != 0:
+        print(res.stdout[-4000:])
+        print(res.stderr[-6000:])
+    if res.returncode != 0:
+        raise N.NativeError('compiling the RHS plugin failed (hipcc output above); source: %s' % src)
+    os.replace(tmp, out)
+    return out
+
+
+def build_and_load(source):
+    path = build(source)
+    lib = _loaded.get(path)
+    if lib is None:
+        import torch  # noqa: F401  (same reason as _native.load: bind to torch's HIP runtime)
+        lib = C.CDLL(path)
+        lib.mi_ode_plugin_get.restype = C.c_void_p
+        lib.mi_ode_plugin_get.argtypes = [C.c_int]
+        _loaded[path] = lib
+    return lib

@@ -12,6 +12,7 @@
 #include "mi_ode_step_fused.h"
 #include "mi_ode_persist.h"
 #include "mi_ode_mlp.h"
+#include "mi_ode_plugin.h"
 
 using namespace mi;
 
@@ -46,6 +47,7 @@ extern "C" int64_t mi_ode_sizeof(int32_t which) {
     case 1: return (int64_t)sizeof(mi_ode_stats);
     case 2: return (int64_t)sizeof(mi_ode_tableau);
     case 3: return (int64_t)sizeof(mi_ode_rhs);
+    case 4: return (int64_t)sizeof(mi_ode_solver);          /* what a RHS plugin must have been compiled against */
     default: return -1;
   }
 }
@@ -54,6 +56,12 @@ extern "C" int64_t mi_ode_sizeof(int32_t which) {
 // helpers
 // ------------------------------------------------------------------------------------------------
 static inline int launch_stage(mi_ode_solver* h, int mode, int nk, StageArgs& A, hipStream_t st) {
+  if (h->family == FAM_PLUGIN) {
+    const int rc = h->plugin->launch_init(h, mode, nk, &A, st);
+    if (rc != 0) { mi_set_error("plugin stage launch failed (mode %d nk %d): plugins provide F0 / INITB only", mode, nk); return rc; }
+    h->n_launches += 1;
+    return 0;
+  }
   return h->is_f32 ? mi_launch_stage_f32(h, mode, nk, A, st) : mi_launch_stage_f64(h, mode, nk, A, st);
 }
 
@@ -110,6 +118,12 @@ static int enqueue_attempt_kernels(mi_ode_solver* h, hipStream_t st, hipEvent_t 
     StepArgs A;
     fill_step_args(h, A);
     if (ev_last) (void)hipEventRecord(ev_last, st);
+    if (h->family == FAM_PLUGIN) {
+      const int rcp = h->plugin->launch_step(h, &A, st);
+      if (rcp != 0) { mi_set_error("plugin step kernel launch failed"); return rcp; }
+      h->n_launches += 1;
+      return 0;
+    }
     return h->is_f32 ? mi_launch_step_f32(h, A, st) : mi_launch_step_f64(h, A, st);
   }
   for (int sigma = 1; sigma <= h->S; ++sigma) {
@@ -237,6 +251,18 @@ static int pick_family(mi_ode_solver* h) {
       if (D > 256) { mi_set_error("fused linear RHS supports dim <= 256 (got %d)", D); return MI_ODE_E_INVALID; }
       h->family = FAM_LINEAR_VALU; return 0;
     }
+    case MI_ODE_RHS_PLUGIN: {
+      const mi_ode_rowlocal_plugin* pl = (const mi_ode_rowlocal_plugin*)r.plugin;
+      if (pl == nullptr) { mi_set_error("MI_ODE_RHS_PLUGIN needs mi_ode_rhs.plugin"); return MI_ODE_E_INVALID; }
+      if (pl->abi != MI_ODE_PLUGIN_ABI || pl->solver_size != sizeof(mi_ode_solver)) {
+        mi_set_error("RHS plugin was built against different headers (abi %d vs %d, handle %zu vs %zu bytes): rebuild it", pl->abi,
+                     MI_ODE_PLUGIN_ABI, pl->solver_size, sizeof(mi_ode_solver));
+        return MI_ODE_E_INVALID;
+      }
+      if (pl->dtype != h->d.dtype || pl->dim != D) { mi_set_error("RHS plugin is for dtype %d dim %d, the state is dtype %d dim %d", pl->dtype, pl->dim, h->d.dtype, D); return MI_ODE_E_INVALID; }
+      h->plugin = pl;
+      h->family = FAM_PLUGIN; return 0;
+    }
     case MI_ODE_RHS_MLP_TANH: {
       const int hd = r.hidden;
       if (!h->is_f32) { mi_set_error("fused MLP kernel is fp32 only"); return MI_ODE_E_INVALID; }
@@ -334,10 +360,13 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   if (rc != 0) { delete h; return rc; }
   {   // whole-attempt fusion: row-local families and the MFMA linear family, adaptive FSAL tableaus
     const bool can = desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
-                                        h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP);
+                                        h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP ||
+                                        h->family == FAM_PLUGIN);
+    if (h->family == FAM_PLUGIN && desc->fusion == 1) { mi_set_error("RHS plugins have no per-stage kernels (fusion = 1)"); delete h; return MI_ODE_E_INVALID; }
     if (h->family == FAM_MLP && desc->fusion == 1) { mi_set_error("the MLP family only has a whole-attempt kernel"); delete h; return MI_ODE_E_INVALID; }
     const bool can_fixed = !desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
-                                               h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA);
+                                               h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA ||
+                                               h->family == FAM_PLUGIN);
     if (desc->fusion == 2 && !can && !can_fixed) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); delete h; return MI_ODE_E_INVALID; }
     h->step_fused = (can && desc->fusion != 1) ? 1 : 0;
     h->ts_dense = (desc->interp != MI_ODE_INTERP_QUARTIC_MID) ? 1 : 0;
@@ -350,7 +379,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   }
   {   // whole integration in one launch (mi_ode_persist.h): single rank, every workgroup co-resident (the in-kernel
       // hand-off spins).  Row-local systems: one trajectory per thread; linear MFMA family: the persistent tile grid.
-    const bool rowlocal = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ;
+    const bool rowlocal = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
+                          h->family == FAM_PLUGIN;
     const bool mfma = h->family == FAM_LINEAR_MFMA && h->step_fused;
     const bool mlp = h->family == FAM_MLP;
     h->init_tiles16 = mfma ? 1 : 0;
@@ -627,6 +657,10 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   {
     const Ctl* cc = h->ctl_host;
     const double na = cc->n_attempt > 0 ? (double)cc->n_attempt : 1.0;
+    if (h->family == FAM_LINEAR_MFMA)
+      fprintf(stderr, "[persist prof] attempts %lld  us: f0 pass %.1f  initial-step pass %.1f  attempt passes %.1f (%.1f each)  hand-offs %.1f\n",
+              cc->n_attempt, 0.01 * cc->prof[0], 0.01 * cc->prof[1], 0.01 * cc->prof[2], 0.01 * cc->prof[2] / na, 0.01 * cc->prof[3]);
+    else
     fprintf(stderr, "[persist prof] attempts %lld  ns/attempt: stages %.0f  reduce+handoff %.0f  controller %.0f  emit %.0f\n",
             cc->n_attempt, 10.0 * cc->prof[0] / na, 10.0 * cc->prof[1] / na, 10.0 * cc->prof[2] / na, 10.0 * cc->prof[3] / na);
   }
@@ -707,7 +741,7 @@ extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, 
   h->n_launches = 0; h->n_polls = 0;
   const size_t pbytes = (size_t)h->n * h->elt;
   if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
-       h->family == FAM_LINEAR_MFMA) && h->d.fusion != 1) {
+       h->family == FAM_LINEAR_MFMA || h->family == FAM_PLUGIN) && h->d.fusion != 1) {
     // trajectories never interact on a fixed grid: the whole integration is ONE launch
     // (k_fixed_rowlocal for the tiny row-local systems, k_fixed_linear_mfma for the linear RHS)
     int rcf = ensure_t_out(h, T);
@@ -719,7 +753,13 @@ extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, 
     FixedArgs F;
     memset(&F, 0, sizeof(F));
     F.y0 = y0_dev; F.out = out_dev; F.t = h->t_out_dev; F.batch = h->d.batch; F.T = T; F.rk4 = euler ? 0 : 1; F.rhs = h->rhs;
-    rcf = h->is_f32 ? mi_launch_fixed_f32(h, F, st) : mi_launch_fixed_f64(h, F, st);
+    if (h->family == FAM_PLUGIN) {
+      rcf = h->plugin->launch_fixed(h, &F, st);
+      if (rcf != 0) { mi_set_error("plugin fixed-grid kernel launch failed"); return rcf; }
+      h->n_launches += 1;
+    } else {
+      rcf = h->is_f32 ? mi_launch_fixed_f32(h, F, st) : mi_launch_fixed_f64(h, F, st);
+    }
     if (rcf != 0) return rcf;
     if (stats) {
       memset(stats, 0, sizeof(*stats));

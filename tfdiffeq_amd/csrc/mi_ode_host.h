@@ -18,7 +18,8 @@ enum Family {
   FAM_LORENZ,        // rowlocal, dim 3
   FAM_LINEAR_VALU,   // any dim <= 256, optional cube / bias
   FAM_LINEAR_MFMA,   // dim in {16, 32, 64, 128}
-  FAM_MLP            // fp32 dim<=64, hidden<=128: whole-attempt MFMA kernel only
+  FAM_MLP,           // fp32 dim<=64, hidden<=128: whole-attempt MFMA kernel only
+  FAM_PLUGIN         // row-local user code behind a mi_ode_rowlocal_plugin table (mi_ode_plugin.h)
 };
 
 struct LaunchInfo {   // filled per (mode) at create time
@@ -29,8 +30,11 @@ struct LaunchInfo {   // filled per (mode) at create time
 
 }  // namespace mi
 
+struct mi_ode_rowlocal_plugin;
+
 struct mi_ode_solver {
   mi_ode_desc d;
+  const mi_ode_rowlocal_plugin* plugin;   // FAM_PLUGIN
   mi::Family family;
   int is_f32;
   size_t elt;                 // sizeof(state dtype)

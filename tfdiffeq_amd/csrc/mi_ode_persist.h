@@ -413,14 +413,20 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
   bool ok;
   {
     Acc acc;
+    MI_TICK(tf0);
     lin_f0_pass<T, D, true>(A.s, y_user, fa, (T*)nullptr, (T*)A.out0, cx, acc);
+    MI_TICK(tf1);
+    MI_TOCK(0, tf0, tf1);
     ok = grid_reduce(A, acc, sh, gen++, r);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_F0, cp); }
     __syncthreads();
   }
   if (cp.auto_first_step && ok) {
     Acc acc;
+    MI_TICK(ti0);
     lin_initb_pass<T, D, true>(A.s, y_user, fa, (T)uniform_d(s_c.h0), cx, acc);
+    MI_TICK(ti1);
+    MI_TOCK(1, ti0, ti1);
     ok = grid_reduce(A, acc, sh, gen++, r);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_INITB, cp); }
   }
@@ -456,8 +462,12 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
     P.j_lo = uniform_i(sh.pub.emit_lo); P.j_hi = uniform_i(sh.pub.emit_hi);
     Acc acc;
+    MI_TICK(ta0);
     lin_attempt_pass<T, D, S, TS, true>(A.s, P, cx, acc, t_out);
+    MI_TICK(ta1);
     ok = grid_reduce(A, acc, sh, gen++, r);                   // (its barriers also fence the reads of sh.pub above)
+    MI_TICK(ta2);
+    MI_TOCK(2, ta0, ta1); MI_TOCK(3, ta1, ta2);
     if (threadIdx.x == 0) {
       AttemptState st = sh.st;
       if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }

@@ -1,0 +1,40 @@
+"""Example right-hand-side plugins (rhs.CustomRowLocal).  `__graft_entry__.build()` precompiles them so that tests and
+first uses on a GPU box hit the in-tree cache (tfdiffeq_amd/_plugins/) instead of running hipcc there."""
+import torch
+
+from . import rhs
+
+LORENZ_BODY = """
+k[0] = p[0] * (y[1] - y[0]);
+k[1] = y[0] * (p[2] - y[2]) - y[1];
+k[2] = y[0] * y[1] - p[1] * y[2];
+"""
+
+
+def lorenz(sigma=10.0, beta=8.0 / 3.0, rho=28.0):
+    """examples/lorenz_attractor.py:28-37 as user device code: the arithmetic of the built-in rhs.Lorenz, literally."""
+    return rhs.CustomRowLocal(3, LORENZ_BODY, params=[sigma, beta, rho],
+                              torch_fn=lambda t, y: torch.stack([sigma * (y[..., 1] - y[..., 0]),
+                                                                 y[..., 0] * (rho - y[..., 2]) - y[..., 1],
+                                                                 y[..., 0] * y[..., 1] - beta * y[..., 2]], dim=-1))
+
+
+def forced_oscillator(amp=0.7, w=2.0):
+    """y'' + y = amp cos(w t): a time-dependent system with parameters."""
+    return rhs.CustomRowLocal(2, "k[0] = y[1];\nk[1] = p[0] * cos(p[1] * t) - y[0];", params=[amp, w],
+                              torch_fn=lambda t, y: torch.stack([y[..., 1], amp * torch.cos(w * t) - y[..., 0]], dim=-1))
+
+
+def van_der_pol(mu=5.0):
+    return rhs.CustomRowLocal(2, "k[0] = y[1];\nk[1] = p[0] * (1 - y[0] * y[0]) * y[1] - y[0];", params=[mu],
+                              torch_fn=lambda t, y: torch.stack([y[..., 1], mu * (1 - y[..., 0] ** 2) * y[..., 1] - y[..., 0]], dim=-1))
+
+
+def prebuild():
+    """Compile every example for both state dtypes (cache hits are free)."""
+    from . import _plugin_build
+    out = []
+    for f in (lorenz(), forced_oscillator(), van_der_pol()):
+        for dt in (torch.float64, torch.float32):
+            out.append(_plugin_build.build(f.source(dt)))
+    return out

@@ -213,3 +213,93 @@ class MLPTanh(DeviceRHS):
                 rhs.b[i] = bd.data_ptr()
                 keep.append(bd)
         return keep
+
+
+# ---------------------------------------------------------------------------------------------
+# user-defined device right-hand sides
+# ---------------------------------------------------------------------------------------------
+_PLUGIN_TEMPLATE = """// generated by tfdiffeq_amd.rhs.CustomRowLocal - do not edit
+#define {dtype_macro} 1
+#include "mi_ode_plugin.h"
+namespace mi {{
+template <typename T>
+struct RhsUser {{
+  static constexpr int D = {dim};
+  T p[8];                                                  // mi_ode_rhs.scalars in the state dtype
+  __device__ explicit RhsUser(const RhsParams& r) {{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = (T)r.s[i];
+  }}
+  // t: stage time, y[D]: state of this trajectory, k[D]: derivative to fill in
+  __device__ __forceinline__ void operator()(T t, const T* y, T* k) const {{
+    (void)t;
+{body}
+  }}
+}};
+}}  // namespace mi
+MI_ODE_DEFINE_ROWLOCAL_PLUGIN(mi::RhsUser)
+"""
+
+
+class CustomRowLocal(DeviceRHS):
+    """A trajectory-local system f(t, y) of small dimension written as device code.
+
+    `body` is HIP C++ that fills `k[0..dim-1]` from `t`, `y[0..dim-1]` and the parameters `p[0..7]` (all of the state
+    dtype `T`).  It is compiled once (hipcc, gfx950; cached by source hash) into a plugin that instantiates the same
+    row-local kernels the built-in catalogue uses, so the system gets the whole-integration kernel (one launch per
+    odeint call), the whole-attempt kernel and the one-launch fixed-grid kernel:
+
+        vdp = rhs.CustomRowLocal(2, "k[0] = y[1]; k[1] = p[0] * (1 - y[0] * y[0]) * y[1] - y[0];", params=[5.0])
+        sol = odeint(vdp, y0, t, method='dopri5')          # y0: [..., 2] on the GPU
+
+    Write the arithmetic the way the reference's Python callable evaluates it (no FMA contraction is applied).
+    `torch_fn(t, y)` is optional: the same function over torch tensors, used where a Python callable is needed (tuple
+    states, `odeint_adjoint`, `options={'force_plane_kernels': True}`)."""
+    kind = N.RHS_PLUGIN
+    MAX_DIM = 8
+
+    def __init__(self, dim, body, params=(), torch_fn=None):
+        super(CustomRowLocal, self).__init__()
+        self.dim = int(dim)
+        if not 1 <= self.dim <= self.MAX_DIM:
+            raise ValueError('CustomRowLocal supports 1 <= dim <= %d (one trajectory per thread, state in registers)' % self.MAX_DIM)
+        self.params = [float(v) for v in params]
+        if len(self.params) > 8:
+            raise ValueError('at most 8 scalar parameters travel by value')
+        self.body = str(body)
+        self.torch_fn = torch_fn
+        self._plugins = {}
+
+    def forward(self, t, y):
+        if self.torch_fn is None:
+            raise NotImplementedError('this CustomRowLocal has no torch_fn: only the fused kernels can evaluate it')
+        return self.torch_fn(t, y)
+
+    def source(self, dtype):
+        body = '\n'.join('    ' + ln for ln in self.body.strip().splitlines())
+        return _PLUGIN_TEMPLATE.format(dtype_macro='MI_ODE_PLUGIN_F32' if dtype == torch.float32 else 'MI_ODE_PLUGIN_F64',
+                                       dim=self.dim, body=body)
+
+    def _plugin(self, dtype):
+        hit = self._plugins.get(dtype)
+        if hit is None:
+            from . import _plugin_build
+            lib = _plugin_build.build_and_load(self.source(dtype))
+            table = lib.mi_ode_plugin_get(N.dtype_code(dtype))
+            if not table:
+                raise N.NativeError('plugin exports no table for %s' % dtype)
+            hit = (lib, int(table))
+            self._plugins[dtype] = hit
+        return hit
+
+    def fill(self, rhs, dtype, device):
+        keep = super(CustomRowLocal, self).fill(rhs, dtype, device)
+        lib, table = self._plugin(dtype)
+        rhs.plugin = table
+        for i, v in enumerate(self.params):
+            rhs.scalars[i] = v
+        keep.append(lib)
+        return keep
+
+    def cache_key(self, dtype, device):
+        return super(CustomRowLocal, self).cache_key(dtype, device) + (self._plugin(dtype)[1],)
