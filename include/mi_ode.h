@@ -199,6 +199,10 @@ int mi_ode_get_state(mi_ode_handle h, void* y_dev, void* f_dev, void* stream);
 /* out[i] = (base ? base[i] : 0) + sum_j (scale * coef[j]) * xs[j][i]       (misc.py:118-121; zeros not skipped) */
 int mi_ode_lincomb(int32_t dtype, int64_t n, const void* base_dev, const void* const* xs_dev, const double* coef,
                    int32_t nx, double scale, void* out_dev, void* stream);
+/* same with the scale (dt) read from device memory at execution time: what a captured hipGraph of an RK attempt needs
+ * (the graph is replayed with a new dt without re-recording) */
+int mi_ode_lincomb_dev(int32_t dtype, int64_t n, const void* base_dev, const void* const* xs_dev, const double* coef,
+                       int32_t nx, const double* scale_dev, void* out_dev, void* stream);
 /* result_dev[4] (double) = {max|y0|, max|y1|, sum err^2, nonfinite(y0)}            (misc.py:256-263) */
 int mi_ode_error_norms(int32_t dtype, int64_t n, const void* err_dev, const void* y0_dev, const void* y1_dev,
                        double* result_dev, void* workspace_dev, void* stream);

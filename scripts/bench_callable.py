@@ -37,4 +37,16 @@ t = torch.tensor([0., 1.0], dtype=torch.float64)
 for m in ('dopri5', 'tsit5', 'rk4'):
     tt = t if m != 'rk4' else torch.linspace(0., 1., 51, dtype=torch.float64)
     run('python callable lorenz b4096 %s' % m, lorenz, y0, tt, method=m, rtol=1e-6, atol=1e-9)
+    if m == 'rk4':
+        run('python callable lorenz b4096 rk4, one hipGraph replay per step', lorenz, y0, tt, method=m, options={'graph': True})
+        t1k = torch.linspace(0., 1., 1001, dtype=torch.float64)
+        run('python callable lorenz b4096 rk4 1000 steps', lorenz, y0, t1k, reps=2, method=m)
+        run('python callable lorenz b4096 rk4 1000 steps, hipGraph', lorenz, y0, t1k, reps=2, method=m, options={'graph': True})
+    if m != 'rk4':
+        run('python callable lorenz b4096 %s, hipGraph per attempt' % m, lorenz, y0, tt, method=m, rtol=1e-6, atol=1e-9,
+            options={'graph': True})
+        t10 = torch.tensor([0., 10.0], dtype=torch.float64)
+        run('python callable lorenz b4096 %s t=[0,10]' % m, lorenz, y0, t10, reps=2, method=m, rtol=1e-6, atol=1e-9)
+        run('python callable lorenz b4096 %s t=[0,10], hipGraph per attempt' % m, lorenz, y0, t10, reps=2, method=m, rtol=1e-6,
+            atol=1e-9, options={'graph': True})
     run('device RHS      lorenz b4096 %s' % m, rhs.Lorenz(), y0, tt, method=m, rtol=1e-6, atol=1e-9)

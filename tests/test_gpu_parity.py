@@ -730,6 +730,60 @@ def test_custom_rhs_plugin_time_dependent_system_against_oracle():
     assert (back[-1] - y0).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize('method', ['dopri5', 'tsit5', 'bosh3', 'dopri8', 'adaptive_heun'])
+def test_graph_captured_attempt_equals_eager_launches(method):
+    """Generic path (Python callable f): one hipGraph replay per attempt == the eager launch sequence, bit for bit."""
+    from tfdiffeq_amd import odeint
+
+    def lorenz(t, y):
+        x, yy, z = y[..., 0], y[..., 1], y[..., 2]
+        return torch.stack([10.0 * (yy - x), x * (28.0 - z) - yy, x * yy - (8.0 / 3.0) * z], dim=-1)
+
+    def forced(t, y):                      # time dependent: the stage times must be right under replay
+        return torch.stack([y[..., 1], 0.7 * torch.cos(2.0 * t) - y[..., 0], -0.1 * y[..., 2]], dim=-1)
+    rng = np.random.default_rng(31)
+    y0 = to_dev(np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((500, 3)), torch.float64)
+    t = torch.tensor(np.linspace(0., 0.6, 7)) * (0.05 if method == 'bosh3' else 1.0)
+    for f in (lorenz, forced):
+        a = odeint(f, y0, t, method=method, rtol=1e-6, atol=1e-9)
+        sa = dict(odeint.last_stats)
+        b = odeint(f, y0, t, method=method, rtol=1e-6, atol=1e-9, options={'graph': True})
+        sb = dict(odeint.last_stats)
+        assert sa['n_attempts'] == sb['n_attempts'] and sa['n_accepted'] == sb['n_accepted'], (sa, sb)
+        assert torch.equal(a, b)
+        c = odeint(f, y0, -t, method=method, rtol=1e-6, atol=1e-9, options={'graph': True})     # reversed time
+        assert torch.equal(c, odeint(f, y0, -t, method=method, rtol=1e-6, atol=1e-9))
+    # tuple state, float32
+    y32 = (y0.float(), y0[:7, :2].float().contiguous())
+    ft = lambda t_, ys: (lorenz(t_, ys[0]), -ys[1])  # noqa: E731
+    a = odeint(ft, y32, t, method=method, rtol=1e-4, atol=1e-6)
+    b = odeint(ft, y32, t, method=method, rtol=1e-4, atol=1e-6, options={'graph': True})
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize('method', ['euler', 'midpoint', 'heun', 'rk4'])
+def test_graph_captured_fixed_grid_step_equals_eager_launches(method):
+    """Fixed grid, Python callable f: one captured step replayed per interval (no host sync) == the eager loop."""
+    from tfdiffeq_amd import odeint
+
+    def forced(t, y):
+        return torch.stack([y[..., 1], 0.7 * torch.cos(2.0 * t) - y[..., 0], -0.1 * y[..., 2] * y[..., 0]], dim=-1)
+    rng = np.random.default_rng(37)
+    for dtype in (torch.float64, torch.float32):
+        y0 = to_dev(rng.standard_normal((300, 3)), dtype)
+        for t in (np.linspace(0., 1., 33), -np.linspace(0., 1., 9) ** 2):
+            tt = torch.tensor(t)
+            a = odeint(forced, y0, tt, method=method)
+            b = odeint(forced, y0, tt, method=method, options={'graph': True})
+            assert torch.equal(a, b), (method, dtype)
+    ys = (to_dev(rng.standard_normal((50, 3)), torch.float64), to_dev(rng.standard_normal((4, 3)), torch.float64))
+    ft = lambda t_, yy: (forced(t_, yy[0]), -yy[1])  # noqa: E731
+    tt = torch.tensor(np.linspace(0., 0.5, 11))
+    a = odeint(ft, ys, tt, method=method)
+    b = odeint(ft, ys, tt, method=method, options={'graph': True})
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_whole_integration_kernel_status_paths():
     from tfdiffeq_amd import odeint, rhs
     y0 = to_dev(np.array([[1., 1., 1.]]), torch.float64)

@@ -93,6 +93,8 @@ _PROTOS = {
     'mi_ode_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     'mi_ode_lincomb': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double),
                                  C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
+    'mi_ode_lincomb_dev': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double),
+                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mi_ode_error_norms': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     'mi_ode_scaled_sumsq': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,

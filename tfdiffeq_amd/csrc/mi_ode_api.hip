@@ -889,8 +889,8 @@ __global__ __launch_bounds__(256) void k_finalize_records(const double* part, in
   }
 }
 
-extern "C" int mi_ode_lincomb(int32_t dtype, int64_t n, const void* base_dev, const void* const* xs_dev, const double* coef,
-                              int32_t nx, double scale, void* out_dev, void* stream) {
+static int lincomb_impl(int32_t dtype, int64_t n, const void* base_dev, const void* const* xs_dev, const double* coef,
+                              int32_t nx, double scale, const double* scale_dev, void* out_dev, void* stream) {
   if (n < 0 || nx < 1 || nx > MI_ODE_MAX_LINCOMB || xs_dev == nullptr || coef == nullptr || out_dev == nullptr) {
     mi_set_error("lincomb: bad argument");
     return MI_ODE_E_INVALID;
@@ -898,7 +898,7 @@ extern "C" int mi_ode_lincomb(int32_t dtype, int64_t n, const void* base_dev, co
   if (n == 0) return 0;
   LincombArgs A;
   memset(&A, 0, sizeof(A));
-  A.base = base_dev; A.scale = scale; A.n = n; A.out = out_dev; A.nx = nx;
+  A.base = base_dev; A.scale = scale; A.scale_dev = scale_dev; A.n = n; A.out = out_dev; A.nx = nx;
   for (int j = 0; j < nx; ++j) { A.x[j] = xs_dev[j]; A.coef[j] = coef[j]; }
   const int g = streaming_grid(n);
   hipStream_t st = (hipStream_t)stream;
@@ -907,6 +907,17 @@ extern "C" int mi_ode_lincomb(int32_t dtype, int64_t n, const void* base_dev, co
   else { mi_set_error("bad dtype"); return MI_ODE_E_INVALID; }
   MI_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int mi_ode_lincomb(int32_t dtype, int64_t n, const void* base_dev, const void* const* xs_dev, const double* coef,
+                              int32_t nx, double scale, void* out_dev, void* stream) {
+  return lincomb_impl(dtype, n, base_dev, xs_dev, coef, nx, scale, nullptr, out_dev, stream);
+}
+
+extern "C" int mi_ode_lincomb_dev(int32_t dtype, int64_t n, const void* base_dev, const void* const* xs_dev, const double* coef,
+                                  int32_t nx, const double* scale_dev, void* out_dev, void* stream) {
+  if (scale_dev == nullptr) { mi_set_error("lincomb_dev: null scale pointer"); return MI_ODE_E_INVALID; }
+  return lincomb_impl(dtype, n, base_dev, xs_dev, coef, nx, 0.0, scale_dev, out_dev, stream);
 }
 
 extern "C" int mi_ode_error_norms(int32_t dtype, int64_t n, const void* err_dev, const void* y0_dev, const void* y1_dev,

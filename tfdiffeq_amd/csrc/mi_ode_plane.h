@@ -11,6 +11,7 @@ struct LincombArgs {
   const void* x[MI_ODE_MAX_LINCOMB];
   double coef[MI_ODE_MAX_LINCOMB];
   double scale;
+  const double* scale_dev;     // non-null: the scale is read from device memory (graph replay with a new dt)
   long long n;
   void* out;
   int nx;
@@ -19,7 +20,7 @@ struct LincombArgs {
 // out = base + add_n([(scale * c_j) * x_j])   -- misc._scaled_dot_product (misc.py:118-121), zeros not skipped
 template <typename T>
 __global__ __launch_bounds__(256) void k_lincomb(LincombArgs A) {
-  const T scale = (T)A.scale;
+  const T scale = A.scale_dev != nullptr ? (T)*A.scale_dev : (T)A.scale;
   T* out = (T*)A.out;
   const T* base = (const T*)A.base;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < A.n; i += (long long)gridDim.x * blockDim.x) {

@@ -1,11 +1,12 @@
 """Mirror of tfdiffeq/fixed_grid.py: Euler, Midpoint, Heun, RK4 (3/8 rule) on a fixed grid."""
-from .misc import _lincomb, _np_dtype, _scalar_tensor
-from .rk_common import _ButcherTableau, rk4_alt_step_func
+import torch
+
+from .misc import _lincomb, _np_dtype
+from .rk_common import _ButcherTableau, _div, _time_arg, _time_pair, rk4_alt_step_func
 from .solvers import FixedGridODESolver
 
-
-def _t(value, like):
-    return _scalar_tensor(value, like)
+# step_func(func, t, dt, y): t / dt are host scalars of the state dtype, or 0-d float64 device tensors when the step is
+# being captured into a hipGraph (graph_step.GraphedFixedStep); the arithmetic is the same either way.
 
 
 class Euler(FixedGridODESolver):
@@ -14,7 +15,8 @@ class Euler(FixedGridODESolver):
 
     def step_func(self, func, t, dt, y):
         """fixed_grid.py:6-7."""
-        return tuple(_lincomb(None, [1.0], [f_], dt) for f_ in func(_t(t + self.eps, y[0]), y))
+        t, _, h = _time_pair(t, dt, y[0])
+        return tuple(_lincomb(None, [1.0], [f_], h) for f_ in func(_time_arg(t + self.eps, y[0]), y))
 
     @property
     def order(self):
@@ -25,9 +27,10 @@ class Midpoint(FixedGridODESolver):
 
     def step_func(self, func, t, dt, y):
         """fixed_grid.py:16-18."""
-        f0 = func(_t(t + self.eps, y[0]), y)
-        y_mid = tuple(_lincomb(y_, [0.5], [f_], dt) for y_, f_ in zip(y, f0))
-        return tuple(_lincomb(None, [1.0], [f_], dt) for f_ in func(_t(t + dt / 2, y[0]), y_mid))
+        t, dt, h = _time_pair(t, dt, y[0])
+        f0 = func(_time_arg(t + self.eps, y[0]), y)
+        y_mid = tuple(_lincomb(y_, [0.5], [f_], h) for y_, f_ in zip(y, f0))
+        return tuple(_lincomb(None, [1.0], [f_], h) for f_ in func(_time_arg(t + _div(dt, 2), y[0]), y_mid))
 
     @property
     def order(self):
@@ -38,10 +41,11 @@ class Heun(FixedGridODESolver):
 
     def step_func(self, func, t, dt, y):
         """fixed_grid.py:28-32."""
-        f_outs = func(_t(t + self.eps, y[0]), y)
-        ft_1_hat = tuple(_lincomb(y_, [1.0], [f_], dt) for y_, f_ in zip(y, f_outs))
-        ft_1_outs = func(_t(t + dt, y[0]), ft_1_hat)
-        return tuple(_lincomb(None, [1.0, 1.0], [a, b], dt / 2.) for a, b in zip(f_outs, ft_1_outs))
+        t, dt, h = _time_pair(t, dt, y[0])
+        f_outs = func(_time_arg(t + self.eps, y[0]), y)
+        ft_1_hat = tuple(_lincomb(y_, [1.0], [f_], h) for y_, f_ in zip(y, f_outs))
+        ft_1_outs = func(_time_arg(t + dt, y[0]), ft_1_hat)
+        return tuple(_lincomb(None, [1.0, 1.0], [a, b], _div(h, 2.)) for a, b in zip(f_outs, ft_1_outs))
 
     @property
     def order(self):
@@ -55,6 +59,8 @@ class RK4(FixedGridODESolver):
 
     def step_func(self, func, t, dt, y):
         """fixed_grid.py:41-42."""
+        if isinstance(dt, torch.Tensor):
+            return rk4_alt_step_func(func, t + self.eps if self.eps else t, dt, y)
         dt_ = _np_dtype(y[0].dtype).type
         return rk4_alt_step_func(func, dt_(t) + dt_(self.eps), dt, y)
 

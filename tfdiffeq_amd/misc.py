@@ -79,7 +79,8 @@ def _possibly_nonzero(x):
 # plane kernels
 # ---------------------------------------------------------------------------------------------
 def _lincomb(base, coefs, xs, scale):
-    """out = base + add_n([(scale * c_j) * x_j])  on device (mi_ode_lincomb)."""
+    """out = base + add_n([(scale * c_j) * x_j])  on device (mi_ode_lincomb).  `scale` is a host scalar, or a 0-d float64
+    device tensor that the kernel reads when it runs (mi_ode_lincomb_dev: graph replays with a new dt)."""
     xs = [_contig(x) for x in xs]
     x0 = xs[0]
     N.require_gpu_tensor(x0, 'state')
@@ -94,6 +95,11 @@ def _lincomb(base, coefs, xs, scale):
     cf = (C.c_double * nx)(*[float(c) for c in coefs])
     base_c = _contig(base) if base is not None else None
     lib = N.load()
+    if isinstance(scale, torch.Tensor):
+        assert scale.dtype == torch.float64 and scale.numel() == 1 and scale.device == x0.device
+        N.check(lib.mi_ode_lincomb_dev(N.dtype_code(x0.dtype), n, _ptr(base_c), ptrs, cf, nx, C.c_void_p(scale.data_ptr()),
+                                       _ptr(out), N.stream_ptr(x0.device)), 'mi_ode_lincomb_dev')
+        return out
     N.check(lib.mi_ode_lincomb(N.dtype_code(x0.dtype), n, _ptr(base_c), ptrs, cf, nx, float(scale), _ptr(out),
                                N.stream_ptr(x0.device)), 'mi_ode_lincomb')
     return out
@@ -211,14 +217,15 @@ def _ratio_from_norms(norms, n_total, rtol, atol, np_dtype):
         return dt(norms[2] / (float(n_total) * float(tol) * float(tol)))
 
 
-def _compute_error_ratio(error_estimate, error_tol=None, rtol=None, atol=None, y0=None, y1=None, exchange=None):
+def _compute_error_ratio(error_estimate, error_tol=None, rtol=None, atol=None, y0=None, y1=None, exchange=None, recs=None):
     """misc.py:250-264.  Returns a tuple of host scalars (state dtype), one per tuple component; the
     reductions run on device and come back in ONE host synchronisation."""
     assert error_tol is None, 'explicit error_tol is not supported'
     assert rtol is not None and atol is not None and y0 is not None and y1 is not None
     rtol = rtol if _is_iterable(rtol) else [rtol] * len(y0)
     atol = atol if _is_iterable(atol) else [atol] * len(y0)
-    recs = torch.stack([_error_norms(e, a, b) for e, a, b in zip(error_estimate, y0, y1)])     # [ncomp, 4]
+    if recs is None:                            # (a captured graph of the attempt has produced them already)
+        recs = torch.stack([_error_norms(e, a, b) for e, a, b in zip(error_estimate, y0, y1)])     # [ncomp, 4]
     counts = torch.tensor([[float(e.numel())] for e in error_estimate], dtype=torch.float64, device=recs.device)
     recs = torch.cat([recs, counts], dim=1)                                                    # + local N
     if exchange is not None:

@@ -7,6 +7,8 @@ The fully fused engine (device RHS inside the stage kernels) lives behind `solve
 """
 import collections
 
+import torch
+
 from .misc import _lincomb, _np_dtype, _scalar_tensor
 
 _ButcherTableau = collections.namedtuple('_ButcherTableau', 'alpha beta c_sol c_error')     # rk_common.py:5
@@ -23,17 +25,27 @@ def _is_fsal_shaped(tableau):
 
 
 def _runge_kutta_step(func, y0, f0, t0, dt, tableau):
-    """Take an arbitrary Runge-Kutta step and estimate error (rk_common.py:22-61)."""
+    """Take an arbitrary Runge-Kutta step and estimate error (rk_common.py:22-61).
+
+    t0 / dt are host scalars, or 0-d float64 DEVICE tensors: then nothing of the step depends on host values and the
+    whole step can be captured in a hipGraph and replayed with new t0 / dt (graph_step.py)."""
     like = y0[0]
-    dt_ = _np_dtype(like.dtype).type
-    t0 = dt_(t0)                                                   # :45
-    dt = dt_(dt)                                                   # :46
+    on_device = isinstance(dt, torch.Tensor)
+    if on_device:
+        t0_s, dt_s = t0.to(like.dtype), dt.to(like.dtype)          # :45-46 (casts to the state dtype, on device)
+    else:
+        dt_ = _np_dtype(like.dtype).type
+        t0 = dt_(t0)                                               # :45
+        dt = dt_(dt)                                               # :46
     k = tuple([f0_] for f0_ in f0)
     yi = None
     for alpha_i, beta_i in zip(tableau.alpha, tableau.beta):
-        ti = t0 + dt_(alpha_i) * dt                                # :50
+        if on_device:
+            ti = t0_s + float(alpha_i) * dt_s                      # :50, a 0-d tensor of the state dtype
+        else:
+            ti = _scalar_tensor(t0 + dt_(alpha_i) * dt, like)      # :50
         yi = tuple(_lincomb(y0_, beta_i, k_, dt) for y0_, k_ in zip(y0, k))    # :51 (one kernel per component)
-        for k_, f_ in zip(k, func(_scalar_tensor(ti, like), yi)):
+        for k_, f_ in zip(k, func(ti, yi)):
             k_.append(f_)
     if not _is_fsal_shaped(tableau):                               # :54-56
         yi = tuple(_lincomb(y0_, tableau.c_sol, k_, dt) for y0_, k_ in zip(y0, k))
@@ -43,30 +55,51 @@ def _runge_kutta_step(func, y0, f0, t0, dt, tableau):
     return (y1, f1, y1_error, k)
 
 
+def _time_pair(t, dt, like):
+    """(t, dt) in the state dtype for the stage times, plus dt as the plane kernels take it: host scalars stay host
+    scalars; 0-d float64 DEVICE tensors (graph capture) stay on the device."""
+    if isinstance(dt, torch.Tensor):
+        t = t if isinstance(t, torch.Tensor) else torch.full((), float(t), dtype=torch.float64, device=dt.device)
+        return t.to(like.dtype), dt.to(like.dtype), dt
+    dt_ = _np_dtype(like.dtype).type
+    return dt_(t), dt_(dt), dt_(dt)
+
+
+def _div(x, c):
+    """x / c with a true IEEE division also for device scalars (torch multiplies a tensor by 1/c when c is a Python
+    number, which is one ulp off for c = 3, 6)."""
+    if isinstance(x, torch.Tensor):
+        return torch.div(x, torch.full((), float(c), dtype=x.dtype, device=x.device))
+    return x / c
+
+
+def _time_arg(value, like):
+    """What func receives as t: a 0-d device tensor in the state dtype."""
+    return value if isinstance(value, torch.Tensor) else _scalar_tensor(value, like)
+
+
 def rk4_step_func(func, t, dt, y, k1=None):
     """Classical RK4 (rk_common.py:64-70; not used by the 'rk4' method, which is the 3/8 rule)."""
     like = y[0]
-    dt_ = _np_dtype(like.dtype).type
-    t, dt = dt_(t), dt_(dt)
+    t, dt, h = _time_pair(t, dt, like)
     if k1 is None:
-        k1 = func(_scalar_tensor(t, like), y)
-    k2 = func(_scalar_tensor(t + dt / 2, like), tuple(_lincomb(y_, [0.5], [k1_], dt) for y_, k1_ in zip(y, k1)))
-    k3 = func(_scalar_tensor(t + dt / 2, like), tuple(_lincomb(y_, [0.5], [k2_], dt) for y_, k2_ in zip(y, k2)))
-    k4 = func(_scalar_tensor(t + dt, like), tuple(_lincomb(y_, [1.0], [k3_], dt) for y_, k3_ in zip(y, k3)))
-    return tuple(_lincomb(None, [1.0, 2.0, 2.0, 1.0], [a, b, c, d], dt / 6) for a, b, c, d in zip(k1, k2, k3, k4))
+        k1 = func(_time_arg(t, like), y)
+    k2 = func(_time_arg(t + _div(dt, 2), like), tuple(_lincomb(y_, [0.5], [k1_], h) for y_, k1_ in zip(y, k1)))
+    k3 = func(_time_arg(t + _div(dt, 2), like), tuple(_lincomb(y_, [0.5], [k2_], h) for y_, k2_ in zip(y, k2)))
+    k4 = func(_time_arg(t + dt, like), tuple(_lincomb(y_, [1.0], [k3_], h) for y_, k3_ in zip(y, k3)))
+    return tuple(_lincomb(None, [1.0, 2.0, 2.0, 1.0], [a, b, c, d], _div(h, 6)) for a, b, c, d in zip(k1, k2, k3, k4))
 
 
 def rk4_alt_step_func(func, t, dt, y, k1=None):
     """3/8-rule RK4, "smaller error with slightly more compute" (rk_common.py:73-81).  Returns dy."""
     like = y[0]
-    dt_ = _np_dtype(like.dtype).type
-    t, dt = dt_(t), dt_(dt)
+    t, dt, h = _time_pair(t, dt, like)
     if k1 is None:
-        k1 = func(_scalar_tensor(t, like), y)
-    k2 = func(_scalar_tensor(t + dt / 3, like),
-              tuple(_lincomb(y_, [1. / 3.], [k1_], dt) for y_, k1_ in zip(y, k1)))
-    k3 = func(_scalar_tensor(t + dt * 2 / 3, like),
-              tuple(_lincomb(y_, [-1. / 3., 1.0], [k1_, k2_], dt) for y_, k1_, k2_ in zip(y, k1, k2)))
-    k4 = func(_scalar_tensor(t + dt, like),
-              tuple(_lincomb(y_, [1.0, -1.0, 1.0], [k1_, k2_, k3_], dt) for y_, k1_, k2_, k3_ in zip(y, k1, k2, k3)))
-    return tuple(_lincomb(None, [1.0, 3.0, 3.0, 1.0], [a, b, c, d], dt / 8) for a, b, c, d in zip(k1, k2, k3, k4))
+        k1 = func(_time_arg(t, like), y)
+    k2 = func(_time_arg(t + _div(dt, 3), like),
+              tuple(_lincomb(y_, [1. / 3.], [k1_], h) for y_, k1_ in zip(y, k1)))
+    k3 = func(_time_arg(t + _div(dt * 2, 3), like),
+              tuple(_lincomb(y_, [-1. / 3., 1.0], [k1_, k2_], h) for y_, k1_, k2_ in zip(y, k1, k2)))
+    k4 = func(_time_arg(t + dt, like),
+              tuple(_lincomb(y_, [1.0, -1.0, 1.0], [k1_, k2_, k3_], h) for y_, k1_, k2_, k3_ in zip(y, k1, k2, k3)))
+    return tuple(_lincomb(None, [1.0, 3.0, 3.0, 1.0], [a, b, c, d], _div(h, 8)) for a, b, c, d in zip(k1, k2, k3, k4))

@@ -283,6 +283,7 @@ class FixedGridODESolver(object):
         unused_kwargs.pop('atol', None)
         self._pg = unused_kwargs.pop('process_group', None)     # accepted for symmetry; fixed grid needs no exchange
         self._fusion = unused_kwargs.pop('fusion', 0)
+        self._graph = bool(unused_kwargs.pop('graph', False))    # plane path: one captured step, replayed per grid interval
         _handle_unused_kwargs(self, unused_kwargs)
         del unused_kwargs
         self.func = func
@@ -337,6 +338,21 @@ class FixedGridODESolver(object):
         assert bool(time_grid[0] == t[0]) and bool(time_grid[-1] == t[-1])
         for y_ in self.y0:
             N.require_gpu_tensor(y_, 'y0')
+        if self._graph and getattr(self, '_default_grid', False) and t.shape[0] > 1:
+            # one captured step, replayed per grid interval with no host synchronisation in the loop (graph_step.py).
+            # dt is formed in the state dtype on the host exactly like below (the values are exact in float64).
+            from .graph_step import GraphedFixedStep
+            g = GraphedFixedStep(self, self.y0)
+            tt = t.numpy()
+            grid64 = tt.astype(np.float64)
+            dts = (tt[1:] - tt[:-1]).astype(np.float64)       # t1 - t0 in the state dtype (solvers.py:94)
+            outs = tuple(torch.empty((t.shape[0],) + tuple(y.shape), dtype=y.dtype, device=y.device) for y in self.y0)
+            for out, y in zip(outs, self.y0):
+                out[0].copy_(y)
+            g.integrate_pairs(grid64[:-1], dts, outs)
+            self.stats = {'engine': 'plane kernels, one hipGraph replay per step', 'n_attempts': int(t.shape[0] - 1),
+                          'n_accepted': int(t.shape[0] - 1), 'status': 0}
+            return outs
         solution = [self.y0]
         j = 1
         y0 = self.y0
@@ -380,6 +396,8 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         self._chunk_attempts = unused_kwargs.pop('chunk_attempts', 0)
         self._force_planes = unused_kwargs.pop('force_plane_kernels', False)
         self._profile = unused_kwargs.pop('profile', False)
+        self._graph = bool(unused_kwargs.pop('graph', False))      # plane path: replay one hipGraph per attempt (graph_step.py)
+        self._graph_attempt = None
         self._fusion = unused_kwargs.pop('fusion', 0)
         _handle_unused_kwargs(self, unused_kwargs)
         self.func = func
@@ -490,13 +508,23 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         y0, f0, _, t0, dt, interp_coeff = rk_state
         dt = np.float64(dt)
         assert t0 + dt > t0, 'underflow in dt {}'.format(dt)
-        y1, f1, y1_error, k = _runge_kutta_step(self.func, y0, f0, t0, dt, tableau=self.tableau)
+        recs = None
+        if self._graph and self._exchange is None:
+            # the whole attempt (S evaluations of f, stage arithmetic, error norms) is one hipGraph replay (graph_step.py)
+            g = self._graph_attempt
+            if g is None or not g.matches(y0):
+                from .graph_step import GraphedAttempt
+                g = self._graph_attempt = GraphedAttempt(self.func, y0, f0, self.tableau)
+            y0, y1, f1, y1_error, k, recs = g.run(y0, f0, t0, dt)
+        else:
+            y1, f1, y1_error, k = _runge_kutta_step(self.func, y0, f0, t0, dt, tableau=self.tableau)
         if self.pooled_ratio:
-            ratios = self._pooled_ratio(y1_error, y0, y1)
+            ratios = self._pooled_ratio(y1_error, y0, y1, recs=recs)
             accept_step = bool(ratios[0] <= 1.)
             dt_next = self._tsit5_step_size(dt, ratios[0])
         else:
-            ratios = _compute_error_ratio(y1_error, atol=self.atol, rtol=self.rtol, y0=y0, y1=y1, exchange=self._exchange)
+            ratios = _compute_error_ratio(y1_error, atol=self.atol, rtol=self.rtol, y0=y0, y1=y1, exchange=self._exchange,
+                                          recs=recs)
             accept_step = bool(np.all(np.asarray([float(r) for r in ratios]) <= 1))
             dt_next = _optimal_step_size(dt, ratios, safety=self.safety, ifactor=self.ifactor, dfactor=self.dfactor,
                                          order=self.order)
@@ -504,13 +532,18 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         self._n_attempts += 1
         if accept_step:
             self._n_accepted += 1
+            if recs is not None:
+                self._graph_attempt.accepted(y1, f1)
             return _RungeKuttaState(y1, f1, t0, t0 + dt, dt_next, (y0, y1, k, dt))
+        if recs is not None:
+            f0 = self._graph_attempt.f0
         return _RungeKuttaState(y0, f0, t0, t0, dt_next, interp_coeff)
 
-    def _pooled_ratio(self, y1_error, y0, y1):
+    def _pooled_ratio(self, y1_error, y0, y1, recs=None):
         """tsit5.py:126-138: scalar rtol/atol, one mean over ALL components."""
         from .misc import _error_norms
-        recs = torch.stack([_error_norms(e, a, b) for e, a, b in zip(y1_error, y0, y1)])
+        if recs is None:
+            recs = torch.stack([_error_norms(e, a, b) for e, a, b in zip(y1_error, y0, y1)])
         counts = torch.tensor([[float(e.numel())] for e in y1_error], dtype=torch.float64, device=recs.device)
         recs = torch.cat([recs, counts], dim=1)
         if self._exchange is not None:
