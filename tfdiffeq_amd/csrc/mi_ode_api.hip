@@ -393,6 +393,10 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     if (desc->fusion == 4 && !can) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local or MFMA-linear RHS, single rank, every workgroup co-resident)"); delete h; return MI_ODE_E_INVALID; }
     h->persist = (can && (desc->fusion == 4 || desc->fusion == 0)) ? 1 : 0;
     h->persist_grid = (int)g;
+    h->persist_sleep_first = g <= 32 ? 16 : 32;
+    h->persist_sleep_poll = 2;
+    if (const char* e0 = getenv("MI_ODE_PERSIST_SLEEP0")) h->persist_sleep_first = atoi(e0);      // tuning sweeps (scripts/gpu_persist_sweep.sh)
+    if (const char* e1 = getenv("MI_ODE_PERSIST_SLEEP1")) h->persist_sleep_poll = atoi(e1);
   }
   // controller / dense-output parameters
   h->cp.rtol = desc->rtol; h->cp.atol = desc->atol;
@@ -636,9 +640,7 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   A.spin_limit = 1 << 21;
   // back-off before the first poll (units of 64 clocks): a failed poll round costs G x G record loads on the fabric, so
   // wait about as long as the publish needs to become visible (measured: G=16 best at <= 24, G=256 best at 32)
-  A.sleep_first = h->persist_grid <= 32 ? 16 : 32; A.sleep_poll = 2;
-  if (const char* e0 = getenv("MI_ODE_PERSIST_SLEEP0")) A.sleep_first = atoi(e0);
-  if (const char* e1 = getenv("MI_ODE_PERSIST_SLEEP1")) A.sleep_poll = atoi(e1);
+  A.sleep_first = h->persist_sleep_first; A.sleep_poll = h->persist_sleep_poll;
   const bool prof = h->d.profile && h->ev_ready;
   if (prof) (void)hipEventRecord(h->ev_a[0], st);
   if (h->family == FAM_MLP) rc = mi_launch_persist_mlp_f32(h, A, h->persist_grid, st);

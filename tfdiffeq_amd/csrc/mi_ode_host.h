@@ -64,6 +64,7 @@ struct mi_ode_solver {
   int step_grid, step_block;
   int persist;                // 1: whole integration in one launch (mi_ode_persist.h)
   int persist_grid;
+  int persist_sleep_first, persist_sleep_poll;   // hand-off back-off (units of 64 clocks)
   int init_tiles16;           // 1: before_integrate runs on the 16-row tile kernels (k_init_linear_mfma), grid = step_grid
   double stamp_base;          // hand-off stamps already used on this handle's record buffer
   int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)

@@ -71,6 +71,8 @@ __device__ __forceinline__ const double* persist_stage_tout(const PersistArgs& A
   return A.s.t_out;
 }
 
+static_assert(sizeof(Ctl) % sizeof(long long) == 0, "Ctl is copied to the host in 8-byte words");
+
 __device__ __forceinline__ void persist_write_back(const PersistArgs& A, const Ctl& c) {
   *A.s.ctl = c;                                               // device copy (mi_ode_get_state / get_stats)
   if (A.ctl_host != nullptr) {
