@@ -181,7 +181,7 @@ def main():
         bytes_attempt = 34 * n_elem_rank * 8                # 34 planes per Dopri5 attempt (per-stage structure)
         cfg = {'workload': 'config 4: linear f=Ay, dim 128, batch %d per GPU (global %d), Dopri5 fp64, '
                            'rtol 1e-6 atol 1e-9, t=[0,1], one odeint call per step' % (args.batch, args.batch * n_gpus),
-               'parallelism': 'batch-sharded x%d, one 8-double all-gather per attempt' % n_gpus,
+               'parallelism': 'batch-sharded x%d; per-attempt record exchange: %s' % (n_gpus, stats.get('cross_rank', '?')),
                'fusion': 'step (whole attempt in one kernel)' if step_fused else 'stage (one kernel per RK stage)',
                'attempts_per_step': attempts, 'accepted': int(stats.get('n_accepted', 0)),
                'nfe': int(stats.get('nfe', 0)), 'host_polls': int(stats.get('n_polls', 0)),

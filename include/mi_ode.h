@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI_ODE_ABI_VERSION 2
+#define MI_ODE_ABI_VERSION 3
 #define MI_ODE_MAX_STAGES 6          /* rows of the tableau (dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -144,6 +144,13 @@ typedef struct mi_ode_desc {
                                  4 whole integration in ONE launch (tiny row-local systems, single rank; auto picks it
                                  when every workgroup can be co-resident; mi_ode_integrate only) */
   int32_t reserved;
+  /* Optional cross-rank hand-off memory for the whole-call kernels (world_size > 1): a HOST memory segment shared by
+   * all ranks of the node (e.g. a /dev/shm mapping), at least mi_ode_xrank_bytes(world_size) bytes, zero-filled before the
+   * first use.  The handle registers it with HIP; its kernels then exchange their per-attempt records through it
+   * (system-scope stores / loads over PCIe or xGMI, no host involvement, no collective launch), so a sharded run keeps
+   * the one-launch-per-call schedule.  The allgather hook stays the fallback (mi_ode_xrank_enable). */
+  void* xrank_host;
+  int64_t xrank_bytes;
 } mi_ode_desc;
 
 typedef struct mi_ode_stats {
@@ -194,6 +201,14 @@ int mi_ode_get_stats(mi_ode_handle h, mi_ode_stats* stats, void* stream);
 int mi_ode_get_profile(mi_ode_handle h, double* out4);
 /* current rk_state: y1, f1 (device, nullable). */
 int mi_ode_get_state(mi_ode_handle h, void* y_dev, void* f_dev, void* stream);
+
+/* Cross-rank hand-off (mi_ode_desc.xrank_host).  mi_ode_xrank_selftest: every rank of the group calls it at the same
+ * point; a few hand-off rounds run through the shared segment with a bounded wait; returns 0 when this rank saw every
+ * peer's records intact.  The caller combines the verdicts (e.g. all-reduce MIN) and calls mi_ode_xrank_enable(h, 1) on
+ * every rank only if all passed; otherwise the allgather hook keeps being used. */
+int64_t mi_ode_xrank_bytes(int32_t world_size);
+int mi_ode_xrank_selftest(mi_ode_handle h, void* stream);
+int mi_ode_xrank_enable(mi_ode_handle h, int32_t on);
 
 /* ---- (B) stateless plane kernels (arbitrary Python f, tuple states) ------------------------- */
 /* out[i] = (base ? base[i] : 0) + sum_j (scale * coef[j]) * xs[j][i]       (misc.py:118-121; zeros not skipped) */

@@ -491,15 +491,15 @@ y4 = torch.randn(8192, 128, generator=torch.Generator().manual_seed(3), dtype=to
 c = odeint(rhs.Linear.from_matrix(A), y4, torch.tensor([0., 1.]), rtol=1e-6, atol=1e-9, method='dopri5')
 d = odeint(rhs.Linear.from_matrix(A), y4, torch.tensor([0., 1.]), rtol=1e-6, atol=1e-9, method='dopri5',
            options={'process_group': dist.group.WORLD})
+sd = dict(odeint.last_stats)
 print(json.dumps({'diff': float((a - b).abs().max()), 'att_a': sa['n_attempts'], 'att_b': sb['n_attempts'],
-                  'launch_a': sa['n_launches'], 'launch_b': sb['n_launches'], 'diff4': float((c - d).abs().max())}))
+                  'launch_a': sa['n_launches'], 'launch_b': sb['n_launches'], 'diff4': float((c - d).abs().max()),
+                  'launch_d': sd['n_launches']}))
 dist.destroy_process_group()
 """
 
 
-def test_exchange_hook_path_on_one_gpu():
-    """The N > 1 control path (k_reduce_partials -> RCCL all-gather hook -> k_controller over rank records) with a
-    1-rank group must reproduce the hook-free path bit for bit."""
+def _run_hook_script(extra_env):
     import json
     import os
     import socket
@@ -510,14 +510,92 @@ def test_exchange_hook_path_on_one_gpu():
     port = s.getsockname()[1]
     s.close()
     env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
-               HSA_ENABLE_IPC_MODE_LEGACY='0')
+               HSA_ENABLE_IPC_MODE_LEGACY='0', **extra_env)
     res = subprocess.run([sys.executable, '-c', _HOOK_SCRIPT], env=env, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-3000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{"diff"')]
     assert lines, (res.stdout[-2000:], res.stderr[-2000:])
-    out = json.loads(lines[-1])
+    return json.loads(lines[-1])
+
+
+def test_exchange_hook_path_on_one_gpu():
+    """The N > 1 fallback control path (k_reduce_partials -> RCCL all-gather hook -> k_controller over rank records)
+    with a 1-rank group must reproduce the hook-free path bit for bit."""
+    out = _run_hook_script({'TFDIFFEQ_AMD_XRANK': '0'})
     assert out['diff'] == 0.0 and out['diff4'] == 0.0, out
     assert out['att_a'] == out['att_b'] and out['launch_b'] > out['launch_a'], out
+
+
+def test_cross_rank_handoff_path_on_one_gpu():
+    """The N > 1 default: whole-call kernels with the cross-rank hand-off through a registered /dev/shm segment (self-test
+    + enable through the 1-rank group): one launch per call, same bits as the single-rank run."""
+    out = _run_hook_script({})
+    assert out['diff'] == 0.0 and out['diff4'] == 0.0, out
+    assert out['att_a'] == out['att_b'] and out['launch_b'] == 1 and out['launch_d'] == 1, out
+
+
+_TWO_RANK_SCRIPT = r"""
+import os, sys, json
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['REPO'])
+from tfdiffeq_amd import odeint, rhs
+rank, world = int(os.environ['RANK']), 2
+torch.cuda.set_device(0)                       # both ranks share the one GPU of the box: their kernels must run concurrently
+dist.init_process_group('gloo', rank=rank, world_size=world)
+rng = np.random.default_rng(1)
+full = np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((3000, 3))
+shard = full[:1700] if rank == 0 else full[1700:]          # uneven shards
+y0 = torch.tensor(shard, device='cuda:0')
+t = torch.tensor([0., 0.25, 0.5, 0.8])
+out = {}
+for method in ('dopri5', 'tsit5'):
+    b = odeint(rhs.Lorenz(), y0, t, rtol=1e-6, atol=1e-9, method=method, options={'process_group': dist.group.WORLD})
+    sb = dict(odeint.last_stats)
+    ref = odeint(rhs.Lorenz(), torch.tensor(full, device='cuda:0'), t, rtol=1e-6, atol=1e-9, method=method)
+    sr = dict(odeint.last_stats)
+    mine = ref[:, :1700] if rank == 0 else ref[:, 1700:]
+    out[method] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
+                   'launches': sb['n_launches'], 'status': sb['status']}
+print('RESULT' + json.dumps({'rank': rank, 'out': out}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_cross_rank_handoff_two_processes_share_the_gpu():
+    """Two ranks (two processes, gloo group, both on cuda:0) integrate uneven shards of one batch with the whole-call
+    kernel: every attempt's record crosses the processes through the shared host segment.  The global controller must
+    reproduce the single-rank step sequence of the whole batch (sums are folded in a different order: 1e-12)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
+                   REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY='0')
+        procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p_ in procs:
+        try:
+            so, se = p_.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p_.returncode == 0, se[-3000:]
+        line = [ln for ln in so.splitlines() if ln.startswith('RESULT')]
+        assert line, (so[-1500:], se[-1500:])
+        outs.append(json.loads(line[-1][6:]))
+    for o in outs:
+        for method, r_ in o['out'].items():
+            assert r_['status'] == 0 and r_['launches'] == 1, (o['rank'], method, r_)
+            assert r_['att'] == r_['att_ref'] and r_['diff'] < 1e-10, (o['rank'], method, r_)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH, RHS_PLUGIN = 1, 2, 3, 4, 5, 6
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
-ABI_VERSION = 2
+ABI_VERSION = 3
 ST_DT_UNDERFLOW, ST_NONFINITE, ST_MAX_STEPS, ST_BAD_T, ST_SYNC_TIMEOUT = 1, 2, 4, 8, 16
 
 
@@ -58,7 +58,8 @@ class Desc(C.Structure):
                 ('exchange_send_dev', C.c_void_p), ('exchange_recv_dev', C.c_void_p),
                 ('linear_variant', C.c_int32), ('chunk_attempts', C.c_int32),
                 ('reserved0', C.c_int32), ('profile', C.c_int32),
-                ('fusion', C.c_int32), ('reserved', C.c_int32)]
+                ('fusion', C.c_int32), ('reserved', C.c_int32),
+                ('xrank_host', C.c_void_p), ('xrank_bytes', C.c_int64)]
 
 
 class Stats(C.Structure):
@@ -88,6 +89,9 @@ _PROTOS = {
     'mi_ode_rk_step_fused': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p,
                                        C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
     'mi_ode_eval_rhs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),
+    'mi_ode_xrank_bytes': (C.c_int64, [C.c_int32]),
+    'mi_ode_xrank_selftest': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mi_ode_xrank_enable': (C.c_int, [C.c_void_p, C.c_int32]),
     'mi_ode_get_stats': (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     'mi_ode_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mi_ode_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

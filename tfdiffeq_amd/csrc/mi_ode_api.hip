@@ -303,6 +303,8 @@ static void fill_mlp_args(mi_ode_solver* h, MlpArgs& M) {
 }
 
 extern "C" int mi_ode_destroy(mi_ode_handle h) {
+  if (h != nullptr && h->xrank_registered) { (void)hipHostUnregister(h->d.xrank_host); h->xrank_registered = 0; }
+  if (h != nullptr && h->gbuf) { (void)hipFree(h->gbuf); h->gbuf = nullptr; }
   if (h == nullptr) return 0;
   if (h->planes) (void)hipFree(h->planes);
   if (h->partials) (void)hipFree(h->partials);
@@ -385,7 +387,23 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     const bool mlp = h->family == FAM_MLP;
     h->init_tiles16 = mfma ? 1 : 0;
     const long long g = (mfma || mlp) ? (long long)h->step_grid : (desc->batch + 255) / 256;
-    bool can = desc->adaptive && (rowlocal || mfma || mlp) && h->d.world_size <= 1 && desc->allgather == nullptr && g <= kPersistMaxGrid;
+    const bool single = h->d.world_size <= 1 && desc->allgather == nullptr;
+    if (desc->xrank_host != nullptr) {           // cross-rank hand-off segment: make it visible to this GPU
+      if (h->d.world_size > kXMaxWorld || desc->xrank_bytes < mi_ode_xrank_bytes(h->d.world_size)) {
+        mi_set_error("xrank_host: world_size <= %d and at least %lld bytes are needed", kXMaxWorld, (long long)mi_ode_xrank_bytes(h->d.world_size));
+        delete h; return MI_ODE_E_INVALID;
+      }
+      void* dptr = nullptr;
+      hipError_t re = hipHostRegister(desc->xrank_host, (size_t)desc->xrank_bytes, hipHostRegisterMapped | hipHostRegisterPortable);
+      if (re == hipSuccess) { h->xrank_registered = 1; re = hipHostGetDevicePointer(&dptr, desc->xrank_host, 0); }
+      if (re != hipSuccess) {
+        (void)hipGetLastError();
+        if (h->xrank_registered) { (void)hipHostUnregister(desc->xrank_host); h->xrank_registered = 0; }
+        dptr = nullptr;                            // not fatal: the allgather hook path remains
+      }
+      h->xrank_dev = (double*)dptr;
+    }
+    bool can = desc->adaptive && (rowlocal || mfma || mlp) && (single || h->xrank_dev != nullptr) && g <= kPersistMaxGrid;
     if (can) {
       const int cap = mlp ? mi_persist_capacity_mlp_f32(h) : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
       can = cap > 0 && g <= cap;
@@ -427,6 +445,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     if (e == hipSuccess) e = hipMalloc((void**)&h->gathered, (size_t)h->d.world_size * kRec * sizeof(double));
   }
   if (e == hipSuccess) e = hipMalloc((void**)&h->ctl, sizeof(Ctl));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->gbuf, 2 * kPRec * sizeof(double));
+  if (e == hipSuccess) e = hipMemset(h->gbuf, 0, 2 * kPRec * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&h->ticket, 64);
   if (e == hipSuccess) e = hipMemset(h->ticket, 0, 64);
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->ctl_host, sizeof(Ctl), hipHostMallocDefault);
@@ -637,6 +657,8 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   A.first_dt = h->cp.auto_first_step ? 0.0 : h->d.first_step;
   for (int i = 0; i < n_out && i < kPersistTSmall; ++i) A.t_small[i] = t_host[1 + i];
   A.stamp_base = h->stamp_base;
+  if (h->xrank_on) { A.xrank = h->xrank_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank; A.xseq_base = h->xseq; }
+  else { A.world = 1; }
   A.spin_limit = 1 << 21;
   // back-off before the first poll (units of 64 clocks): a failed poll round costs G x G record loads on the fabric, so
   // wait about as long as the publish needs to become visible (measured: G=16 best at <= 24, G=256 best at 32)
@@ -668,6 +690,8 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   }
 #endif
   h->stamp_base += (double)h->ctl_host->n_attempt + 16.0;      // hand-offs of this call: attempts + 2 (+ margin)
+  h->xseq += (unsigned)h->ctl_host->n_attempt + 16u;           // identical on every rank (the attempt count is global)
+  if (h->xseq >= 0xE0000000u) h->xseq = 0;                      // wrap below the self-test range; 0 + gen + 1 != stale values
   if (stats) fill_stats(h, stats);
   return (int)h->ctl_host->status;
 }
@@ -681,9 +705,10 @@ extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const doubl
       if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = MI_ODE_ST_BAD_T; }
       return MI_ODE_ST_BAD_T;                  // _assert_increasing (misc.py:158-159)
     }
-  if (h->persist && T > 1 && h->d.adaptive) {
+  const bool multi = h->d.world_size > 1 || h->d.allgather != nullptr;
+  if (h->persist && T > 1 && h->d.adaptive && (!multi || h->xrank_on)) {
     const int prc = integrate_persist(h, y0_dev, t_host, T, out_dev, stats, st);
-    if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4) return prc;
+    if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4 || multi) return prc;   // (a rank must not change schedule alone)
     h->persist = 0;        // the grid hand-off timed out (co-residency lost to another persistent kernel?): this
   }                        // handle goes back to one launch per attempt, starting with this call
   int rc = begin_impl(h, y0_dev, t_host[0], out_dev, stream);   // before_integrate runs even when T == 1 (solvers.py:31);
@@ -698,6 +723,37 @@ extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const doubl
   }
   if (stats) fill_stats(h, stats);
   return status;
+}
+
+extern "C" int64_t mi_ode_xrank_bytes(int32_t world_size) {
+  return (int64_t)2 * (world_size < 1 ? 1 : world_size) * kXRec * (int64_t)sizeof(double);
+}
+
+extern "C" int mi_ode_xrank_selftest(mi_ode_handle h, void* stream) {
+  if (h == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (h->xrank_dev == nullptr) { mi_set_error("no cross-rank segment registered"); return 1; }
+  hipStream_t st = (hipStream_t)stream;
+  PersistArgs A;
+  memset(&A, 0, sizeof(A));
+  A.xrank = h->xrank_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank;
+  A.spin_limit = 1 << 18;                       // ~ a second: peers arrive within the skew of the group's barrier
+  h->xrank_test_stamp += 64.0;
+  A.stamp_base = 1e15 + h->xrank_test_stamp;    // disjoint from the stamps of real calls
+  A.xseq_base = 0xF0000000u + (unsigned)h->xrank_test_stamp;
+  int* res_dev = (int*)h->ticket + 8;
+  MI_HIP(hipMemsetAsync(res_dev, 0, sizeof(int), st));
+  hipLaunchKernelGGL(k_xrank_selftest<0>, dim3(1), dim3(64), 0, st, A, 4, res_dev);
+  int res = 0;
+  MI_HIP(hipMemcpyAsync(&res, res_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+  MI_HIP(hipStreamSynchronize(st));
+  return res == 1 ? 0 : 1;
+}
+
+extern "C" int mi_ode_xrank_enable(mi_ode_handle h, int32_t on) {
+  if (h == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (on && h->xrank_dev == nullptr) { mi_set_error("no cross-rank segment registered"); return MI_ODE_E_INVALID; }
+  h->xrank_on = on ? 1 : 0;
+  return 0;
 }
 
 extern "C" int mi_ode_get_stats(mi_ode_handle h, mi_ode_stats* stats, void* stream) {

@@ -66,6 +66,12 @@ struct mi_ode_solver {
   int persist_grid;
   int persist_sleep_first, persist_sleep_poll;   // hand-off back-off (units of 64 clocks)
   int init_tiles16;           // 1: before_integrate runs on the 16-row tile kernels (k_init_linear_mfma), grid = step_grid
+  double* xrank_dev;          // device view of desc.xrank_host (registered), or null
+  double* gbuf;               // device: the global record WG 0 broadcasts after a cross-rank hand-off (2 parities)
+  int xrank_on;               // 1: multi-rank calls use the whole-call kernel with the cross-rank hand-off
+  int xrank_registered;
+  double xrank_test_stamp;    // self-test rounds use their own stamp / sequence ranges
+  unsigned xseq;              // cross-rank sequence numbers already used (identical on every rank)
   double stamp_base;          // hand-off stamps already used on this handle's record buffer
   int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)
   int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation

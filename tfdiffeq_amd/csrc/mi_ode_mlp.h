@@ -309,7 +309,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
   cp.t_out = persist_stage_tout(A, sh.tout);
   const double* t_out = cp.t_out;
   unsigned gen = 0;
-  double r[5], rec[kRec];
+  double r[5], rec[kRec], n_tot = 0.0;
   if (threadIdx.x == 0) { persist_init_ctl(s_c, A); sh.ok = 1; }
   __syncthreads();
 
@@ -325,8 +325,8 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
     P.y0 = y_user; P.f0 = nullptr; P.y1 = nullptr; P.f1 = fa; P.hs = 0.f; P.t0 = 0.f; P.j_lo = P.j_hi = 0;
     Acc acc;
     mlp_pass<DP, HP, MLP_F0, S, TS, true>(A.s, P, nullptr, A.out0, cx, acc, t_out);
-    ok = grid_reduce(A, acc, sh, gen++, r);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_F0, cp); }
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
     __syncthreads();
   }
   if (cp.auto_first_step && ok) {
@@ -334,8 +334,8 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
     P.y0 = y_user; P.f0 = fa; P.y1 = nullptr; P.f1 = nullptr; P.hs = (float)uniform_d(s_c.h0); P.t0 = 0.f; P.j_lo = P.j_hi = 0;
     Acc acc;
     mlp_pass<DP, HP, MLP_INITB, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
-    ok = grid_reduce(A, acc, sh, gen++, r);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_INITB, cp); }
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
   }
   auto publish = [&](const AttemptState& st) {                // thread 0: what the next attempt needs
     sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.accepted = st.accepted; sh.pub.done = st.done;
@@ -368,11 +368,11 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
     P.j_lo = uniform_i(sh.pub.emit_lo); P.j_hi = uniform_i(sh.pub.emit_hi);
     Acc acc;
     mlp_pass<DP, HP, MLP_STEP, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
-    ok = grid_reduce(A, acc, sh, gen++, r);
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
     if (threadIdx.x == 0) {
       AttemptState st = sh.st;
       if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
-      else { fill_record(rec, r, (double)cp.n_local); attempt_core(st, rec, cp); }
+      else { fill_record(rec, r, n_tot); attempt_core(st, rec, cp); }
       publish(st);
       sh.st = st;
     }

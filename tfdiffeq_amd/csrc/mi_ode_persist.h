@@ -42,6 +42,11 @@ struct PersistArgs {
   Ctl* ctl_host;               // pinned host copy of the final scalar state (zero-copy store: the host only synchronises)
   double t0, first_dt;         // scalar state at entry (the kernel builds its Ctl itself: no upload)
   double t_small[kPersistTSmall];   // the output times when n_out <= kPersistTSmall (else s.t_out, device)
+  // batch-sharded runs: records also cross ranks, through a registered host segment (null: single rank)
+  double* xrank;               // [2 parities][world][kXRec] doubles, host memory seen by every rank's GPU
+  double* gbuf;                // device, [2 parities][kPRec]: the global record, broadcast by workgroup 0
+  int world, rank;
+  unsigned xseq_base;          // sequence numbers of this call's cross-rank hand-offs are xseq_base + 1, + 2, ...
   double stamp_base;           // stamps of this call are stamp_base + 1, + 2, ... (above every earlier call's)
   int n_out;                   // T - 1
   int spin_limit;              // bound on the spin iterations of one hand-off
@@ -144,6 +149,9 @@ struct PersistPub {
   int accepted, emit_lo, emit_hi, done;
 };
 
+constexpr int kXRec = 16;                                       // 8-byte words per rank record in the host segment (12 used)
+constexpr int kXMaxWorld = 64;
+
 struct PersistShared {
   Ctl c;                                                      // prologue (before_integrate) and the final write-back
   PersistPub pub;
@@ -151,15 +159,100 @@ struct PersistShared {
   double red[80];
   double vals[5][kPersistMaxGrid];                            // every workgroup's record, staged for the fixed-order fold
   double tout[kPersistTout];                                  // the requested output times, when they fit
+  double xr[6][kXMaxWorld];                                   // cross-rank hand-off: every rank's record
   int ok;                                                     // 1 until a hand-off times out
 };
+
+// ---- cross-rank hand-off through host memory ------------------------------------------------------------------
+// Encoding (the "LL" idea of collective libraries): every 8-byte word carries 4 bytes of payload and a 4-byte
+// sequence number, and an aligned 8-byte store is single-copy atomic for every agent of the system.  A double travels as
+// two such words; a reader accepts a record when all of its words show the expected sequence number.  Nothing depends
+// on the ORDER in which PCIe / xGMI deliver the writes, and there is no fence.
+__device__ __forceinline__ void ll_store(unsigned long long* p, double v, unsigned seq) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+  __hip_atomic_store(p, (b & 0xffffffffull) | ((unsigned long long)seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __hip_atomic_store(p + 1, (b >> 32) | ((unsigned long long)seq << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// all 6 values of one rank record; false if some word does not carry `seq` yet
+__device__ __forceinline__ bool ll_load_record(const unsigned long long* p, unsigned seq, double (&v)[6]) {
+  unsigned long long w[12];
+#pragma unroll
+  for (int i = 0; i < 12; ++i) w[i] = __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 12; ++i) ok = ok && ((unsigned)(w[i] >> 32) == seq);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) v[i] = __longlong_as_double((long long)((w[2 * i] & 0xffffffffull) | (w[2 * i + 1] << 32)));
+  return ok;
+}
+
+// Cross-rank hand-off (batch-sharded runs).  On entry thread 0 of EVERY workgroup holds this rank's record r[0..4];
+// on exit it holds the record combined over all ranks (rank order, the fold of k_controller) and n_tot = sum of the
+// ranks' element counts.  Workgroup 0 is the gateway: it publishes the rank record in the host segment, lane q of its
+// first wavefront polls rank q's record, thread 0 folds and broadcasts the result through device memory as stamped
+// pairs that the other workgroups poll.  Bounded waits, as everywhere.
+__device__ __forceinline__ void cross_rank(const PersistArgs& A, PersistShared& sh, unsigned gen, double stamp, double (&r)[5],
+                                           double& n_tot, double n_local) {
+  const int W = A.world;
+  const unsigned seq = A.xseq_base + gen + 1u;                // never 0 (zero-filled memory), grows with every hand-off
+  double* g = A.gbuf + (long long)(gen & 1u) * kPRec;
+  if (blockIdx.x == 0) {
+    unsigned long long* seg = (unsigned long long*)A.xrank;
+    if (threadIdx.x == 0) {
+      unsigned long long* slot = seg + ((long long)(gen & 1u) * W + A.rank) * kXRec;
+#pragma unroll
+      for (int i = 0; i < 5; ++i) ll_store(slot + 2 * i, r[i], seq);
+      ll_store(slot + 10, n_local, seq);
+    }
+    if ((int)threadIdx.x < W) {
+      const unsigned long long* p = seg + ((long long)(gen & 1u) * W + threadIdx.x) * kXRec;
+      double v[6];
+      int spins = 0;
+      while (!ll_load_record(p, seq, v)) {
+        for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(1);
+        if (++spins > A.spin_limit) { sh.ok = 0; break; }
+      }
+#pragma unroll
+      for (int i = 0; i < 6; ++i) sh.xr[i][threadIdx.x] = v[i];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      double m0 = 0, m1 = 0, s0 = 0, s1 = 0, fl = 0, n = 0;
+      for (int q = 0; q < W; ++q) {                           // k_controller's fold over the gathered rank records
+        m0 = fmax(m0, sh.xr[0][q]); m1 = fmax(m1, sh.xr[1][q]); s0 += sh.xr[2][q]; s1 += sh.xr[3][q];
+        fl = fmax(fl, sh.xr[4][q]); n += sh.xr[5][q];
+      }
+      const double st = sh.ok ? stamp : -stamp - 1.0;         // a failed gateway tells everyone (they stop polling)
+      store_pair_sc1(g + 0, m0, st); store_pair_sc1(g + 2, m1, st); store_pair_sc1(g + 4, s0, st);
+      store_pair_sc1(g + 6, s1, st); store_pair_sc1(g + 8, fl, st); store_pair_sc1(g + 10, n, st);
+    }
+  }
+  if (threadIdx.x == 0) {
+    d2_t v[5];
+    int spins = 0;
+    const double bad = -stamp - 1.0;
+    for (;;) {
+      load_record_sc1(g, v);
+      if (v[0].y == bad) { sh.ok = 0; break; }
+      if (v[0].y == stamp && v[1].y == stamp && v[2].y == stamp && v[3].y == stamp && v[4].y == stamp) {
+        const double ns = rec_load<true>(g + 11), nv = rec_load<true>(g + 10);
+        if (ns == stamp) { n_tot = nv; break; }
+      }
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > A.spin_limit) { sh.ok = 0; break; }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r[i] = v[i].x;
+  }
+  __syncthreads();
+}
 
 // Block record -> (grid hand-off) -> combined record {max a, max b, sum a, sum b, flag} in THREAD 0's registers.
 // Returns false (to every thread) on a hand-off timeout.  `gen` counts hand-offs (uniform over the grid).  Thread i
 // polls record i (one round trip once the slowest workgroup has published), wavefront 0 folds in
 // reduce_block_records' fixed order.
-__device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc, PersistShared& sh, unsigned gen,
-                                            double (&r)[5]) {
+__device__ __forceinline__ bool grid_reduce_rank(const PersistArgs& A, const Acc& acc, PersistShared& sh, unsigned gen,
+                                                 double (&r)[5]) {
   const int G = (int)gridDim.x;
   block_reduce_thread0(acc, sh.red, r);
   if (G == 1) return true;                                    // one record: folding it with zeros is exact
@@ -197,6 +290,18 @@ __device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc
   return ok;
 }
 
+// ... and over all ranks when the run is batch-sharded.  n_tot (thread 0): elements behind the combined record.
+__device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc, PersistShared& sh, unsigned gen,
+                                            double (&r)[5], double& n_tot) {
+  bool ok = grid_reduce_rank(A, acc, sh, gen, r);
+  n_tot = (double)A.s.cp.n_local;
+  if (A.world > 1 || A.xrank != nullptr) {
+    if (ok) cross_rank(A, sh, gen, A.stamp_base + (double)(gen + 1u), r, n_tot, (double)A.s.cp.n_local);
+    ok = ok && sh.ok != 0;
+  }
+  return ok;
+}
+
 __device__ __forceinline__ void fill_record(double (&rec)[kRec], const double (&r)[5], double n) {
   rec[R_MAXA] = r[0]; rec[R_MAXB] = r[1]; rec[R_SUMA] = r[2]; rec[R_SUMB] = r[3]; rec[R_FLAG] = r[4];
   rec[R_N] = n; rec[6] = 0; rec[7] = 0;
@@ -217,7 +322,7 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = row < A.s.batch;
   unsigned gen = 0;
-  double r[5], rec[kRec];
+  double r[5], rec[kRec], n_tot = 0.0;
 
   if (threadIdx.x == 0) { persist_init_ctl(s_c, A); sh.ok = 1; }
   Row y;
@@ -256,8 +361,8 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
         acc.sumb += q1 * q1;                                  // misc.py:228
       }
     }
-    ok = grid_reduce(A, acc, sh, gen++, r);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_F0, cp); }
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
     __syncthreads();
   }
   if (cp.auto_first_step && ok) {                             // k_stage_rowlocal<M_INITB> (misc.py:235-245)
@@ -276,8 +381,8 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
         acc.suma += q * q;
       }
     }
-    ok = grid_reduce(A, acc, sh, gen++, r);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_INITB, cp); }
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
   }
   // thread 0 keeps the scalar state of the loop in registers from here on and publishes what the others need
   AttemptState st;
@@ -337,11 +442,11 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
       }
     }
     MI_TICK(tk1);
-    ok = grid_reduce(A, acc, sh, gen++, r);                   // (its barriers also fence the reads of sh.pub above)
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);                   // (its barriers also fence the reads of sh.pub above)
     MI_TICK(tk2);
     if (threadIdx.x == 0) {
       if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
-      else { fill_record(rec, r, (double)cp.n_local); attempt_core(st, rec, cp); }
+      else { fill_record(rec, r, n_tot); attempt_core(st, rec, cp); }
       sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.emit_t0 = st.emit_t0; sh.pub.emit_t1 = st.emit_t1;
       sh.pub.emit_dt = st.emit_dt; sh.pub.accepted = st.accepted; sh.pub.emit_lo = st.emit_lo;
       sh.pub.emit_hi = st.emit_hi; sh.pub.done = st.done;
@@ -402,7 +507,7 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
   cp.t_out = persist_stage_tout(A, sh.tout);
   const double* t_out = cp.t_out;
   unsigned gen = 0;
-  double r[5], rec[kRec];
+  double r[5], rec[kRec], n_tot = 0.0;
   if (threadIdx.x == 0) { persist_init_ctl(s_c, A); sh.ok = 1; }
   __syncthreads();
 
@@ -419,8 +524,8 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     lin_f0_pass<T, D, true>(A.s, y_user, fa, (T*)nullptr, (T*)A.out0, cx, acc);
     MI_TICK(tf1);
     MI_TOCK(0, tf0, tf1);
-    ok = grid_reduce(A, acc, sh, gen++, r);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_F0, cp); }
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
     __syncthreads();
   }
   if (cp.auto_first_step && ok) {
@@ -429,8 +534,8 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     lin_initb_pass<T, D, true>(A.s, y_user, fa, (T)uniform_d(s_c.h0), cx, acc);
     MI_TICK(ti1);
     MI_TOCK(1, ti0, ti1);
-    ok = grid_reduce(A, acc, sh, gen++, r);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, (double)cp.n_local); controller_apply(&s_c, rec, PH_INITB, cp); }
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
   }
   // The scalar state of the loop rests in LDS between attempts (thread 0 pulls it into registers only around
   // attempt_core): the tile passes need the whole register file.
@@ -467,13 +572,13 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     MI_TICK(ta0);
     lin_attempt_pass<T, D, S, TS, true>(A.s, P, cx, acc, t_out);
     MI_TICK(ta1);
-    ok = grid_reduce(A, acc, sh, gen++, r);                   // (its barriers also fence the reads of sh.pub above)
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);                   // (its barriers also fence the reads of sh.pub above)
     MI_TICK(ta2);
     MI_TOCK(2, ta0, ta1); MI_TOCK(3, ta1, ta2);
     if (threadIdx.x == 0) {
       AttemptState st = sh.st;
       if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
-      else { fill_record(rec, r, (double)cp.n_local); attempt_core(st, rec, cp); }
+      else { fill_record(rec, r, n_tot); attempt_core(st, rec, cp); }
       publish(st);
       sh.st = st;
     }
@@ -499,4 +604,31 @@ constexpr size_t persist_linear_lds_bytes() {
   return (size_t)16 * (D + MfmaTraits<T>::VEC) * sizeof(T);
 }
 
+// Self-test of the cross-rank hand-off: `rounds` exchanges of synthetic records through the host segment; *result = 1
+// when every round delivered every rank's values intact (one workgroup, launched by every rank at the same point).
+template <int UNUSED>          // (a template only so that every translation unit including this header may see it)
+__global__ __launch_bounds__(64) void k_xrank_selftest(PersistArgs A, int rounds, int* result) {
+  __shared__ PersistShared sh;
+  if (threadIdx.x == 0) sh.ok = 1;
+  __syncthreads();
+  bool good = true;
+  for (int round = 0; round < rounds; ++round) {
+    double r[5], n_tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) r[i] = (double)(A.rank * 10 + i + round);
+    cross_rank(A, sh, (unsigned)round, A.stamp_base + (double)(round + 1), r, n_tot, (double)(A.rank + 1));
+    if (threadIdx.x == 0) {
+      const int W = A.world;
+      double s0 = 0, s1 = 0, n = 0;
+      for (int q = 0; q < W; ++q) { s0 += (double)(q * 10 + 2 + round); s1 += (double)(q * 10 + 3 + round); n += (double)(q + 1); }
+      good = good && sh.ok && r[0] == (double)((W - 1) * 10 + round) && r[1] == (double)((W - 1) * 10 + 1 + round) && r[2] == s0 &&
+             r[3] == s1 && r[4] == (double)((W - 1) * 10 + 4 + round) && n_tot == n;
+    }
+    __syncthreads();
+    if (!sh.ok) break;
+  }
+  if (threadIdx.x == 0) *result = good ? 1 : 0;
+}
+
 }  // namespace mi
+

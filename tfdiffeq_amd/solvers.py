@@ -14,6 +14,7 @@ Two execution engines sit behind that contract:
 There is no CPU path: state tensors must live on the MI355X.
 """
 import abc
+import os
 import collections
 import ctypes as C
 import math
@@ -46,6 +47,42 @@ def _fill_tableau(tb_struct, tableau, c_mid):
     if c_mid is not None:
         for j, v in enumerate(c_mid):
             tb_struct.c_mid[j] = float(v)
+
+
+def _xrank_segment(group, nbytes):
+    """(mmap, address, size) of a zero-filled /dev/shm segment shared by the ranks of `group` on this node, or None.
+    Collective over the group (one broadcast, two barriers)."""
+    import mmap
+    import uuid
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    size = ((int(nbytes) + 4095) // 4096) * 4096
+    name = [None]
+    if rank == 0:
+        name[0] = 'mi_ode_xrank_%d_%s' % (os.getpid(), uuid.uuid4().hex[:12])
+    dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0), group=group)
+    path = os.path.join('/dev/shm', name[0])
+    seg = None
+    try:
+        if rank == 0:
+            fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
+            os.ftruncate(fd, size)                      # zero filled
+        dist.barrier(group=group)
+        if rank != 0:
+            fd = os.open(path, os.O_RDWR)               # FileNotFoundError on another node: no segment for this rank
+        mm = mmap.mmap(fd, size, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+        os.close(fd)
+        addr = C.addressof(C.c_char.from_buffer(mm))
+        seg = (mm, addr, size)
+    except OSError:
+        seg = None
+    dist.barrier(group=group)
+    if rank == 0:
+        try:
+            os.unlink(path)                             # the mappings keep it alive
+        except OSError:
+            pass
+    return seg
 
 
 class _FusedEngine(object):
@@ -101,12 +138,32 @@ class _FusedEngine(object):
                         return 1
                 self._hook = N.ALLGATHER_FN(hook)
                 d.allgather = self._hook
+        self._xr = None
+        if process_group is not None and os.environ.get('TFDIFFEQ_AMD_XRANK', '1') != '0' and adaptive:
+            # cross-rank hand-off memory for the whole-call kernels: one host segment shared by the ranks of this node
+            self._xr = _xrank_segment(process_group, int(self.lib.mi_ode_xrank_bytes(d.world_size)))
+            if self._xr is not None:
+                d.xrank_host, d.xrank_bytes = self._xr[1], self._xr[2]
         self.desc = d
         h = C.c_void_p()
         with torch.cuda.device(self.device):
             N.check(self.lib.mi_ode_create(C.byref(d), C.byref(h)), 'mi_ode_create')
         self.h = h
         self.stats = N.Stats()
+        self.xrank = False
+        if process_group is not None and os.environ.get('TFDIFFEQ_AMD_XRANK', '1') != '0' and adaptive:
+            # every rank tests the hand-off through the segment; it is used only if ALL ranks saw all peers (a rank on
+            # another node, or a failed registration, turns it off for everybody: the allgather hook then stays in charge)
+            import torch.distributed as dist
+            ok = 0
+            if self._xr is not None:
+                with torch.cuda.device(self.device):
+                    ok = 1 if self.lib.mi_ode_xrank_selftest(self.h, self._stream()) == 0 else 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+            if int(flag.item()) == 1:
+                N.check(self.lib.mi_ode_xrank_enable(self.h, 1), 'mi_ode_xrank_enable')
+                self.xrank = True
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -454,6 +511,8 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             out = eng.integrate(t.to(torch.float64).numpy(), self.y0[0])
         finally:
             self.stats = eng.stats.as_dict()
+            self.stats['cross_rank'] = ('in-kernel hand-off through a shared host segment' if eng.xrank else
+                                        ('allgather hook' if eng._hook is not None else 'single rank'))
             if self._profile:
                 self.stats['profile'] = [a - b for a, b in zip(eng.profile(), prof0)]
         return (out,)
