@@ -556,6 +556,35 @@ for method in ('dopri5', 'tsit5'):
     mine = ref[:, :1700] if rank == 0 else ref[:, 1700:]
     out[method] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
                    'launches': sb['n_launches'], 'status': sb['status']}
+# the MFMA tile kernel (linear RHS, dim 128) and the MLP kernel with the same cross-rank hand-off: small shards so that both
+# processes' persistent grids fit on the one GPU together
+g2 = torch.Generator().manual_seed(2)
+S = torch.randn(128, 128, generator=g2, dtype=torch.float64)
+A = -0.5 * torch.eye(128, dtype=torch.float64) + 0.5 * (S - S.t()) / np.sqrt(128)
+fullL = torch.randn(812, 128, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+yl = (fullL[:512] if rank == 0 else fullL[512:]).cuda()
+tl = torch.tensor([0., 0.4, 1.0])
+b = odeint(rhs.Linear.from_matrix(A), yl, tl, rtol=1e-6, atol=1e-9, method='dopri5', options={'process_group': dist.group.WORLD})
+sb = dict(odeint.last_stats)
+ref = odeint(rhs.Linear.from_matrix(A), fullL.cuda(), tl, rtol=1e-6, atol=1e-9, method='dopri5')
+sr = dict(odeint.last_stats)
+mine = ref[:, :512] if rank == 0 else ref[:, 512:]
+out['linear128'] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
+                    'launches': sb['n_launches'], 'status': sb['status']}
+gm = torch.Generator().manual_seed(4)
+def glorot(i, o):
+    lim = (6.0 / (i + o)) ** 0.5
+    return ((torch.rand(i, o, generator=gm) * 2 - 1) * lim).cuda()
+mlp = rhs.MLPTanh(glorot(64, 128), torch.zeros(128).cuda(), glorot(128, 128), torch.zeros(128).cuda(), glorot(128, 64), torch.zeros(64).cuda())
+fullM = torch.randn(700, 64, generator=torch.Generator().manual_seed(5))
+ym = (fullM[:400] if rank == 0 else fullM[400:]).cuda()
+b = odeint(mlp, ym, tl, rtol=1e-4, atol=1e-5, method='dopri5', options={'process_group': dist.group.WORLD})
+sb = dict(odeint.last_stats)
+ref = odeint(mlp, fullM.cuda(), tl, rtol=1e-4, atol=1e-5, method='dopri5')
+sr = dict(odeint.last_stats)
+mine = ref[:, :400] if rank == 0 else ref[:, 400:]
+out['mlp'] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
+              'launches': sb['n_launches'], 'status': sb['status']}
 print('RESULT' + json.dumps({'rank': rank, 'out': out}), flush=True)
 dist.barrier()
 dist.destroy_process_group()
@@ -595,7 +624,7 @@ def test_cross_rank_handoff_two_processes_share_the_gpu():
     for o in outs:
         for method, r_ in o['out'].items():
             assert r_['status'] == 0 and r_['launches'] == 1, (o['rank'], method, r_)
-            assert r_['att'] == r_['att_ref'] and r_['diff'] < 1e-10, (o['rank'], method, r_)
+            assert r_['att'] == r_['att_ref'] and r_['diff'] < (1e-4 if method == 'mlp' else 1e-10), (o['rank'], method, r_)
 
 
 # ---------------------------------------------------------------------------------------------

@@ -63,18 +63,24 @@ def _xrank_segment(group, nbytes):
     dist.broadcast_object_list(name, src=dist.get_global_rank(group, 0), group=group)
     path = os.path.join('/dev/shm', name[0])
     seg = None
-    try:
-        if rank == 0:
+    # every rank passes the same two barriers whatever fails locally (a failure only means "no segment for me"; the
+    # caller's all-reduce then switches the mechanism off for the whole group)
+    fd = -1
+    if rank == 0:
+        try:
             fd = os.open(path, os.O_CREAT | os.O_EXCL | os.O_RDWR, 0o600)
             os.ftruncate(fd, size)                      # zero filled
-        dist.barrier(group=group)
+        except OSError:
+            fd = -1
+    dist.barrier(group=group)
+    try:
         if rank != 0:
             fd = os.open(path, os.O_RDWR)               # FileNotFoundError on another node: no segment for this rank
-        mm = mmap.mmap(fd, size, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
-        os.close(fd)
-        addr = C.addressof(C.c_char.from_buffer(mm))
-        seg = (mm, addr, size)
-    except OSError:
+        if fd >= 0:
+            mm = mmap.mmap(fd, size, mmap.MAP_SHARED, mmap.PROT_READ | mmap.PROT_WRITE)
+            os.close(fd)
+            seg = (mm, C.addressof(C.c_char.from_buffer(mm)), size)
+    except (OSError, ValueError):
         seg = None
     dist.barrier(group=group)
     if rank == 0:
