@@ -736,7 +736,7 @@ extern "C" int mi_ode_xrank_selftest(mi_ode_handle h, void* stream) {
   PersistArgs A;
   memset(&A, 0, sizeof(A));
   A.xrank = h->xrank_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank;
-  A.spin_limit = 1 << 18;                       // ~ a second: peers arrive within the skew of the group's barrier
+  A.spin_limit = 1 << 20;                       // several seconds: covers module-load skew between the ranks
   h->xrank_test_stamp += 64.0;
   A.stamp_base = 1e15 + h->xrank_test_stamp;    // disjoint from the stamps of real calls
   A.xseq_base = 0xF0000000u + (unsigned)h->xrank_test_stamp;

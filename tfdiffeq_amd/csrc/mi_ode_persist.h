@@ -239,7 +239,7 @@ __device__ __forceinline__ void cross_rank(const PersistArgs& A, PersistShared& 
         if (ns == stamp) { n_tot = nv; break; }
       }
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > A.spin_limit) { sh.ok = 0; break; }
+      if (++spins > 8 * A.spin_limit) { sh.ok = 0; break; }    // (outlasts the gateway's own bounded wait: it reports failures)
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) r[i] = v[i].x;
