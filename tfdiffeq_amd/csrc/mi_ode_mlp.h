@@ -258,7 +258,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
 #pragma unroll
         for (int j = 0; j <= S; ++j) kk[j] = k[j][i];
         float err, ymid;
-        step_finish<float, S>(y0e[i], kk, hs, A, err, ymid);
+        step_finish<float, S>(y0e[i], kk, hs, A, err, ymid, !TS && P.j_hi > P.j_lo);
         const long long idx = row * d + col;
         P.y1[idx] = ys[i];
         P.f1[idx] = k[S][i];

@@ -427,14 +427,13 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
       stage(std::integral_constant<int, 6>{});
     }
     Acc acc;
-    T ymid[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
       T kk[S + 1];
 #pragma unroll
       for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
-      T err;
-      step_finish<T, S>(y.v[d], kk, hs, A.s, err, ymid[d]);
+      T err, unused_mid;
+      step_finish<T, S>(y.v[d], kk, hs, A.s, err, unused_mid, false);      // y_mid only if an output falls into the step (below)
       if (live) {
         acc.maxa = fmax(acc.maxa, (double)fabs(y.v[d]));
         acc.maxb = fmax(acc.maxb, (double)fabs(ys[d]));
@@ -464,7 +463,9 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
           T kk[S + 1];
 #pragma unroll
           for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
-          step_emit<T, S, TS>(A.s, P, y.v[d], ys[d], kk, ymid[d], row * D + d, t_out);
+          T err_unused, ymid = y.v[d];
+          if constexpr (!TS) step_finish<T, S>(y.v[d], kk, hs, A.s, err_unused, ymid, true);
+          step_emit<T, S, TS>(A.s, P, y.v[d], ys[d], kk, ymid, row * D + d, t_out);
         }
       }
 #pragma unroll

@@ -114,17 +114,21 @@ __device__ __forceinline__ T step_combine(T y0, const T* k, T hs, const StepArgs
   return y0 + acc;
 }
 
-// err (rk_common.py:60) and y_mid (dopri5.py:42) from all S+1 stage derivatives
+// err (rk_common.py:60) and y_mid (dopri5.py:42) from all S+1 stage derivatives.  y_mid only feeds the dense output:
+// `need_mid` (wave-uniform: an output time falls into this attempt) skips its 2(S+1) operations otherwise.
 template <typename T, int S>
-__device__ __forceinline__ void step_finish(T y0, const T* k, T hs, const StepArgs& A, T& err, T& ymid) {
+__device__ __forceinline__ void step_finish(T y0, const T* k, T hs, const StepArgs& A, T& err, T& ymid, bool need_mid = true) {
   T er = (hs * (T)A.e[0]) * k[0];
 #pragma unroll
   for (int j = 1; j <= S; ++j) er = er + (hs * (T)A.e[j]) * k[j];
   err = er;
-  T ym = (hs * (T)A.cmid[0]) * k[0];
+  ymid = y0;
+  if (need_mid) {
+    T ym = (hs * (T)A.cmid[0]) * k[0];
 #pragma unroll
-  for (int j = 1; j <= S; ++j) ym = ym + (hs * (T)A.cmid[j]) * k[j];
-  ymid = y0 + ym;
+    for (int j = 1; j <= S; ++j) ym = ym + (hs * (T)A.cmid[j]) * k[j];
+    ymid = y0 + ym;
+  }
 }
 
 // speculative dense output of one element for every requested time inside the attempt
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
 #pragma unroll
       for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
       T err, ymid;
-      step_finish<T, S>(y0.v[d], kk, hs, A, err, ymid);
+      step_finish<T, S>(y0.v[d], kk, hs, A, err, ymid, !TS && P.j_hi > P.j_lo);
       y1.v[d] = ys[d];                                       // FSAL: y1 = y_S (rk_common.py:58)
       f1.v[d] = k[S][d];
       acc.maxa = fmax(acc.maxa, (double)fabs(y0.v[d]));
@@ -405,7 +409,7 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
 #pragma unroll
         for (int j = 0; j <= S; ++j) kk[j] = k[j][i];
         T err, ymid;
-        step_finish<T, S>(y0e[i], kk, hs, A, err, ymid);
+        step_finish<T, S>(y0e[i], kk, hs, A, err, ymid, !TS && P.j_hi > P.j_lo);
         const long long idx = row * D + cx.col;
         P.y1[idx] = ys[i];
         P.f1[idx] = k[S][i];
