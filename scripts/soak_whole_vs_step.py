@@ -52,15 +52,17 @@ for it in range(n_runs):
         f = rhs.MLPTanh(mk(d_, h_), torch.zeros(h_, device=dev), mk(h_, h_), torch.zeros(h_, device=dev), mk(h_, d_), torch.zeros(d_, device=dev))
         y0 = rng.standard_normal((batch, d_))
     y0 = torch.tensor(y0, dtype=dtype, device=dev)
+    if os.environ.get('SOAK_VERBOSE'):
+        print(it, kind, method, dtype, batch, T, float(span), tol, flush=True)
     sign = -1.0 if rng.random() < 0.3 else 1.0
     try:
-        a = odeint(f, y0, sign * t, method=method, options={'fusion': 'step'}, **tol)
+        a = odeint(f, y0, sign * t, method=method, options={'fusion': 'step', 'max_num_steps': 3000}, **tol)
         sa = dict(odeint.last_stats)
-        b = odeint(f, y0, sign * t, method=method, **tol)          # auto: the whole-call kernel wherever it is eligible
+        b = odeint(f, y0, sign * t, method=method, options={'max_num_steps': 3000}, **tol)      # auto: whole-call kernel if eligible
         sb = dict(odeint.last_stats)
     except AssertionError as e:            # dt underflow etc.: must happen on both schedules alike
         try:
-            odeint(f, y0, sign * t, method=method, **tol)
+            odeint(f, y0, sign * t, method=method, options={'max_num_steps': 3000}, **tol)
             print('MISMATCH: only the step schedule raised', kind, method, batch, e)
             bad += 1
         except AssertionError:

@@ -434,7 +434,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   hipError_t e = hipSuccess;
   e = hipMalloc((void**)&h->planes, (size_t)h->stride * kNumPlanes);
   if (e == hipSuccess) e = hipMalloc((void**)&h->partials, (size_t)kMaxBlocks * kRec * sizeof(double));
-  if (e == hipSuccess) e = hipMemset(h->partials, 0, (size_t)kMaxBlocks * kRec * sizeof(double));   // no stale stamps
+  if (e == hipSuccess) e = hipMemset(h->partials, 0, (size_t)kMaxBlocks * kRec * sizeof(double));   // no stale sequence numbers
   if (desc->exchange_send_dev != nullptr && desc->exchange_recv_dev != nullptr) {
     h->rank_rec = desc->exchange_send_dev;
     h->gathered = desc->exchange_recv_dev;
@@ -656,8 +656,8 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   A.t0 = t_host[0];
   A.first_dt = h->cp.auto_first_step ? 0.0 : h->d.first_step;
   for (int i = 0; i < n_out && i < kPersistTSmall; ++i) A.t_small[i] = t_host[1 + i];
-  A.stamp_base = h->stamp_base;
-  if (h->xrank_on) { A.xrank = h->xrank_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank; A.xseq_base = h->xseq; }
+  A.seq_base = h->seq;
+  if (h->xrank_on) { A.xrank = h->xrank_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank; }
   else { A.world = 1; }
   A.spin_limit = 1 << 21;
   // back-off before the first poll (units of 64 clocks): a failed poll round costs G x G record loads on the fabric, so
@@ -689,9 +689,9 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
             cc->n_attempt, 10.0 * cc->prof[0] / na, 10.0 * cc->prof[1] / na, 10.0 * cc->prof[2] / na, 10.0 * cc->prof[3] / na);
   }
 #endif
-  h->stamp_base += (double)h->ctl_host->n_attempt + 16.0;      // hand-offs of this call: attempts + 2 (+ margin)
-  h->xseq += (unsigned)h->ctl_host->n_attempt + 16u;           // identical on every rank (the attempt count is global)
-  if (h->xseq >= 0xE0000000u) h->xseq = 0;                      // wrap below the self-test range; 0 + gen + 1 != stale values
+  h->seq += (unsigned)h->ctl_host->n_attempt + 16u;            // hand-offs of this call: attempts + 2 (+ margin); identical on
+  if (h->seq >= 0xE0000000u) h->seq = 0;                        // every rank.  Wraps below the self-test range; a slot is
+                                                                // rewritten every other hand-off, so an old number never matches
   if (stats) fill_stats(h, stats);
   return (int)h->ctl_host->status;
 }
@@ -737,9 +737,8 @@ extern "C" int mi_ode_xrank_selftest(mi_ode_handle h, void* stream) {
   memset(&A, 0, sizeof(A));
   A.xrank = h->xrank_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank;
   A.spin_limit = 1 << 20;                       // several seconds: covers module-load skew between the ranks
-  h->xrank_test_stamp += 64.0;
-  A.stamp_base = 1e15 + h->xrank_test_stamp;    // disjoint from the stamps of real calls
-  A.xseq_base = 0xF0000000u + (unsigned)h->xrank_test_stamp;
+  h->xrank_tests += 64u;
+  A.seq_base = 0xF0000000u + (h->xrank_tests & 0x0FFFFFFu);   // disjoint from the numbers of real calls
   int* res_dev = (int*)h->ticket + 8;
   MI_HIP(hipMemsetAsync(res_dev, 0, sizeof(int), st));
   hipLaunchKernelGGL(k_xrank_selftest<0>, dim3(1), dim3(64), 0, st, A, 4, res_dev);

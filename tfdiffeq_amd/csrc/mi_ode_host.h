@@ -70,9 +70,8 @@ struct mi_ode_solver {
   double* gbuf;               // device: the global record WG 0 broadcasts after a cross-rank hand-off (2 parities)
   int xrank_on;               // 1: multi-rank calls use the whole-call kernel with the cross-rank hand-off
   int xrank_registered;
-  double xrank_test_stamp;    // self-test rounds use their own stamp / sequence ranges
-  unsigned xseq;              // cross-rank sequence numbers already used (identical on every rank)
-  double stamp_base;          // hand-off stamps already used on this handle's record buffer
+  unsigned xrank_tests;       // self-test rounds use their own sequence range
+  unsigned seq;               // hand-off sequence numbers already used on this handle (identical on every rank)
   int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)
   int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation
   // bookkeeping

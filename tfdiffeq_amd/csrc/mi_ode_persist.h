@@ -9,10 +9,10 @@
 //     fixed order and applies the controller to its own copy of the scalar state (same bits everywhere, no broadcast
 //     phase); accepted steps write the requested outputs from registers (dense output, dopri5.py:87/interp.py);
 //   * HBM traffic = y0 in + solution rows out.
-// Grid hand-off: every workgroup publishes its record as stamped 16-byte {value, stamp} pairs (sc1 write-through
-// stores), polls everybody's pairs with sc1 loads until the stamps match, and folds (no atomics, no fences - see
-// below).  Records are double-buffered by hand-off parity: a workgroup can be at most one hand-off ahead of the
-// slowest one.
+// Grid hand-off: every workgroup publishes its record as sequence-numbered 8-byte words (sc1 write-through stores),
+// polls everybody's records with sc1 loads until all words carry the expected number, and folds (no atomics, no
+// fences - see below).  Records are double-buffered by hand-off parity: a workgroup can be at most one hand-off ahead
+// of the slowest one.
 // All workgroups must be co-resident: the host only picks this kernel when gridDim.x <= CUs x occupancy, and the
 // spin is bounded (MI_ODE_ST_SYNC_TIMEOUT) so that a scheduling surprise ends in an error, not a hang.
 // The arithmetic is that of k_stage_rowlocal<M_F0 / M_INITB> and k_step_rowlocal, operation for operation, and the
@@ -46,8 +46,7 @@ struct PersistArgs {
   double* xrank;               // [2 parities][world][kXRec] doubles, host memory seen by every rank's GPU
   double* gbuf;                // device, [2 parities][kPRec]: the global record, broadcast by workgroup 0
   int world, rank;
-  unsigned xseq_base;          // sequence numbers of this call's cross-rank hand-offs are xseq_base + 1, + 2, ...
-  double stamp_base;           // stamps of this call are stamp_base + 1, + 2, ... (above every earlier call's)
+  unsigned seq_base;           // sequence numbers of this call's hand-offs are seq_base + 1, + 2, ... (never 0)
   int n_out;                   // T - 1
   int spin_limit;              // bound on the spin iterations of one hand-off
   int sleep_first, sleep_poll; // back-off (units of 64 clocks): before the first poll / between polls
@@ -99,21 +98,25 @@ __device__ __forceinline__ void set_outputs_apply(Ctl* c, int n_out) {
 }
 
 // ---- grid hand-off records -------------------------------------------------------------------------------------
-// A record is 5 x {value, stamp} pairs (16 bytes each, 128-byte stride).  A pair travels in ONE 16-byte sc1
-// (agent-scope, write-through) store and is read back with ONE 16-byte sc1 load, so a value and its stamp are always
-// seen together: no "drain, then publish a flag" round trip, no atomics, no fences.  Stamps of a call are
-// stamp_base + 1, + 2, ...; the host raises stamp_base past every stamp of the previous call on the handle.
-typedef double d2_t __attribute__((ext_vector_type(2)));
-constexpr int kPRec = 16;                                     // doubles per hand-off record (5 pairs + padding)
+// "LL" encoding (as in collective libraries): every 8-byte word carries 4 bytes of payload and a 4-byte sequence
+// number, and an aligned 8-byte access is single-copy atomic for every agent - so a reader that finds the expected
+// sequence number in all words of a record has the record, whatever order the writes became visible in.  No flag
+// published after a drain, no atomics, no fences.  A double travels as two words (written with one 16-byte store, read
+// with one 16-byte load: only the 8-byte halves need to be atomic).  A record is 5 values = 10 words (128-byte stride).
+// Sequence numbers of a call are seq_base + 1, + 2, ...; the host advances seq_base past those of the previous call.
+typedef unsigned long long u64x2_t __attribute__((ext_vector_type(2)));
+constexpr int kPRec = 16;                                     // 8-byte words per hand-off record (10 used)
 constexpr int kPersistMaxGrid = kMaxBlocks * kRec / (2 * kPRec);   // two parity buffers inside the `partials` allocation
 
-__device__ __forceinline__ void store_pair_sc1(double* p, double value, double stamp) {
-  d2_t v = {value, stamp};
+__device__ __forceinline__ void store_ll_sc1(double* p, double value, unsigned seq) {
+  const unsigned long long b = (unsigned long long)__double_as_longlong(value);
+  u64x2_t v = {(b & 0xffffffffull) | ((unsigned long long)seq << 32), (b >> 32) | ((unsigned long long)seq << 32)};
   asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
 }
 
-// all five pairs of one record: five loads in flight, one wait
-__device__ __forceinline__ void load_record_sc1(const double* p, d2_t (&v)[5]) {
+// all five values of one record: five 16-byte loads in flight, one wait; false while some word lacks `seq`
+__device__ __forceinline__ bool load_record_sc1(const double* p, unsigned seq, double (&val)[5]) {
+  u64x2_t v[5];
   asm volatile(
       "global_load_dwordx4 %0, %5, off sc1\n\t"
       "global_load_dwordx4 %1, %5, off offset:16 sc1\n\t"
@@ -124,6 +127,20 @@ __device__ __forceinline__ void load_record_sc1(const double* p, d2_t (&v)[5]) {
       : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4])
       : "v"(p)
       : "memory");
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    ok = ok && ((unsigned)(v[i].x >> 32) == seq) && ((unsigned)(v[i].y >> 32) == seq);
+    val[i] = __longlong_as_double((long long)((v[i].x & 0xffffffffull) | (v[i].y << 32)));
+  }
+  return ok;
+}
+// one value (the sixth word pair of the cross-rank broadcast record)
+__device__ __forceinline__ bool load_ll_sc1(const double* p, unsigned seq, double& val) {
+  const unsigned long long w0 = (unsigned long long)__hip_atomic_load((const long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long w1 = (unsigned long long)__hip_atomic_load((const long long*)p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  val = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+  return (unsigned)(w0 >> 32) == seq && (unsigned)(w1 >> 32) == seq;
 }
 
 // Values read from LDS land in VGPRs even when every lane reads the same word; the tile passes have no VGPRs to
@@ -189,12 +206,13 @@ __device__ __forceinline__ bool ll_load_record(const unsigned long long* p, unsi
 // Cross-rank hand-off (batch-sharded runs).  On entry thread 0 of EVERY workgroup holds this rank's record r[0..4];
 // on exit it holds the record combined over all ranks (rank order, the fold of k_controller) and n_tot = sum of the
 // ranks' element counts.  Workgroup 0 is the gateway: it publishes the rank record in the host segment, lane q of its
-// first wavefront polls rank q's record, thread 0 folds and broadcasts the result through device memory as stamped
-// pairs that the other workgroups poll.  Bounded waits, as everywhere.
-__device__ __forceinline__ void cross_rank(const PersistArgs& A, PersistShared& sh, unsigned gen, double stamp, double (&r)[5],
-                                           double& n_tot, double n_local) {
+// first wavefront polls rank q's record, thread 0 folds and broadcasts the result through device memory (same word
+// encoding) to the other workgroups.  Bounded waits, as everywhere.
+__device__ __forceinline__ void cross_rank(const PersistArgs& A, PersistShared& sh, unsigned gen, double (&r)[5], double& n_tot,
+                                           double n_local) {
   const int W = A.world;
-  const unsigned seq = A.xseq_base + gen + 1u;                // never 0 (zero-filled memory), grows with every hand-off
+  const unsigned seq = A.seq_base + gen + 1u;
+  const unsigned bad = seq ^ 0x80000000u;                     // "the gateway gave up" (never a valid number of this hand-off)
   double* g = A.gbuf + (long long)(gen & 1u) * kPRec;
   if (blockIdx.x == 0) {
     unsigned long long* seg = (unsigned long long*)A.xrank;
@@ -222,27 +240,23 @@ __device__ __forceinline__ void cross_rank(const PersistArgs& A, PersistShared& 
         m0 = fmax(m0, sh.xr[0][q]); m1 = fmax(m1, sh.xr[1][q]); s0 += sh.xr[2][q]; s1 += sh.xr[3][q];
         fl = fmax(fl, sh.xr[4][q]); n += sh.xr[5][q];
       }
-      const double st = sh.ok ? stamp : -stamp - 1.0;         // a failed gateway tells everyone (they stop polling)
-      store_pair_sc1(g + 0, m0, st); store_pair_sc1(g + 2, m1, st); store_pair_sc1(g + 4, s0, st);
-      store_pair_sc1(g + 6, s1, st); store_pair_sc1(g + 8, fl, st); store_pair_sc1(g + 10, n, st);
+      const unsigned st = sh.ok ? seq : bad;                  // a failed gateway tells everyone (they stop polling)
+      store_ll_sc1(g + 0, m0, st); store_ll_sc1(g + 2, m1, st); store_ll_sc1(g + 4, s0, st);
+      store_ll_sc1(g + 6, s1, st); store_ll_sc1(g + 8, fl, st); store_ll_sc1(g + 10, n, st);
     }
   }
   if (threadIdx.x == 0) {
-    d2_t v[5];
+    double v[5], nv = 0.0;
     int spins = 0;
-    const double bad = -stamp - 1.0;
     for (;;) {
-      load_record_sc1(g, v);
-      if (v[0].y == bad) { sh.ok = 0; break; }
-      if (v[0].y == stamp && v[1].y == stamp && v[2].y == stamp && v[3].y == stamp && v[4].y == stamp) {
-        const double ns = rec_load<true>(g + 11), nv = rec_load<true>(g + 10);
-        if (ns == stamp) { n_tot = nv; break; }
-      }
+      if (load_record_sc1(g, seq, v) && load_ll_sc1(g + 10, seq, nv)) { n_tot = nv; break; }
+      double dummy;
+      if (load_ll_sc1(g, bad, dummy)) { sh.ok = 0; break; }
       __builtin_amdgcn_s_sleep(2);
       if (++spins > 8 * A.spin_limit) { sh.ok = 0; break; }    // (outlasts the gateway's own bounded wait: it reports failures)
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) r[i] = v[i].x;
+    for (int i = 0; i < 5; ++i) r[i] = v[i];
   }
   __syncthreads();
 }
@@ -257,25 +271,24 @@ __device__ __forceinline__ bool grid_reduce_rank(const PersistArgs& A, const Acc
   block_reduce_thread0(acc, sh.red, r);
   if (G == 1) return true;                                    // one record: folding it with zeros is exact
   double* buf = A.s.partials + (long long)(gen & 1u) * G * kPRec;
-  const double stamp = A.stamp_base + (double)(gen + 1u);
+  const unsigned seq = A.seq_base + gen + 1u;
   if (threadIdx.x == 0) {
     double* mine = buf + (long long)blockIdx.x * kPRec;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) store_pair_sc1(mine + 2 * i, r[i], stamp);
+    for (int i = 0; i < 5; ++i) store_ll_sc1(mine + 2 * i, r[i], seq);
   }
   for (int b = threadIdx.x; b < G; b += blockDim.x) {
     const double* p = buf + (long long)b * kPRec;
-    d2_t v[5];
+    double v[5];
     int spins = 0;
     for (int i = 0; i < A.sleep_first; ++i) __builtin_amdgcn_s_sleep(1);
     for (;;) {
-      load_record_sc1(p, v);
-      if (v[0].y == stamp && v[1].y == stamp && v[2].y == stamp && v[3].y == stamp && v[4].y == stamp) break;
+      if (load_record_sc1(p, seq, v)) break;
       for (int i = 0; i < A.sleep_poll; ++i) __builtin_amdgcn_s_sleep(1);
       if (++spins > A.spin_limit) { sh.ok = 0; break; }
     }
 #pragma unroll
-    for (int i = 0; i < 5; ++i) sh.vals[i][b] = v[i].x;
+    for (int i = 0; i < 5; ++i) sh.vals[i][b] = v[i];
   }
   __syncthreads();
   const bool ok = sh.ok != 0;
@@ -296,7 +309,7 @@ __device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc
   bool ok = grid_reduce_rank(A, acc, sh, gen, r);
   n_tot = (double)A.s.cp.n_local;
   if (A.world > 1 || A.xrank != nullptr) {
-    if (ok) cross_rank(A, sh, gen, A.stamp_base + (double)(gen + 1u), r, n_tot, (double)A.s.cp.n_local);
+    if (ok) cross_rank(A, sh, gen, r, n_tot, (double)A.s.cp.n_local);
     ok = ok && sh.ok != 0;
   }
   return ok;
@@ -617,7 +630,7 @@ __global__ __launch_bounds__(64) void k_xrank_selftest(PersistArgs A, int rounds
     double r[5], n_tot = 0.0;
 #pragma unroll
     for (int i = 0; i < 5; ++i) r[i] = (double)(A.rank * 10 + i + round);
-    cross_rank(A, sh, (unsigned)round, A.stamp_base + (double)(round + 1), r, n_tot, (double)(A.rank + 1));
+    cross_rank(A, sh, (unsigned)round, r, n_tot, (double)(A.rank + 1));
     if (threadIdx.x == 0) {
       const int W = A.world;
       double s0 = 0, s1 = 0, n = 0;
