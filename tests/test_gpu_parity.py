@@ -1098,6 +1098,33 @@ def test_odeint_adjoint_gradients_against_matrix_exponential():
         odeint_adjoint(lambda t_, y_: -y_, y0.detach(), torch.tensor([0., 1.]))
 
 
+def test_odeint_adjoint_drops_graph_option_for_the_backward_solve():
+    """options={'graph': True} is honoured by the forward solve only: the backward dynamics call torch.autograd.grad,
+    which cannot run under stream capture - the adjoint wrapper removes the option there (with a warning)."""
+    import warnings
+    from tfdiffeq_amd import odeint_adjoint
+
+    class Lin(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.A = torch.nn.Parameter(to_dev(np.array([[-0.1, 2.0], [-2.0, -0.1]])))
+
+        def forward(self, t, y):
+            return y @ self.A.t()
+    grads = []
+    for opts in (None, {'graph': True}):
+        f = Lin().to(dev())
+        y0 = to_dev(np.array([[2.0, 0.0], [1.0, 1.0]])).requires_grad_(True)
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter('always')
+            ys = odeint_adjoint(f, y0, torch.tensor([0., 1.0], dtype=torch.float64), rtol=1e-8, atol=1e-10, method='dopri5', options=opts)
+            (ys[1] ** 2).sum().backward()
+        if opts:
+            assert any('graph' in str(x.message) for x in w)
+        grads.append((y0.grad.clone(), f.A.grad.clone()))
+    assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
+
+
 def test_odeblock_and_odenet_modules():
     """tests/model_tests.py shapes + the fused-MLP fast path of ODEBlock equals the generic path."""
     from tfdiffeq_amd.models import ODEBlock, ODEFunc, ODENet
