@@ -539,12 +539,14 @@ import os, sys, json
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, os.environ['REPO'])
 from tfdiffeq_amd import odeint, rhs
-rank, world = int(os.environ['RANK']), 2
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
 torch.cuda.set_device(0)                       # both ranks share the one GPU of the box: their kernels must run concurrently
 dist.init_process_group('gloo', rank=rank, world_size=world)
 rng = np.random.default_rng(1)
 full = np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((3000, 3))
-shard = full[:1700] if rank == 0 else full[1700:]          # uneven shards
+cuts = [0] + sorted(int(c) for c in np.random.default_rng(9).choice(np.arange(100, 2900), size=world - 1, replace=False)) + [3000]
+lo, hi = cuts[rank], cuts[rank + 1]                           # uneven shards
+shard = full[lo:hi]
 y0 = torch.tensor(shard, device='cuda:0')
 t = torch.tensor([0., 0.25, 0.5, 0.8])
 out = {}
@@ -553,7 +555,7 @@ for method in ('dopri5', 'tsit5'):
     sb = dict(odeint.last_stats)
     ref = odeint(rhs.Lorenz(), torch.tensor(full, device='cuda:0'), t, rtol=1e-6, atol=1e-9, method=method)
     sr = dict(odeint.last_stats)
-    mine = ref[:, :1700] if rank == 0 else ref[:, 1700:]
+    mine = ref[:, lo:hi]
     out[method] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
                    'launches': sb['n_launches'], 'status': sb['status']}
 # the MFMA tile kernel (linear RHS, dim 128) and the MLP kernel with the same cross-rank hand-off: small shards so that both
@@ -562,13 +564,14 @@ g2 = torch.Generator().manual_seed(2)
 S = torch.randn(128, 128, generator=g2, dtype=torch.float64)
 A = -0.5 * torch.eye(128, dtype=torch.float64) + 0.5 * (S - S.t()) / np.sqrt(128)
 fullL = torch.randn(812, 128, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
-yl = (fullL[:512] if rank == 0 else fullL[512:]).cuda()
+lcut = [round(812 * q / world) for q in range(world + 1)]
+yl = fullL[lcut[rank]:lcut[rank + 1]].cuda()
 tl = torch.tensor([0., 0.4, 1.0])
 b = odeint(rhs.Linear.from_matrix(A), yl, tl, rtol=1e-6, atol=1e-9, method='dopri5', options={'process_group': dist.group.WORLD})
 sb = dict(odeint.last_stats)
 ref = odeint(rhs.Linear.from_matrix(A), fullL.cuda(), tl, rtol=1e-6, atol=1e-9, method='dopri5')
 sr = dict(odeint.last_stats)
-mine = ref[:, :512] if rank == 0 else ref[:, 512:]
+mine = ref[:, lcut[rank]:lcut[rank + 1]]
 out['linear128'] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
                     'launches': sb['n_launches'], 'status': sb['status']}
 gm = torch.Generator().manual_seed(4)
@@ -577,12 +580,13 @@ def glorot(i, o):
     return ((torch.rand(i, o, generator=gm) * 2 - 1) * lim).cuda()
 mlp = rhs.MLPTanh(glorot(64, 128), torch.zeros(128).cuda(), glorot(128, 128), torch.zeros(128).cuda(), glorot(128, 64), torch.zeros(64).cuda())
 fullM = torch.randn(700, 64, generator=torch.Generator().manual_seed(5))
-ym = (fullM[:400] if rank == 0 else fullM[400:]).cuda()
+mcut = [round(700 * q / world) for q in range(world + 1)]
+ym = fullM[mcut[rank]:mcut[rank + 1]].cuda()
 b = odeint(mlp, ym, tl, rtol=1e-4, atol=1e-5, method='dopri5', options={'process_group': dist.group.WORLD})
 sb = dict(odeint.last_stats)
 ref = odeint(mlp, fullM.cuda(), tl, rtol=1e-4, atol=1e-5, method='dopri5')
 sr = dict(odeint.last_stats)
-mine = ref[:, :400] if rank == 0 else ref[:, 400:]
+mine = ref[:, mcut[rank]:mcut[rank + 1]]
 out['mlp'] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
               'launches': sb['n_launches'], 'status': sb['status']}
 print('RESULT' + json.dumps({'rank': rank, 'out': out}), flush=True)
@@ -591,8 +595,9 @@ dist.destroy_process_group()
 """
 
 
-def test_cross_rank_handoff_two_processes_share_the_gpu():
-    """Two ranks (two processes, gloo group, both on cuda:0) integrate uneven shards of one batch with the whole-call
+@pytest.mark.parametrize('world', [2, 4])
+def test_cross_rank_handoff_two_processes_share_the_gpu(world):
+    """`world` ranks (separate processes, gloo group, all on cuda:0) integrate uneven shards of one batch with the whole-call
     kernel: every attempt's record crosses the processes through the shared host segment.  The global controller must
     reproduce the single-rank step sequence of the whole batch (sums are folded in a different order: 1e-12)."""
     import json
@@ -605,8 +610,8 @@ def test_cross_rank_handoff_two_processes_share_the_gpu():
     port = s.getsockname()[1]
     s.close()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE='2',
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                    REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY='0')
         procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
