@@ -43,8 +43,8 @@
 extern "C" {
 #endif
 
-#define MI_ODE_ABI_VERSION 3
-#define MI_ODE_MAX_STAGES 6          /* rows of the tableau (dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3) */
+#define MI_ODE_ABI_VERSION 4
+#define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
 

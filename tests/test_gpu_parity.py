@@ -251,7 +251,7 @@ def test_fused_engine_reproduces_reference_runs(name, fusion):
     'whole': the whole adaptive integration in one launch (tiny row-local systems)."""
     _, meta0 = load(name)
     if fusion == 'whole' and (meta0['rhs'] not in ('cubic_linear', 'lotka_volterra', 'lorenz') or
-                              meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') or
+                              meta0['method'] not in ('dopri5', 'bosh3', 'tsit5', 'dopri8', 'adaptive_heun') or
                               (meta0['rhs'] == 'cubic_linear' and len(meta0['rhs_params']['W']) != 2)):
         pytest.skip('whole-integration kernel: adaptive solvers on the row-local catalogue systems')
     if fusion == 'step' and meta0['rhs'] == 'linear' and len(meta0['rhs_params']['W']) not in (2, 16, 32, 64, 128):
@@ -894,6 +894,49 @@ def test_graph_captured_fixed_grid_step_equals_eager_launches(method):
     a = odeint(ft, ys, tt, method=method)
     b = odeint(ft, ys, tt, method=method, options={'graph': True})
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize('method', ['dopri8', 'adaptive_heun'])
+@pytest.mark.parametrize('problem', ['lorenz', 'lv', 'spiral', 'plugin'])
+def test_wide_and_non_fsal_tableaus_on_the_row_local_kernels(problem, method):
+    """dopri8 (13 rows) and adaptive_heun (1 row, not FSAL shaped: y1 from c_sol, f1 = k[-1] as in rk_common.py:55-58)
+    run on the row-local whole-call / whole-attempt kernels: identical bits between the two schedules, and the
+    plane-kernel engine (the reference's loop over stateless kernels) as the cross-check."""
+    from tfdiffeq_amd import odeint, plugin_examples, rhs
+    rng = np.random.default_rng(43)
+    if problem == 'lorenz':
+        f, y0, t = rhs.Lorenz(), np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((700, 3)), np.linspace(0., 0.5, 6)
+    elif problem == 'lv':
+        f, y0, t = rhs.LotkaVolterra(), 1 + 0.5 * rng.uniform(size=(3000, 2)), np.linspace(0., 2.0, 5)
+    elif problem == 'spiral':
+        f = rhs.CubicLinear(torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64))
+        y0, t = rng.uniform(-2, 2, size=(64, 2)), np.linspace(0., 2.0, 9)
+    else:
+        f, y0, t = plugin_examples.forced_oscillator(), rng.standard_normal((300, 2)), np.linspace(0., 3.0, 7)
+    tol = dict(rtol=1e-7, atol=1e-9) if method == 'dopri8' else dict(rtol=1e-4, atol=1e-6)
+    if method == 'adaptive_heun':
+        t = t[0] + 0.2 * (t - t[0])                      # a second-order method: keep the attempt count moderate
+    for dtype in (torch.float64, torch.float32):
+        if dtype == torch.float32:
+            tol = dict(rtol=1e-4, atol=1e-6)
+        y = to_dev(y0, dtype)
+        for tt in (torch.tensor(t), torch.tensor(-t)):
+            if problem == 'spiral' and float(tt[-1]) < 0:
+                continue                                 # the cubic spiral blows up backwards
+            a = odeint(f, y, tt, method=method, options={'fusion': 'step'}, **tol)
+            sa = dict(odeint.last_stats)
+            b = odeint(f, y, tt, method=method, options={'fusion': 'whole'}, **tol)
+            sb = dict(odeint.last_stats)
+            assert sb['n_launches'] == 1 and sa['n_launches'] > 1
+            assert torch.equal(a, b) and sa['n_attempts'] == sb['n_attempts'] and sa['nfe'] == sb['nfe']
+            c = odeint(f, y, tt, method=method, options={'force_plane_kernels': True}, **tol)
+            sc = dict(odeint.last_stats)
+            scale = max(1.0, c.abs().max().item())
+            if dtype == torch.float64:
+                assert abs(sc['n_attempts'] - sa['n_attempts']) <= 1, (sa, sc)
+                assert (a - c).abs().max().item() <= 1e-9 * scale
+            else:
+                assert (a - c).abs().max().item() <= 2e-3 * scale
 
 
 def test_whole_integration_kernel_status_paths():

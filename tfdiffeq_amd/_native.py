@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('TFDIFFEQ_AMD_LIB') or os.path.join(_HERE, 'libmi_ode.so')   # env override: kernel-variant sweeps
 CSRC = os.path.join(_HERE, 'csrc')
 
-MAX_STAGES = 6
+MAX_STAGES = 13
 MAX_K = MAX_STAGES + 1
 MAX_LINCOMB = 14
 REC = 8
@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH, RHS_PLUGIN = 1, 2, 3, 4, 5, 6
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
-ABI_VERSION = 3
+ABI_VERSION = 4
 ST_DT_UNDERFLOW, ST_NONFINITE, ST_MAX_STEPS, ST_BAD_T, ST_SYNC_TIMEOUT = 1, 2, 4, 8, 16
 
 

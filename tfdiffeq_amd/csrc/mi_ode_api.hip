@@ -290,7 +290,7 @@ static void fill_step_args(mi_ode_solver* h, StepArgs& A) {
     A.alpha[i] = tb.alpha[i];
     for (int j = 0; j <= i; ++j) A.beta[i][j] = tb.beta[i][j];
   }
-  for (int j = 0; j <= h->S; ++j) { A.e[j] = tb.c_error[j]; A.cmid[j] = tb.c_mid[j]; }
+  for (int j = 0; j <= h->S; ++j) { A.e[j] = tb.c_error[j]; A.cmid[j] = tb.c_mid[j]; A.csol[j] = tb.c_sol[j]; }
   A.partials = h->partials; A.rhs = h->rhs;
   A.ticket = h->fused_ctl ? h->ticket : nullptr;
   A.cp = h->cp;
@@ -330,8 +330,11 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   const mi_ode_tableau& tb = desc->tableau;
   if (tb.n_stages < 0 || tb.n_stages > MI_ODE_MAX_STAGES) { mi_set_error("bad n_stages"); return MI_ODE_E_INVALID; }
   if (desc->adaptive) {
-    if (!tb.fsal) { mi_set_error("fused adaptive engine needs an FSAL-shaped tableau (rk_common.py:54)"); return MI_ODE_E_INVALID; }
-    if (tb.n_stages != 3 && tb.n_stages != 6) { mi_set_error("fused adaptive engine supports 3- and 6-row tableaus"); return MI_ODE_E_INVALID; }
+    // kernels are instantiated for: 3 and 6 rows, FSAL shaped (bosh3, dopri5, tsit5; every family and schedule);
+    // 13 rows FSAL shaped (dopri8) and 1 row not FSAL shaped (adaptive_heun): row-local families, schedules 2-4 only
+    const bool classic = tb.fsal && (tb.n_stages == 3 || tb.n_stages == 6);
+    const bool wide = (tb.fsal && tb.n_stages == 13) || (!tb.fsal && tb.n_stages == 1);
+    if (!classic && !wide) { mi_set_error("fused adaptive engine: no kernels for a %d-row %s tableau", tb.n_stages, tb.fsal ? "FSAL-shaped" : "non-FSAL"); return MI_ODE_E_INVALID; }
     if (desc->interp != MI_ODE_INTERP_QUARTIC_MID && tb.n_stages != 6) { mi_set_error("tsit5 dense output needs 7 stage derivatives"); return MI_ODE_E_INVALID; }
   }
   mi_ode_solver* h = new mi_ode_solver();
@@ -358,6 +361,14 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   h->rhs.hidden = desc->rhs.hidden;
   int rc = pick_family(h);
   if (rc != 0) { delete h; return rc; }
+  if (desc->adaptive && tb.n_stages != 3 && tb.n_stages != 6) {
+    const bool rowlocal_fam = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
+                              h->family == FAM_PLUGIN;
+    if (!rowlocal_fam || desc->fusion == 1) {
+      mi_set_error("%d-row tableaus run on the row-local whole-attempt / whole-call kernels only (no per-stage, MFMA or MLP kernels)", tb.n_stages);
+      delete h; return MI_ODE_E_INVALID;
+    }
+  }
   rc = h->is_f32 ? mi_stage_geometry_f32(h) : mi_stage_geometry_f64(h);
   if (rc != 0) { delete h; return rc; }
   {   // whole-attempt fusion: row-local families and the MFMA linear family, adaptive FSAL tableaus
@@ -432,7 +443,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   for (int j = 0; j < kMaxK; ++j) h->ip.c_mid[j] = tb.c_mid[j];
   // workspace
   hipError_t e = hipSuccess;
-  e = hipMalloc((void**)&h->planes, (size_t)h->stride * kNumPlanes);
+  e = hipMalloc((void**)&h->planes, (size_t)h->stride * (2 + h->S + 1));     // y_a, y_b, k_0..k_S
   if (e == hipSuccess) e = hipMalloc((void**)&h->partials, (size_t)kMaxBlocks * kRec * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->partials, 0, (size_t)kMaxBlocks * kRec * sizeof(double));   // no stale sequence numbers
   if (desc->exchange_send_dev != nullptr && desc->exchange_recv_dev != nullptr) {

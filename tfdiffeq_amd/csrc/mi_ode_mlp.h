@@ -242,14 +242,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
 #pragma unroll
       for (int i = 0; i < 4; ++i) k[SG][i] = sign * kn[i];
     };
-    stage(std::integral_constant<int, 1>{});
-    stage(std::integral_constant<int, 2>{});
-    stage(std::integral_constant<int, 3>{});
-    if constexpr (S == 6) {
-      stage(std::integral_constant<int, 4>{});
-      stage(std::integral_constant<int, 5>{});
-      stage(std::integral_constant<int, 6>{});
-    }
+    for_stages<1, S>(stage);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = row0 + rbase + i;

@@ -320,7 +320,7 @@ __device__ __forceinline__ void fill_record(double (&rec)[kRec], const double (&
   rec[R_N] = n; rec[6] = 0; rec[7] = 0;
 }
 
-template <typename T, int S, bool TS, class RHS>
+template <typename T, int S, bool TS, class RHS, bool FSAL = true>
 __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
   constexpr int D = RHS::D;
   using Row = RowVec<T, D>;
@@ -431,14 +431,7 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
 #pragma unroll
       for (int d = 0; d < D; ++d) k[SG][d] = sign * kn[d];
     };
-    stage(std::integral_constant<int, 1>{});
-    stage(std::integral_constant<int, 2>{});
-    stage(std::integral_constant<int, 3>{});
-    if constexpr (S == 6) {
-      stage(std::integral_constant<int, 4>{});
-      stage(std::integral_constant<int, 5>{});
-      stage(std::integral_constant<int, 6>{});
-    }
+    for_stages<1, S>(stage);
     Acc acc;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -447,6 +440,7 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
       for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
       T err, unused_mid;
       step_finish<T, S>(y.v[d], kk, hs, A.s, err, unused_mid, false);      // y_mid only if an output falls into the step (below)
+      if constexpr (!FSAL) ys[d] = step_y1_general<T, S>(y.v[d], kk, hs, A.s);  // rk_common.py:55-56
       if (live) {
         acc.maxa = fmax(acc.maxa, (double)fabs(y.v[d]));
         acc.maxb = fmax(acc.maxb, (double)fabs(ys[d]));

@@ -52,6 +52,8 @@ struct RowLocalPlugin {
     if (h->S == 6 && h->ts_dense) hipLaunchKernelGGL((k_step_rowlocal<T, 6, true, RHS>), grid, block, 0, st, *A);
     else if (h->S == 6) hipLaunchKernelGGL((k_step_rowlocal<T, 6, false, RHS>), grid, block, 0, st, *A);
     else if (h->S == 3 && !h->ts_dense) hipLaunchKernelGGL((k_step_rowlocal<T, 3, false, RHS>), grid, block, 0, st, *A);
+    else if (h->S == 13 && h->d.tableau.fsal && !h->ts_dense) hipLaunchKernelGGL((k_step_rowlocal<T, 13, false, RHS, true>), grid, block, 0, st, *A);
+    else if (h->S == 1 && !h->d.tableau.fsal && !h->ts_dense) hipLaunchKernelGGL((k_step_rowlocal<T, 1, false, RHS, false>), grid, block, 0, st, *A);
     else return MI_ODE_E_INVALID;
     return hipGetLastError() == hipSuccess ? 0 : MI_ODE_E_HIP;
   }
@@ -65,6 +67,8 @@ struct RowLocalPlugin {
   static const void* persist_fn(int S, int ts_dense) {
     if (S == 6) return ts_dense ? (const void*)k_persist_rowlocal<T, 6, true, RHS> : (const void*)k_persist_rowlocal<T, 6, false, RHS>;
     if (S == 3 && !ts_dense) return (const void*)k_persist_rowlocal<T, 3, false, RHS>;
+    if (S == 13 && !ts_dense) return (const void*)k_persist_rowlocal<T, 13, false, RHS, true>;      // dopri8 (FSAL shaped)
+    if (S == 1 && !ts_dense) return (const void*)k_persist_rowlocal<T, 1, false, RHS, false>;       // adaptive_heun (not FSAL shaped)
     return nullptr;
   }
   static const mi_ode_rowlocal_plugin* table(int dtype) {

@@ -35,6 +35,7 @@ struct StepArgs {
   double beta[MI_ODE_MAX_STAGES][MI_ODE_MAX_STAGES];
   double alpha[MI_ODE_MAX_STAGES];
   double e[kMaxK];             // c_error
+  double csol[kMaxK];          // c_sol (only read for tableaus that are not FSAL shaped)
   double cmid[kMaxK];          // dense-output mid-point weights
   double* partials;
   RhsParams rhs;
@@ -105,6 +106,22 @@ __device__ __forceinline__ bool resolve_step(const StepArgs& A, StepPlanes<T, S>
   return true;
 }
 
+// stages 1..S at compile time: f(integral_constant<int, sigma>)
+template <int SG, int S, class F>
+__device__ __forceinline__ void for_stages(F&& f) {
+  f(std::integral_constant<int, SG>{});
+  if constexpr (SG < S) for_stages<SG + 1, S>(f);
+}
+
+// y1 of a tableau that is not FSAL shaped (rk_common.py:55-56): y0 + add_n((dt * c_sol_j) * k_j), all S+1 derivatives
+template <typename T, int S>
+__device__ __forceinline__ T step_y1_general(T y0, const T* k, T hs, const StepArgs& A) {
+  T acc = (hs * (T)A.csol[0]) * k[0];
+#pragma unroll
+  for (int j = 1; j <= S; ++j) acc = acc + (hs * (T)A.csol[j]) * k[j];
+  return y0 + acc;
+}
+
 // y_sigma for stage SG (1-based) from y0 and k[0..SG-1]: misc._scaled_dot_product order (rk_common.py:51)
 template <typename T, int SG>
 __device__ __forceinline__ T step_combine(T y0, const T* k, T hs, const StepArgs& A) {
@@ -151,7 +168,7 @@ __device__ __forceinline__ void step_emit(const StepArgs& A, const StepPlanes<T,
 // ------------------------------------------------------------------------------------------------
 // (1) tiny row-local systems: one thread per trajectory, everything in registers, one launch per attempt
 // ------------------------------------------------------------------------------------------------
-template <typename T, int S, bool TS, class RHS>
+template <typename T, int S, bool TS, class RHS, bool FSAL = true>
 __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
   constexpr int D = RHS::D;
   using Row = RowVec<T, D>;
@@ -185,14 +202,7 @@ __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
 #pragma unroll
       for (int d = 0; d < D; ++d) k[SG][d] = sign * kn[d];
     };
-    stage(std::integral_constant<int, 1>{});
-    stage(std::integral_constant<int, 2>{});
-    stage(std::integral_constant<int, 3>{});
-    if constexpr (S == 6) {
-      stage(std::integral_constant<int, 4>{});
-      stage(std::integral_constant<int, 5>{});
-      stage(std::integral_constant<int, 6>{});
-    }
+    for_stages<1, S>(stage);
     Row y1, f1;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -201,6 +211,7 @@ __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
       for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
       T err, ymid;
       step_finish<T, S>(y0.v[d], kk, hs, A, err, ymid, !TS && P.j_hi > P.j_lo);
+      if constexpr (!FSAL) ys[d] = step_y1_general<T, S>(y0.v[d], kk, hs, A);     // rk_common.py:55-56
       y1.v[d] = ys[d];                                       // FSAL: y1 = y_S (rk_common.py:58)
       f1.v[d] = k[S][d];
       acc.maxa = fmax(acc.maxa, (double)fabs(y0.v[d]));
@@ -393,14 +404,7 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
       }
       cx.rhs_eval(ys, k[SG]);
     };
-    stage(std::integral_constant<int, 1>{});
-    stage(std::integral_constant<int, 2>{});
-    stage(std::integral_constant<int, 3>{});
-    if constexpr (S == 6) {
-      stage(std::integral_constant<int, 4>{});
-      stage(std::integral_constant<int, 5>{});
-      stage(std::integral_constant<int, 6>{});
-    }
+    for_stages<1, S>(stage);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = row0 + cx.row_of(i);

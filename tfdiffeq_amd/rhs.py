@@ -66,6 +66,7 @@ class DeviceRHS(object):
                 tuple(int(v or 0) for v in r.b), int(r.hidden))
 
     fixed_grid_fused = True
+    row_local = False             # True: runs on the one-trajectory-per-thread kernels (which also cover dopri8 / adaptive_heun)
 
     def supports(self, y0):
         """True when the fused kernels can take this state tensor."""
@@ -87,6 +88,7 @@ class _MatRHS(DeviceRHS):
         self.W = W
         self.b = None if b is None else torch.as_tensor(b)
         self.dim = int(W.shape[0])
+        self.row_local = self.dim == 2 and self.b is None       # 2x2 systems travel by value to the row-local kernels
 
     def fill(self, rhs, dtype, device):
         keep = super(_MatRHS, self).fill(rhs, dtype, device)
@@ -135,6 +137,7 @@ class CubicLinear(_MatRHS):
 class LotkaVolterra(DeviceRHS):
     kind = N.RHS_LOTKA_VOLTERRA
     dim = 2
+    row_local = True
 
     def __init__(self, a=1.5, b=1.0, c=3.0, d=1.0):
         super(LotkaVolterra, self).__init__()
@@ -155,6 +158,7 @@ class LotkaVolterra(DeviceRHS):
 class Lorenz(DeviceRHS):
     kind = N.RHS_LORENZ
     dim = 3
+    row_local = True
 
     def __init__(self, sigma=10., beta=8. / 3., rho=28.):
         super(Lorenz, self).__init__()
@@ -257,6 +261,7 @@ class CustomRowLocal(DeviceRHS):
     states, `odeint_adjoint`, `options={'force_plane_kernels': True}`)."""
     kind = N.RHS_PLUGIN
     MAX_DIM = 8
+    row_local = True
 
     def __init__(self, dim, body, params=(), torch_fn=None):
         super(CustomRowLocal, self).__init__()

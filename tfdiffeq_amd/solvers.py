@@ -486,8 +486,12 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         if rhs is None:
             return None
         from .rk_common import _is_fsal_shaped
-        if not _is_fsal_shaped(self.tableau) or len(self.tableau.alpha) not in (3, 6):
-            return None
+        fsal, rows = _is_fsal_shaped(self.tableau), len(self.tableau.alpha)
+        if not (fsal and rows in (3, 6)):
+            # dopri8 (13 rows) and adaptive_heun (1 row, not FSAL shaped): row-local kernels only, no per-stage schedule
+            wide = (fsal and rows == 13) or (not fsal and rows == 1)
+            if not (wide and getattr(rhs, 'row_local', False) and self._fusion not in (1, 'stage')):
+                return None
         rtol0 = self.rtol if self.pooled_ratio else self.rtol[0]
         atol0 = self.atol if self.pooled_ratio else self.atol[0]
         first = None
