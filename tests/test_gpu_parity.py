@@ -1173,6 +1173,20 @@ def test_odeint_adjoint_drops_graph_option_for_the_backward_solve():
     assert torch.equal(grads[0][0], grads[1][0]) and torch.equal(grads[0][1], grads[1][1])
 
 
+def test_ode_demo_example_trains():
+    """examples/ode_demo.py (the reference's demo: fit the cubic spiral with a small neural ODE through the adjoint)
+    runs and the loss goes down."""
+    import importlib.util
+    import os
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'examples', 'ode_demo.py')
+    spec = importlib.util.spec_from_file_location('ode_demo_example', path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    losses = mod.main(['--niters', '40', '--test_freq', '40', '--data_size', '400'])
+    assert len(losses) == 40 and all(np.isfinite(losses))
+    assert np.mean(losses[-10:]) < np.mean(losses[:10])
+
+
 def test_odeblock_and_odenet_modules():
     """tests/model_tests.py shapes + the fused-MLP fast path of ODEBlock equals the generic path."""
     from tfdiffeq_amd.models import ODEBlock, ODEFunc, ODENet
