@@ -939,6 +939,46 @@ def test_wide_and_non_fsal_tableaus_on_the_row_local_kernels(problem, method):
                 assert (a - c).abs().max().item() <= 2e-3 * scale
 
 
+_TIMEOUT_SCRIPT = r"""
+import os, sys, json
+import numpy as np, torch
+sys.path.insert(0, os.environ['REPO'])
+from tfdiffeq_amd import odeint, rhs
+rng = np.random.default_rng(1)
+y0 = torch.tensor(np.array([1., 1., 1.]) + 1e-3 * rng.standard_normal((20000, 3)), device='cuda:0')
+t = torch.tensor([0., 0.25, 0.5])
+a = odeint(rhs.Lorenz(), y0, t, rtol=1e-6, atol=1e-9, method='dopri5')           # hand-off times out -> per-attempt schedule
+sa = dict(odeint.last_stats)
+b = odeint(rhs.Lorenz(), y0, t, rtol=1e-6, atol=1e-9, method='dopri5')           # the handle stays on that schedule
+sb = dict(odeint.last_stats)
+c = odeint(rhs.Lorenz(), y0, t, rtol=1e-6, atol=1e-9, method='dopri5', options={'fusion': 'step'})
+err = None
+try:
+    odeint(rhs.Lorenz(), y0, t, rtol=1e-6, atol=1e-9, method='dopri5', options={'fusion': 'whole'})
+except RuntimeError as e:
+    err = str(e)
+print('RESULT' + json.dumps({'eq': bool(torch.equal(a, c) and torch.equal(b, c)), 'la': sa['n_launches'], 'lb': sb['n_launches'],
+                             'status': sa['status'], 'err': err}))
+"""
+
+
+def test_handoff_timeout_falls_back_to_one_launch_per_attempt():
+    """A hand-off that cannot complete (here: the poll bound forced to zero) must not hang or corrupt anything: with the
+    automatic schedule the handle reverts to one launch per attempt and the call succeeds; an explicit fusion='whole'
+    reports the engine fault."""
+    import json
+    import os
+    import subprocess
+    import sys
+    env = dict(os.environ, REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), MI_ODE_PERSIST_SPIN_LIMIT='0',
+               MI_ODE_PERSIST_SLEEP0='0')
+    res = subprocess.run([sys.executable, '-c', _TIMEOUT_SCRIPT], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-3000:]
+    out = json.loads([ln for ln in res.stdout.splitlines() if ln.startswith('RESULT')][-1][6:])
+    assert out['eq'] and out['status'] == 0 and out['la'] > 1 and out['lb'] > 1, out
+    assert out['err'] is not None and 'hand-off timed out' in out['err'], out
+
+
 def test_whole_integration_kernel_status_paths():
     from tfdiffeq_amd import odeint, rhs
     y0 = to_dev(np.array([[1., 1., 1.]]), torch.float64)

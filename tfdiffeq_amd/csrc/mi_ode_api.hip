@@ -426,6 +426,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     h->persist_sleep_poll = 2;
     if (const char* e0 = getenv("MI_ODE_PERSIST_SLEEP0")) h->persist_sleep_first = atoi(e0);      // tuning sweeps (scripts/gpu_persist_sweep.sh)
     if (const char* e1 = getenv("MI_ODE_PERSIST_SLEEP1")) h->persist_sleep_poll = atoi(e1);
+    h->persist_spin_limit = 1 << 21;              // a few seconds
+    if (const char* e2 = getenv("MI_ODE_PERSIST_SPIN_LIMIT")) h->persist_spin_limit = atoi(e2);  // tests: force the time-out path
   }
   // controller / dense-output parameters
   h->cp.rtol = desc->rtol; h->cp.atol = desc->atol;
@@ -670,7 +672,7 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   A.seq_base = h->seq;
   if (h->xrank_on) { A.xrank = h->xrank_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank; }
   else { A.world = 1; }
-  A.spin_limit = 1 << 21;
+  A.spin_limit = h->persist_spin_limit;
   // back-off before the first poll (units of 64 clocks): a failed poll round costs G x G record loads on the fabric, so
   // wait about as long as the publish needs to become visible (measured: G=16 best at <= 24, G=256 best at 32)
   A.sleep_first = h->persist_sleep_first; A.sleep_poll = h->persist_sleep_poll;

@@ -65,6 +65,7 @@ struct mi_ode_solver {
   int persist;                // 1: whole integration in one launch (mi_ode_persist.h)
   int persist_grid;
   int persist_sleep_first, persist_sleep_poll;   // hand-off back-off (units of 64 clocks)
+  int persist_spin_limit;     // bound on the polls of one hand-off
   int init_tiles16;           // 1: before_integrate runs on the 16-row tile kernels (k_init_linear_mfma), grid = step_grid
   double* xrank_dev;          // device view of desc.xrank_host (registered), or null
   double* gbuf;               // device: the global record WG 0 broadcasts after a cross-rank hand-off (2 parities)
