@@ -20,12 +20,14 @@ t_start = time.time()
 for it in range(n_runs):
     kind = rng.choice(['lorenz', 'lv', 'spiral', 'linear', 'mlp'])
     method = rng.choice(['dopri5', 'tsit5', 'bosh3'])
+    if kind in ('lorenz', 'lv', 'spiral') and rng.random() < 0.3:
+        method = rng.choice(['dopri8', 'adaptive_heun'])       # wide / non-FSAL tableaus: row-local kernels only
     dtype = torch.float64 if (kind != 'mlp' and rng.random() < 0.7) else torch.float32
     if kind == 'mlp':
         dtype = torch.float32
     tol = dict(rtol=10.0 ** rng.uniform(-7, -4), atol=10.0 ** rng.uniform(-9, -6)) if dtype == torch.float64 else dict(rtol=1e-4, atol=1e-6)
     T = int(rng.integers(2, 12))
-    span = 10.0 ** rng.uniform(-1.5, 0.3) * (0.05 if method == 'bosh3' else 1.0)
+    span = 10.0 ** rng.uniform(-1.5, 0.3) * (0.05 if method in ('bosh3', 'adaptive_heun') else 1.0)
     t = torch.tensor(np.sort(np.concatenate([[0.0], rng.uniform(0, span, size=T - 1)])))
     if (t[1:] - t[:-1]).min() <= 0:
         continue
