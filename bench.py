@@ -113,6 +113,11 @@ def main():
                     help="'stage': one kernel per RK stage (34 planes/attempt, HBM-bound); 'step': whole attempt in one kernel; "
                          "'whole'/'auto' (single GPU): the whole call in one launch")
     args = ap.parse_args()
+    # stdout carries exactly ONE line (the JSON result): libraries that print to file descriptor 1 (RCCL's start-up
+    # banner does) are sent to stderr for the duration of the run
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import torch.distributed as dist
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -274,7 +279,8 @@ def main():
             res['cpu_baseline'] = cpu_baseline()
         else:
             res['cpu_baseline'] = None
-        print(json.dumps(res))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(res) + '\n').encode())
     if use_dist:
         dist.destroy_process_group()
 
