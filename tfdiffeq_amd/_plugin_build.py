@@ -13,18 +13,35 @@ FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-ffp-contract=o
 _loaded = {}
 
 
+def _owned_private(path):
+    """True if `path` belongs to this user and nobody else may write to it (what gets dlopen'ed must not be
+    plantable by another account of the host)."""
+    try:
+        st = os.stat(path)
+    except OSError:
+        return False
+    return st.st_uid == os.getuid() and (st.st_mode & 0o022) == 0
+
+
 def plugin_dir():
     d = os.environ.get('TFDIFFEQ_AMD_PLUGIN_DIR')
     if not d:
         d = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_plugins')      # in-tree: travels with the checkout
     try:
-        os.makedirs(d, exist_ok=True)
-        if os.access(d, os.W_OK):
+        os.makedirs(d, mode=0o755, exist_ok=True)
+        if os.access(d, os.W_OK) and _owned_private(d):
             return d
     except OSError:
         pass
-    d = os.path.join(tempfile.gettempdir(), 'tfdiffeq_amd_plugins')
-    os.makedirs(d, exist_ok=True)
+    # package directory not writable (site-packages install): a per-user cache, never a world-shared /tmp path
+    base = os.environ.get('XDG_CACHE_HOME') or os.path.join(os.path.expanduser('~'), '.cache')
+    d = os.path.join(base, 'tfdiffeq_amd', 'plugins')
+    try:
+        os.makedirs(d, mode=0o700, exist_ok=True)
+    except OSError:
+        d = tempfile.mkdtemp(prefix='tfdiffeq_amd_plugins_')                            # 0700, unpredictable name
+    if not _owned_private(d):
+        raise N.NativeError('refusing to use the plugin cache %s: it is not owned by this user or is writable by others' % d)
     return d
 
 
@@ -42,6 +59,8 @@ def build(source, verbose=False):
     key = hashlib.sha256((source + _headers_digest() + ' '.join(FLAGS)).encode()).hexdigest()[:24]
     out = os.path.join(plugin_dir(), 'rhs_%s.so' % key)
     if os.path.exists(out):
+        if not _owned_private(out):
+            raise N.NativeError('refusing to load %s: not owned by this user or writable by others' % out)
         return out
     src = out[:-3] + '.hip'
     with open(src, 'w') as fh:

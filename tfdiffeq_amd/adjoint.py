@@ -55,8 +55,14 @@ class _OdeintAdjointMethod(torch.autograd.Function):
                 tt_ = tt.detach().requires_grad_(True)
                 y_ = tuple(v.detach().requires_grad_(True) for v in y)
                 func_eval = func(tt_, y_)
-                vjp = torch.autograd.grad(func_eval, (tt_,) + y_ + f_params, tuple(-a for a in adj_y),
-                                          allow_unused=True, retain_graph=False)
+                # a derivative with no autograd dependence on (t, y, params) - a constant or forcing-only RHS - has zero
+                # vjps (the reference asks for UnconnectedGradients.ZERO, adjoint.py:83-95); autograd.grad would raise
+                live = [(f_, -a) for f_, a in zip(func_eval, adj_y) if f_.requires_grad]
+                if live:
+                    vjp = torch.autograd.grad([f_ for f_, _ in live], (tt_,) + y_ + f_params, [a for _, a in live],
+                                              allow_unused=True, retain_graph=False)
+                else:
+                    vjp = (None,) * (1 + n_tensors + len(f_params))
             vjp_t, vjp_y, vjp_params = vjp[0], vjp[1:1 + n_tensors], vjp[1 + n_tensors:]
             vjp_t = torch.zeros_like(tt) if vjp_t is None else vjp_t
             vjp_y = tuple(torch.zeros_like(v) if g is None else g for g, v in zip(vjp_y, y))

@@ -41,6 +41,17 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     Raises ValueError (options without method), KeyError (unknown method), TypeError (non-floating inputs),
     AssertionError (non-monotone t, dt underflow, non-finite state, max_num_steps) - as the reference does.
     """
+    if _wants_grad(func, y0):
+        # The reference back-propagates through the solver's eager ops (odeint.py:28-81 under a GradientTape).  The
+        # kernels here are not taped: gradients come from the adjoint solve, which integrates the same system.
+        import torch
+        if isinstance(func, torch.nn.Module):
+            from .adjoint import odeint_adjoint
+            _warn_once('odeint: inputs require grad - gradients are computed with the adjoint method (odeint_adjoint)')
+            return odeint_adjoint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)
+        raise RuntimeError('odeint: y0 requires grad but `func` is not a torch.nn.Module, so no gradient can be returned '
+                           '(the kernels are not recorded by autograd). Wrap f in a torch.nn.Module (gradients then come '
+                           'from odeint_adjoint), or call under torch.no_grad() / detach y0.')
     tensor_input, func, y0, t = _check_inputs(func, y0, t)
 
     if options is None:
@@ -59,3 +70,21 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
 
 
 odeint.last_stats = {}
+_warned = set()
+
+
+def _warn_once(msg):
+    if msg not in _warned:
+        _warned.add(msg)
+        import warnings
+        warnings.warn(msg, stacklevel=3)
+
+
+def _wants_grad(func, y0):
+    import torch
+    if not torch.is_grad_enabled():
+        return False
+    ys = y0 if isinstance(y0, (tuple, list)) else (y0,)
+    if any(isinstance(y, torch.Tensor) and y.requires_grad for y in ys):
+        return True
+    return isinstance(func, torch.nn.Module) and any(p.requires_grad for p in func.parameters())
