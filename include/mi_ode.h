@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI_ODE_ABI_VERSION 4
+#define MI_ODE_ABI_VERSION 5
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -209,6 +209,61 @@ int mi_ode_get_state(mi_ode_handle h, void* y_dev, void* f_dev, void* stream);
 int64_t mi_ode_xrank_bytes(int32_t world_size);
 int mi_ode_xrank_selftest(mi_ode_handle h, void* stream);
 int mi_ode_xrank_enable(mi_ode_handle h, int32_t on);
+
+/* The same hand-off through PEER DEVICE MEMORY - the transport for the GPUs of one xGMI node (the only
+ * cross-rank traffic of the path is one 6-double record per rank per step attempt; no reference counterpart, the
+ * reference is single-device).  Every rank owns a mailbox in its own HBM:
+ *   mi_ode_xpeer_prepare  allocates it (uncached device memory, mi_ode_xrank_bytes(world_size) bytes, zeroed) and returns
+ *                         its hipIpcMemHandle_t (MI_ODE_IPC_HANDLE_BYTES bytes) for the caller to all-gather over any
+ *                         channel it has (torch.distributed in the Python shim, MPI, a file ...);
+ *   mi_ode_xpeer_connect  takes the handles of ALL ranks in rank order, maps the peers' mailboxes into this process
+ *                         (hipIpcOpenMemHandle; entry `rank` is this rank's own allocation) and hands the pointer table
+ *                         to the kernels.  From then on mi_ode_xrank_selftest / mi_ode_xrank_enable use this transport
+ *                         (it takes precedence over xrank_host): each rank's gateway lane q stores the rank record
+ *                         into rank q's mailbox over the link to q and polls only its own, local mailbox.
+ * Both return 0 or a negative error; a failure leaves the handle on its previous transport. */
+#define MI_ODE_IPC_HANDLE_BYTES 64
+int mi_ode_xpeer_prepare(mi_ode_handle h, void* ipc_handle_out);
+int mi_ode_xpeer_connect(mi_ode_handle h, const void* all_ipc_handles, int32_t world_size);
+
+/* RCCL from inside the library, for the launch-per-attempt schedule (ranks on several nodes, or no usable mailbox):
+ * the per-attempt record exchange becomes ncclAllGather(send, recv, 8, ncclDouble, comm, stream) enqueued by
+ * libmi_ode itself between the attempt kernel and the controller kernel - no callback into the host language.
+ * librccl is taken from the process if it is already loaded (PyTorch-ROCm ships one), else dlopen'ed.
+ *   mi_ode_rccl_unique_id   ncclGetUniqueId into id_out (MI_ODE_RCCL_ID_BYTES bytes); rank 0 calls it and broadcasts the bytes;
+ *   mi_ode_rccl_connect     ncclCommInitRank(world_size, id, rank) (collective over the ranks); the communicator belongs to the
+ *                           handle and is destroyed with it.  Takes precedence over mi_ode_desc.allgather.  id == NULL: drop the
+ *                           communicator again (when some rank could not join, every rank has to fall back together). */
+#define MI_ODE_RCCL_ID_BYTES 128
+int mi_ode_rccl_unique_id(void* id_out);
+int mi_ode_rccl_connect(mi_ode_handle h, const void* id, int32_t world_size, int32_t rank);
+
+/* ---- function-level parity surface of the step controller ----------------------------------- */
+/* The scalar tail of one step attempt exactly as the kernels run it (csrc/mi_ode_ctrl_dev.h, ONE device thread per case):
+ *   phase 2 (attempt): misc._compute_error_ratio's scalar part + accept test + misc._optimal_step_size / tsit5._optimal_step_size
+ *                      (misc.py:256-287, tsit5.py:53-62, dopri5.py:103-121)
+ *   phase 0 / 1      : the two halves of misc._select_initial_step (misc.py:227-245)
+ * on caller-supplied numbers, so that the DEVICE arithmetic can be driven with the reference's own vectors.
+ * in[c]  (8 doubles per case): {max|y0|, max|y1|, sum_a, sum_b, nonfinite flag, N (elements behind the sums), -, -}
+ * st[c]  (4 doubles per case): {t1, dt, h0, d1}   (rk_state.t1 / rk_state.dt; h0, d1: what phase 0 produced, for phase 1)
+ * out[c] (8 doubles per case): {ratio, accepted, dt_next, t1_next, t0_next, status bits, h0, d0 (phase 0) | d1 in out[c][6..7]}
+ *          phase 0 writes {-, -, -, -, -, -, h0, d0} and d1 into out[c][2]; phase 1 writes the first step size into out[c][2].
+ * All pointers are HOST memory; the call is synchronous. */
+typedef struct mi_ode_ctrl_params {
+  double rtol, atol, safety, ifactor, dfactor;   /* safety / ifactor / dfactor: the float32-rounded values (misc.py:137-144) */
+  int32_t order, init_order;                     /* dopri5.py:68,74 */
+  int32_t controller;                            /* enum mi_ode_controller */
+  int32_t dtype;                                 /* enum mi_ode_dtype of the STATE: float32 states take the float32 detours */
+} mi_ode_ctrl_params;
+int mi_ode_controller_update(const mi_ode_ctrl_params* p, int32_t phase, int32_t n_cases, const double* in_host,
+                             const double* st_host, double* out_host, void* stream);
+/* y_sigma = y0 + add_n((dt * beta_j) * k_j)  - one stage combination of rk_common._runge_kutta_step (rk_common.py:51);
+ * the same kernel as mi_ode_lincomb, under the name SURVEY.md 8(b) gives it */
+int mi_ode_rk_stage_combine(int32_t dtype, int64_t n, const void* y0_dev, const void* const* k_dev, const double* beta_row,
+                            int32_t n_k, double dt, void* out_dev, void* stream);
+/* {max|y0|, max|y1|, sum err^2, nonfinite} of one attempt (misc.py:256-263): mi_ode_error_norms under its 8(b) name */
+int mi_ode_rk_error_reduce(int32_t dtype, int64_t n, const void* err_dev, const void* y0_dev, const void* y1_dev,
+                           double* result_dev, void* workspace_dev, void* stream);
 
 /* ---- (B) stateless plane kernels (arbitrary Python f, tuple states) ------------------------- */
 /* out[i] = (base ? base[i] : 0) + sum_j (scale * coef[j]) * xs[j][i]       (misc.py:118-121; zeros not skipped) */

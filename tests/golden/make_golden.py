@@ -519,7 +519,52 @@ def gen_adams():
     adams.VariableCoefficientAdamsBashforth._adaptive_adams_step = orig
 
 
+# --------------------------------------------------------------------------
+# DETEST (tests/DETEST/detest.py:9-351, run.py:25-60): the reference's 25 known-problem set, solved by the reference
+# --------------------------------------------------------------------------
+def gen_detest():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('ref_detest', '/root/reference/tests/DETEST/detest.py')
+    detest = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(detest)
+    out, skipped = {}, []
+    names = [c + i for c in 'ABCDE' for i in '12345']
+    for name in names:
+        diffeq, init, _ = getattr(detest, name)()
+        t0, y0 = init()
+
+        class Counted(object):
+            def __init__(self, f):
+                self.f, self.nfe = f, 0
+
+            def __call__(self, t, y):
+                self.nfe += 1
+                return self.f(t, y)
+        tgrid = tf.stack([t0, tf.convert_to_tensor(20., dtype=tf.float64)])
+        try:
+            rows = []
+            for tol in (1e-3, 1e-6):
+                fc = Counted(diffeq)
+                orig, log = _trace_solver(*TRACED['dopri5'])
+                try:
+                    est = tfdiffeq.odeint(fc, y0, tgrid, atol=tol, rtol=tol, method='dopri5')
+                finally:
+                    setattr(TRACED['dopri5'][0], TRACED['dopri5'][1], orig)
+                out['%s_y20_tol%g' % (name, tol)] = np.asarray(est[1]._a)
+                rows.append((tol, fc.nfe, len(log), int(sum(r[2] for r in log))))
+            out[name + '_y0'] = np.asarray(y0._a)
+            out[name + '_runs'] = np.asarray(rows)            # (tol, nfe, attempts, accepted)
+        except Exception as e:                               # a problem the stand-in cannot carry
+            skipped.append((name, repr(e)[:200]))
+    save('fn_detest', {'t_end': 20.0, 'method': 'dopri5', 'tols': [1e-3, 1e-6], 'skipped': skipped,
+                       'run_columns': ['tol', 'nfe', 'attempts', 'accepted']}, **out)
+    print('detest: %d problems captured, skipped: %s' % (len([k for k in out if k.endswith('_runs')]), skipped))
+
+
 if __name__ == '__main__':
+    if '--detest-only' in sys.argv:
+        gen_detest()
+        sys.exit(0)
     np.random.seed(0)
     if '--next-only' not in sys.argv and '--adams-only' not in sys.argv:
         gen_function_vectors()
@@ -527,3 +572,4 @@ if __name__ == '__main__':
     if '--adams-only' not in sys.argv:
         gen_next_solvers()
     gen_adams()
+    gen_detest()

@@ -175,7 +175,9 @@ def convert_to_tensor(value, dtype=None, **_):
             a = np.stack([_np_of(v, like=tdt[0]) for v in value])
         else:
             a = np.asarray(value)
-            if a.dtype == np.float64:
+            if dtype is not None and a.dtype.kind in 'fi':
+                a = a.astype(np.dtype(dtype))          # TF converts python numbers straight to the requested dtype
+            elif a.dtype == np.float64:
                 a = a.astype(np.float32)
             elif a.dtype == np.int64:
                 a = a.astype(np.int32)
@@ -295,6 +297,14 @@ def concat(xs, axis=0, **_):
 
 def expand_dims(x, axis, **_):
     return Tensor(np.expand_dims(_t(x)._a, axis))
+
+
+def transpose(x, perm=None, **_):
+    return Tensor(np.transpose(_t(x)._a, perm))
+
+
+def squeeze(x, axis=None, **_):
+    return Tensor(np.squeeze(_t(x)._a, axis=axis))
 
 
 def zeros(shape, dtype=float32, **_):

@@ -494,7 +494,7 @@ d = odeint(rhs.Linear.from_matrix(A), y4, torch.tensor([0., 1.]), rtol=1e-6, ato
 sd = dict(odeint.last_stats)
 print(json.dumps({'diff': float((a - b).abs().max()), 'att_a': sa['n_attempts'], 'att_b': sb['n_attempts'],
                   'launch_a': sa['n_launches'], 'launch_b': sb['n_launches'], 'diff4': float((c - d).abs().max()),
-                  'launch_d': sd['n_launches']}))
+                  'launch_d': sd['n_launches'], 'transport': sb['cross_rank'], 'transport4': sd['cross_rank']}))
 dist.destroy_process_group()
 """
 
@@ -518,20 +518,26 @@ def _run_hook_script(extra_env):
     return json.loads(lines[-1])
 
 
-def test_exchange_hook_path_on_one_gpu():
-    """The N > 1 fallback control path (k_reduce_partials -> RCCL all-gather hook -> k_controller over rank records)
-    with a 1-rank group must reproduce the hook-free path bit for bit."""
-    out = _run_hook_script({'TFDIFFEQ_AMD_XRANK': '0'})
+@pytest.mark.parametrize('mode,needle', [('hook', 'hook'), ('rccl', 'ncclAllGather')])
+def test_launch_per_attempt_exchange_on_one_gpu(mode, needle):
+    """The launch-per-attempt control path of sharded runs (k_reduce_partials -> all-gather of the rank records ->
+    k_controller over them) with a 1-rank RCCL group must reproduce the exchange-free path bit for bit - with the all-gather
+    issued by libmi_ode itself (ncclAllGather resolved from the process' librccl, mi_ode_rccl_connect) and with the
+    torch.distributed callback it falls back to."""
+    out = _run_hook_script({'TFDIFFEQ_AMD_XRANK': mode})
     assert out['diff'] == 0.0 and out['diff4'] == 0.0, out
     assert out['att_a'] == out['att_b'] and out['launch_b'] > out['launch_a'], out
+    assert needle in out['transport'] and needle in out['transport4'], out
 
 
-def test_cross_rank_handoff_path_on_one_gpu():
-    """The N > 1 default: whole-call kernels with the cross-rank hand-off through a registered /dev/shm segment (self-test
-    + enable through the 1-rank group): one launch per call, same bits as the single-rank run."""
-    out = _run_hook_script({})
+@pytest.mark.parametrize('mode,needle', [('peer', 'peer device memory'), ('host', 'host segment'), ('1', 'peer device memory')])
+def test_cross_rank_handoff_path_on_one_gpu(mode, needle):
+    """The in-kernel hand-off of sharded runs - mailboxes in peer device memory (hipIpc; the default) or the /dev/shm
+    segment - self-tested and enabled through the 1-rank group: one launch per call, same bits as the single-rank run."""
+    out = _run_hook_script({'TFDIFFEQ_AMD_XRANK': mode})
     assert out['diff'] == 0.0 and out['diff4'] == 0.0, out
     assert out['att_a'] == out['att_b'] and out['launch_b'] == 1 and out['launch_d'] == 1, out
+    assert needle in out['transport'] and needle in out['transport4'], out
 
 
 _TWO_RANK_SCRIPT = r"""
@@ -557,7 +563,7 @@ for method in ('dopri5', 'tsit5'):
     sr = dict(odeint.last_stats)
     mine = ref[:, lo:hi]
     out[method] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
-                   'launches': sb['n_launches'], 'status': sb['status']}
+                   'launches': sb['n_launches'], 'status': sb['status'], 'transport': sb['cross_rank']}
 # the MFMA tile kernel (linear RHS, dim 128) and the MLP kernel with the same cross-rank hand-off: small shards so that both
 # processes' persistent grids fit on the one GPU together
 g2 = torch.Generator().manual_seed(2)
@@ -595,11 +601,14 @@ dist.destroy_process_group()
 """
 
 
+@pytest.mark.parametrize('mode,needle', [('peer', 'peer device memory'), ('host', 'host segment')])
 @pytest.mark.parametrize('world', [2, 4])
-def test_cross_rank_handoff_two_processes_share_the_gpu(world):
+def test_cross_rank_handoff_two_processes_share_the_gpu(world, mode, needle):
     """`world` ranks (separate processes, gloo group, all on cuda:0) integrate uneven shards of one batch with the whole-call
-    kernel: every attempt's record crosses the processes through the shared host segment.  The global controller must
-    reproduce the single-rank step sequence of the whole batch (sums are folded in a different order: 1e-12)."""
+    kernel: every attempt's record crosses the processes - pushed into the peers' mailboxes in device memory (each process
+    maps the others' allocations with hipIpcOpenMemHandle; on a multi-GPU node the same stores ride xGMI) or through the
+    shared host segment.  The global controller must reproduce the single-rank step sequence of the whole batch (sums are
+    folded in a different order: 1e-12)."""
     import json
     import os
     import socket
@@ -612,7 +621,8 @@ def test_cross_rank_handoff_two_processes_share_the_gpu(world):
     procs = []
     for rank in range(world):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                   REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY='0')
+                   REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   TFDIFFEQ_AMD_XRANK=mode)
         procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p_ in procs:
@@ -630,6 +640,7 @@ def test_cross_rank_handoff_two_processes_share_the_gpu(world):
         for method, r_ in o['out'].items():
             assert r_['status'] == 0 and r_['launches'] == 1, (o['rank'], method, r_)
             assert r_['att'] == r_['att_ref'] and r_['diff'] < (1e-4 if method == 'mlp' else 1e-10), (o['rank'], method, r_)
+            assert needle in r_.get('transport', needle), (o['rank'], method, r_)
 
 
 # ---------------------------------------------------------------------------------------------

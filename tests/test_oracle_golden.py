@@ -231,3 +231,62 @@ def test_next_solver_function_vectors():
         _close(np.stack(k[0]), d[name + '_k'], 1e-13, name + ' k')
         coeff = O.interp_fit_mid((y0,), y1, k, dt, cm)
         _close(O.interp_evaluate(coeff, t0, t0 + dt, t0 + 0.3 * dt)[0], d[name + '_interp_eval'], 1e-12, name + ' dense')
+
+
+# ---------------------------------------------------------------------------------------------
+# the torch-CPU eager restatement that bench.py times as `cpu_baseline` (oracle/ode_torch_cpu.py)
+# ---------------------------------------------------------------------------------------------
+def _torch_rhs(meta):
+    import torch
+    p = meta['rhs_params']
+    if meta['rhs'] == 'linear':
+        W = torch.tensor(p['W'], dtype=torch.float64)
+        return lambda t, y: y @ W
+    if meta['rhs'] == 'cubic_linear':
+        W = torch.tensor(p['W'], dtype=torch.float64)
+        return lambda t, y: (y ** 3) @ W
+    if meta['rhs'] == 'lorenz':
+        s, be, r = p['sigma'], p['beta'], p['rho']
+        return lambda t, y: torch.stack([s * (y[..., 1] - y[..., 0]), y[..., 0] * (r - y[..., 2]) - y[..., 1],
+                                         y[..., 0] * y[..., 1] - be * y[..., 2]], -1)
+    a, b, c, d = p['a'], p['b'], p['c'], p['d']
+    return lambda t, y: torch.stack([a * y[..., 0] - b * y[..., 0] * y[..., 1], -c * y[..., 1] + d * y[..., 0] * y[..., 1]], -1)
+
+
+@pytest.mark.parametrize('name', ['run_linear_b48_d16_dopri5', 'run_linear_b48_d16_dopri5_T5', 'run_spiral_b64_dopri5',
+                                  'run_lorenz_b64_dopri5', 'run_lv_b32_dopri5'])
+def test_torch_cpu_restatement_reproduces_reference_runs(name):
+    """Same solution (fp64 <= 1e-12) and the IDENTICAL accept / reject sequence as the reference's own run."""
+    import torch
+    from oracle import ode_torch_cpu as TC
+    d, meta = load(name)
+    kw = {}
+    if meta['rtol'] is not None:
+        kw['rtol'] = meta['rtol']
+    if meta['atol'] is not None:
+        kw['atol'] = meta['atol']
+    sol, st = TC.odeint_dopri5(_torch_rhs(meta), torch.tensor(d['y0']), d['t'], **kw)
+    assert np.abs(sol.numpy() - d['y']).max() < 1e-12
+    assert st.n_attempts == len(d['trace']) and st.n_accepted == int(d['trace'][:, 2].sum())
+    assert st.nfe == 2 + 6 * st.n_attempts
+
+
+# ---------------------------------------------------------------------------------------------
+# DETEST (tests/DETEST/detest.py:9-351): the restated problem set + the oracle against the reference's own results
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', [c + i for c in 'ABCDE' for i in '12345'])
+def test_detest_problem_matches_the_reference_run(name):
+    """Every problem from t = 0 to 20 with dopri5 at tol 1e-3 and 1e-6 (run.py:25-60): the oracle on the restated problem
+    takes the IDENTICAL accept / reject sequence and NFE as the reference did and lands on the same y(20)."""
+    from oracle import detest_problems as DP
+    d, meta = load('fn_detest')
+    f, y0 = DP.problem(name, np)
+    np.testing.assert_array_equal(np.asarray(y0), d[name + '_y0'])
+    for tol, nfe, att, acc in d[name + '_runs']:
+        with np.errstate(all='ignore'):
+            sol, st = O.odeint(f, np.asarray(y0), np.array([0., DP.T_END]), rtol=tol, atol=tol, method='dopri5', return_stats=True)
+        assert (st.nfe, st.n_attempts, st.n_accepted) == (int(nfe), int(att), int(acc)), (name, tol)
+        ref = d['%s_y20_tol%g' % (name, tol)]
+        assert np.abs(sol[1] - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max()), (name, tol)
+        if name in DP.EXACT and tol == 1e-6:
+            assert abs(float(sol[1]) - DP.EXACT[name](DP.T_END)) < 2e-5 * max(1.0, abs(DP.EXACT[name](DP.T_END)))

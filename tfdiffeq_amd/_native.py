@@ -21,7 +21,9 @@ F32, F64 = 0, 1
 RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH, RHS_PLUGIN = 1, 2, 3, 4, 5, 6
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
-ABI_VERSION = 4
+ABI_VERSION = 5
+IPC_HANDLE_BYTES = 64
+RCCL_ID_BYTES = 128
 ST_DT_UNDERFLOW, ST_NONFINITE, ST_MAX_STEPS, ST_BAD_T, ST_SYNC_TIMEOUT = 1, 2, 4, 8, 16
 
 
@@ -62,6 +64,11 @@ class Desc(C.Structure):
                 ('xrank_host', C.c_void_p), ('xrank_bytes', C.c_int64)]
 
 
+class CtrlParams(C.Structure):
+    _fields_ = [('rtol', C.c_double), ('atol', C.c_double), ('safety', C.c_double), ('ifactor', C.c_double), ('dfactor', C.c_double),
+                ('order', C.c_int32), ('init_order', C.c_int32), ('controller', C.c_int32), ('dtype', C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [('n_attempts', C.c_int64), ('n_accepted', C.c_int64), ('n_rejected', C.c_int64), ('nfe', C.c_int64),
                 ('t', C.c_double), ('dt', C.c_double), ('last_ratio', C.c_double),
@@ -92,9 +99,19 @@ _PROTOS = {
     'mi_ode_xrank_bytes': (C.c_int64, [C.c_int32]),
     'mi_ode_xrank_selftest': (C.c_int, [C.c_void_p, C.c_void_p]),
     'mi_ode_xrank_enable': (C.c_int, [C.c_void_p, C.c_int32]),
+    'mi_ode_xpeer_prepare': (C.c_int, [C.c_void_p, C.c_void_p]),
+    'mi_ode_xpeer_connect': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32]),
+    'mi_ode_rccl_unique_id': (C.c_int, [C.c_void_p]),
+    'mi_ode_rccl_connect': (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]),
     'mi_ode_get_stats': (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     'mi_ode_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mi_ode_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    'mi_ode_controller_update': (C.c_int, [C.POINTER(CtrlParams), C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                           C.POINTER(C.c_double), C.c_void_p]),
+    'mi_ode_rk_stage_combine': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double),
+                                          C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
+    'mi_ode_rk_error_reduce': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p]),
     'mi_ode_lincomb': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double),
                                  C.c_int32, C.c_double, C.c_void_p, C.c_void_p]),
     'mi_ode_lincomb_dev': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double),

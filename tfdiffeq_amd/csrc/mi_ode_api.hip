@@ -1,5 +1,6 @@
 // libmi_ode.so - C ABI (include/mi_ode.h) of the MI355X-native explicit RK engine: handle
 // management, the host side of the attempt loop, and the stateless plane entry points.
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -50,6 +51,43 @@ extern "C" int64_t mi_ode_sizeof(int32_t which) {
     case 4: return (int64_t)sizeof(mi_ode_solver);          /* what a RHS plugin must have been compiled against */
     default: return -1;
   }
+}
+
+// ---- librccl, resolved at run time (the process usually has PyTorch-ROCm's copy loaded already) -------------------------
+typedef int (*nccl_get_unique_id_fn)(void*);
+typedef int (*nccl_comm_init_rank_fn)(void**, int, const void*, int);      // (ncclComm_t*, nranks, ncclUniqueId by value, rank)
+typedef int (*nccl_all_gather_fn)(const void*, void*, size_t, int, void*, hipStream_t);
+typedef int (*nccl_comm_destroy_fn)(void*);
+typedef const char* (*nccl_error_string_fn)(int);
+struct NcclUniqueId { char internal[MI_ODE_RCCL_ID_BYTES]; };
+typedef int (*nccl_comm_init_rank_byval_fn)(void**, int, NcclUniqueId, int);
+static struct {
+  int tried, ok;
+  nccl_get_unique_id_fn get_id;
+  nccl_comm_init_rank_byval_fn init_rank;
+  nccl_all_gather_fn all_gather;
+  nccl_comm_destroy_fn destroy;
+  nccl_error_string_fn err;
+} g_nccl;
+
+static int load_rccl() {
+  if (g_nccl.tried) return g_nccl.ok ? 0 : MI_ODE_E_EXCHANGE;
+  g_nccl.tried = 1;
+  void* lib = RTLD_DEFAULT;
+  if (dlsym(RTLD_DEFAULT, "ncclAllGather") == nullptr) {
+    lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (lib == nullptr) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib == nullptr) lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (lib == nullptr) { mi_set_error("librccl not found: %s", dlerror()); return MI_ODE_E_EXCHANGE; }
+  }
+  g_nccl.get_id = (nccl_get_unique_id_fn)dlsym(lib, "ncclGetUniqueId");
+  g_nccl.init_rank = (nccl_comm_init_rank_byval_fn)dlsym(lib, "ncclCommInitRank");
+  g_nccl.all_gather = (nccl_all_gather_fn)dlsym(lib, "ncclAllGather");
+  g_nccl.destroy = (nccl_comm_destroy_fn)dlsym(lib, "ncclCommDestroy");
+  g_nccl.err = (nccl_error_string_fn)dlsym(lib, "ncclGetErrorString");
+  if (!g_nccl.get_id || !g_nccl.init_rank || !g_nccl.all_gather || !g_nccl.destroy) { mi_set_error("librccl lacks the expected entry points"); return MI_ODE_E_EXCHANGE; }
+  g_nccl.ok = 1;
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -137,17 +175,25 @@ static int enqueue_attempt_kernels(mi_ode_solver* h, hipStream_t st, hipEvent_t 
 // reduce -> (exchange) -> controller
 static int enqueue_controller(mi_ode_solver* h, int phase, hipStream_t st) {
   const int nblocks = ((phase == PH_ATTEMPT && h->step_fused) || h->init_tiles16) ? h->step_grid : h->stage_grid;
-  if (h->d.world_size > 1 || h->d.allgather != nullptr) {
+  if (h->d.world_size > 1 || h->d.allgather != nullptr || h->nccl_comm != nullptr) {
     hipLaunchKernelGGL(k_reduce_partials, dim3(1), dim3(256), 0, st, (const Ctl*)h->ctl, (const double*)h->partials,
                        nblocks, h->n, h->rank_rec);
-    if (h->d.allgather == nullptr) {
-      mi_set_error("world_size > 1 needs an allgather hook");
-      return MI_ODE_E_INVALID;
-    }
-    const int rc = h->d.allgather(h->d.allgather_user, h->rank_rec, h->gathered, kRec, (void*)st);
-    if (rc != 0) {
-      mi_set_error("allgather hook returned %d", rc);
-      return MI_ODE_E_EXCHANGE;
+    if (h->nccl_comm != nullptr) {                 // RCCL straight from here: stream-ordered between the two kernels
+      const int nrc = g_nccl.all_gather(h->rank_rec, h->gathered, (size_t)kRec, /*ncclDouble*/ 8, h->nccl_comm, st);
+      if (nrc != 0) {
+        mi_set_error("ncclAllGather failed: %s", g_nccl.err ? g_nccl.err(nrc) : "?");
+        return MI_ODE_E_EXCHANGE;
+      }
+    } else {
+      if (h->d.allgather == nullptr) {
+        mi_set_error("world_size > 1 needs mi_ode_rccl_connect or an allgather hook");
+        return MI_ODE_E_INVALID;
+      }
+      const int rc = h->d.allgather(h->d.allgather_user, h->rank_rec, h->gathered, kRec, (void*)st);
+      if (rc != 0) {
+        mi_set_error("allgather hook returned %d", rc);
+        return MI_ODE_E_EXCHANGE;
+      }
     }
     hipLaunchKernelGGL(k_controller, dim3(1), dim3(256), 0, st, h->ctl, (const double*)nullptr, 0,
                        (const double*)h->gathered, (int)h->d.world_size, phase, h->cp);
@@ -302,7 +348,20 @@ static void fill_mlp_args(mi_ode_solver* h, MlpArgs& M) {
   M.rtol = h->d.rtol; M.atol = h->d.atol; M.hidden = h->d.rhs.hidden;
 }
 
+static void close_peers(mi_ode_solver* h) {
+  for (int q = 0; q < h->xpeer_world && q < 64; ++q)
+    if (h->xpeer_open[q] != nullptr && h->xpeer_open[q] != h->xpeer_local) (void)hipIpcCloseMemHandle(h->xpeer_open[q]);
+  memset(h->xpeer_open, 0, sizeof(h->xpeer_open));
+  h->xpeer_world = 0;
+  if (h->xpeer_tab_dev) { (void)hipFree(h->xpeer_tab_dev); h->xpeer_tab_dev = nullptr; }
+}
+
 extern "C" int mi_ode_destroy(mi_ode_handle h) {
+  if (h != nullptr) {
+    close_peers(h);
+    if (h->xpeer_local) { (void)hipFree(h->xpeer_local); h->xpeer_local = nullptr; }
+    if (h->nccl_comm && g_nccl.ok) { (void)g_nccl.destroy(h->nccl_comm); h->nccl_comm = nullptr; }
+  }
   if (h != nullptr && h->xrank_registered) { (void)hipHostUnregister(h->d.xrank_host); h->xrank_registered = 0; }
   if (h != nullptr && h->gbuf) { (void)hipFree(h->gbuf); h->gbuf = nullptr; }
   if (h == nullptr) return 0;
@@ -414,19 +473,23 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       }
       h->xrank_dev = (double*)dptr;
     }
-    bool can = desc->adaptive && (rowlocal || mfma || mlp) && (single || h->xrank_dev != nullptr) && g <= kPersistMaxGrid;
-    if (can) {
+    bool capable = desc->adaptive && (rowlocal || mfma || mlp) && g <= kPersistMaxGrid;
+    if (capable) {
       const int cap = mlp ? mi_persist_capacity_mlp_f32(h) : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
-      can = cap > 0 && g <= cap;
+      capable = cap > 0 && g <= cap;
     }
-    if (desc->fusion == 4 && !can) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local or MFMA-linear RHS, single rank, every workgroup co-resident)"); delete h; return MI_ODE_E_INVALID; }
+    h->persist_capable = capable ? 1 : 0;          // (a peer mailbox connected later can still switch the one-launch schedule on)
+    const bool can = capable && (single || h->xrank_dev != nullptr);
+    if (desc->fusion == 4 && !can && single) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local or MFMA-linear RHS, single rank, every workgroup co-resident)"); delete h; return MI_ODE_E_INVALID; }
     h->persist = (can && (desc->fusion == 4 || desc->fusion == 0)) ? 1 : 0;
     h->persist_grid = (int)g;
     h->persist_sleep_first = g <= 32 ? 16 : 32;
     h->persist_sleep_poll = 2;
     if (const char* e0 = getenv("MI_ODE_PERSIST_SLEEP0")) h->persist_sleep_first = atoi(e0);      // tuning sweeps (scripts/gpu_persist_sweep.sh)
     if (const char* e1 = getenv("MI_ODE_PERSIST_SLEEP1")) h->persist_sleep_poll = atoi(e1);
-    h->persist_spin_limit = 1 << 21;              // a few seconds
+    h->persist_spin_limit = 1 << 17;              // ~0.2 s of polling: skew between resident workgroups never gets near it
+    h->persist_spin_first = 1 << 12;              // first hand-off of a launch = residency check: ~5 ms (a poll round is ~1 us)
+    if (const char* e3 = getenv("MI_ODE_PERSIST_SPIN_FIRST")) h->persist_spin_first = atoi(e3);
     if (const char* e2 = getenv("MI_ODE_PERSIST_SPIN_LIMIT")) h->persist_spin_limit = atoi(e2);  // tests: force the time-out path
   }
   // controller / dense-output parameters
@@ -670,9 +733,11 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   A.first_dt = h->cp.auto_first_step ? 0.0 : h->d.first_step;
   for (int i = 0; i < n_out && i < kPersistTSmall; ++i) A.t_small[i] = t_host[1 + i];
   A.seq_base = h->seq;
-  if (h->xrank_on) { A.xrank = h->xrank_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank; }
-  else { A.world = 1; }
+  if (h->xrank_on) {
+    A.xrank = h->xrank_dev; A.xpeers = h->xpeer_tab_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank;
+  } else { A.world = 1; }
   A.spin_limit = h->persist_spin_limit;
+  A.spin_first = h->persist_spin_first < h->persist_spin_limit ? h->persist_spin_first : h->persist_spin_limit;
   // back-off before the first poll (units of 64 clocks): a failed poll round costs G x G record loads on the fabric, so
   // wait about as long as the publish needs to become visible (measured: G=16 best at <= 24, G=256 best at 32)
   A.sleep_first = h->persist_sleep_first; A.sleep_poll = h->persist_sleep_poll;
@@ -718,7 +783,7 @@ extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const doubl
       if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = MI_ODE_ST_BAD_T; }
       return MI_ODE_ST_BAD_T;                  // _assert_increasing (misc.py:158-159)
     }
-  const bool multi = h->d.world_size > 1 || h->d.allgather != nullptr;
+  const bool multi = h->d.world_size > 1 || h->d.allgather != nullptr || h->nccl_comm != nullptr;
   if (h->persist && T > 1 && h->d.adaptive && (!multi || h->xrank_on)) {
     const int prc = integrate_persist(h, y0_dev, t_host, T, out_dev, stats, st);
     if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4 || multi) return prc;   // (a rank must not change schedule alone)
@@ -744,12 +809,12 @@ extern "C" int64_t mi_ode_xrank_bytes(int32_t world_size) {
 
 extern "C" int mi_ode_xrank_selftest(mi_ode_handle h, void* stream) {
   if (h == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
-  if (h->xrank_dev == nullptr) { mi_set_error("no cross-rank segment registered"); return 1; }
+  if (h->xrank_dev == nullptr && h->xpeer_tab_dev == nullptr) { mi_set_error("no cross-rank mailbox or segment connected"); return 1; }
   hipStream_t st = (hipStream_t)stream;
   PersistArgs A;
   memset(&A, 0, sizeof(A));
-  A.xrank = h->xrank_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank;
-  A.spin_limit = 1 << 20;                       // several seconds: covers module-load skew between the ranks
+  A.xrank = h->xrank_dev; A.xpeers = h->xpeer_tab_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank;
+  A.spin_limit = A.spin_first = 1 << 20;        // several seconds: covers module-load skew between the ranks
   h->xrank_tests += 64u;
   A.seq_base = 0xF0000000u + (h->xrank_tests & 0x0FFFFFFu);   // disjoint from the numbers of real calls
   int* res_dev = (int*)h->ticket + 8;
@@ -763,8 +828,94 @@ extern "C" int mi_ode_xrank_selftest(mi_ode_handle h, void* stream) {
 
 extern "C" int mi_ode_xrank_enable(mi_ode_handle h, int32_t on) {
   if (h == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
-  if (on && h->xrank_dev == nullptr) { mi_set_error("no cross-rank segment registered"); return MI_ODE_E_INVALID; }
+  if (on && h->xrank_dev == nullptr && h->xpeer_tab_dev == nullptr) { mi_set_error("no cross-rank mailbox or segment connected"); return MI_ODE_E_INVALID; }
   h->xrank_on = on ? 1 : 0;
+  if (on && h->persist_capable && (h->d.fusion == 0 || h->d.fusion == 4)) h->persist = 1;   // the sharded run keeps the one-launch schedule
+  return 0;
+}
+
+// ---- peer-device-memory mailboxes (include/mi_ode.h) -----------------------------------------------------------------
+extern "C" int mi_ode_xpeer_prepare(mi_ode_handle h, void* ipc_handle_out) {
+  if (h == nullptr || ipc_handle_out == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  static_assert(sizeof(hipIpcMemHandle_t) <= MI_ODE_IPC_HANDLE_BYTES, "MI_ODE_IPC_HANDLE_BYTES too small");
+  if (h->d.world_size > kXMaxWorld) { mi_set_error("peer mailboxes: world_size <= %d", kXMaxWorld); return MI_ODE_E_INVALID; }
+  if (h->xpeer_local == nullptr) {
+    const size_t bytes = (size_t)mi_ode_xrank_bytes(h->d.world_size);
+    void* p = nullptr;
+    // uncached (MTYPE_UC) device memory: what a peer stores over xGMI must be what the local poll reads, no L2 copy in between
+    hipError_t e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached);
+    if (e != hipSuccess) { (void)hipGetLastError(); e = hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained); }
+    if (e != hipSuccess) { (void)hipGetLastError(); mi_set_error("peer mailbox allocation failed: %s", hipGetErrorString(e)); return MI_ODE_E_HIP; }
+    e = hipMemset(p, 0, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(p); mi_set_error("peer mailbox clear failed: %s", hipGetErrorString(e)); return MI_ODE_E_HIP; }
+    h->xpeer_local = p;
+  }
+  hipIpcMemHandle_t ih;
+  hipError_t e = hipIpcGetMemHandle(&ih, h->xpeer_local);
+  if (e != hipSuccess) { (void)hipGetLastError(); mi_set_error("hipIpcGetMemHandle failed: %s", hipGetErrorString(e)); return MI_ODE_E_HIP; }
+  memset(ipc_handle_out, 0, MI_ODE_IPC_HANDLE_BYTES);
+  memcpy(ipc_handle_out, &ih, sizeof(ih));
+  return 0;
+}
+
+extern "C" int mi_ode_xpeer_connect(mi_ode_handle h, const void* all_ipc_handles, int32_t world_size) {
+  if (h == nullptr || all_ipc_handles == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (h->xpeer_local == nullptr) { mi_set_error("mi_ode_xpeer_connect before mi_ode_xpeer_prepare"); return MI_ODE_E_INVALID; }
+  if (world_size != h->d.world_size || world_size < 1 || world_size > kXMaxWorld) { mi_set_error("peer mailboxes: bad world_size %d", world_size); return MI_ODE_E_INVALID; }
+  close_peers(h);
+  h->xpeer_world = world_size;
+  const char* hs = (const char*)all_ipc_handles;
+  for (int q = 0; q < world_size; ++q) {
+    if (q == h->d.rank) { h->xpeer_open[q] = h->xpeer_local; continue; }
+    hipIpcMemHandle_t ih;
+    memcpy(&ih, hs + (size_t)q * MI_ODE_IPC_HANDLE_BYTES, sizeof(ih));
+    void* p = nullptr;
+    const hipError_t e = hipIpcOpenMemHandle(&p, ih, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      mi_set_error("hipIpcOpenMemHandle(rank %d) failed: %s", q, hipGetErrorString(e));
+      close_peers(h);
+      return MI_ODE_E_HIP;
+    }
+    h->xpeer_open[q] = p;
+  }
+  hipError_t e = hipMalloc((void**)&h->xpeer_tab_dev, (size_t)kXMaxWorld * sizeof(double*));
+  if (e == hipSuccess) e = hipMemcpy(h->xpeer_tab_dev, h->xpeer_open, (size_t)world_size * sizeof(double*), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { mi_set_error("peer table upload failed: %s", hipGetErrorString(e)); close_peers(h); return MI_ODE_E_HIP; }
+  return 0;
+}
+
+extern "C" int mi_ode_rccl_unique_id(void* id_out) {
+  if (id_out == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  int rc = load_rccl();
+  if (rc != 0) return rc;
+  NcclUniqueId id;
+  memset(&id, 0, sizeof(id));
+  const int nrc = g_nccl.get_id(&id);
+  if (nrc != 0) { mi_set_error("ncclGetUniqueId failed: %s", g_nccl.err ? g_nccl.err(nrc) : "?"); return MI_ODE_E_EXCHANGE; }
+  memcpy(id_out, &id, sizeof(id));
+  return 0;
+}
+
+extern "C" int mi_ode_rccl_connect(mi_ode_handle h, const void* id, int32_t world_size, int32_t rank) {
+  if (h == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (id == nullptr) {                            // disconnect: back to the allgather hook (all ranks must take the same path)
+    if (h->nccl_comm && g_nccl.ok) (void)g_nccl.destroy(h->nccl_comm);
+    h->nccl_comm = nullptr;
+    return 0;
+  }
+  if (world_size != h->d.world_size || rank != h->d.rank) { mi_set_error("rccl_connect: world_size / rank differ from the handle's"); return MI_ODE_E_INVALID; }
+  int rc = load_rccl();
+  if (rc != 0) return rc;
+  if (h->nccl_comm) { (void)g_nccl.destroy(h->nccl_comm); h->nccl_comm = nullptr; }
+  NcclUniqueId uid;
+  memcpy(&uid, id, sizeof(uid));
+  void* comm = nullptr;
+  const int nrc = g_nccl.init_rank(&comm, world_size, uid, rank);
+  if (nrc != 0 || comm == nullptr) { mi_set_error("ncclCommInitRank failed: %s", g_nccl.err ? g_nccl.err(nrc) : "?"); return MI_ODE_E_EXCHANGE; }
+  h->nccl_comm = comm;
+  h->fused_ctl = 0;                               // the controller must see the gathered records: it runs as its own launch
   return 0;
 }
 
@@ -947,6 +1098,61 @@ extern "C" int mi_ode_rk_step_fused(mi_ode_handle h, const void* y0_dev, const v
 }
 
 // ------------------------------------------------------------------------------------------------
+// function-level parity surface of the controller: controller_apply on caller-supplied numbers, one thread per case
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_controller_probe(CtrlParams P, int phase, int n, const double* in, const double* st, double* out,
+                                                         const double* far_t) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= n) return;
+  Ctl ctl;
+  int* w = (int*)&ctl;
+  for (int i = 0; i < (int)(sizeof(Ctl) / sizeof(int)); ++i) w[i] = 0;
+  ctl.t0 = ctl.t1 = st[c * 4 + 0]; ctl.dt = st[c * 4 + 1]; ctl.h0 = st[c * 4 + 2]; ctl.d1 = st[c * 4 + 3];
+  ctl.idx_y1 = 1;
+  ctl.n_out = 1;                                   // one output time far ahead: the attempt never finishes the integration
+  P.t_out = far_t;
+  double rec[kRec];
+  for (int i = 0; i < kRec; ++i) rec[i] = in[c * kRec + i];
+  controller_apply(&ctl, rec, phase, P);
+  double* o = out + c * 8;
+  o[0] = ctl.ratio; o[1] = (double)ctl.accepted; o[2] = ctl.dt; o[3] = ctl.t1; o[4] = ctl.t0; o[5] = (double)ctl.status;
+  o[6] = ctl.h0; o[7] = phase == PH_F0 ? ctl.d0 : ctl.d1;
+  if (phase == PH_F0) o[2] = ctl.d1;
+}
+
+extern "C" int mi_ode_controller_update(const mi_ode_ctrl_params* p, int32_t phase, int32_t n_cases, const double* in_host,
+                                        const double* st_host, double* out_host, void* stream) {
+  if (p == nullptr || in_host == nullptr || st_host == nullptr || out_host == nullptr || n_cases < 1 || phase < 0 || phase > 2) {
+    mi_set_error("controller_update: bad argument");
+    return MI_ODE_E_INVALID;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  CtrlParams P;
+  memset(&P, 0, sizeof(P));
+  P.rtol = p->rtol; P.atol = p->atol; P.safety = p->safety; P.ifactor = p->ifactor; P.dfactor = p->dfactor;
+  P.inv_ifactor = 1.0 / p->ifactor; P.inv_dfactor = 1.0 / p->dfactor;
+  P.max_num_steps = 2147483647LL; P.n_local = 0; P.order = p->order; P.init_order = p->init_order;
+  P.controller = p->controller; P.is_f32 = p->dtype == MI_ODE_F32; P.n_stages = 6; P.auto_first_step = 1;
+  double* dev = nullptr;
+  const size_t n_in = (size_t)n_cases * kRec, n_st = (size_t)n_cases * 4, n_out = (size_t)n_cases * 8;
+  MI_HIP(hipMalloc((void**)&dev, (n_in + n_st + n_out + 1) * sizeof(double)));
+  const double far_t = 1e300;
+  hipError_t e = hipMemcpyAsync(dev, in_host, n_in * sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(dev + n_in, st_host, n_st * sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipMemcpyAsync(dev + n_in + n_st + n_out, &far_t, sizeof(double), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(k_controller_probe, dim3((n_cases + 63) / 64), dim3(64), 0, st, P, (int)phase, (int)n_cases, (const double*)dev,
+                       (const double*)(dev + n_in), dev + n_in + n_st, (const double*)(dev + n_in + n_st + n_out));
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(out_host, dev + n_in + n_st, n_out * sizeof(double), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(dev);
+  if (e != hipSuccess) { mi_set_error("controller_update failed: %s", hipGetErrorString(e)); return MI_ODE_E_HIP; }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // (B) stateless plane kernels
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize_records(const double* part, int nblocks, double* result, int what) {
@@ -988,6 +1194,18 @@ extern "C" int mi_ode_lincomb_dev(int32_t dtype, int64_t n, const void* base_dev
                                   int32_t nx, const double* scale_dev, void* out_dev, void* stream) {
   if (scale_dev == nullptr) { mi_set_error("lincomb_dev: null scale pointer"); return MI_ODE_E_INVALID; }
   return lincomb_impl(dtype, n, base_dev, xs_dev, coef, nx, 0.0, scale_dev, out_dev, stream);
+}
+
+extern "C" int mi_ode_rk_stage_combine(int32_t dtype, int64_t n, const void* y0_dev, const void* const* k_dev, const double* beta_row,
+                                       int32_t n_k, double dt, void* out_dev, void* stream) {
+  return lincomb_impl(dtype, n, y0_dev, k_dev, beta_row, n_k, dt, nullptr, out_dev, stream);
+}
+
+extern "C" int mi_ode_error_norms(int32_t dtype, int64_t n, const void* err_dev, const void* y0_dev, const void* y1_dev,
+                                  double* result_dev, void* workspace_dev, void* stream);
+extern "C" int mi_ode_rk_error_reduce(int32_t dtype, int64_t n, const void* err_dev, const void* y0_dev, const void* y1_dev,
+                                      double* result_dev, void* workspace_dev, void* stream) {
+  return mi_ode_error_norms(dtype, n, err_dev, y0_dev, y1_dev, result_dev, workspace_dev, stream);
 }
 
 extern "C" int mi_ode_error_norms(int32_t dtype, int64_t n, const void* err_dev, const void* y0_dev, const void* y1_dev,

@@ -63,14 +63,21 @@ struct mi_ode_solver {
   int step_fused;             // 1: whole-attempt kernel in use
   int step_grid, step_block;
   int persist;                // 1: whole integration in one launch (mi_ode_persist.h)
+  int persist_capable;        // 1: such a kernel exists for this problem and its grid is co-resident (transport aside)
   int persist_grid;
   int persist_sleep_first, persist_sleep_poll;   // hand-off back-off (units of 64 clocks)
   int persist_spin_limit;     // bound on the polls of one hand-off
+  int persist_spin_first;     // ... of the first hand-off of a launch (residency check)
   int init_tiles16;           // 1: before_integrate runs on the 16-row tile kernels (k_init_linear_mfma), grid = step_grid
   double* xrank_dev;          // device view of desc.xrank_host (registered), or null
   double* gbuf;               // device: the global record WG 0 broadcasts after a cross-rank hand-off (2 parities)
   int xrank_on;               // 1: multi-rank calls use the whole-call kernel with the cross-rank hand-off
   int xrank_registered;
+  void* xpeer_local;          // this rank's mailbox in its own HBM (mi_ode_xpeer_prepare), or null
+  void* xpeer_open[64];       // peers' mailboxes as mapped here by hipIpcOpenMemHandle (entry `rank` = xpeer_local)
+  double** xpeer_tab_dev;     // device copy of that pointer table (what the kernels read), or null
+  int xpeer_world;
+  void* nccl_comm;            // ncclComm_t created by mi_ode_rccl_connect, or null
   unsigned xrank_tests;       // self-test rounds use their own sequence range
   unsigned seq;               // hand-off sequence numbers already used on this handle (identical on every rank)
   int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)

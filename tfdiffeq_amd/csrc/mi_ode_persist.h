@@ -44,11 +44,14 @@ struct PersistArgs {
   double t_small[kPersistTSmall];   // the output times when n_out <= kPersistTSmall (else s.t_out, device)
   // batch-sharded runs: records also cross ranks, through a registered host segment (null: single rank)
   double* xrank;               // [2 parities][world][kXRec] doubles, host memory seen by every rank's GPU
+  double* const* xpeers;       // preferred: device array of `world` pointers, entry q = rank q's mailbox ([2][world][kXRec], PEER DEVICE
+                               // memory mapped into this process with hipIpcOpenMemHandle; entry `rank` = this rank's own); null: use xrank
   double* gbuf;                // device, [2 parities][kPRec]: the global record, broadcast by workgroup 0
   int world, rank;
   unsigned seq_base;           // sequence numbers of this call's hand-offs are seq_base + 1, + 2, ... (never 0)
   int n_out;                   // T - 1
   int spin_limit;              // bound on the spin iterations of one hand-off
+  int spin_first;              // ... of the FIRST grid hand-off of a launch: the residency check (see grid_reduce_rank)
   int sleep_first, sleep_poll; // back-off (units of 64 clocks): before the first poll / between polls
 };
 
@@ -176,7 +179,7 @@ struct PersistShared {
   double red[80];
   double vals[5][kPersistMaxGrid];                            // every workgroup's record, staged for the fixed-order fold
   double tout[kPersistTout];                                  // the requested output times, when they fit
-  double xr[6][kXMaxWorld];                                   // cross-rank hand-off: every rank's record
+  double xr[6][kXMaxWorld + 1];                               // cross-rank hand-off: every rank's record (+ one staging column)
   int ok;                                                     // 1 until a hand-off times out
 };
 
@@ -205,9 +208,14 @@ __device__ __forceinline__ bool ll_load_record(const unsigned long long* p, unsi
 
 // Cross-rank hand-off (batch-sharded runs).  On entry thread 0 of EVERY workgroup holds this rank's record r[0..4];
 // on exit it holds the record combined over all ranks (rank order, the fold of k_controller) and n_tot = sum of the
-// ranks' element counts.  Workgroup 0 is the gateway: it publishes the rank record in the host segment, lane q of its
-// first wavefront polls rank q's record, thread 0 folds and broadcasts the result through device memory (same word
-// encoding) to the other workgroups.  Bounded waits, as everywhere.
+// ranks' element counts.  Workgroup 0 is the gateway: it publishes the rank record, lane q of its first wavefront polls
+// rank q's record, thread 0 folds and broadcasts the result through device memory (same word encoding) to the other
+// workgroups.  Bounded waits, as everywhere.  Two transports, same "LL" word encoding:
+//   * peer device memory (A.xpeers): every rank owns a mailbox in its own HBM (uncached / fine-grained allocation,
+//     exported with hipIpcGetMemHandle); lane q PUSHES this rank's record into rank q's mailbox - one posted store
+//     stream over the xGMI link to that peer - and then polls slot q of its OWN mailbox, i.e. local memory.  No poll
+//     ever crosses a link, no host memory, no PCIe;
+//   * a host segment shared by the ranks (A.xrank): one slot per rank, written once, polled by everybody over PCIe.
 __device__ __forceinline__ void cross_rank(const PersistArgs& A, PersistShared& sh, unsigned gen, double (&r)[5], double& n_tot,
                                            double n_local) {
   const int W = A.world;
@@ -215,18 +223,34 @@ __device__ __forceinline__ void cross_rank(const PersistArgs& A, PersistShared& 
   const unsigned bad = seq ^ 0x80000000u;                     // "the gateway gave up" (never a valid number of this hand-off)
   double* g = A.gbuf + (long long)(gen & 1u) * kPRec;
   if (blockIdx.x == 0) {
-    unsigned long long* seg = (unsigned long long*)A.xrank;
-    if (threadIdx.x == 0) {
-      unsigned long long* slot = seg + ((long long)(gen & 1u) * W + A.rank) * kXRec;
+    const unsigned long long* poll = nullptr;
+    if (A.xpeers != nullptr) {
+      if (threadIdx.x == 0) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) ll_store(slot + 2 * i, r[i], seq);
-      ll_store(slot + 10, n_local, seq);
+        for (int i = 0; i < 5; ++i) sh.xr[i][kXMaxWorld] = r[i];              // hand the record to the pushing lanes
+      }
+      __syncthreads();
+      if ((int)threadIdx.x < W) {
+        unsigned long long* slot = (unsigned long long*)A.xpeers[threadIdx.x] + ((long long)(gen & 1u) * W + A.rank) * kXRec;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) ll_store(slot + 2 * i, sh.xr[i][kXMaxWorld], seq);
+        ll_store(slot + 10, n_local, seq);
+        poll = (const unsigned long long*)A.xpeers[A.rank] + ((long long)(gen & 1u) * W + threadIdx.x) * kXRec;
+      }
+    } else {
+      unsigned long long* seg = (unsigned long long*)A.xrank;
+      if (threadIdx.x == 0) {
+        unsigned long long* slot = seg + ((long long)(gen & 1u) * W + A.rank) * kXRec;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) ll_store(slot + 2 * i, r[i], seq);
+        ll_store(slot + 10, n_local, seq);
+      }
+      if ((int)threadIdx.x < W) poll = seg + ((long long)(gen & 1u) * W + threadIdx.x) * kXRec;
     }
     if ((int)threadIdx.x < W) {
-      const unsigned long long* p = seg + ((long long)(gen & 1u) * W + threadIdx.x) * kXRec;
       double v[6];
       int spins = 0;
-      while (!ll_load_record(p, seq, v)) {
+      while (!ll_load_record(poll, seq, v)) {
         for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(1);
         if (++spins > A.spin_limit) { sh.ok = 0; break; }
       }
@@ -277,6 +301,14 @@ __device__ __forceinline__ bool grid_reduce_rank(const PersistArgs& A, const Acc
 #pragma unroll
     for (int i = 0; i < 5; ++i) store_ll_sc1(mine + 2 * i, r[i], seq);
   }
+  // Co-residency is not something a launch can promise (another stream's kernel, a second process, an occupancy query
+  // that is one block per CU too optimistic - MI355X_MICROARCH.md "Residency and cooperative launch").  The FIRST
+  // hand-off of a launch doubles as the residency check: every workgroup that runs publishes within the duration of
+  // one init pass, a workgroup that was not admitted can only start after a resident one exits - i.e. never.  So the
+  // first hand-off gives up after milliseconds (the host then falls back to one launch per attempt, having lost almost
+  // nothing); once every workgroup has been seen they stay resident (no pre-emption of running waves) and the later
+  // hand-offs only absorb skew.
+  const int limit = gen == 0 ? A.spin_first : A.spin_limit;
   for (int b = threadIdx.x; b < G; b += blockDim.x) {
     const double* p = buf + (long long)b * kPRec;
     double v[5];
@@ -285,7 +317,7 @@ __device__ __forceinline__ bool grid_reduce_rank(const PersistArgs& A, const Acc
     for (;;) {
       if (load_record_sc1(p, seq, v)) break;
       for (int i = 0; i < A.sleep_poll; ++i) __builtin_amdgcn_s_sleep(1);
-      if (++spins > A.spin_limit) { sh.ok = 0; break; }
+      if (++spins > limit) { sh.ok = 0; break; }
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) sh.vals[i][b] = v[i];
@@ -308,7 +340,7 @@ __device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc
                                             double (&r)[5], double& n_tot) {
   bool ok = grid_reduce_rank(A, acc, sh, gen, r);
   n_tot = (double)A.s.cp.n_local;
-  if (A.world > 1 || A.xrank != nullptr) {
+  if (A.world > 1 || A.xrank != nullptr || A.xpeers != nullptr) {
     if (ok) cross_rank(A, sh, gen, r, n_tot, (double)A.s.cp.n_local);
     ok = ok && sh.ok != 0;
   }

@@ -144,8 +144,16 @@ class _FusedEngine(object):
                         return 1
                 self._hook = N.ALLGATHER_FN(hook)
                 d.allgather = self._hook
+        # Cross-rank transports, best first (TFDIFFEQ_AMD_XRANK = peer | host | rccl | hook | 0 restricts the choice; default: all):
+        #   peer  in-kernel hand-off through mailboxes in PEER DEVICE memory (xGMI), one launch per call
+        #   host  in-kernel hand-off through a /dev/shm segment every GPU maps (PCIe), one launch per call
+        #   rccl  launch per attempt, ncclAllGather enqueued by libmi_ode itself
+        #   hook  launch per attempt, torch.distributed all-gather through the ctypes callback (last resort)
+        want = os.environ.get('TFDIFFEQ_AMD_XRANK', '1')
+        allow = {'1': ('peer', 'host', 'rccl'), 'peer': ('peer', 'rccl'), 'host': ('host', 'rccl'), 'rccl': ('rccl',), 'hook': (),
+                 '0': ('rccl',)}.get(want, ('peer', 'host', 'rccl'))
         self._xr = None
-        if process_group is not None and os.environ.get('TFDIFFEQ_AMD_XRANK', '1') != '0' and adaptive:
+        if process_group is not None and 'host' in allow and adaptive:
             # cross-rank hand-off memory for the whole-call kernels: one host segment shared by the ranks of this node
             self._xr = _xrank_segment(process_group, int(self.lib.mi_ode_xrank_bytes(d.world_size)))
             if self._xr is not None:
@@ -157,19 +165,59 @@ class _FusedEngine(object):
         self.h = h
         self.stats = N.Stats()
         self.xrank = False
-        if process_group is not None and os.environ.get('TFDIFFEQ_AMD_XRANK', '1') != '0' and adaptive:
-            # every rank tests the hand-off through the segment; it is used only if ALL ranks saw all peers (a rank on
-            # another node, or a failed registration, turns it off for everybody: the allgather hook then stays in charge)
+        self.transport = 'single rank' if process_group is None else 'allgather hook (torch.distributed)'
+        if process_group is not None:
             import torch.distributed as dist
-            ok = 0
-            if self._xr is not None:
+
+            def all_agree(ok):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self.device if dist.get_backend(process_group) == 'nccl' else 'cpu')
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
+                return int(flag.item()) == 1
+
+            def selftest_and_enable():
+                # every rank tests the hand-off; it is used only if ALL ranks saw all peers (a rank on another node, or a failed
+                # mapping, turns it off for everybody)
                 with torch.cuda.device(self.device):
-                    ok = 1 if self.lib.mi_ode_xrank_selftest(self.h, self._stream()) == 0 else 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=self.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
-            if int(flag.item()) == 1:
-                N.check(self.lib.mi_ode_xrank_enable(self.h, 1), 'mi_ode_xrank_enable')
-                self.xrank = True
+                    ok = self.lib.mi_ode_xrank_selftest(self.h, self._stream()) == 0
+                if all_agree(ok):
+                    N.check(self.lib.mi_ode_xrank_enable(self.h, 1), 'mi_ode_xrank_enable')
+                    return True
+                return False
+
+            world, rank = d.world_size, d.rank
+            if 'rccl' in allow and dist.get_backend(process_group) == 'nccl':
+                # the launch-per-attempt schedule then needs no callback into Python (rank 0 draws the id, everybody joins)
+                ids = [None]
+                if rank == 0:
+                    buf = (C.c_char * N.RCCL_ID_BYTES)()
+                    ids[0] = bytes(buf) if self.lib.mi_ode_rccl_unique_id(buf) == 0 else None
+                dist.broadcast_object_list(ids, src=dist.get_global_rank(process_group, 0), group=process_group)
+                ok = False
+                if ids[0] is not None:
+                    with torch.cuda.device(self.device):
+                        ok = self.lib.mi_ode_rccl_connect(self.h, ids[0], world, rank) == 0
+                if all_agree(ok):
+                    self.transport = 'ncclAllGather enqueued by libmi_ode (launch per attempt)'
+                elif ok:                       # some rank could not join: everybody drops back to the hook together
+                    self.lib.mi_ode_rccl_connect(self.h, None, 0, 0)
+            if adaptive and 'peer' in allow:
+                buf = (C.c_char * N.IPC_HANDLE_BYTES)()
+                with torch.cuda.device(self.device):
+                    ok = self.lib.mi_ode_xpeer_prepare(self.h, buf) == 0
+                handles = [None] * world
+                dist.all_gather_object(handles, bytes(buf) if ok else None, group=process_group)
+                ok = ok and all(hd is not None for hd in handles)
+                if ok:
+                    blob = b''.join(handles)
+                    with torch.cuda.device(self.device):
+                        ok = self.lib.mi_ode_xpeer_connect(self.h, blob, world) == 0
+                if all_agree(ok) and selftest_and_enable():
+                    self.xrank = True
+                    self.transport = 'in-kernel hand-off through peer device memory (xGMI mailboxes), one launch per call'
+            if adaptive and not self.xrank and self._xr is not None and 'host' in allow:
+                if selftest_and_enable():
+                    self.xrank = True
+                    self.transport = 'in-kernel hand-off through a shared host segment, one launch per call'
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -521,8 +569,7 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             out = eng.integrate(t.to(torch.float64).numpy(), self.y0[0])
         finally:
             self.stats = eng.stats.as_dict()
-            self.stats['cross_rank'] = ('in-kernel hand-off through a shared host segment' if eng.xrank else
-                                        ('allgather hook' if eng._hook is not None else 'single rank'))
+            self.stats['cross_rank'] = eng.transport
             if self._profile:
                 self.stats['profile'] = [a - b for a, b in zip(eng.profile(), prof0)]
         return (out,)
