@@ -187,6 +187,12 @@ int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const double* t_host, 
 /* FixedGridODESolver.integrate(t) with grid = t (solvers.py:82-104); no host synchronisation inside. */
 int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, const double* t_host, int32_t T,
                                 void* out_dev, mi_ode_stats* stats, void* stream);
+/* The same on a time grid of its own (FixedGridODESolver(step_size=... | grid_constructor=..., eps=...), solvers.py:41-56, 86-100):
+ * steps are taken on grid_host[0..G-1] (grid[0] == t[0], grid[G-1] == t[T-1]); a requested time that is not a grid point is
+ * linearly interpolated inside the step that reaches it (_linear_interp, solvers.py:106-115); `eps` is added to the time the
+ * step function evaluates f at (fixed_grid.py:7, 42).  One launch; row-local and MFMA-linear RHS families. */
+int mi_ode_fixed_grid_integrate_on(mi_ode_handle h, const void* y0_dev, const double* grid_host, int32_t G,
+                                   const double* t_host, int32_t T, double eps, void* out_dev, mi_ode_stats* stats, void* stream);
 /* One attempt with a given dt - the parity surface mirroring _runge_kutta_step (rk_common.py:22-61):
  * y1/f1/err_norms outputs are device pointers (nullable); err_norms = {max|y0|, max|y1|, sum err^2, nonfinite}.
  * k_out (nullable): [S+1, batch*dim] stage derivatives. */

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 output of bench.py into profiles/: per-kernel durations (kernel trace) and HBM traffic per
 launch from the FETCH_SIZE / WRITE_SIZE PMC passes, corrected as /opt/skills/guides/MI355X_MICROARCH.md (HBM section)
 prescribes for gfx950: FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> x2; WRITE_SIZE as is; both in KiB.
-Usage: python scripts/pmc_summary.py gpurun_out <tag> profiles/r01_<tag>"""
+Usage: python scripts/pmc_summary.py gpurun_out <tag> profiles/r02_<tag> [--no-raw]"""
 import collections
 import csv
 import json
@@ -11,6 +11,7 @@ import shutil
 import sys
 
 src, tag, dst = sys.argv[1], sys.argv[2], sys.argv[3]
+RAW = '--no-raw' not in sys.argv          # copy the raw per-dispatch counter CSVs next to the summary
 os.makedirs(os.path.dirname(dst) or '.', exist_ok=True)
 out = {'note': 'real launches only (no-op launches after done are excluded by taking values >= 50% of the max)'}
 ks = os.path.join(src, 'prof_' + tag, 'r_kernel_stats.csv')
@@ -31,7 +32,8 @@ for C in ('FETCH_SIZE', 'WRITE_SIZE'):
     f = os.path.join(src, 'pmc_' + tag + '_' + C, 'r_counter_collection.csv')
     if not os.path.exists(f):
         continue
-    shutil.copy(f, dst + '_pmc_' + C + '.csv')
+    if RAW:
+        shutil.copy(f, dst + '_pmc_' + C + '.csv')
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r['Counter_Name'] == C:

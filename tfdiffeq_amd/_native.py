@@ -93,6 +93,8 @@ _PROTOS = {
                                    C.POINTER(Stats), C.c_void_p]),
     'mi_ode_fixed_grid_integrate': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.c_void_p,
                                               C.POINTER(Stats), C.c_void_p]),
+    'mi_ode_fixed_grid_integrate_on': (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_double), C.c_int32,
+                                                 C.c_double, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     'mi_ode_rk_step_fused': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p,
                                        C.c_void_p, C.POINTER(C.c_double), C.c_void_p, C.c_void_p]),
     'mi_ode_eval_rhs': (C.c_int, [C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p]),

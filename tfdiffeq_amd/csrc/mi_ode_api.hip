@@ -274,7 +274,8 @@ static void fill_stats(mi_ode_solver* h, mi_ode_stats* s) {
 static int pick_family(mi_ode_solver* h) {
   const mi_ode_rhs& r = h->d.rhs;
   const int D = (int)h->d.dim;
-  const bool mfma_dim = (D == 16 || D == 32 || D == 64 || D == 128);
+  const bool mfma_dim = D >= 3 && D <= 128;                // any dim up to 128: zero padded to the next tile width (16, 32, 64, 128)
+  h->lin_dp = D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : 128));
   h->rhs.cube = 0;
   switch (r.kind) {
     case MI_ODE_RHS_LOTKA_VOLTERRA:
@@ -293,7 +294,7 @@ static int pick_family(mi_ode_solver* h) {
       }
       h->rhs.cube = cube ? 1 : 0;
       if (!cube && mfma_dim && h->d.linear_variant != 1) { h->family = FAM_LINEAR_MFMA; return 0; }
-      if (h->d.linear_variant == 2) { mi_set_error("MFMA linear kernel needs dim in {16,32,64,128} and no cube"); return MI_ODE_E_INVALID; }
+      if (h->d.linear_variant == 2) { mi_set_error("MFMA linear kernel needs 3 <= dim <= 128 and no cube"); return MI_ODE_E_INVALID; }
       if (D > 256) { mi_set_error("fused linear RHS supports dim <= 256 (got %d)", D); return MI_ODE_E_INVALID; }
       h->family = FAM_LINEAR_VALU; return 0;
     }
@@ -947,8 +948,23 @@ extern "C" int mi_ode_get_state(mi_ode_handle h, void* y_dev, void* f_dev, void*
 // ------------------------------------------------------------------------------------------------
 // fixed grid (solvers.py:82-104): everything is known on the host, nothing synchronises
 // ------------------------------------------------------------------------------------------------
+static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_host, int32_t G, const double* t_host, int32_t T, double eps,
+                      void* out_dev, mi_ode_stats* stats, void* stream);
+
 extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, const double* t_host, int32_t T,
                                            void* out_dev, mi_ode_stats* stats, void* stream) {
+  return fixed_impl(h, y0_dev, t_host, T, t_host, T, 0.0, out_dev, stats, stream);
+}
+
+extern "C" int mi_ode_fixed_grid_integrate_on(mi_ode_handle h, const void* y0_dev, const double* grid_host, int32_t G,
+                                              const double* t_host, int32_t T, double eps, void* out_dev, mi_ode_stats* stats,
+                                              void* stream) {
+  if (grid_host == nullptr || G < 1) { mi_set_error("bad grid"); return MI_ODE_E_INVALID; }
+  return fixed_impl(h, y0_dev, grid_host, G, t_host, T, eps, out_dev, stats, stream);
+}
+
+static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_host, int32_t G, const double* t_host, int32_t T, double eps,
+                      void* out_dev, mi_ode_stats* stats, void* stream) {
   if (h == nullptr || y0_dev == nullptr || t_host == nullptr || out_dev == nullptr || T < 1) { mi_set_error("bad argument"); return MI_ODE_E_INVALID; }
   if (h->d.adaptive) { mi_set_error("fixed-grid call on an adaptive handle"); return MI_ODE_E_INVALID; }
   hipStream_t st = (hipStream_t)stream;
@@ -959,21 +975,32 @@ extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, 
       if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = MI_ODE_ST_BAD_T; }
       return MI_ODE_ST_BAD_T;
     }
+  const bool own_grid = grid_host != t_host || eps != 0.0;
+  if (own_grid) {
+    for (int i = 1; i < G; ++i)
+      if (!(grid_host[i] > grid_host[i - 1])) { mi_set_error("the time grid must increase"); return MI_ODE_ST_BAD_T; }
+    if (!(grid_host[0] == t_host[0] && grid_host[G - 1] == t_host[T - 1])) {               // solvers.py:87
+      mi_set_error("the time grid must start at t[0] and end at t[-1]");
+      return MI_ODE_ST_BAD_T;
+    }
+  }
   h->n_launches = 0; h->n_polls = 0;
   const size_t pbytes = (size_t)h->n * h->elt;
   if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
        h->family == FAM_LINEAR_MFMA || h->family == FAM_PLUGIN) && h->d.fusion != 1) {
     // trajectories never interact on a fixed grid: the whole integration is ONE launch
     // (k_fixed_rowlocal for the tiny row-local systems, k_fixed_linear_mfma for the linear RHS)
-    int rcf = ensure_t_out(h, T);
+    int rcf = ensure_t_out(h, T + (own_grid ? G : 0));
     if (rcf != 0) return rcf;
     MI_HIP(hipStreamSynchronize(st));
     memcpy(h->t_out_host, t_host, (size_t)T * sizeof(double));
-    MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)T * sizeof(double), hipMemcpyHostToDevice, st));
+    if (own_grid) memcpy(h->t_out_host + T, grid_host, (size_t)G * sizeof(double));
+    MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)(T + (own_grid ? G : 0)) * sizeof(double), hipMemcpyHostToDevice, st));
     h->t_out_busy = 1;
     FixedArgs F;
     memset(&F, 0, sizeof(F));
-    F.y0 = y0_dev; F.out = out_dev; F.t = h->t_out_dev; F.batch = h->d.batch; F.T = T; F.rk4 = euler ? 0 : 1; F.rhs = h->rhs;
+    F.grid = own_grid ? h->t_out_dev + T : h->t_out_dev; F.M = (own_grid ? G : T) - 1; F.eps = eps;
+    F.y0 = y0_dev; F.out = out_dev; F.t = h->t_out_dev; F.batch = h->d.batch; F.T = T; F.rk4 = euler ? 0 : 1; F.dim = (int)h->d.dim; F.rhs = h->rhs;
     if (h->family == FAM_PLUGIN) {
       rcf = h->plugin->launch_fixed(h, &F, st);
       if (rcf != 0) { mi_set_error("plugin fixed-grid kernel launch failed"); return rcf; }
@@ -984,13 +1011,14 @@ extern "C" int mi_ode_fixed_grid_integrate(mi_ode_handle h, const void* y0_dev, 
     if (rcf != 0) return rcf;
     if (stats) {
       memset(stats, 0, sizeof(*stats));
-      stats->nfe = (long long)(euler ? 1 : 4) * (T - 1);
-      stats->n_attempts = stats->n_accepted = T - 1;
+      stats->nfe = (long long)(euler ? 1 : 4) * ((own_grid ? G : T) - 1);
+      stats->n_attempts = stats->n_accepted = (own_grid ? G : T) - 1;
       stats->t = t_host[T - 1];
       stats->n_launches = h->n_launches;
     }
     return 0;
   }
+  if (own_grid) { mi_set_error("a custom time grid / eps needs the one-launch fixed-grid kernels (row-local or MFMA-linear RHS, fusion != 1)"); return MI_ODE_E_INVALID; }
   MI_HIP(hipMemcpyAsync(out_dev, y0_dev, pbytes, hipMemcpyDeviceToDevice, st));
   char* k0 = h->planes + 2 * h->stride;
   char* k1 = k0 + h->stride;

@@ -82,6 +82,7 @@ struct mi_ode_solver {
   unsigned seq;               // hand-off sequence numbers already used on this handle (identical on every rank)
   int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)
   int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation
+  int lin_dp;                 // FAM_LINEAR_MFMA: tile width the kernels are instantiated for (16 / 32 / 64 / 128 >= dim, zero padded)
   // bookkeeping
   long long n_launches;
   int n_polls;

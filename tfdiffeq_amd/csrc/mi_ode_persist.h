@@ -542,7 +542,7 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
   __shared__ PersistShared sh;
   Ctl& s_c = sh.c;
   LinCtx<T, D> cx;
-  cx.init(A.s.rhs, (T*)smem_raw);
+  cx.init(A.s.rhs, (T*)smem_raw, A.s.dim);
   CtrlParams cp = A.s.cp;
   cp.t_out = persist_stage_tout(A, sh.tout);
   const double* t_out = cp.t_out;
@@ -628,7 +628,7 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
 
   // final state for mi_ode_get_state: plane indices as controller_apply's rotation would have left them
   if (cur_y == y_user) {                                      // no accepted step (error exit): seed plane 0 with y0
-    const long long n = A.s.batch * D;
+    const long long n = A.s.batch * A.s.dim;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) ya[i] = y_user[i];
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {

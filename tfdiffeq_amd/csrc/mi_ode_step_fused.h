@@ -235,10 +235,14 @@ __global__ __launch_bounds__(256) void k_step_rowlocal(StepArgs A) {
 struct FixedArgs {
   const void* y0;
   void* out;                   // [T, batch*D]
-  const double* t;             // device: the grid (= requested times), float64
+  const double* t;             // device: the requested output times, float64 (values already rounded to the state dtype)
+  const double* grid;          // device: the time grid the steps are taken on (solvers.py:86: grid_constructor(func, y0, t));
+  int M;                       // M intervals; by default the grid IS t (M = T - 1)
+  double eps;                  // FixedGridODESolver(eps=...): added to the time the step function evaluates f at (fixed_grid.py:7, 42)
   long long batch;
   int T;
   int rk4;                     // 0: Euler, 1: RK4 (3/8 rule)
+  int dim;                     // row length (tile kernels: may be smaller than their instantiated width)
   RhsParams rhs;
 };
 
@@ -255,33 +259,48 @@ __global__ __launch_bounds__(256) void k_fixed_rowlocal(FixedArgs A) {
        row += (long long)gridDim.x * blockDim.x) {
     Row y = *(const Row*)(y0p + row * D);
     *(Row*)(out + row * D) = y;                              // solution = [y0]
-    for (int i = 0; i + 1 < A.T; ++i) {
-      const T t0 = (T)A.t[i];                                // solvers.py:84: the grid is cast to the STATE dtype
-      const T dt = (T)A.t[i + 1] - t0;
+    int j = 1;
+    const T eps = (T)A.eps;
+    for (int i = 0; i < A.M; ++i) {
+      const T t0 = (T)A.grid[i];                             // solvers.py:84: the grid is cast to the STATE dtype
+      const T t1 = (T)A.grid[i + 1];
+      const T dt = t1 - t0;
+      const T te = t0 + eps;                                 // fixed_grid.py:7 / :42: the step function sees t + eps
       T k1[D], k2[D], k3[D], k4[D], ys[D];
-      rhs(sign * t0, y.v, k1);
+      Row yn;
+      rhs(sign * te, y.v, k1);
 #pragma unroll
       for (int d = 0; d < D; ++d) k1[d] = sign * k1[d];
       if (!A.rk4) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) y.v[d] = y.v[d] + dt * k1[d];                       // fixed_grid.py:7
+        for (int d = 0; d < D; ++d) yn.v[d] = y.v[d] + dt * k1[d];                       // fixed_grid.py:7
       } else {
 #pragma unroll
         for (int d = 0; d < D; ++d) ys[d] = y.v[d] + dt * k1[d] / (T)3;                 // rk_common.py:77
-        rhs(sign * (t0 + dt / (T)3), ys, k2);
+        rhs(sign * (te + dt / (T)3), ys, k2);
 #pragma unroll
         for (int d = 0; d < D; ++d) { k2[d] = sign * k2[d]; ys[d] = y.v[d] + dt * (k1[d] / (T)-3 + k2[d]); }   // :78
-        rhs(sign * (t0 + dt * (T)2 / (T)3), ys, k3);
+        rhs(sign * (te + dt * (T)2 / (T)3), ys, k3);
 #pragma unroll
         for (int d = 0; d < D; ++d) { k3[d] = sign * k3[d]; ys[d] = y.v[d] + dt * (k1[d] - k2[d] + k3[d]); }   // :79
-        rhs(sign * (t0 + dt), ys, k4);
+        rhs(sign * (te + dt), ys, k4);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
           k4[d] = sign * k4[d];
-          y.v[d] = y.v[d] + (k1[d] + (T)3 * k2[d] + (T)3 * k3[d] + k4[d]) * (dt / (T)8);                       // :81
+          yn.v[d] = y.v[d] + (k1[d] + (T)3 * k2[d] + (T)3 * k3[d] + k4[d]) * (dt / (T)8);                       // :81
         }
       }
-      *(Row*)(out + (long long)(i + 1) * n + row * D) = y;
+      // solvers.py:97-100: every requested time the step reaches, exactly y0 / y1 on a grid hit, else _linear_interp (:106-115)
+      while (j < A.T && t1 >= (T)A.t[j]) {
+        const T tj = (T)A.t[j];
+        Row o;
+#pragma unroll
+        for (int d = 0; d < D; ++d)
+          o.v[d] = (tj == t0) ? y.v[d] : ((tj == t1) ? yn.v[d] : y.v[d] + ((yn.v[d] - y.v[d]) / (t1 - t0)) * (tj - t0));
+        *(Row*)(out + (long long)j * n + row * D) = o;
+        ++j;
+      }
+      y = yn;
     }
   }
 }
@@ -312,21 +331,24 @@ struct LinCtx {
   static constexpr int KS = D / 4;
   using CH = Chunk<T, VEC>;
   int lane, wave, li, lg, col;
-  T bf[KS];
-  T bias_v, sign;
+  int d;                                                     // the state's true row length, d <= D: the tile kernels are instantiated
+  bool colok;                                                // for D in {16, 32, 64, 128} and run any smaller dim zero padded (columns >= d
+  T bf[KS];                                                  // are never loaded or stored; W rows / columns >= d are zero, so the padding
+  T bias_v, sign;                                            // contributes exact zeros to every product, sum and norm)
   bool has_bias;
   T* s_ys;                                                   // [R_][LD]
 
-  __device__ __forceinline__ void init(const RhsParams& rhs, T* lds) {
+  __device__ __forceinline__ void init(const RhsParams& rhs, T* lds, int dim) {
     const int tid = threadIdx.x;
     lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
     col = 16 * wave + li;
+    d = dim; colok = col < dim;
     const T* W = (const T*)rhs.w[0];
     const T* bias = (const T*)rhs.b[0];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bf[s] = W[(long long)(lg * KS + s) * D + col];
+    for (int s = 0; s < KS; ++s) bf[s] = (colok && lg * KS + s < dim) ? W[(long long)(lg * KS + s) * dim + col] : (T)0;
     has_bias = bias != nullptr;
-    bias_v = has_bias ? bias[col] : (T)0;
+    bias_v = (has_bias && colok) ? bias[col] : (T)0;
     sign = (T)rhs.sign;
     s_ys = lds;
   }
@@ -375,9 +397,9 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = t_i * R_ + cx.row_of(i);
-      const bool ok = row < A.batch;
-      y0n[i] = ok ? stream_load<SC0>(P.y0 + row * D + cx.col) : (T)0;
-      f0n[i] = ok ? stream_load<SC0>(P.f0 + row * D + cx.col) : (T)0;
+      const bool ok = row < A.batch && cx.colok;
+      y0n[i] = ok ? stream_load<SC0>(P.y0 + row * cx.d + cx.col) : (T)0;
+      f0n[i] = ok ? stream_load<SC0>(P.f0 + row * cx.d + cx.col) : (T)0;
     }
   };
   if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -408,13 +430,13 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = row0 + cx.row_of(i);
-      if (row < A.batch) {
+      if (row < A.batch && cx.colok) {
         T kk[S + 1];
 #pragma unroll
         for (int j = 0; j <= S; ++j) kk[j] = k[j][i];
         T err, ymid;
         step_finish<T, S>(y0e[i], kk, hs, A, err, ymid, !TS && P.j_hi > P.j_lo);
-        const long long idx = row * D + cx.col;
+        const long long idx = row * cx.d + cx.col;
         P.y1[idx] = ys[i];
         P.f1[idx] = k[S][i];
         step_emit<T, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, t_out);
@@ -438,7 +460,7 @@ __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = t_i * R_ + cx.row_of(i);
-      y0n[i] = row < A.batch ? stream_load<SC0>(y0 + row * D + cx.col) : (T)0;
+      y0n[i] = (row < A.batch && cx.colok) ? stream_load<SC0>(y0 + row * cx.d + cx.col) : (T)0;
     }
   };
   if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -451,8 +473,8 @@ __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = tile_i * R_ + cx.row_of(i);
-      if (row < A.batch) {
-        const long long idx = row * D + cx.col;
+      if (row < A.batch && cx.colok) {
+        const long long idx = row * cx.d + cx.col;
         f0_out[idx] = kn[i];
         if (copy_a != nullptr) copy_a[idx] = y0e[i];
         if (copy_b != nullptr) copy_b[idx] = y0e[i];
@@ -477,9 +499,9 @@ __device__ __forceinline__ void lin_initb_pass(const StepArgs& A, const T* y0, c
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = t_i * R_ + cx.row_of(i);
-      const bool ok = row < A.batch;
-      y0n[i] = ok ? stream_load<SC0>(y0 + row * D + cx.col) : (T)0;
-      f0n[i] = ok ? stream_load<SC0>(f0 + row * D + cx.col) : (T)0;
+      const bool ok = row < A.batch && cx.colok;
+      y0n[i] = ok ? stream_load<SC0>(y0 + row * cx.d + cx.col) : (T)0;
+      f0n[i] = ok ? stream_load<SC0>(f0 + row * cx.d + cx.col) : (T)0;
     }
   };
   if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -492,7 +514,7 @@ __device__ __forceinline__ void lin_initb_pass(const StepArgs& A, const T* y0, c
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = tile_i * R_ + cx.row_of(i);
-      if (row < A.batch) {
+      if (row < A.batch && cx.colok) {
         const T sc = (T)A.cp.atol + fabs(y0e[i]) * (T)A.cp.rtol;
         const double q = (double)((kn[i] - f0e[i]) / sc);            // misc.py:237
         acc.suma += q * q;
@@ -509,7 +531,7 @@ __global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
   T* s_ys = (T*)smem_raw;
   double* red = (double*)(s_ys + LinCtx<T, D>::R_ * LinCtx<T, D>::LD);
   LinCtx<T, D> cx;
-  cx.init(A.rhs, s_ys);
+  cx.init(A.rhs, s_ys, A.dim);
   Acc acc;
   lin_attempt_pass<T, D, S, TS, false>(A, P, cx, acc, A.t_out);
   finish_attempt(A, acc, red);
@@ -531,7 +553,7 @@ __global__ __launch_bounds__(D * 4) void k_init_linear_mfma(InitArgs I) {
   T* s_ys = (T*)smem_raw;
   double* red = (double*)(s_ys + LinCtx<T, D>::R_ * LinCtx<T, D>::LD);
   LinCtx<T, D> cx;
-  cx.init(A.rhs, s_ys);
+  cx.init(A.rhs, s_ys, A.dim);
   Acc acc;
   T* plane_y = (T*)(A.planes + (long long)c->idx_y0 * A.stride);
   T* plane_f = (T*)(A.planes + (long long)c->idx_k[0] * A.stride);
@@ -550,10 +572,10 @@ template <typename T, int D>
 __global__ __launch_bounds__(D * 4) void k_fixed_linear_mfma(FixedArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   LinCtx<T, D> cx;
-  cx.init(A.rhs, (T*)smem_raw);
+  cx.init(A.rhs, (T*)smem_raw, A.dim);
   constexpr int R_ = LinCtx<T, D>::R_;
   const long long ntiles = (A.batch + R_ - 1) / R_;
-  const long long n = A.batch * D;
+  const long long n = A.batch * A.dim;
   const T* y0p = (const T*)A.y0;
   T* out = (T*)A.out;
   for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
@@ -563,19 +585,21 @@ __global__ __launch_bounds__(D * 4) void k_fixed_linear_mfma(FixedArgs A) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = tile_i * R_ + cx.row_of(i);
-      ok[i] = row < A.batch;
-      idx[i] = row * D + cx.col;
+      ok[i] = row < A.batch && cx.colok;
+      idx[i] = row * cx.d + cx.col;
       y[i] = ok[i] ? y0p[idx[i]] : (T)0;
       if (ok[i]) out[idx[i]] = y[i];                          // solution = [y0]
     }
-    for (int s = 0; s + 1 < A.T; ++s) {
-      const T t0 = (T)A.t[s];                                 // solvers.py:84: the grid is cast to the STATE dtype
-      const T dt = (T)A.t[s + 1] - t0;
-      T k1[4], k2[4], k3[4], k4[4], ys[4];
+    int j = 1;
+    for (int s = 0; s < A.M; ++s) {
+      const T t0 = (T)A.grid[s];                              // solvers.py:84: the grid is cast to the STATE dtype
+      const T t1 = (T)A.grid[s + 1];
+      const T dt = t1 - t0;                                   // (the linear RHS does not depend on t: eps has no effect here)
+      T k1[4], k2[4], k3[4], k4[4], ys[4], yn[4];
       cx.rhs_eval(y, k1);
       if (!A.rk4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = y[i] + dt * k1[i];                           // fixed_grid.py:7
+        for (int i = 0; i < 4; ++i) yn[i] = y[i] + dt * k1[i];                          // fixed_grid.py:7
       } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) ys[i] = y[i] + dt * k1[i] / (T)3;                   // rk_common.py:77
@@ -587,11 +611,17 @@ __global__ __launch_bounds__(D * 4) void k_fixed_linear_mfma(FixedArgs A) {
         for (int i = 0; i < 4; ++i) ys[i] = y[i] + dt * (k1[i] - k2[i] + k3[i]);        // :79
         cx.rhs_eval(ys, k4);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) y[i] = y[i] + (k1[i] + (T)3 * k2[i] + (T)3 * k3[i] + k4[i]) * (dt / (T)8);   // :81
+        for (int i = 0; i < 4; ++i) yn[i] = y[i] + (k1[i] + (T)3 * k2[i] + (T)3 * k3[i] + k4[i]) * (dt / (T)8);   // :81
+      }
+      while (j < A.T && t1 >= (T)A.t[j]) {                   // solvers.py:97-100, _linear_interp :106-115
+        const T tj = (T)A.t[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (ok[i]) out[(long long)j * n + idx[i]] = (tj == t0) ? y[i] : ((tj == t1) ? yn[i] : y[i] + ((yn[i] - y[i]) / (t1 - t0)) * (tj - t0));
+        ++j;
       }
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-        if (ok[i]) out[(long long)(s + 1) * n + idx[i]] = y[i];
+      for (int i = 0; i < 4; ++i) y[i] = yn[i];
     }
   }
 }

@@ -258,15 +258,23 @@ class _FusedEngine(object):
             raise ValueError('engine was created for %s %s on %s' % (self.shape, self.dtype, self.device))
         return y0.contiguous()
 
-    def integrate(self, t, y0=None):
+    def integrate(self, t, y0=None, grid=None, eps=0.0):
+        """grid / eps: fixed-grid engines only - the time grid the steps are taken on (default: t itself) and the `eps` of
+        FixedGridODESolver (solvers.py:41-56)."""
         y0 = self._check_y0(y0)
         arr, p = self._times(t)
         T = arr.shape[0]
         out = torch.empty((T,) + self.shape, dtype=self.dtype, device=self.device)
         with torch.cuda.device(self.device):
-            fn = self.lib.mi_ode_integrate if self.desc.adaptive else self.lib.mi_ode_fixed_grid_integrate
-            rc = N.check(fn(self.h, C.c_void_p(y0.data_ptr()), p, T, C.c_void_p(out.data_ptr()),
-                            C.byref(self.stats), self._stream()), 'mi_ode_integrate')
+            if grid is not None or eps != 0.0:
+                garr, gp = self._times(arr if grid is None else grid)
+                rc = N.check(self.lib.mi_ode_fixed_grid_integrate_on(self.h, C.c_void_p(y0.data_ptr()), gp, garr.shape[0], p, T, float(eps),
+                                                                     C.c_void_p(out.data_ptr()), C.byref(self.stats), self._stream()),
+                             'mi_ode_fixed_grid_integrate_on')
+            else:
+                fn = self.lib.mi_ode_integrate if self.desc.adaptive else self.lib.mi_ode_fixed_grid_integrate
+                rc = N.check(fn(self.h, C.c_void_p(y0.data_ptr()), p, T, C.c_void_p(out.data_ptr()),
+                                C.byref(self.stats), self._stream()), 'mi_ode_integrate')
         self._raise_for_status(rc)
         return out
 
@@ -436,16 +444,30 @@ class FixedGridODESolver(object):
         _assert_increasing(t)
         t = t.to(self.y0[0].dtype)                    # :84 time in the STATE dtype here
         rhs = _fusable(self.func, self.y0)
-        if (rhs is not None and rhs.fixed_grid_fused and self._fused_tableau is not None
-                and getattr(self, '_default_grid', False) and self.eps == 0.0):
+        default_grid = getattr(self, '_default_grid', False)
+        time_grid = None
+        if rhs is not None and rhs.fixed_grid_fused and self._fused_tableau is not None:
             y = self.y0[0]
             key = ('fixed', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
                    _tableau_key(self._fused_tableau, None), self._fusion)
             eng = _cached_engine(key, lambda: _FusedEngine(rhs, y, False, self._fused_tableau, fusion=self._fusion))
-            out = eng.integrate(t.to(torch.float64).numpy(), y)
-            self.stats = eng.stats.as_dict()
-            return (out,)
-        time_grid = self.grid_constructor(self.func, self.y0, t)
+            if default_grid and self.eps == 0.0:
+                out = eng.integrate(t.to(torch.float64).numpy(), y)
+                self.stats = eng.stats.as_dict()
+                return (out,)
+            if self._fusion not in (1, 'stage'):
+                # a grid of its own (step_size / grid_constructor) and / or eps: still one launch - the kernel walks the grid
+                # and interpolates the requested times linearly inside the step that reaches them (solvers.py:86-115)
+                time_grid = self.grid_constructor(self.func, self.y0, t)
+                assert bool(time_grid[0] == t[0]) and bool(time_grid[-1] == t[-1])            # solvers.py:87
+                try:
+                    out = eng.integrate(t.to(torch.float64).numpy(), y, grid=time_grid.to(torch.float64).numpy(), eps=float(self.eps))
+                    self.stats = eng.stats.as_dict()
+                    return (out,)
+                except N.NativeError:
+                    pass                                  # no one-launch kernel for this family: the per-step loop below
+        if time_grid is None:
+            time_grid = self.grid_constructor(self.func, self.y0, t)
         assert bool(time_grid[0] == t[0]) and bool(time_grid[-1] == t[-1])
         for y_ in self.y0:
             N.require_gpu_tensor(y_, 'y0')
