@@ -444,8 +444,22 @@ class AdaptiveRK(object):
 class FixedGrid(object):
     """solvers.py:39-115 with the Euler / RK4 step functions of fixed_grid.py:4-46."""
 
-    def __init__(self, func, y0, method, eps=0.0):
+    def __init__(self, func, y0, method, eps=0.0, grid_constructor=None, step_size=None):
         self.func, self.y0, self.method, self.eps = func, y0, method, eps
+        if grid_constructor is not None:
+            # solvers.py:49-56: the branch that would accept a grid_constructor is the one that raises - in the reference a
+            # custom grid constructor can never be used
+            raise ValueError("step_size and grid_constructor are exclusive arguments.")
+        if step_size is not None:
+            # solvers.py:58-71 cannot run in the reference (F7: .item() / item assignment on TF tensors); this is its evident
+            # intent - a uniform grid of `step_size` from t[0], clipped to t[-1] - and an oracle EXTENSION, not pinned by it
+            def grid_constructor(func_, y0_, t):
+                n = int(np.ceil((t[-1] - t[0]) / step_size + 1))
+                g = (np.arange(0, n).astype(t.dtype) * t.dtype.type(step_size) + t[0]).astype(t.dtype)
+                if g[-1] > t[-1]:
+                    g[-1] = t[-1]
+                return g
+        self.grid_constructor = grid_constructor
         self.stats = Stats()
 
     def _f(self, t, y):
@@ -465,7 +479,8 @@ class FixedGrid(object):
     def integrate(self, t):
         assert bool(np.all(t[1:] > t[:-1])), 't must be strictly increasing or decrasing'
         t = t.astype(self.y0[0].dtype)                   # solvers.py:84  time in the STATE dtype
-        grid = t                                         # default grid_constructor (:53-54)
+        grid = t if self.grid_constructor is None else np.asarray(self.grid_constructor(self.func, self.y0, t)).astype(t.dtype)   # :53-54, :86
+        assert grid[0] == t[0] and grid[-1] == t[-1]     # :87
         solution = [self.y0]
         j, y0 = 1, self.y0
         for t0, t1 in zip(grid[:-1], grid[1:]):

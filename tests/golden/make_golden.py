@@ -520,6 +520,28 @@ def gen_adams():
 
 
 # --------------------------------------------------------------------------
+# fixed-grid solvers on a time grid of their own (solvers.py:41-56, 86-115) and with eps (fixed_grid.py:7, 42)
+# --------------------------------------------------------------------------
+def gen_fixed_grids():
+    """eps is the only fixed-grid option the reference can actually run: a grid_constructor argument always raises (the
+    else branch of solvers.py:49-56) and step_size dies on `.item()` (solvers.py:58-71)."""
+    cases = [('run_sine_euler_eps', rhs_sine(), np.float64(3.0), np.linspace(1., 2., 41), 'euler', 1e-3),
+             ('run_sine_rk4_eps', rhs_sine(), np.float64(3.0), np.linspace(1., 2., 11), 'rk4', 1e-3)]
+    for name, rhs, y0, t, method, eps in cases:
+        rhs.nfe = 0
+        sol = tfdiffeq.odeint(rhs, tt(y0), tt(t), method=method, options={'eps': eps})
+        save(name, {'rhs': rhs.name, 'rhs_params': rhs.params, 'method': method, 'rtol': None, 'atol': None, 'options': {'eps': eps},
+                    'max_attempts': None, 'note': 'fixed_grid.py:7, 42', 'tuple_state': False},
+             y=sol, y0=np.asarray(y0), t=np.asarray(t), nfe=np.asarray(rhs.nfe))
+    for bad in ({'grid_constructor': lambda f, y0, t: t}, {'step_size': 0.1}):
+        try:
+            tfdiffeq.odeint(rhs_sine(), tt(np.float64(3.0)), tt(np.linspace(1., 2., 5)), method='rk4', options=bad)
+            print('fixed grid option', list(bad), 'ran in the reference (unexpected)')
+        except Exception as e:
+            print('fixed grid option', list(bad), 'fails in the reference:', type(e).__name__, str(e)[:80])
+
+
+# --------------------------------------------------------------------------
 # DETEST (tests/DETEST/detest.py:9-351, run.py:25-60): the reference's 25 known-problem set, solved by the reference
 # --------------------------------------------------------------------------
 def gen_detest():
@@ -565,6 +587,9 @@ if __name__ == '__main__':
     if '--detest-only' in sys.argv:
         gen_detest()
         sys.exit(0)
+    if '--fixed-grids-only' in sys.argv:
+        gen_fixed_grids()
+        sys.exit(0)
     np.random.seed(0)
     if '--next-only' not in sys.argv and '--adams-only' not in sys.argv:
         gen_function_vectors()
@@ -572,4 +597,5 @@ if __name__ == '__main__':
     if '--adams-only' not in sys.argv:
         gen_next_solvers()
     gen_adams()
+    gen_fixed_grids()
     gen_detest()

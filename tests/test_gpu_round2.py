@@ -526,3 +526,35 @@ def test_linear_rhs_of_any_dim_runs_on_the_padded_tile_kernels(dim, dtype):
     got = odeint(f, to_dev(y0), torch.tensor(tg), method='rk4')
     ref4 = O.odeint(lambda t_, y: y @ A.T + b, y0, tg.astype(dtype), method='rk4')
     assert np.abs(got.cpu().numpy() - ref4).max() < (1e-12 if f64 else 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------
+# fixed-grid solvers on a grid of their own (step_size) and with eps: still one launch
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('method', ['rk4', 'euler'])
+def test_fixed_grid_with_step_size_runs_in_one_launch_and_interpolates_like_the_reference(method):
+    """FixedGridODESolver(step_size=...) (solvers.py:41-71: dead code in the reference, F7 - the oracle restates its intent) takes
+    steps on its own uniform grid and interpolates the requested times linearly (solvers.py:106-115).  The one-launch kernels
+    walk that grid themselves: row-local family (Lotka-Volterra) and MFMA-linear family, against the oracle and against the
+    per-step plane-kernel loop."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(31)
+    t = np.array([0., 0.33, 1.0, 1.7, 2.0])
+    y0 = 1.0 + 0.5 * rng.uniform(size=(300, 2))
+    opts = {'step_size': 0.0625 if method == 'rk4' else 0.03125}
+    ref = O.odeint(make_rhs('lotka_volterra', {'a': 1.5, 'b': 1., 'c': 3., 'd': 1.}), y0, t, method=method, options=opts)
+    got = odeint(rhs.LotkaVolterra(1.5, 1., 3., 1.), to_dev(y0), torch.tensor(t), method=method, options=opts)
+    st = dict(odeint.last_stats)
+    assert st['n_launches'] == 1, st
+    assert np.abs(got.cpu().numpy() - ref).max() < 1e-13
+    lv = rhs.LotkaVolterra(1.5, 1., 3., 1.)
+    loop = odeint(lambda t_, y_: lv.forward(t_, y_), to_dev(y0), torch.tensor(t), method=method, options=opts)     # opaque callable: plane path
+    assert float((loop - got).abs().max()) < 1e-13
+    W = 0.3 * rng.standard_normal((16, 16))
+    yl = rng.standard_normal((200, 16))
+    ref = O.odeint(lambda t_, y: y @ W, yl, t, method=method, options=opts)
+    got = odeint(rhs.Linear(torch.tensor(W)), to_dev(yl), torch.tensor(t), method=method, options=opts)
+    assert dict(odeint.last_stats)['n_launches'] == 1
+    assert np.abs(got.cpu().numpy() - ref).max() < 1e-12
+    with pytest.raises(ValueError, match='exclusive'):                 # solvers.py:49-56: the reference rejects ANY grid_constructor
+        odeint(rhs.LotkaVolterra(1.5, 1., 3., 1.), to_dev(y0), torch.tensor(t), method=method, options={'grid_constructor': lambda f, y, tt_: tt_})

@@ -114,7 +114,8 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
         adjoint_atol = atol
     if adjoint_options is None:
         adjoint_options = options
-    if adjoint_options and adjoint_options.get('graph'):
+    import os
+    if adjoint_options and adjoint_options.get('graph') and os.environ.get('TFDIFFEQ_AMD_ADJOINT_GRAPH') != '1':
         # the backward dynamics call torch.autograd.grad, which cannot run under hipGraph stream capture
         import warnings
         warnings.warn("odeint_adjoint: the 'graph' option is not used for the backward solve (autograd inside f)")

@@ -27,6 +27,19 @@ struct MlpGeom {
   static constexpr size_t lds_bytes() { return (size_t)R * (LDX + 2 * LDH) * sizeof(float) + 80 * sizeof(double); }
 };
 
+// tanh for the hidden layers: 2^(x * 2/ln 2) on the transcendental unit (v_exp_f32), one reciprocal, and the odd Taylor
+// polynomial below |x| = 1/4 where 1 - 2/(e+1) would cancel: 15 VALU instructions instead of the 27 of ocml's tanhf (the
+// fp32 VALU shares its issue slots with the fp32 matrix pipe, scripts/micro/mfma_fill.hip: the activation was ~1/5 of the
+// kernel).  Max relative error 5e-7 (absolute 1.3e-7) over the whole range (the reference's tf.tanh is a rational fp32 approximation of the
+// same class, not a correctly rounded one either).
+__device__ __forceinline__ float mlp_tanh(float x) {
+  const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // exp(2x); +inf / 0 at the ends give exactly +-1
+  const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
+  const float x2 = x * x;
+  const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.053968254f)));
+  return fabsf(x) < 0.25f ? small : big;
+}
+
 // One evaluation of the MLP for the tile whose input rows sit in s_x.  Every thread of the workgroup must call it.
 // Owner threads (wave < NW3) receive their 4 output elements (rows rb*16 + 4*(lane>>4) + i, column 16*cb + (lane&15)).
 template <int DP, int HP>
@@ -54,8 +67,8 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s_h1[(4 * lg + i) * G::LDH + col] = tanhf(c0[i] + b1v);
-      s_h1[(16 + 4 * lg + i) * G::LDH + col] = tanhf(c1[i] + b1v);
+      s_h1[(4 * lg + i) * G::LDH + col] = mlp_tanh(c0[i] + b1v);
+      s_h1[(16 + 4 * lg + i) * G::LDH + col] = mlp_tanh(c1[i] + b1v);
     }
   }
   __syncthreads();
@@ -75,8 +88,8 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s_h2[(4 * lg + i) * G::LDH + col] = tanhf(c0[i] + b2v);
-      s_h2[(16 + 4 * lg + i) * G::LDH + col] = tanhf(c1[i] + b2v);
+      s_h2[(4 * lg + i) * G::LDH + col] = mlp_tanh(c0[i] + b2v);
+      s_h2[(16 + 4 * lg + i) * G::LDH + col] = mlp_tanh(c1[i] + b2v);
     }
   }
   __syncthreads();

@@ -506,8 +506,11 @@ class FixedGridODESolver(object):
             return y0
         if t == t1:
             return y1
-        w = (t - t0) / (t1 - t0)
-        return tuple(_lincomb(y0_, [-w, w], [y0_, y1_], 1.0) for y0_, y1_ in zip(y0, y1))
+        # the reference's operation order: slope = (y1 - y0) / (t1 - t0); y0 + slope * (t - t0), scalars in the state dtype.
+        # Only reachable with step_size (the default grid hits every requested time exactly), so plain torch ops do.
+        dt_ = _np_dtype(y0[0].dtype).type
+        span, off = dt_(t1) - dt_(t0), dt_(t) - dt_(t0)
+        return tuple(y0_ + ((y1_ - y0_) / span) * off for y0_, y1_ in zip(y0, y1))
 
 
 # ---------------------------------------------------------------------------------------------
