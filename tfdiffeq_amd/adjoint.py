@@ -114,9 +114,9 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
         adjoint_atol = atol
     if adjoint_options is None:
         adjoint_options = options
-    import os
-    if adjoint_options and adjoint_options.get('graph') and os.environ.get('TFDIFFEQ_AMD_ADJOINT_GRAPH') != '1':
-        # the backward dynamics call torch.autograd.grad, which cannot run under hipGraph stream capture
+    if adjoint_options and adjoint_options.get('graph'):
+        # the backward dynamics call torch.autograd.grad, which cannot run under hipGraph stream capture (probed again in round 2:
+        # the capture aborts inside the autograd engine - AccumulateGrad stream mismatch - and takes the process with it)
         import warnings
         warnings.warn("odeint_adjoint: the 'graph' option is not used for the backward solve (autograd inside f)")
         adjoint_options = {k: v for k, v in adjoint_options.items() if k != 'graph'}
