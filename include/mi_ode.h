@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI_ODE_ABI_VERSION 5
+#define MI_ODE_ABI_VERSION 6
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -169,7 +169,8 @@ int mi_ode_abi_version(void);
 const char* mi_ode_status_string(uint32_t status_bits);   /* reference assertion text for the first set bit */
 const char* mi_ode_last_error(void);                      /* thread-local text of the last negative return */
 int64_t mi_ode_reduce_workspace_bytes(void);              /* scratch the stateless reductions need */
-int64_t mi_ode_sizeof(int32_t which);                     /* 0: mi_ode_desc, 1: mi_ode_stats, 2: mi_ode_tableau, 3: mi_ode_rhs
+int64_t mi_ode_sizeof(int32_t which);                     /* 0: mi_ode_desc, 1: mi_ode_stats, 2: mi_ode_tableau, 3: mi_ode_rhs,
+                                                             5: mi_ode_ctrl_params, 6: mi_ode_adjoint_desc
                                                              (lets a foreign-language binding verify its struct layout) */
 
 /* ---- (A) fused engine ---------------------------------------------------------------------- */
@@ -243,6 +244,38 @@ int mi_ode_xpeer_connect(mi_ode_handle h, const void* all_ipc_handles, int32_t w
 #define MI_ODE_RCCL_ID_BYTES 128
 int mi_ode_rccl_unique_id(void* id_out);
 int mi_ode_rccl_connect(mi_ode_handle h, const void* id, int32_t world_size, int32_t rank);
+
+/* ---- (A') fused backward segment of odeint_adjoint --------------------------------------------------------------- */
+/* tfdiffeq/adjoint.py:57-178: the reference's backward pass calls odeint on the augmented tuple state
+ *     (y, adj_y, adj_t, adj_params)   with dynamics   (f, -adj_y^T df/dy, -adj_y^T df/dt, -adj_y^T df/dparams)
+ * over [t_i, t_{i-1}] (adjoint.py:148-153), once per output interval.  This entry point is that call for the ODEFunc MLP
+ * (MI_ODE_RHS_MLP_TANH, fp32, state [batch, dim]) in ONE launch: dopri5 over all four components, per-component error
+ * ratios and their max (misc.py:250-287), initial step over all components (misc.py:183-247), dense output at t_end
+ * (interp.py:6-67).  adj_params is one flat vector in CANONICAL order W1 [dim,hidden], b1, W2 [hidden,hidden], b2,
+ * W3 [hidden,dim], b3 (weights [in, out] row-major as in mi_ode_rhs.w); mi_ode_adjoint_num_params() entries. */
+typedef struct mi_ode_adjoint_desc {
+  int64_t batch;
+  int32_t dim, hidden;
+  mi_ode_tableau tableau;     /* dopri5: 6 rows, FSAL shaped, c_mid filled, c_sol[1] = c_error[1] = c_mid[1] = 0 */
+  double rtol, atol;          /* scalars: adjoint.py passes them through to every component (dopri5.py:60-61) */
+  double safety, ifactor, dfactor;
+  int32_t order, init_order;
+  int64_t max_num_steps;
+} mi_ode_adjoint_desc;
+typedef struct mi_ode_adjoint* mi_ode_adjoint_handle;
+int mi_ode_adjoint_create(const mi_ode_adjoint_desc* desc, mi_ode_adjoint_handle* out);
+int mi_ode_adjoint_destroy(mi_ode_adjoint_handle h);
+int64_t mi_ode_adjoint_num_params(mi_ode_adjoint_handle h);
+/* One backward interval t_start -> t_end (either direction; decreasing time is handled as misc._check_inputs does,
+ * misc.py:311-321).  All state pointers are DEVICE memory, fp32; adj_t is a device scalar.  rhs: the weights (sign is ignored).
+ * y_out is nullable (the reference discards it, adjoint.py:155-160).  Blocks until done; returns status bits or an error. */
+int mi_ode_adjoint_segment(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, const void* y_dev, const void* adj_y_dev,
+                           const void* adj_t_dev, const void* adj_params_dev, double t_start, double t_end, void* y_out_dev,
+                           void* adj_y_out_dev, void* adj_t_out_dev, void* adj_params_out_dev, mi_ode_stats* stats, void* stream);
+/* One evaluation of the augmented dynamics (adjoint.py:69-105), the function-level parity surface of the kernel:
+ * f_out = f(y), vjp_y_out = -adj_y^T df/dy, vjp_params_out = -adj_y^T df/dparams (canonical order). */
+int mi_ode_adjoint_dynamics(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, const void* y_dev, const void* adj_y_dev,
+                            void* f_out_dev, void* vjp_y_out_dev, void* vjp_params_out_dev, void* stream);
 
 /* ---- function-level parity surface of the step controller ----------------------------------- */
 /* The scalar tail of one step attempt exactly as the kernels run it (csrc/mi_ode_ctrl_dev.h, ONE device thread per case):

@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH, RHS_PLUGIN = 1, 2, 3, 4, 5, 6
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
-ABI_VERSION = 5
+ABI_VERSION = 6
 IPC_HANDLE_BYTES = 64
 RCCL_ID_BYTES = 128
 ST_DT_UNDERFLOW, ST_NONFINITE, ST_MAX_STEPS, ST_BAD_T, ST_SYNC_TIMEOUT = 1, 2, 4, 8, 16
@@ -69,6 +69,12 @@ class CtrlParams(C.Structure):
                 ('order', C.c_int32), ('init_order', C.c_int32), ('controller', C.c_int32), ('dtype', C.c_int32)]
 
 
+class AdjointDesc(C.Structure):
+    _fields_ = [('batch', C.c_int64), ('dim', C.c_int32), ('hidden', C.c_int32), ('tableau', Tableau),
+                ('rtol', C.c_double), ('atol', C.c_double), ('safety', C.c_double), ('ifactor', C.c_double), ('dfactor', C.c_double),
+                ('order', C.c_int32), ('init_order', C.c_int32), ('max_num_steps', C.c_int64)]
+
+
 class Stats(C.Structure):
     _fields_ = [('n_attempts', C.c_int64), ('n_accepted', C.c_int64), ('n_rejected', C.c_int64), ('nfe', C.c_int64),
                 ('t', C.c_double), ('dt', C.c_double), ('last_ratio', C.c_double),
@@ -108,6 +114,13 @@ _PROTOS = {
     'mi_ode_get_stats': (C.c_int, [C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     'mi_ode_get_state': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mi_ode_get_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    'mi_ode_adjoint_create': (C.c_int, [C.POINTER(AdjointDesc), C.POINTER(C.c_void_p)]),
+    'mi_ode_adjoint_destroy': (C.c_int, [C.c_void_p]),
+    'mi_ode_adjoint_num_params': (C.c_int64, [C.c_void_p]),
+    'mi_ode_adjoint_segment': (C.c_int, [C.c_void_p, C.POINTER(Rhs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    'mi_ode_adjoint_dynamics': (C.c_int, [C.c_void_p, C.POINTER(Rhs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p]),
     'mi_ode_controller_update': (C.c_int, [C.POINTER(CtrlParams), C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.c_void_p]),
     'mi_ode_rk_stage_combine': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double),
@@ -165,7 +178,7 @@ def load():
         fn.argtypes = args
     if lib.mi_ode_abi_version() != ABI_VERSION:
         raise NativeError('libmi_ode.so ABI version mismatch')
-    for which, st in ((0, Desc), (1, Stats), (2, Tableau), (3, Rhs)):
+    for which, st in ((0, Desc), (1, Stats), (2, Tableau), (3, Rhs), (5, CtrlParams), (6, AdjointDesc)):
         if lib.mi_ode_sizeof(which) != C.sizeof(st):
             raise NativeError('struct layout mismatch for %s: C %d vs ctypes %d'
                               % (st.__name__, lib.mi_ode_sizeof(which), C.sizeof(st)))

@@ -9,14 +9,159 @@ Same algorithm and argument contract as the reference (adjoint.py:35-224), re-st
   * vector-Jacobian products of `func` come from torch.autograd.grad (reference: tf.GradientTape, adjoint.py:76-95).
 Unlike the reference there is no module-global `_arguments` (adjoint.py:32, 217): the call is re-entrant.
 """
+import ctypes as C
+import os
+
+import numpy as np
 import torch
 
+from . import _native as N
 from .odeint import odeint
+
+# The backward solve of the ODEFunc tanh MLP runs as ONE kernel launch per output interval (csrc/mi_ode_adjoint.h) when the
+# problem qualifies (`_fused_plan`); FUSED = False (or TFDIFFEQ_AMD_FUSED_ADJOINT=0) keeps every case on the plane kernels.
+FUSED = os.environ.get('TFDIFFEQ_AMD_FUSED_ADJOINT', '1') != '0'
+_ENGINES = {}
 
 
 def _flatten(seq):
     flat = [p.reshape(-1) for p in seq]
     return torch.cat(flat) if len(flat) > 0 else torch.tensor([])
+
+
+class _FusedAdjointEngine(object):
+    """Owns one mi_ode_adjoint handle: the augmented system (y, adj_y, adj_t, adj_params) of adjoint.py:57-178 for a
+    [batch, dim] float32 state and the dim -> hidden -> hidden -> dim tanh MLP."""
+
+    def __init__(self, batch, dim, hidden, rtol, atol, safety, ifactor, dfactor, max_num_steps, device):
+        from .dopri5 import _DORMAND_PRINCE_SHAMPINE_TABLEAU, DPS_C_MID
+        from .solvers import _fill_tableau
+        self.lib = N.load()
+        self.device = torch.device(device)
+        d = N.AdjointDesc()
+        d.batch, d.dim, d.hidden = int(batch), int(dim), int(hidden)
+        _fill_tableau(d.tableau, _DORMAND_PRINCE_SHAMPINE_TABLEAU, DPS_C_MID)
+        d.rtol, d.atol = float(rtol), float(atol)
+        d.safety, d.ifactor, d.dfactor = float(safety), float(ifactor), float(dfactor)
+        d.order, d.init_order = 5, 4                     # dopri5.py:68, 74
+        d.max_num_steps = int(max_num_steps)
+        self.desc = d
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(self.lib.mi_ode_adjoint_create(C.byref(d), C.byref(h)), 'mi_ode_adjoint_create')
+        self.h = h
+        self.batch, self.dim = int(batch), int(dim)
+        self.n_params = int(self.lib.mi_ode_adjoint_num_params(h))
+        self.stats = N.Stats()
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.mi_ode_adjoint_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _rhs(self, mlp):
+        r = N.Rhs()
+        keep = mlp.fill(r, torch.float32, self.device)
+        return r, keep
+
+    def segment(self, mlp, y, adj_y, adj_t, adj_params, t_start, t_end):
+        """odeint(augmented_dynamics, (y, adj_y, adj_t, adj_params), [t_start, t_end])[..][1] (adjoint.py:148-160) without
+        the y component.  All tensors float32 on the device; adj_params in canonical order."""
+        r, keep = self._rhs(mlp)
+        y, adj_y = y.contiguous(), adj_y.contiguous()
+        a_out = torch.empty_like(adj_y)
+        t_out = torch.empty_like(adj_t)
+        p_out = torch.empty_like(adj_params)
+        with torch.cuda.device(self.device):
+            rc = N.check(self.lib.mi_ode_adjoint_segment(
+                self.h, C.byref(r), y.data_ptr(), adj_y.data_ptr(), adj_t.data_ptr(), adj_params.data_ptr(), float(t_start), float(t_end),
+                None, a_out.data_ptr(), t_out.data_ptr(), p_out.data_ptr(), C.byref(self.stats), N.stream_ptr(self.device)),
+                'mi_ode_adjoint_segment')
+        del keep
+        if rc != 0:
+            if rc & N.ST_SYNC_TIMEOUT:
+                raise RuntimeError(N.status_message(rc))
+            msg = N.status_message(rc)
+            if rc & N.ST_MAX_STEPS:
+                msg = 'max_num_steps exceeded ({}>={})'.format(self.desc.max_num_steps, self.desc.max_num_steps)
+            if rc & N.ST_DT_UNDERFLOW:
+                msg = 'underflow in dt {}'.format(self.stats.dt)
+            raise AssertionError(msg)                      # what the reference's solver raises (dopri5.py:85-100)
+        return a_out, t_out, p_out
+
+    def dynamics(self, mlp, y, adj_y):
+        """One evaluation of the augmented dynamics (adjoint.py:69-105): (f, -adj_y^T df/dy, -adj_y^T df/dparams)."""
+        r, keep = self._rhs(mlp)
+        y, adj_y = y.contiguous(), adj_y.contiguous()
+        f, vy = torch.empty_like(y), torch.empty_like(y)
+        vp = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            N.check(self.lib.mi_ode_adjoint_dynamics(self.h, C.byref(r), y.data_ptr(), adj_y.data_ptr(), f.data_ptr(), vy.data_ptr(),
+                                                     vp.data_ptr(), N.stream_ptr(self.device)), 'mi_ode_adjoint_dynamics')
+        del keep
+        return f, vy, vp
+
+
+def _cached_adjoint_engine(*key):
+    eng = _ENGINES.get(key)
+    if eng is None:
+        while len(_ENGINES) >= 4:
+            _ENGINES.pop(next(iter(_ENGINES))).close()
+        eng = _ENGINES[key] = _FusedAdjointEngine(*key)
+    return eng
+
+
+def clear_adjoint_engines():
+    while _ENGINES:
+        _ENGINES.pop(next(iter(_ENGINES))).close()
+
+
+def canonical_to_module_order(base, theta):
+    """adj_params in the kernel's canonical order (W1 [in,out], b1, W2, b2, W3, b3) -> the flat order of base.parameters()
+    (torch.nn.Linear keeps [out, in] weights)."""
+    d, hd = base.fc1.in_features, base.fc1.out_features
+    sizes = [d * hd, hd, hd * hd, hd, hd * d, d]
+    w1, b1, w2, b2, w3, b3 = torch.split(theta, sizes)
+    return torch.cat([w1.reshape(d, hd).t().reshape(-1), b1, w2.reshape(hd, hd).t().reshape(-1), b2,
+                      w3.reshape(hd, d).t().reshape(-1), b3])
+
+
+def _fused_plan(func, n_tensors, cfg, like, f_params):
+    """(engine, MLPTanh descriptor, base module) if the backward solve can run on the fused kernel, else None."""
+    if not FUSED or n_tensors != 1 or not isinstance(func, _TupleModule):
+        return None
+    base = func.base_func
+    get = getattr(base, 'device_rhs', None)
+    if get is None or cfg['adjoint_method'] not in (None, 'dopri5'):
+        return None
+    if not (like.is_cuda and like.dtype == torch.float32 and like.dim() >= 2):
+        return None
+    try:
+        layers = (base.fc1, base.fc2, base.fc3)
+    except AttributeError:
+        return None
+    want = [p for l in layers for p in (l.weight, l.bias)]
+    if len(f_params) != 6 or any(a is not b for a, b in zip(f_params, want)):
+        return None                                      # frozen / extra parameters: the generic path handles those
+    opts = dict(cfg['adjoint_options'] or {})
+    max_num_steps = opts.pop('max_num_steps', 2 ** 31 - 1)
+    if opts or isinstance(cfg['adjoint_rtol'], (tuple, list)) or isinstance(cfg['adjoint_atol'], (tuple, list)):
+        return None                                      # first_step / safety / ... : not wired into the fused controller
+    mlp = get()
+    y1 = like[0]
+    if mlp is None or not mlp.supports(y1):
+        return None
+    batch = y1.numel() // y1.shape[-1]
+    f32 = lambda v: float(np.float32(v))                 # noqa: E731  (misc.py:137-144: python float -> float32 -> float64)
+    eng = _cached_adjoint_engine(batch, int(y1.shape[-1]), int(mlp.hidden), float(cfg['adjoint_rtol']), float(cfg['adjoint_atol']),
+                                 f32(0.9), f32(10.0), f32(0.2), int(max_num_steps), str(like.device))
+    return eng, mlp, base
 
 
 class _TupleModule(torch.nn.Module):
@@ -72,6 +217,31 @@ class _OdeintAdjointMethod(torch.autograd.Function):
             return (*[f.detach() for f in func_eval], *vjp_y, vjp_t.to(like.dtype), vjp_params.to(like.dtype))
 
         T = ans[0].shape[0]
+        plan = _fused_plan(func, n_tensors, cfg, like, f_params)
+        if plan is not None:
+            eng, mlp, base = plan
+            segs = []
+            with torch.no_grad():
+                g_out = grad_output[0]
+                adj_y = g_out[-1].contiguous()
+                theta = torch.zeros(eng.n_params, dtype=torch.float32, device=like.device)
+                adj_time = torch.zeros((), dtype=torch.float32, device=like.device)
+                time_vjps = []
+                t_dev = t.to(device=like.device)
+                for i in range(T - 1, 0, -1):
+                    func_i = func(t_dev[i].to(like.dtype), (ans[0][i],))[0]
+                    dLd_cur_t = torch.dot(func_i.reshape(-1), g_out[i].reshape(-1))              # adjoint.py:134-140
+                    adj_time = adj_time - dLd_cur_t
+                    time_vjps.append(dLd_cur_t.reshape(1))
+                    adj_y, adj_time, theta = eng.segment(mlp, ans[0][i], adj_y, adj_time, theta, float(t[i]), float(t[i - 1]))
+                    segs.append(eng.stats.as_dict())
+                    adj_y = adj_y + g_out[i - 1]
+                time_vjps.append(adj_time.reshape(1))
+                time_vjps = torch.cat(time_vjps[::-1]).to(dtype=t.dtype, device=t.device)
+                grad_params = canonical_to_module_order(base, theta).to(flat_params.dtype)
+            odeint_adjoint.last_backward_stats = {'engine': 'fused adjoint kernel (one launch per interval)', 'segments': segs}
+            return (None, None, None, time_vjps, grad_params, adj_y)
+        odeint_adjoint.last_backward_stats = {'engine': 'plane kernels'}
         with torch.no_grad():
             adj_y = tuple(g[-1] for g in grad_output)
             adj_params = torch.zeros_like(flat_params, dtype=like.dtype) if flat_params.numel() > 0 else \
@@ -134,3 +304,6 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
     if tensor_input:
         ys = ys[0]
     return ys
+
+
+odeint_adjoint.last_backward_stats = {}

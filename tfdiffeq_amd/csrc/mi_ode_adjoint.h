@@ -1,0 +1,945 @@
+// One backward segment of odeint_adjoint (/root/reference/tfdiffeq/adjoint.py:57-178) in ONE launch, for the ODEFunc
+// MLP  f(y) = W3^T tanh(W2^T tanh(W1^T y + b1) + b2) + b3  (tfdiffeq/models/dense_odenet.py:41-92), fp32.
+//
+// The reference integrates the heterogeneous tuple (y, adj_y, adj_t, adj_params) over [t_i, t_{i-1}] with odeint, i.e.
+// with the dopri5 step of rk_common.py:22-61 per component, the per-component error ratios of misc.py:250-264, their
+// python max() in misc.py:267-287 and the initial step of misc.py:183-247 over all components.  Here:
+//   * components y and a = adj_y ([batch, dim] each) live on the persistent 32-row tile grid of the forward MLP
+//     kernel: a workgroup owns its tiles for the whole segment; per stage one forward pass (three MFMA layers) and one
+//     backward-data pass (the three transposed layers) give k_y = s f and k_a = -s a^T df/dy; the stage derivatives
+//     of both components stay in registers, as in mi_ode_mlp.h;
+//   * component adj_t is a scalar with zero derivative (f does not depend on t): thread 0 carries it;
+//   * component theta = adj_params (P = all weights and biases, canonical order W1 b1 W2 b2 W3 b3, weights [in, out])
+//     has k_theta = -s sum_rows X^T Delta (X: layer inputs, Delta: back-propagated signals).  theta never feeds back
+//     into f, so only LINEAR COMBINATIONS over the stages are needed: theta_1 = theta_0 + sum_j (dt c_sol_j) k_j,
+//     err = sum_j (dt c_err_j) k_j.  The tile pass writes the activations of the stages to an L2/MALL-resident
+//     scratch (transposed, [column][32 rows]); a second pass per attempt runs the weight-gradient GEMMs
+//     X^T [c_sol Delta | c_err Delta] with K = all rows x all stages of the workgroup's tiles, accumulators in
+//     registers (no atomics), then the workgroups exchange their partial [2][P] blocks through HBM, each reduces its
+//     1/G slice of theta in a fixed order and contributes that slice's norms to the second hand-off of the attempt;
+//   * FSAL for theta: the activations of stage 6 of an accepted step are stage 0 of the next one (ping-pong slot);
+//   * dense output at t_{i-1} (interp.py:6-67): y and a from registers in the attempt that covers it (speculative, as
+//     in the forward kernels); theta in an epilogue after the accepted last step (two more GEMM passes: y_mid, f_1, f_0).
+// Controller: every workgroup applies it redundantly to the same combined records (mi_ode_persist.h).
+// Bound: fp32 matrix pipe - per row and stage 65536 MAC (forward + backward data) + 65536 MAC (weight gradients, two
+// combinations) at 64-128-128-64, against 2.5 KB of scratch traffic.
+#pragma once
+#include "mi_ode_mlp.h"
+
+namespace mi {
+
+template <int DP, int HP>
+struct AdjGeom {
+  static constexpr int CB = DP / 16, HB = HP / 16;
+  static constexpr int NW12 = HB;                           // waves that own 16 hidden columns
+  static constexpr int NW3 = 2 * CB;                        // waves that own state elements (2 row blocks x CB)
+  static constexpr int NW = NW12 > NW3 ? NW12 : NW3;
+  static constexpr int R = 32;                              // rows per tile
+  static constexpr int LDX = DP + 4, LDH = HP + 4;          // LDS row strides of the activation tiles
+  static constexpr int LW1 = HP + 1, LW3 = DP + 1;          // ... of W1 [DP][HP] and W3 [HP][DP]: odd, so that the rows AND the
+                                                            // columns of a 4 x 16 operand block fall into distinct banks
+  static constexpr int KS1 = DP / 4, KS2 = HP / 4;          // k values per lane group in a K = DP / K = HP product
+  static constexpr int CH1 = KS1 < 16 ? KS1 : 16, CH2 = KS2 < 16 ? KS2 : 16;
+  static constexpr int NSLOT = 6;                           // activation slots per tile: 0/1 = stage 0 <-> stage S (ping-pong), 2..5
+  static constexpr int SLOT = R * (2 * DP + 4 * HP);        // floats per (tile, slot)
+  static constexpr int OFF_X = 0, OFF_A = R * DP, OFF_H1 = 2 * R * DP, OFF_H2 = OFF_H1 + R * HP, OFF_G2 = OFF_H2 + R * HP,
+                       OFF_G1 = OFF_G2 + R * HP;
+  static constexpr size_t lds_bytes() { return (size_t)(DP * LW1 + HP * LW3 + 2 * R * LDX + 2 * R * LDH) * sizeof(float); }
+};
+
+// k index held by lane group lg at slot s of a product whose lane groups hold KS values each: chunks of <= 16 consecutive
+// k per group, so that a group's 4 x f32 operand reads are contiguous and the 4 groups stay 16 banks apart
+template <int CH>
+__device__ __forceinline__ constexpr int adj_k(int lg, int s) { return (s / CH) * 4 * CH + lg * CH + s % CH; }
+
+struct AdjResult {             // pinned host record, written by the kernel's last act
+  double t1, dt, ratio, h0;
+  long long n_attempt, n_accept;
+  unsigned status;
+  int handoffs;
+};
+
+struct AdjArgs {
+  PersistArgs p;               // hand-off plumbing, tableau, weights (p.s.rhs), controller parameters, p.t0 = start time
+  const float* y_in;           // [batch, dim] state at the start time
+  const float* a_in;           // [batch, dim] adj_y
+  float* y_out;                // [batch, dim] at t_end (nullable).            EVAL: f(y)
+  float* a_out;                // [batch, dim] at t_end.                       EVAL: -a^T df/dy
+  const float* th_in;          // [P] adj_params at the start (canonical order)
+  float* th_out;               // [P] at t_end.                                EVAL: -a^T df/dtheta
+  const float* adjt_in;        // device scalar adj_t
+  float* adjt_out;
+  float* planes;               // 8 planes of batch*dim floats: y a/b, a a/b, f_y a/b, f_a a/b
+  float* theta;                // 3 x Ppad floats: theta a/b, f0_theta
+  float* act;                  // [tiles][NSLOT][SLOT] activation scratch
+  float* wpart;                // [grid][3][Ppad] weight-gradient partials
+  AdjResult* res;
+  double t_end;
+  float cb[6][8], ce[8], cm[8];   // the tableau in the state dtype (beta rows, c_error, c_mid): scalar operands, no conversions in the kernel
+  int mode;                    // 0: segment, 1: one evaluation of the augmented dynamics
+  int P, Ppad, SL;             // parameters, padded, slice per workgroup
+};
+
+typedef float adj_f4 __attribute__((ext_vector_type(4)));
+// The tile and weight-gradient passes are separate (non-inlined) functions - one register allocation each, instead of one
+// for a kernel that contains six of them - so they receive the workgroup's LDS as 32-bit LDS addresses and keep every
+// access in the LDS address space (ds_read / ds_write, not flat).
+#define MI_LDS __attribute__((address_space(3)))
+#define MI_GLOBAL __attribute__((address_space(1)))
+#define MI_CONST __attribute__((address_space(4)))
+typedef MI_GLOBAL float g_float;
+typedef MI_GLOBAL adj_f4 g_f4;
+typedef MI_LDS float lds_float;
+typedef MI_LDS adj_f4 lds_f4;
+
+template <int DP, int HP>
+struct AdjCtx {
+  using G = AdjGeom<DP, HP>;
+  lds_float *s_w1, *s_w3, *s_x, *s_a, *s_hA, *s_hB;
+  float w2f[G::KS2], w2t[G::KS2];                           // W2[k][col] and W2[col][k] of this wave's 16 hidden columns
+  float b1v, b2v, b3v, sign;
+  int lane, wave, li, lg, d, hd, col, col12, rbase;
+  bool owner;
+
+  // pointers, lane roles, biases (every pass); `smem`: LDS address of the dynamic segment
+  template <class RHS>
+  __device__ __forceinline__ void bind(const RHS& rhs, int dim, unsigned smem) {
+    s_w1 = (lds_float*)(size_t)smem;
+    s_w3 = s_w1 + DP * G::LW1;
+    s_x = s_w3 + HP * G::LW3;
+    s_a = s_x + G::R * G::LDX;
+    s_hA = s_a + G::R * G::LDX;
+    s_hB = s_hA + G::R * G::LDH;
+    lane = threadIdx.x & 63; wave = threadIdx.x >> 6; li = lane & 15; lg = lane >> 4;
+    d = dim; hd = rhs.hidden;
+    const g_float* B1 = (const g_float*)rhs.b[0];
+    const g_float* B2 = (const g_float*)rhs.b[1];
+    const g_float* B3 = (const g_float*)rhs.b[2];
+    sign = (float)rhs.sign;
+    col12 = 16 * wave + li;
+    b1v = (B1 != nullptr && wave < G::NW12 && col12 < hd) ? B1[col12] : 0.f;
+    b2v = (B2 != nullptr && wave < G::NW12 && col12 < hd) ? B2[col12] : 0.f;
+    col = 16 * (wave % G::CB) + li;
+    b3v = (B3 != nullptr && wave < G::NW3 && col < d) ? B3[col] : 0.f;
+    owner = wave < G::NW3 && col < d;
+    rbase = 16 * (wave / G::CB) + 4 * lg;
+  }
+  // W1 and W3 into LDS, zero padded (once per launch)
+  template <class RHS>
+  __device__ __forceinline__ void stage_weights(const RHS& rhs) {
+    const g_float* W1 = (const g_float*)rhs.w[0];
+    const g_float* W3 = (const g_float*)rhs.w[2];
+    for (int i = threadIdx.x; i < DP * HP; i += blockDim.x) {
+      const int k = i / HP, n = i % HP;
+      s_w1[k * G::LW1 + n] = (k < d && n < hd) ? W1[(unsigned)(k * hd + n)] : 0.f;
+    }
+    for (int i = threadIdx.x; i < HP * DP; i += blockDim.x) {
+      const int k = i / DP, n = i % DP;
+      s_w3[k * G::LW3 + n] = (k < hd && n < d) ? W3[(unsigned)(k * d + n)] : 0.f;
+    }
+    __syncthreads();
+  }
+
+  // The W2 slices live in registers only while a tile pass runs (the weight-gradient passes need the registers for their
+  // accumulators): every tile pass starts by (re)loading them - 2 x KS2 L2 hits per lane.
+  template <class RHS>
+  __device__ __forceinline__ void load_w2(const RHS& rhs) {
+    const g_float* W2 = (const g_float*)rhs.w[1];
+#pragma unroll
+    for (int s = 0; s < G::KS2; ++s) {
+      const int k = adj_k<G::CH2>(lg, s);
+      const bool ok = wave < G::NW12 && k < hd && col12 < hd;
+      w2f[s] = ok ? W2[(unsigned)(k * hd + col12)] : 0.f;     // (32-bit lane offsets off one scalar base: no 64-bit address per load)
+      w2t[s] = ok ? W2[(unsigned)(col12 * hd + k)] : 0.f;
+    }
+  }
+
+  // One evaluation for the tile whose stage inputs are xs (y component) and as (a component), 4 elements per owner
+  // thread.  f4 = f(xs), v4 = as^T df/dy (both unsigned).  act != nullptr: the six activation planes go to that slot.
+  // Every thread of the workgroup must call it.
+  __device__ __forceinline__ void eval(const float* xs, const float* as, float* f4, float* v4, g_float* act) {
+    constexpr int KS1 = G::KS1, KS2 = G::KS2;
+    if (wave < G::NW3) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        s_x[(rbase + i) * G::LDX + col] = xs[i];
+        s_a[(rbase + i) * G::LDX + col] = as[i];
+      }
+      if (act != nullptr) {
+        *(g_f4*)(act + (unsigned)(G::OFF_X + col * G::R + rbase)) = adj_f4{xs[0], xs[1], xs[2], xs[3]};
+        *(g_f4*)(act + (unsigned)(G::OFF_A + col * G::R + rbase)) = adj_f4{as[0], as[1], as[2], as[3]};
+      }
+    }
+    __syncthreads();
+    float h1k[8], h2k[8];
+    if (wave < G::NW12) {                                   // layer 1: [32 x DP] @ W1[:, 16 columns]
+      adj_f4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < KS1 / 4; ++m) {
+        const int k0 = adj_k<G::CH1>(lg, 4 * m);
+        const adj_f4 a0 = *(const lds_f4*)(s_x + li * G::LDX + k0), a1 = *(const lds_f4*)(s_x + (16 + li) * G::LDX + k0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float b = s_w1[(k0 + v) * G::LW1 + col12];
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[v], b, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[v], b, c1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        h1k[i] = mlp_tanh(c0[i] + b1v);
+        h1k[4 + i] = mlp_tanh(c1[i] + b1v);
+        s_hA[(4 * lg + i) * G::LDH + col12] = h1k[i];
+        s_hA[(16 + 4 * lg + i) * G::LDH + col12] = h1k[4 + i];
+      }
+      if (act != nullptr) {
+        *(g_f4*)(act + (unsigned)(G::OFF_H1 + col12 * G::R + 4 * lg)) = adj_f4{h1k[0], h1k[1], h1k[2], h1k[3]};
+        *(g_f4*)(act + (unsigned)(G::OFF_H1 + col12 * G::R + 16 + 4 * lg)) = adj_f4{h1k[4], h1k[5], h1k[6], h1k[7]};
+      }
+    }
+    __syncthreads();
+    if (wave < G::NW12) {                                   // layer 2: [32 x HP] @ W2[:, 16 columns]
+      adj_f4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < KS2 / 4; ++m) {
+        const int k0 = adj_k<G::CH2>(lg, 4 * m);
+        const adj_f4 a0 = *(const lds_f4*)(s_hA + li * G::LDH + k0), a1 = *(const lds_f4*)(s_hA + (16 + li) * G::LDH + k0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[v], w2f[4 * m + v], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[v], w2f[4 * m + v], c1, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        h2k[i] = mlp_tanh(c0[i] + b2v);
+        h2k[4 + i] = mlp_tanh(c1[i] + b2v);
+        s_hB[(4 * lg + i) * G::LDH + col12] = h2k[i];
+        s_hB[(16 + 4 * lg + i) * G::LDH + col12] = h2k[4 + i];
+      }
+      if (act != nullptr) {
+        *(g_f4*)(act + (unsigned)(G::OFF_H2 + col12 * G::R + 4 * lg)) = adj_f4{h2k[0], h2k[1], h2k[2], h2k[3]};
+        *(g_f4*)(act + (unsigned)(G::OFF_H2 + col12 * G::R + 16 + 4 * lg)) = adj_f4{h2k[4], h2k[5], h2k[6], h2k[7]};
+      }
+    }
+    __syncthreads();
+    if (wave < G::NW3) {                                    // layer 3: f = h2 @ W3[:, 16 state columns] + b3
+      const int rb = wave / G::CB;
+      adj_f4 c = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < KS2 / 4; ++m) {
+        const int k0 = adj_k<G::CH2>(lg, 4 * m);
+        const adj_f4 a = *(const lds_f4*)(s_hB + (16 * rb + li) * G::LDH + k0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v], s_w3[(k0 + v) * G::LW3 + col], c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f4[i] = c[i] + b3v;
+    }
+    if (wave < G::NW12) {                                   // layer 3 transposed: g2 = (a @ W3^T) * (1 - h2^2)
+      adj_f4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < KS1 / 4; ++m) {
+        const int k0 = adj_k<G::CH1>(lg, 4 * m);
+        const adj_f4 a0 = *(const lds_f4*)(s_a + li * G::LDX + k0), a1 = *(const lds_f4*)(s_a + (16 + li) * G::LDX + k0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          const float b = s_w3[col12 * G::LW3 + k0 + v];
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[v], b, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[v], b, c1, 0, 0, 0);
+        }
+      }
+      float g[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        g[i] = c0[i] * (1.0f - h2k[i] * h2k[i]);
+        g[4 + i] = c1[i] * (1.0f - h2k[4 + i] * h2k[4 + i]);
+        s_hA[(4 * lg + i) * G::LDH + col12] = g[i];         // (h1's tile was last read before the previous barrier)
+        s_hA[(16 + 4 * lg + i) * G::LDH + col12] = g[4 + i];
+      }
+      if (act != nullptr) {
+        *(g_f4*)(act + (unsigned)(G::OFF_G2 + col12 * G::R + 4 * lg)) = adj_f4{g[0], g[1], g[2], g[3]};
+        *(g_f4*)(act + (unsigned)(G::OFF_G2 + col12 * G::R + 16 + 4 * lg)) = adj_f4{g[4], g[5], g[6], g[7]};
+      }
+    }
+    __syncthreads();
+    if (wave < G::NW12) {                                   // layer 2 transposed: g1 = (g2 @ W2^T) * (1 - h1^2)
+      adj_f4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < KS2 / 4; ++m) {
+        const int k0 = adj_k<G::CH2>(lg, 4 * m);
+        const adj_f4 a0 = *(const lds_f4*)(s_hA + li * G::LDH + k0), a1 = *(const lds_f4*)(s_hA + (16 + li) * G::LDH + k0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[v], w2t[4 * m + v], c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[v], w2t[4 * m + v], c1, 0, 0, 0);
+        }
+      }
+      float g[8];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        g[i] = c0[i] * (1.0f - h1k[i] * h1k[i]);
+        g[4 + i] = c1[i] * (1.0f - h1k[4 + i] * h1k[4 + i]);
+        s_hB[(4 * lg + i) * G::LDH + col12] = g[i];         // (h2's tile was last read before the previous barrier)
+        s_hB[(16 + 4 * lg + i) * G::LDH + col12] = g[4 + i];
+      }
+      if (act != nullptr) {
+        *(g_f4*)(act + (unsigned)(G::OFF_G1 + col12 * G::R + 4 * lg)) = adj_f4{g[0], g[1], g[2], g[3]};
+        *(g_f4*)(act + (unsigned)(G::OFF_G1 + col12 * G::R + 16 + 4 * lg)) = adj_f4{g[4], g[5], g[6], g[7]};
+      }
+    }
+    __syncthreads();
+    if (wave < G::NW3) {                                    // layer 1 transposed: v = g1 @ W1^T
+      const int rb = wave / G::CB;
+      adj_f4 c = {0, 0, 0, 0};
+#pragma unroll
+      for (int m = 0; m < KS2 / 4; ++m) {
+        const int k0 = adj_k<G::CH2>(lg, 4 * m);
+        const adj_f4 a = *(const lds_f4*)(s_hB + (16 * rb + li) * G::LDH + k0);
+#pragma unroll
+        for (int v = 0; v < 4; ++v) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v], s_w1[col * G::LW1 + k0 + v], c, 0, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v4[i] = c[i];
+    }
+  }
+};
+
+// rk_common.py:51 / :60 / dopri5.py:42 for one element, misc._scaled_dot_product order: ((dt c_0) k_0 + (dt c_1) k_1) + ...
+template <int NK, class C>
+__device__ __forceinline__ float adj_dot(const C* c, const float* k, float hs) {
+  float acc = (hs * c[0]) * k[0];
+#pragma unroll
+  for (int j = 1; j < NK; ++j) acc = acc + (hs * c[j]) * k[j];
+  return acc;
+}
+
+// ---- workgroup-shared state of the segment -----------------------------------------------------------------------------
+enum AdjMode { ADJ_F0 = 0, ADJ_INITB = 1, ADJ_STEP = 2 };
+
+struct AdjPlanes {             // what a tile pass works on (thread 0 fills it in LDS before the call)
+  const float *y0, *a0, *fy0, *fa0;
+  float *y1, *a1, *fy1, *fa1;
+  double t_start, t_new, dt64;
+  float hs;                    // dt (h0 for INITB) in the state dtype
+  int emit;                    // the attempt covers t_end: write the dense output (speculative)
+  int s0_cur;                  // activation slot that holds stage 0 of the current state
+};
+
+struct AdjWList {              // one weight-gradient pass: activation slots and their coefficients (<= 2 combinations)
+  int n;
+  int slot[8];
+  float c[2][8];
+};
+
+struct AdjShared {
+  AdjPlanes P;
+  AdjWList wl[2];
+  double blk[2][5];            // block records of the last tile pass: y component, a component
+  double red[80];
+  float d0[4], d1[4], d2[4];   // misc._select_initial_step intermediates per component (y, a, adj_t, theta)
+  float h0;
+  double ymax, amax, thmax;    // max |.| of the current state (the accepted y1 of the previous step)
+  float adjt;
+  int s0_cur, th_cur;
+};
+typedef MI_LDS AdjShared lds_AdjShared;
+
+__device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+
+// ---- tile passes ---------------------------------------------------------------------------------------------------
+// Block records (thread 0 -> ash->blk[0] for y, blk[1] for a).  F0: {max |y0|, -, sum (y0/sc)^2, sum (f0/sc)^2, non-finite};
+// INITB: {-, -, sum ((f1-f0)/sc)^2}; STEP: {-, max |y1|, sum err^2}.
+template <int DP, int HP, int MODE, int S>
+__device__ __attribute__((noinline)) void adj_tile_pass(const AdjArgs* A_, unsigned smem, unsigned ash_off) {
+  using G = AdjGeom<DP, HP>;
+  const MI_CONST AdjArgs& A = *(const MI_CONST AdjArgs*)uniform_p(A_);     // scalar loads
+  lds_AdjShared* ash = (lds_AdjShared*)(size_t)__builtin_amdgcn_readfirstlane((int)ash_off);
+  smem = (unsigned)__builtin_amdgcn_readfirstlane((int)smem);
+  const MI_CONST StepArgs& SA = A.p.s;
+  AdjCtx<DP, HP> cx;
+  cx.bind(SA.rhs, SA.dim, smem);
+  struct {
+    const g_float *y0, *a0, *fy0, *fa0;
+    g_float *y1, *a1, *fy1, *fa1;
+    double t_start, t_new, dt64;
+    float hs;
+    int emit, s0_cur;
+  } P;
+  P.y0 = (const g_float*)uniform_p(ash->P.y0); P.a0 = (const g_float*)uniform_p(ash->P.a0);
+  P.fy0 = (const g_float*)uniform_p(ash->P.fy0); P.fa0 = (const g_float*)uniform_p(ash->P.fa0);
+  P.y1 = (g_float*)uniform_p(ash->P.y1); P.a1 = (g_float*)uniform_p(ash->P.a1);
+  P.fy1 = (g_float*)uniform_p(ash->P.fy1); P.fa1 = (g_float*)uniform_p(ash->P.fa1);
+  P.t_start = uniform_d(ash->P.t_start); P.t_new = uniform_d(ash->P.t_new); P.dt64 = uniform_d(ash->P.dt64);
+  P.hs = uniform_f(ash->P.hs); P.emit = uniform_i(ash->P.emit); P.s0_cur = uniform_i(ash->P.s0_cur);
+  g_float* const y_out = (g_float*)A.y_out;
+  g_float* const a_out = (g_float*)A.a_out;
+  g_float* const act_base = (g_float*)A.act;
+  const double t_end = A.t_end;
+  Acc accY, accA;
+  const int d = cx.d, col = cx.col, rbase = cx.rbase;
+  const bool owner = cx.owner;
+  const float sign = cx.sign;
+  const float rtol = (float)SA.cp.rtol, atol = (float)SA.cp.atol;
+  const long long ntiles = (SA.batch + G::R - 1) / G::R;
+  cx.load_w2(SA.rhs);
+  for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+    const long long row0 = tile_i * G::R;
+    g_float* act_tile = act_base + tile_i * (long long)(G::NSLOT * G::SLOT);
+    const long long ebase = row0 * d;                       // wave-uniform; element i of this lane sits eo[i] further on
+    unsigned eo[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) eo[i] = (unsigned)((rbase + i) * d + col);
+    float hs = P.hs;
+    asm volatile("" : "+v"(hs));
+    float y0e[4], a0e[4], ky[(MODE == ADJ_STEP ? S : 0) + 1][4], ka[(MODE == ADJ_STEP ? S : 0) + 1][4], ys[4], as[4], fn[4], vn[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long row = row0 + rbase + i;
+      const bool ok = owner && row < SA.batch;
+      y0e[i] = ok ? (P.y0 + ebase)[eo[i]] : 0.f;
+      a0e[i] = ok ? (P.a0 + ebase)[eo[i]] : 0.f;
+      ky[0][i] = (ok && MODE != ADJ_F0) ? (P.fy0 + ebase)[eo[i]] : 0.f;
+      ka[0][i] = (ok && MODE != ADJ_F0) ? (P.fa0 + ebase)[eo[i]] : 0.f;
+    }
+    if (MODE == ADJ_F0) {
+      cx.eval(y0e, a0e, fn, vn, act_tile + (long long)P.s0_cur * G::SLOT);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long row = row0 + rbase + i;
+        if (owner && row < SA.batch) {
+          const float fy = sign * fn[i], fa = -(sign * vn[i]);
+          (P.fy1 + ebase)[eo[i]] = fy;
+          (P.fa1 + ebase)[eo[i]] = fa;
+          const float scy = atol + fabsf(y0e[i]) * rtol, sca = atol + fabsf(a0e[i]) * rtol;     // misc.py:225
+          const double q0 = (double)(y0e[i] / scy), q1 = (double)(fy / scy), p0 = (double)(a0e[i] / sca), p1 = (double)(fa / sca);
+          accY.suma += q0 * q0; accY.sumb += q1 * q1; accA.suma += p0 * p0; accA.sumb += p1 * p1;
+          accY.maxa = fmax(accY.maxa, (double)fabsf(y0e[i])); accA.maxa = fmax(accA.maxa, (double)fabsf(a0e[i]));
+          if (!finite_(y0e[i]) || !finite_(a0e[i])) accY.flag = 1;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    if (MODE == ADJ_INITB) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ys[i] = y0e[i] + hs * ky[0][i]; as[i] = a0e[i] + hs * ka[0][i]; }          // misc.py:235
+      cx.eval(ys, as, fn, vn, act_tile + 2LL * G::SLOT);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long row = row0 + rbase + i;
+        if (owner && row < SA.batch) {
+          const float scy = atol + fabsf(y0e[i]) * rtol, sca = atol + fabsf(a0e[i]) * rtol;
+          const double q = (double)((sign * fn[i] - ky[0][i]) / scy), p = (double)((-(sign * vn[i]) - ka[0][i]) / sca);   // misc.py:237
+          accY.suma += q * q; accA.suma += p * p;
+        }
+      }
+      __syncthreads();
+      continue;
+    }
+    if constexpr (MODE == ADJ_STEP) {
+      auto stage = [&](auto sg_c) {
+        constexpr int SG = decltype(sg_c)::value;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float kk[SG], kq[SG];
+#pragma unroll
+          for (int j = 0; j < SG; ++j) { kk[j] = ky[j][i]; kq[j] = ka[j][i]; }
+          ys[i] = y0e[i] + adj_dot<SG>(A.cb[SG - 1], kk, hs);          // rk_common.py:51
+          as[i] = a0e[i] + adj_dot<SG>(A.cb[SG - 1], kq, hs);
+        }
+        // stage 1 (c_sol = c_err = c_mid = 0 there for the FSAL pairs in use) leaves no activations; stage S is stage 0 of
+        // the next step if this one is accepted
+        g_float* act = SG == 1 ? nullptr : act_tile + (long long)(SG == S ? 1 - P.s0_cur : SG) * G::SLOT;
+        cx.eval(ys, as, fn, vn, act);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ky[SG][i] = sign * fn[i]; ka[SG][i] = -(sign * vn[i]); }
+      };
+      for_stages<1, S>(stage);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const long long row = row0 + rbase + i;
+        if (owner && row < SA.batch) {
+          float kk[S + 1], kq[S + 1];
+#pragma unroll
+          for (int j = 0; j <= S; ++j) { kk[j] = ky[j][i]; kq[j] = ka[j][i]; }
+          const float erry = adj_dot<S + 1>(A.ce, kk, hs), erra = adj_dot<S + 1>(A.ce, kq, hs);       // rk_common.py:60
+          (P.y1 + ebase)[eo[i]] = ys[i]; (P.fy1 + ebase)[eo[i]] = ky[S][i];
+          (P.a1 + ebase)[eo[i]] = as[i]; (P.fa1 + ebase)[eo[i]] = ka[S][i];
+          if (P.emit) {                                     // interp.py:6-67 at t_end, from registers
+            const float x = interp_x<float>(P.t_start, P.t_new, t_end);
+            const float ymid = y0e[i] + adj_dot<S + 1>(A.cm, kk, hs), amid = a0e[i] + adj_dot<S + 1>(A.cm, kq, hs);   // dopri5.py:42
+            float co[5];
+            if (y_out != nullptr) {
+              quartic_from_mid<float>(y0e[i], ys[i], ymid, kk[0], kk[S], (float)P.dt64, co);
+              (y_out + ebase)[eo[i]] = quartic_eval<float>(co, x);
+            }
+            quartic_from_mid<float>(a0e[i], as[i], amid, kq[0], kq[S], (float)P.dt64, co);
+            (a_out + ebase)[eo[i]] = quartic_eval<float>(co, x);
+          }
+          accY.maxb = fmax(accY.maxb, (double)fabsf(ys[i])); accA.maxb = fmax(accA.maxb, (double)fabsf(as[i]));
+          accY.suma += (double)erry * (double)erry; accA.suma += (double)erra * (double)erra;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  double r[5];
+  block_reduce_thread0(accY, (double*)ash->red, r);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 5; ++i) ash->blk[0][i] = r[i];
+  block_reduce_thread0(accA, (double*)ash->red, r);
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 5; ++i) ash->blk[1][i] = r[i];
+  __syncthreads();
+}
+
+// ---- weight-gradient pass -----------------------------------------------------------------------------------------
+// sum over this workgroup's tiles and the listed activation slots of  coef * X^T Delta  for the three layers (+ column
+// sums for the biases), NC coefficient sets at once; the result goes to this workgroup's block of A.wpart, combinations
+// c_base .. c_base + NC - 1, canonical parameter order.  The list is ash->wl[list].
+template <int DP, int HP, int NC>
+__device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsigned ash_off, int list, int c_base) {
+  using G = AdjGeom<DP, HP>;
+  constexpr int CB = G::CB, HB = G::HB;
+  const MI_CONST AdjArgs& A = *(const MI_CONST AdjArgs*)uniform_p(A_);
+  lds_AdjShared* ash = (lds_AdjShared*)(size_t)__builtin_amdgcn_readfirstlane((int)ash_off);
+  list = __builtin_amdgcn_readfirstlane(list);
+  c_base = __builtin_amdgcn_readfirstlane(c_base);
+  const MI_LDS AdjWList& L = ash->wl[list];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  const int d = A.p.s.dim, hd = A.p.s.rhs.hidden;
+  if (w < G::NW12) {
+    adj_f4 g1[NC][CB], g2[NC][HB], g3[NC][CB];
+    float s1[NC], s2[NC], s3[NC][CB];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      s1[c] = s2[c] = 0.f;
+#pragma unroll
+      for (int b = 0; b < CB; ++b) { g1[c][b] = adj_f4{0, 0, 0, 0}; g3[c][b] = adj_f4{0, 0, 0, 0}; s3[c][b] = 0.f; }
+#pragma unroll
+      for (int b = 0; b < HB; ++b) g2[c][b] = adj_f4{0, 0, 0, 0};
+    }
+    const long long ntiles = (A.p.s.batch + G::R - 1) / G::R;
+    const int colw = 16 * w + li;                           // this lane's column inside the wave's 16-column block
+    const int nlist = uniform_i(L.n);
+    for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+      const g_float* act_tile = (const g_float*)A.act + tile_i * (long long)(G::NSLOT * G::SLOT);
+      for (int q = 0; q < nlist; ++q) {
+        const g_float* act = act_tile + (long long)uniform_i(L.slot[q]) * G::SLOT;
+        float cf[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) cf[c] = uniform_f(L.c[c][q]);
+#pragma unroll 1
+        for (int half = 0; half < 2; ++half) {
+          // MFMA k slot lg of step j <-> tile row 8 lg + j: a lane reads 4 consecutive rows of its column at once
+          const int r0 = 8 * lg + 4 * half;
+          {                                                 // layer 2: W2 += h1^T (c g2)
+            const adj_f4 bg2 = *(const g_f4*)(act + (unsigned)(G::OFF_G2 + colw * G::R + r0));
+            adj_f4 ah1[HB];
+#pragma unroll
+            for (int b = 0; b < HB; ++b) ah1[b] = *(const g_f4*)(act + (unsigned)(G::OFF_H1 + (16 * b + li) * G::R + r0));
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int c = 0; c < NC; ++c) {
+                const float sb2 = cf[c] * bg2[j];
+                s2[c] += sb2;
+#pragma unroll
+                for (int b = 0; b < HB; ++b) g2[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah1[b][j], sb2, g2[c][b], 0, 0, 0);
+              }
+          }
+          {                                                 // layer 1: W1 += x^T (c g1);  layer 3: W3 += h2^T (c a)
+            const adj_f4 bg1 = *(const g_f4*)(act + (unsigned)(G::OFF_G1 + colw * G::R + r0));
+            const adj_f4 ah2 = *(const g_f4*)(act + (unsigned)(G::OFF_H2 + colw * G::R + r0));
+            adj_f4 ba[CB], ax[CB];
+#pragma unroll
+            for (int b = 0; b < CB; ++b) {
+              ba[b] = *(const g_f4*)(act + (unsigned)(G::OFF_A + (16 * b + li) * G::R + r0));
+              ax[b] = *(const g_f4*)(act + (unsigned)(G::OFF_X + (16 * b + li) * G::R + r0));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+              for (int c = 0; c < NC; ++c) {
+                const float sb1 = cf[c] * bg1[j];
+                s1[c] += sb1;
+#pragma unroll
+                for (int b = 0; b < CB; ++b) g1[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[b][j], sb1, g1[c][b], 0, 0, 0);
+#pragma unroll
+                for (int b = 0; b < CB; ++b) {
+                  const float sa = cf[c] * ba[b][j];
+                  s3[c][b] += sa;
+                  g3[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah2[j], sa, g3[c][b], 0, 0, 0);
+                }
+              }
+          }
+        }
+      }
+    }
+    // canonical order: W1 [d][hd], b1 [hd], W2 [hd][hd], b2 [hd], W3 [hd][d], b3 [d]
+    const int oW1 = 0, oB1 = d * hd, oW2 = oB1 + hd, oB2 = oW2 + hd * hd, oW3 = oB2 + hd, oB3 = oW3 + hd * d;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      g_float* out = (g_float*)A.wpart + ((long long)blockIdx.x * 3 + c_base + c) * A.Ppad;
+      // accumulator element i of block (mb, nb): row m = 16 mb + 4 lg + i (input unit), column n = 16 nb + li (output unit)
+#pragma unroll
+      for (int b = 0; b < CB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * b + 4 * lg + i;
+          if (m < d && colw < hd) out[(unsigned)(oW1 + m * hd + colw)] = g1[c][b][i];
+        }
+#pragma unroll
+      for (int b = 0; b < HB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * b + 4 * lg + i;
+          if (m < hd && colw < hd) out[(unsigned)(oW2 + m * hd + colw)] = g2[c][b][i];
+        }
+#pragma unroll
+      for (int b = 0; b < CB; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int m = 16 * w + 4 * lg + i, n = 16 * b + li;
+          if (m < hd && n < d) out[(unsigned)(oW3 + m * d + n)] = g3[c][b][i];
+        }
+      // bias gradients: a lane summed rows 8 lg .. 8 lg + 7 of every tile; fold the four lane groups
+      float t1 = s1[c], t2 = s2[c];
+      t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
+      t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
+      if (lg == 0 && colw < hd) { out[(unsigned)(oB1 + colw)] = t1; out[(unsigned)(oB2 + colw)] = t2; }
+#pragma unroll
+      for (int b = 0; b < CB; ++b) {
+        float t3 = s3[c][b];
+        t3 += __shfl_xor(t3, 16, 64); t3 += __shfl_xor(t3, 32, 64);
+        if (w == 0 && lg == 0 && 16 * b + li < d) out[(unsigned)(oB3 + 16 * b + li)] = t3;
+      }
+    }
+  }
+  __threadfence();                                          // the partials must be in memory before this workgroup's next record says so
+  __syncthreads();
+}
+
+// this workgroup's slice of theta: sum the partials of all workgroups in a fixed order, hand (p, sums) to f
+template <int NCOMB, class F>
+__device__ __forceinline__ void adj_slice(const AdjArgs& A, F&& f) {
+  const int G_ = (int)gridDim.x;
+  for (int e = threadIdx.x; e < A.SL; e += blockDim.x) {
+    const int p = (int)blockIdx.x * A.SL + e;
+    if (p >= A.P) break;
+    float s[3] = {0.f, 0.f, 0.f};
+    for (int g = 0; g < G_; ++g) {
+#pragma unroll
+      for (int c = 0; c < NCOMB; ++c) s[c] += ((const g_float*)A.wpart + ((long long)g * 3 + c) * A.Ppad)[(unsigned)p];
+    }
+    f(p, s);
+  }
+}
+
+// ---- the controller over the four components (y, a, adj_t, theta) ----------------------------------------------
+__device__ __forceinline__ float adj_pymax(const float* v, int n) {       // python max(): first maximal element (misc.py:230)
+  float best = v[0];
+  for (int i = 1; i < n; ++i)
+    if (v[i] > best) best = v[i];
+  return best;
+}
+__device__ __forceinline__ float adj_rms(double sumsq, double n) { return sqrtf((float)sumsq) / powf((float)n, 0.5f); }   // misc.py:170-175
+__device__ __forceinline__ float nan_minf(float a, float b) { return (isnan(a) || isnan(b)) ? NAN : fminf(a, b); }
+__device__ __forceinline__ float nan_maxf(float a, float b) { return (isnan(a) || isnan(b)) ? NAN : fmaxf(a, b); }
+
+// thread 0 holds a block record: make it this workgroup's contribution to a hand-off
+__device__ __forceinline__ Acc adj_record(double m0, double m1, double s0, double s1, int flag) {
+  Acc a;
+  if (threadIdx.x == 0) { a.maxa = m0; a.maxb = m1; a.suma = s0; a.sumb = s1; a.flag = flag; }
+  return a;
+}
+
+template <int DP, int HP, int S>
+__global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(const AdjArgs* __restrict__ Ap) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ PersistShared sh;
+  __shared__ AdjShared ash_;
+  const AdjArgs& A = *Ap;
+  AdjShared& ash = ash_;
+  const unsigned smem = (unsigned)(size_t)(MI_LDS char*)smem_raw;
+  const unsigned ash_off = (unsigned)(size_t)(MI_LDS AdjShared*)&ash_;
+  Ctl& s_c = sh.c;
+  const StepArgs& SA = A.p.s;
+  {
+    AdjCtx<DP, HP> cx;
+    cx.bind(SA.rhs, SA.dim, smem);
+    cx.stage_weights(SA.rhs);
+  }
+  CtrlParams cp = SA.cp;
+  if (threadIdx.x == 0) { sh.tout[0] = A.t_end; persist_init_ctl(s_c, A.p); sh.ok = 1; ash.s0_cur = 0; ash.th_cur = 0; ash.adjt = *A.adjt_in; }
+  cp.t_out = sh.tout;
+  __syncthreads();
+  const long long npl = SA.batch * (long long)SA.dim;
+  float* const ypl[2] = {A.planes, A.planes + npl};
+  float* const apl[2] = {A.planes + 2 * npl, A.planes + 3 * npl};
+  float* const fypl[2] = {A.planes + 4 * npl, A.planes + 5 * npl};
+  float* const fapl[2] = {A.planes + 6 * npl, A.planes + 7 * npl};
+  float* const thp[2] = {A.theta, A.theta + A.Ppad};
+  float* const f0th = A.theta + 2 * (long long)A.Ppad;
+  const float msign = -(float)SA.rhs.sign;                  // k_theta = -s X^T Delta
+  const float rtol = (float)cp.rtol, atol = (float)cp.atol;
+  const double n_state = (double)cp.n_local, n_theta = (double)A.P;
+  unsigned gen = 0;
+  double r1[5], r2[5], r3[5], n_tot = 0.0;
+  bool ok = true;
+
+  // ---- before_integrate: f0 of every component and the norms of misc._select_initial_step ------------------------
+  {
+    if (threadIdx.x == 0) {
+      AdjPlanes& P = ash.P;
+      P.y0 = A.y_in; P.a0 = A.a_in; P.fy0 = nullptr; P.fa0 = nullptr; P.y1 = nullptr; P.a1 = nullptr;
+      P.fy1 = (A.mode == 1 && A.y_out != nullptr) ? A.y_out : fypl[0];
+      P.fa1 = (A.mode == 1) ? A.a_out : fapl[0];
+      P.hs = 0.f; P.emit = 0; P.s0_cur = 0; P.t_start = P.t_new = P.dt64 = 0.0;
+      AdjWList& L = ash.wl[0];
+      L.n = 1; L.slot[0] = 0; L.c[0][0] = msign; L.c[1][0] = 0.f;
+    }
+    __syncthreads();
+    adj_tile_pass<DP, HP, ADJ_F0, S>(Ap, smem, ash_off);
+    adj_wgrad_pass<DP, HP, 1>(Ap, ash_off, 0, 0);
+    const Acc h1 = adj_record(ash.blk[0][0], ash.blk[1][0], ash.blk[0][2], ash.blk[0][3], (int)ash.blk[0][4]);
+    ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
+    __threadfence();
+    Acc accT;
+    if (ok) {
+      adj_slice<1>(A, [&](int p, const float* s) {
+        const float th0 = A.th_in[p];
+        if (A.mode == 1) { A.th_out[p] = s[0]; return; }
+        thp[0][p] = th0;
+        f0th[p] = s[0];
+        const float sc = atol + fabsf(th0) * rtol;
+        const double q0 = (double)(th0 / sc), q1 = (double)(s[0] / sc);
+        accT.suma += q0 * q0; accT.sumb += q1 * q1;
+        accT.maxa = fmax(accT.maxa, (double)fabsf(th0));
+      });
+    }
+    if (A.mode == 1) {                                      // one evaluation of the augmented dynamics: done
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.res->status = ok ? 0u : (unsigned)MI_ODE_ST_SYNC_TIMEOUT; A.res->n_attempt = 0; A.res->n_accept = 0; A.res->handoffs = (int)gen;
+      }
+      return;
+    }
+    Acc h2;
+    h2.maxa = accT.maxa;
+    if (threadIdx.x == 0) { h2.suma = ash.blk[1][2]; h2.sumb = ash.blk[1][3]; }
+    ok = ok && grid_reduce(A.p, h2, sh, gen++, r2, n_tot);
+    Acc h3;
+    h3.suma = accT.suma; h3.sumb = accT.sumb;
+    ok = ok && grid_reduce(A.p, h3, sh, gen++, r3, n_tot);
+    if (threadIdx.x == 0 && ok) {
+      s_c.nfe += 1;
+      s_c.y0_nonfinite = r1[4] != 0.0;
+      ash.ymax = r1[0]; ash.amax = r1[1]; ash.thmax = r2[0];
+      const float at = ash.adjt, sct = atol + fabsf(at) * rtol;
+      const double qt = (double)(at / sct);
+      ash.d0[0] = adj_rms(r1[2], n_state); ash.d1[0] = adj_rms(r1[3], n_state);
+      ash.d0[1] = adj_rms(r2[2], n_state); ash.d1[1] = adj_rms(r2[3], n_state);
+      ash.d0[2] = adj_rms(qt * qt, 1.0);   ash.d1[2] = adj_rms(0.0, 1.0);
+      ash.d0[3] = adj_rms(r3[2], n_theta); ash.d1[3] = adj_rms(r3[3], n_theta);
+      float h0;
+      if (adj_pymax(ash.d0, 4) < 1e-5f || adj_pymax(ash.d1, 4) < 1e-5f) h0 = 1e-6f;                    // misc.py:230-231
+      else {
+        float q[4];
+        for (int i = 0; i < 4; ++i) q[i] = ash.d0[i] / ash.d1[i];
+        h0 = 0.01f * adj_pymax(q, 4);                                                                  // misc.py:233
+      }
+      ash.h0 = h0;
+      s_c.h0 = h0; s_c.d0 = ash.d0[0]; s_c.d1 = ash.d1[0];
+    }
+    __syncthreads();
+  }
+  if (ok) {                                                 // misc.py:235-245
+    if (threadIdx.x == 0) {
+      AdjPlanes& P = ash.P;
+      P.y0 = A.y_in; P.a0 = A.a_in; P.fy0 = fypl[0]; P.fa0 = fapl[0]; P.y1 = nullptr; P.a1 = nullptr; P.fy1 = nullptr; P.fa1 = nullptr;
+      P.hs = ash.h0; P.emit = 0; P.s0_cur = 0; P.t_start = P.t_new = P.dt64 = 0.0;
+      AdjWList& L = ash.wl[0];
+      L.n = 1; L.slot[0] = 2; L.c[0][0] = msign; L.c[1][0] = 0.f;
+    }
+    __syncthreads();
+    adj_tile_pass<DP, HP, ADJ_INITB, S>(Ap, smem, ash_off);
+    adj_wgrad_pass<DP, HP, 1>(Ap, ash_off, 0, 0);
+    const Acc h1 = adj_record(0.0, 0.0, ash.blk[0][2], ash.blk[1][2], 0);
+    ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
+    __threadfence();
+    Acc accT;
+    if (ok) {
+      adj_slice<1>(A, [&](int p, const float* s) {
+        const float sc = atol + fabsf(thp[0][p]) * rtol;
+        const double q = (double)((s[0] - f0th[p]) / sc);
+        accT.suma += q * q;
+      });
+    }
+    Acc h2;
+    h2.suma = accT.suma;
+    ok = ok && grid_reduce(A.p, h2, sh, gen++, r2, n_tot);
+    if (threadIdx.x == 0 && ok) {
+      s_c.nfe += 1;
+      const float h0 = ash.h0;
+      ash.d2[0] = adj_rms(r1[2], n_state) / h0;
+      ash.d2[1] = adj_rms(r1[3], n_state) / h0;
+      ash.d2[2] = adj_rms(0.0, 1.0) / h0;
+      ash.d2[3] = adj_rms(r2[2], n_theta) / h0;
+      float h1v;
+      if (adj_pymax(ash.d1, 4) <= 1e-15f && adj_pymax(ash.d2, 4) <= 1e-15f) h1v = nan_maxf(1e-6f, h0 * 1e-3f);    // misc.py:239-241
+      else {
+        float q[8];
+        for (int i = 0; i < 4; ++i) { q[i] = ash.d1[i]; q[4 + i] = ash.d2[i]; }
+        h1v = powf(0.01f / adj_pymax(q, 8), (float)(1.0 / (double)(cp.init_order + 1)));                           // misc.py:243
+      }
+      s_c.dt = (double)nan_minf(100.0f * h0, h1v);                                                                 // misc.py:245
+    }
+  }
+  auto publish = [&](const AttemptState& st) {
+    sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.accepted = st.accepted; sh.pub.done = st.done;
+    sh.pub.emit_lo = 0; sh.pub.emit_hi = (!(A.t_end > st.t1 + st.dt)) ? 1 : 0;      // the next attempt reaches t_end
+  };
+  if (threadIdx.x == 0) {
+    if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
+    else set_outputs_apply(&s_c, 1);
+    AttemptState st;
+    st.load(s_c);
+    st.accepted = 0;
+    publish(st);
+    sh.st = st;
+  }
+  __syncthreads();
+
+  // ---- the adaptive loop (dopri5.py:82-121) over the tuple state ------------------------------------------------------
+  int cur = -1;                                             // -1: the state is still the caller's buffers
+  int fcur = 0;
+  while (!uniform_i(sh.pub.done)) {
+    const double dt_u = uniform_d(sh.pub.dt), t1_u = uniform_d(sh.pub.t1);
+    const int s0c = uniform_i(ash.s0_cur), thc = uniform_i(ash.th_cur);
+    const int nxt = cur < 0 ? 0 : 1 - cur;
+    const float hs = (float)dt_u;
+    if (threadIdx.x == 0) {
+      AdjPlanes& P = ash.P;
+      P.y0 = cur < 0 ? A.y_in : ypl[cur]; P.a0 = cur < 0 ? A.a_in : apl[cur];
+      P.y1 = ypl[nxt]; P.a1 = apl[nxt];
+      P.fy0 = fypl[fcur]; P.fa0 = fapl[fcur]; P.fy1 = fypl[1 - fcur]; P.fa1 = fapl[1 - fcur];
+      P.hs = hs; P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
+      P.emit = sh.pub.emit_hi; P.s0_cur = s0c;
+      AdjWList& L = ash.wl[0];                              // theta_1 - theta_0 and the error estimate (rk_common.py:51-60)
+      L.n = 0;
+      for (int j = 0; j <= S; ++j) {
+        const float cs = (j < S ? (hs * A.cb[S - 1][j]) : 0.f) * msign, ce = (hs * A.ce[j]) * msign;
+        if (cs == 0.f && ce == 0.f) continue;
+        L.slot[L.n] = j == 0 ? s0c : (j == S ? 1 - s0c : j);
+        L.c[0][L.n] = cs; L.c[1][L.n] = ce;
+        ++L.n;
+      }
+    }
+    __syncthreads();
+    adj_tile_pass<DP, HP, ADJ_STEP, S>(Ap, smem, ash_off);
+    adj_wgrad_pass<DP, HP, 2>(Ap, ash_off, 0, 0);
+    const Acc h1 = adj_record(ash.blk[0][1], ash.blk[1][1], ash.blk[0][2], ash.blk[1][2], 0);
+    ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
+    __threadfence();
+    Acc accT;
+    if (ok) {
+      const float* th0p = thp[thc];
+      float* th1p = thp[1 - thc];
+      adj_slice<2>(A, [&](int p, const float* s) {
+        const float th1 = th0p[p] + s[0];
+        th1p[p] = th1;
+        accT.maxb = fmax(accT.maxb, (double)fabsf(th1));
+        accT.suma += (double)s[1] * (double)s[1];
+      });
+    }
+    Acc h2;
+    h2.maxa = accT.maxb; h2.suma = accT.suma;
+    ok = ok && grid_reduce(A.p, h2, sh, gen++, r2, n_tot);
+    if (threadIdx.x == 0) {
+      AttemptState st = sh.st;
+      if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
+      else {
+        double rec[kRec], ratios[4];
+        rec[R_SUMB] = 0; rec[R_FLAG] = 0; rec[6] = rec[7] = 0;
+        rec[R_MAXA] = ash.ymax; rec[R_MAXB] = r1[0]; rec[R_SUMA] = r1[2]; rec[R_N] = n_state; ratios[0] = error_ratio(rec, cp);
+        rec[R_MAXA] = ash.amax; rec[R_MAXB] = r1[1]; rec[R_SUMA] = r1[3]; rec[R_N] = n_state; ratios[1] = error_ratio(rec, cp);
+        {                                                   // adj_t: zero derivative, zero error estimate (misc.py:256-263 all the same)
+          const float tolt = atol + rtol * fabsf(ash.adjt);
+          const float q = 0.0f / tolt;
+          ratios[2] = (double)(q * q);
+        }
+        rec[R_MAXA] = ash.thmax; rec[R_MAXB] = r2[0]; rec[R_SUMA] = r2[2]; rec[R_N] = n_theta; ratios[3] = error_ratio(rec, cp);
+        double rmax = ratios[0];
+        bool accept = ratios[0] <= 1.0;
+        for (int i = 1; i < 4; ++i) {
+          if (ratios[i] > rmax) rmax = ratios[i];           // python max() (misc.py:270)
+          accept = accept && (ratios[i] <= 1.0);            // dopri5.py:108
+        }
+        attempt_tail(st, rmax, accept, cp);
+        if (st.accepted) { ash.ymax = r1[0]; ash.amax = r1[1]; ash.thmax = r2[0]; ash.s0_cur = 1 - s0c; ash.th_cur = 1 - thc; }
+      }
+      publish(st);
+      sh.st = st;
+    }
+    __syncthreads();
+    if (uniform_i(sh.pub.accepted)) { cur = nxt; fcur = 1 - fcur; }
+  }
+
+  // ---- theta at t_end: interp.py:6-67 over the accepted last step (y_mid, f_1 and f_0 are three more combinations) ----
+  const bool finished = uniform_i((int)sh.st.status) == 0 && uniform_i(sh.st.accepted) != 0;
+  if (finished) {
+    const double dt_l = uniform_d(sh.st.emit_dt), ts_l = uniform_d(sh.st.emit_t0), tn_l = uniform_d(sh.st.emit_t1);
+    const int s0c = uniform_i(ash.s0_cur), thc = uniform_i(ash.th_cur);      // after the swap: s0c holds stage S, 1 - s0c stage 0
+    const float hs = (float)dt_l;
+    if (threadIdx.x == 0) {
+      AdjWList& L = ash.wl[0];
+      L.n = 0;
+      for (int j = 0; j <= S; ++j) {
+        const float cm = (hs * A.cm[j]) * msign, c1 = j == S ? msign : 0.f;
+        if (cm == 0.f && c1 == 0.f) continue;
+        L.slot[L.n] = j == 0 ? 1 - s0c : (j == S ? s0c : j);
+        L.c[0][L.n] = cm; L.c[1][L.n] = c1;
+        ++L.n;
+      }
+      AdjWList& L0 = ash.wl[1];
+      L0.n = 1; L0.slot[0] = 1 - s0c; L0.c[0][0] = msign; L0.c[1][0] = 0.f;
+    }
+    __syncthreads();
+    adj_wgrad_pass<DP, HP, 2>(Ap, ash_off, 0, 0);
+    adj_wgrad_pass<DP, HP, 1>(Ap, ash_off, 1, 2);
+    Acc h1;
+    ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
+    __threadfence();
+    if (ok) {
+      const float x = interp_x<float>(ts_l, tn_l, A.t_end);
+      const float* th0p = thp[1 - thc];
+      const float* th1p = thp[thc];
+      adj_slice<3>(A, [&](int p, const float* s) {
+        const float th0 = th0p[p], th1 = th1p[p];
+        float co[5];
+        quartic_from_mid<float>(th0, th1, th0 + s[0], s[2], s[1], hs, co);
+        A.th_out[p] = quartic_eval<float>(co, x);
+      });
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float at = ash.adjt;
+        float co[5];
+        quartic_from_mid<float>(at, at, at, 0.f, 0.f, hs, co);
+        *A.adjt_out = quartic_eval<float>(co, x);
+      }
+    }
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    AttemptState st = sh.st;
+    if (finished && !ok) st.status |= MI_ODE_ST_SYNC_TIMEOUT;
+    AdjResult res;
+    res.t1 = st.t1; res.dt = st.dt; res.ratio = st.ratio; res.h0 = (double)ash.h0;
+    res.n_attempt = st.n_attempt; res.n_accept = st.n_accept; res.status = st.status; res.handoffs = (int)gen;
+    const long long* src = (const long long*)&res;
+    long long* dst = (long long*)A.res;
+    for (int i = 0; i < (int)(sizeof(AdjResult) / sizeof(long long)); ++i)
+      __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+}  // namespace mi

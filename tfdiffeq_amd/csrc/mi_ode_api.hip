@@ -49,6 +49,8 @@ extern "C" int64_t mi_ode_sizeof(int32_t which) {
     case 2: return (int64_t)sizeof(mi_ode_tableau);
     case 3: return (int64_t)sizeof(mi_ode_rhs);
     case 4: return (int64_t)sizeof(mi_ode_solver);          /* what a RHS plugin must have been compiled against */
+    case 5: return (int64_t)sizeof(mi_ode_ctrl_params);
+    case 6: return (int64_t)sizeof(mi_ode_adjoint_desc);
     default: return -1;
   }
 }

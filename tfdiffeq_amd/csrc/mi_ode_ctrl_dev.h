@@ -74,24 +74,27 @@ struct AttemptState {
   }
 };
 
-// dopri5.py:103-121 on the combined record of one attempt: error ratio, accept test, next step size, output cursor,
-// termination checks.  Shared by k_controller, the whole-attempt kernels' last workgroup and the whole-integration kernel.
-__device__ __forceinline__ void attempt_core(AttemptState& c, const double* rec, const CtrlParams& P) {
+// misc._compute_error_ratio (misc.py:256-263) of ONE state component from its combined record, in the state dtype
+__device__ __forceinline__ double error_ratio(const double* rec, const CtrlParams& P) {
   const double N = rec[R_N];
+  if (P.is_f32) {
+    const float tol = (float)P.atol + (float)P.rtol * (float)fmax(rec[R_MAXA], rec[R_MAXB]);
+    return (double)(float)(rec[R_SUMA] / (N * (double)tol * (double)tol));
+  }
+  const double tol = P.atol + P.rtol * fmax(rec[R_MAXA], rec[R_MAXB]);
+  return rec[R_SUMA] / (N * tol * tol);
+}
+
+// dopri5.py:103-121 after the error ratio: accept test, next step size, output cursor,
+// termination checks.  Shared by k_controller, the whole-attempt kernels' last workgroup and the whole-integration kernel.
+// Takes the ratio that drives the step size (the python max() over the components' ratios, misc.py:270) and the
+// accept test (every component's ratio <= 1, dopri5.py:108).  One-component states: ratio, ratio <= 1.
+__device__ __forceinline__ void attempt_tail(AttemptState& c, double ratio, bool accept, const CtrlParams& P) {
   c.n_attempt += 1;
   c.nfe += P.n_stages;
   c.n_steps_out += 1;
   const double dt = c.dt, t_start = c.t1;
-  double ratio;
-  if (P.is_f32) {                                          // misc.py:256-263 in the state dtype
-    const float tol = (float)P.atol + (float)P.rtol * (float)fmax(rec[R_MAXA], rec[R_MAXB]);
-    ratio = (double)(float)(rec[R_SUMA] / (N * (double)tol * (double)tol));
-  } else {
-    const double tol = P.atol + P.rtol * fmax(rec[R_MAXA], rec[R_MAXB]);
-    ratio = rec[R_SUMA] / (N * tol * tol);
-  }
   c.ratio = ratio;
-  const bool accept = ratio <= 1.0;                        // NaN -> rejected (dopri5.py:108)
   const double dt_next = optimal_step(dt, ratio, P);
   c.accepted = accept ? 1 : 0;
   c.emit_lo = c.emit_hi = c.next_out;
@@ -112,6 +115,11 @@ __device__ __forceinline__ void attempt_core(AttemptState& c, const double* rec,
   if (c.next_out >= c.n_out) { c.done = 1; return; }
   if (c.n_steps_out >= P.max_num_steps) { c.status |= MI_ODE_ST_MAX_STEPS; c.done = 1; return; }   // dopri5.py:85
   if (!(c.t1 + dt_next > c.t1)) { c.status |= MI_ODE_ST_DT_UNDERFLOW; c.done = 1; }               // dopri5.py:98
+}
+
+__device__ __forceinline__ void attempt_core(AttemptState& c, const double* rec, const CtrlParams& P) {
+  const double ratio = error_ratio(rec, P);
+  attempt_tail(c, ratio, ratio <= 1.0, P);                 // NaN -> rejected (dopri5.py:108)
 }
 
 // One thread: apply the phase logic to the combined record `rec` with exactly the reference's scalar arithmetic.
