@@ -57,6 +57,8 @@ struct AdjResult {             // pinned host record, written by the kernel's la
   long long n_attempt, n_accept;
   unsigned status;
   int handoffs;
+  long long prof[6];           // workgroup 0, 10 ns ticks: tile passes, weight-gradient passes, first hand-offs, theta slices, second
+                               // hand-offs (+ controller), epilogue
 };
 
 struct AdjArgs {
@@ -76,7 +78,9 @@ struct AdjArgs {
   AdjResult* res;
   double t_end;
   float cb[6][8], ce[8], cm[8];   // the tableau in the state dtype (beta rows, c_error, c_mid): scalar operands, no conversions in the kernel
-  int mode;                    // 0: segment, 1: one evaluation of the augmented dynamics
+  int mode;                    // 0: segment, 1: one evaluation of the augmented dynamics; 2 / 3: time `bench_iters` tile passes /
+                               // weight-gradient passes of one attempt (no hand-offs; tuning aid, MI_ODE_ADJOINT_BENCH)
+  int bench_iters;
   int P, Ppad, SL;             // parameters, padded, slice per workgroup
 };
 
@@ -499,16 +503,18 @@ __device__ __attribute__((noinline)) void adj_tile_pass(const AdjArgs* A_, unsig
 // sums for the biases), NC coefficient sets at once; the result goes to this workgroup's block of A.wpart, combinations
 // c_base .. c_base + NC - 1, canonical parameter order.  The list is ash->wl[list].
 template <int DP, int HP, int NC>
-__device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsigned ash_off, int list, int c_base) {
+__device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsigned smem, unsigned ash_off, int list, int c_base) {
   using G = AdjGeom<DP, HP>;
   constexpr int CB = G::CB, HB = G::HB;
   const MI_CONST AdjArgs& A = *(const MI_CONST AdjArgs*)uniform_p(A_);
   lds_AdjShared* ash = (lds_AdjShared*)(size_t)__builtin_amdgcn_readfirstlane((int)ash_off);
+  smem = (unsigned)__builtin_amdgcn_readfirstlane((int)smem);
   list = __builtin_amdgcn_readfirstlane(list);
   c_base = __builtin_amdgcn_readfirstlane(c_base);
   const MI_LDS AdjWList& L = ash->wl[list];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   const int d = A.p.s.dim, hd = A.p.s.rhs.hidden;
+  (void)smem;
   if (w < G::NW12) {
     adj_f4 g1[NC][CB], g2[NC][HB], g3[NC][CB];
     float s1[NC], s2[NC], s3[NC][CB];
@@ -523,59 +529,70 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
     const long long ntiles = (A.p.s.batch + G::R - 1) / G::R;
     const int colw = 16 * w + li;                           // this lane's column inside the wave's 16-column block
     const int nlist = uniform_i(L.n);
-    for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
-      const g_float* act_tile = (const g_float*)A.act + tile_i * (long long)(G::NSLOT * G::SLOT);
-      for (int q = 0; q < nlist; ++q) {
-        const g_float* act = act_tile + (long long)uniform_i(L.slot[q]) * G::SLOT;
-        float cf[NC];
+    const long long my_tiles = (long long)blockIdx.x < ntiles ? (ntiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+    const int nsteps = (int)(my_tiles * nlist * 2);         // (tile, listed slot, half tile) in this order
+    const g_float* const act_base = (const g_float*)A.act;
+    // Operands of one step.  MFMA k slot lg of sub-step j <-> tile row 8 lg + 4 half + j: a lane reads 4 consecutive rows of
+    // its column at once.  Group "2": layer 2 (g2, h1); group "13": layers 1 and 3 (g1, x; a, h2).
+    // (Staging the planes all waves share - x, a, h1 - through LDS was tried: two more barriers per item, slower.)
+    auto step_ptr = [&](int step) -> const g_float* {
+      const int half = step & 1, q = (step >> 1) % nlist;
+      const long long tile_i = blockIdx.x + (long long)((step >> 1) / nlist) * gridDim.x;
+      return act_base + (tile_i * G::NSLOT + uniform_i(L.slot[q])) * (long long)G::SLOT + 4 * half;
+    };
+    adj_f4 bg2, ah1[HB], bg1, ah2, ba[CB], ax[CB];
+    auto load2 = [&](int step) {
+      const g_float* act = step_ptr(step);
+      bg2 = *(const g_f4*)(act + (unsigned)(G::OFF_G2 + colw * G::R + 8 * lg));
 #pragma unroll
-        for (int c = 0; c < NC; ++c) cf[c] = uniform_f(L.c[c][q]);
-#pragma unroll 1
-        for (int half = 0; half < 2; ++half) {
-          // MFMA k slot lg of step j <-> tile row 8 lg + j: a lane reads 4 consecutive rows of its column at once
-          const int r0 = 8 * lg + 4 * half;
-          {                                                 // layer 2: W2 += h1^T (c g2)
-            const adj_f4 bg2 = *(const g_f4*)(act + (unsigned)(G::OFF_G2 + colw * G::R + r0));
-            adj_f4 ah1[HB];
+      for (int b = 0; b < HB; ++b) ah1[b] = *(const g_f4*)(act + (unsigned)(G::OFF_H1 + (16 * b + li) * G::R + 8 * lg));
+    };
+    auto load13 = [&](int step) {
+      const g_float* act = step_ptr(step);
+      bg1 = *(const g_f4*)(act + (unsigned)(G::OFF_G1 + colw * G::R + 8 * lg));
+      ah2 = *(const g_f4*)(act + (unsigned)(G::OFF_H2 + colw * G::R + 8 * lg));
 #pragma unroll
-            for (int b = 0; b < HB; ++b) ah1[b] = *(const g_f4*)(act + (unsigned)(G::OFF_H1 + (16 * b + li) * G::R + r0));
+      for (int b = 0; b < CB; ++b) {
+        ba[b] = *(const g_f4*)(act + (unsigned)(G::OFF_A + (16 * b + li) * G::R + 8 * lg));
+        ax[b] = *(const g_f4*)(act + (unsigned)(G::OFF_X + (16 * b + li) * G::R + 8 * lg));
+      }
+    };
+    if (nsteps > 0) load2(0);
+    for (int step = 0; step < nsteps; ++step) {             // software pipeline: the loads of one group fly during the MFMAs of the other
+      const int q = (step >> 1) % nlist;
+      float cf[NC];
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+      for (int c = 0; c < NC; ++c) cf[c] = uniform_f(L.c[c][q]);
+      load13(step);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-              for (int c = 0; c < NC; ++c) {
-                const float sb2 = cf[c] * bg2[j];
-                s2[c] += sb2;
+      for (int j = 0; j < 4; ++j)                           // layer 2: W2 += h1^T (c g2)
 #pragma unroll
-                for (int b = 0; b < HB; ++b) g2[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah1[b][j], sb2, g2[c][b], 0, 0, 0);
-              }
-          }
-          {                                                 // layer 1: W1 += x^T (c g1);  layer 3: W3 += h2^T (c a)
-            const adj_f4 bg1 = *(const g_f4*)(act + (unsigned)(G::OFF_G1 + colw * G::R + r0));
-            const adj_f4 ah2 = *(const g_f4*)(act + (unsigned)(G::OFF_H2 + colw * G::R + r0));
-            adj_f4 ba[CB], ax[CB];
+        for (int c = 0; c < NC; ++c) {
+          const float sb2 = cf[c] * bg2[j];
+          s2[c] += sb2;
 #pragma unroll
-            for (int b = 0; b < CB; ++b) {
-              ba[b] = *(const g_f4*)(act + (unsigned)(G::OFF_A + (16 * b + li) * G::R + r0));
-              ax[b] = *(const g_f4*)(act + (unsigned)(G::OFF_X + (16 * b + li) * G::R + r0));
-            }
+          for (int b = 0; b < HB; ++b) g2[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah1[b][j], sb2, g2[c][b], 0, 0, 0);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (step + 1 < nsteps) load2(step + 1);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < 4; ++j)                           // layer 1: W1 += x^T (c g1);  layer 3: W3 += h2^T (c a)
 #pragma unroll
-              for (int c = 0; c < NC; ++c) {
-                const float sb1 = cf[c] * bg1[j];
-                s1[c] += sb1;
+        for (int c = 0; c < NC; ++c) {
+          const float sb1 = cf[c] * bg1[j];
+          s1[c] += sb1;
 #pragma unroll
-                for (int b = 0; b < CB; ++b) g1[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[b][j], sb1, g1[c][b], 0, 0, 0);
+          for (int b = 0; b < CB; ++b) g1[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[b][j], sb1, g1[c][b], 0, 0, 0);
 #pragma unroll
-                for (int b = 0; b < CB; ++b) {
-                  const float sa = cf[c] * ba[b][j];
-                  s3[c][b] += sa;
-                  g3[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah2[j], sa, g3[c][b], 0, 0, 0);
-                }
-              }
+          for (int b = 0; b < CB; ++b) {
+            const float sa = cf[c] * ba[b][j];
+            s3[c][b] += sa;
+            g3[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah2[j], sa, g3[c][b], 0, 0, 0);
           }
         }
-      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     // canonical order: W1 [d][hd], b1 [hd], W2 [hd][hd], b2 [hd], W3 [hd][d], b3 [d]
     const int oW1 = 0, oB1 = d * hd, oW2 = oB1 + hd, oB2 = oW2 + hd * hd, oW3 = oB2 + hd, oB3 = oW3 + hd * d;
@@ -621,19 +638,46 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
   __syncthreads();
 }
 
-// this workgroup's slice of theta: sum the partials of all workgroups in a fixed order, hand (p, sums) to f
+// this workgroup's slice of theta: sum the partials of all workgroups in a fixed order, hand (p, sums) to f.
+// 128 elements at a time; thread group q (of blockDim / 128) sums workgroups q, q + groups, ... (8 loads in flight), the
+// groups' sums are folded in order through LDS (`scratch`: >= groups x 3 x 128 floats, free between the passes).
 template <int NCOMB, class F>
-__device__ __forceinline__ void adj_slice(const AdjArgs& A, F&& f) {
+__device__ __forceinline__ void adj_slice(const AdjArgs& A, lds_float* scratch, F&& f) {
   const int G_ = (int)gridDim.x;
-  for (int e = threadIdx.x; e < A.SL; e += blockDim.x) {
-    const int p = (int)blockIdx.x * A.SL + e;
-    if (p >= A.P) break;
+  const int ngroups = (int)blockDim.x / 128, grp = (int)threadIdx.x / 128, el = (int)threadIdx.x % 128;
+  const g_float* wp = (const g_float*)A.wpart;
+  for (int e0 = 0; e0 < A.SL; e0 += 128) {
+    const int e = e0 + el, p = (int)blockIdx.x * A.SL + e;
+    const bool live = e < A.SL && p < A.P;
     float s[3] = {0.f, 0.f, 0.f};
-    for (int g = 0; g < G_; ++g) {
+    if (live) {
+      int g = grp;
+      for (; g + 7 * ngroups < G_; g += 8 * ngroups) {
+        float v[8][NCOMB];
 #pragma unroll
-      for (int c = 0; c < NCOMB; ++c) s[c] += ((const g_float*)A.wpart + ((long long)g * 3 + c) * A.Ppad)[(unsigned)p];
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int c = 0; c < NCOMB; ++c) v[u][c] = (wp + ((long long)(g + u * ngroups) * 3 + c) * A.Ppad)[(unsigned)p];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int c = 0; c < NCOMB; ++c) s[c] += v[u][c];
+      }
+      for (; g < G_; g += ngroups)
+#pragma unroll
+        for (int c = 0; c < NCOMB; ++c) s[c] += (wp + ((long long)g * 3 + c) * A.Ppad)[(unsigned)p];
     }
-    f(p, s);
+    __syncthreads();                                        // (scratch may still be read by the previous chunk)
+#pragma unroll
+    for (int c = 0; c < NCOMB; ++c) scratch[(grp * 3 + c) * 128 + el] = s[c];
+    __syncthreads();
+    if (grp == 0 && live) {
+      float t[3] = {0.f, 0.f, 0.f};
+      for (int q = 0; q < ngroups; ++q)
+#pragma unroll
+        for (int c = 0; c < NCOMB; ++c) t[c] += scratch[(q * 3 + c) * 128 + el];
+      f(p, t);
+    }
   }
 }
 
@@ -671,6 +715,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     cx.bind(SA.rhs, SA.dim, smem);
     cx.stage_weights(SA.rhs);
   }
+  lds_float* const slice_scratch = (lds_float*)(size_t)smem + (DP * AdjGeom<DP, HP>::LW1 + HP * AdjGeom<DP, HP>::LW3);   // the activation tiles' LDS
   CtrlParams cp = SA.cp;
   if (threadIdx.x == 0) { sh.tout[0] = A.t_end; persist_init_ctl(s_c, A.p); sh.ok = 1; ash.s0_cur = 0; ash.th_cur = 0; ash.adjt = *A.adjt_in; }
   cp.t_out = sh.tout;
@@ -688,6 +733,8 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
   unsigned gen = 0;
   double r1[5], r2[5], r3[5], n_tot = 0.0;
   bool ok = true;
+  long long prof[6] = {0, 0, 0, 0, 0, 0};
+  const long long tk_begin = (long long)wall_clock64();
 
   // ---- before_integrate: f0 of every component and the norms of misc._select_initial_step ------------------------
   {
@@ -702,13 +749,13 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     }
     __syncthreads();
     adj_tile_pass<DP, HP, ADJ_F0, S>(Ap, smem, ash_off);
-    adj_wgrad_pass<DP, HP, 1>(Ap, ash_off, 0, 0);
+    adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 0, 0);
     const Acc h1 = adj_record(ash.blk[0][0], ash.blk[1][0], ash.blk[0][2], ash.blk[0][3], (int)ash.blk[0][4]);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
     __threadfence();
     Acc accT;
     if (ok) {
-      adj_slice<1>(A, [&](int p, const float* s) {
+      adj_slice<1>(A, slice_scratch, [&](int p, const float* s) {
         const float th0 = A.th_in[p];
         if (A.mode == 1) { A.th_out[p] = s[0]; return; }
         thp[0][p] = th0;
@@ -722,6 +769,29 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     if (A.mode == 1) {                                      // one evaluation of the augmented dynamics: done
       if (blockIdx.x == 0 && threadIdx.x == 0) {
         A.res->status = ok ? 0u : (unsigned)MI_ODE_ST_SYNC_TIMEOUT; A.res->n_attempt = 0; A.res->n_accept = 0; A.res->handoffs = (int)gen;
+      }
+      return;
+    }
+    if (A.mode >= 2) {                                      // pass micro-benchmarks
+      if (threadIdx.x == 0) {
+        AdjPlanes& P = ash.P;
+        P.y0 = A.y_in; P.a0 = A.a_in; P.y1 = ypl[0]; P.a1 = apl[0];
+        P.fy0 = fypl[0]; P.fa0 = fapl[0]; P.fy1 = fypl[1]; P.fa1 = fapl[1];
+        P.hs = 0.05f; P.t_start = 0.0; P.dt64 = 0.05; P.t_new = 0.05; P.emit = 0; P.s0_cur = 0;
+        AdjWList& L = ash.wl[0];
+        L.n = 6;
+        for (int q = 0; q < 6; ++q) { L.slot[q] = q == 0 ? 0 : (q == 5 ? 1 : q + 1); L.c[0][q] = 0.01f * (q + 1); L.c[1][q] = -0.02f * (q + 1); }
+      }
+      __syncthreads();
+      const long long tb0 = (long long)wall_clock64();
+      for (int it = 0; it < A.bench_iters; ++it) {
+        if (A.mode == 2) adj_tile_pass<DP, HP, ADJ_STEP, S>(Ap, smem, ash_off);
+        else adj_wgrad_pass<DP, HP, 2>(Ap, smem, ash_off, 0, 0);
+      }
+      if (blockIdx.x == 0 && threadIdx.x == 0) {
+        A.res->prof[A.mode == 2 ? 0 : 1] = (long long)wall_clock64() - tb0;
+        A.res->prof[A.mode == 2 ? 1 : 0] = 0; A.res->prof[2] = A.res->prof[3] = A.res->prof[4] = A.res->prof[5] = 0;
+        A.res->status = 0; A.res->n_attempt = A.bench_iters; A.res->n_accept = 0; A.res->handoffs = (int)gen;
       }
       return;
     }
@@ -764,13 +834,13 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     }
     __syncthreads();
     adj_tile_pass<DP, HP, ADJ_INITB, S>(Ap, smem, ash_off);
-    adj_wgrad_pass<DP, HP, 1>(Ap, ash_off, 0, 0);
+    adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 0, 0);
     const Acc h1 = adj_record(0.0, 0.0, ash.blk[0][2], ash.blk[1][2], 0);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
     __threadfence();
     Acc accT;
     if (ok) {
-      adj_slice<1>(A, [&](int p, const float* s) {
+      adj_slice<1>(A, slice_scratch, [&](int p, const float* s) {
         const float sc = atol + fabsf(thp[0][p]) * rtol;
         const double q = (double)((s[0] - f0th[p]) / sc);
         accT.suma += q * q;
@@ -837,26 +907,32 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
       }
     }
     __syncthreads();
+    const long long tk0 = (long long)wall_clock64();
     adj_tile_pass<DP, HP, ADJ_STEP, S>(Ap, smem, ash_off);
-    adj_wgrad_pass<DP, HP, 2>(Ap, ash_off, 0, 0);
+    const long long tk1 = (long long)wall_clock64();
+    adj_wgrad_pass<DP, HP, 2>(Ap, smem, ash_off, 0, 0);
+    const long long tk2 = (long long)wall_clock64();
     const Acc h1 = adj_record(ash.blk[0][1], ash.blk[1][1], ash.blk[0][2], ash.blk[1][2], 0);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
     __threadfence();
+    const long long tk3 = (long long)wall_clock64();
     Acc accT;
     if (ok) {
       const float* th0p = thp[thc];
       float* th1p = thp[1 - thc];
-      adj_slice<2>(A, [&](int p, const float* s) {
+      adj_slice<2>(A, slice_scratch, [&](int p, const float* s) {
         const float th1 = th0p[p] + s[0];
         th1p[p] = th1;
         accT.maxb = fmax(accT.maxb, (double)fabsf(th1));
         accT.suma += (double)s[1] * (double)s[1];
       });
     }
+    const long long tk4 = (long long)wall_clock64();
     Acc h2;
     h2.maxa = accT.maxb; h2.suma = accT.suma;
     ok = ok && grid_reduce(A.p, h2, sh, gen++, r2, n_tot);
     if (threadIdx.x == 0) {
+      prof[0] += tk1 - tk0; prof[1] += tk2 - tk1; prof[2] += tk3 - tk2; prof[3] += tk4 - tk3; prof[4] += (long long)wall_clock64() - tk4;
       AttemptState st = sh.st;
       if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
       else {
@@ -886,6 +962,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     if (uniform_i(sh.pub.accepted)) { cur = nxt; fcur = 1 - fcur; }
   }
 
+  const long long tk_epi = (long long)wall_clock64();
   // ---- theta at t_end: interp.py:6-67 over the accepted last step (y_mid, f_1 and f_0 are three more combinations) ----
   const bool finished = uniform_i((int)sh.st.status) == 0 && uniform_i(sh.st.accepted) != 0;
   if (finished) {
@@ -906,8 +983,8 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
       L0.n = 1; L0.slot[0] = 1 - s0c; L0.c[0][0] = msign; L0.c[1][0] = 0.f;
     }
     __syncthreads();
-    adj_wgrad_pass<DP, HP, 2>(Ap, ash_off, 0, 0);
-    adj_wgrad_pass<DP, HP, 1>(Ap, ash_off, 1, 2);
+    adj_wgrad_pass<DP, HP, 2>(Ap, smem, ash_off, 0, 0);
+    adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 1, 2);
     Acc h1;
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
     __threadfence();
@@ -915,7 +992,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
       const float x = interp_x<float>(ts_l, tn_l, A.t_end);
       const float* th0p = thp[1 - thc];
       const float* th1p = thp[thc];
-      adj_slice<3>(A, [&](int p, const float* s) {
+      adj_slice<3>(A, slice_scratch, [&](int p, const float* s) {
         const float th0 = th0p[p], th1 = th1p[p];
         float co[5];
         quartic_from_mid<float>(th0, th1, th0 + s[0], s[2], s[1], hs, co);
@@ -935,6 +1012,9 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     AdjResult res;
     res.t1 = st.t1; res.dt = st.dt; res.ratio = st.ratio; res.h0 = (double)ash.h0;
     res.n_attempt = st.n_attempt; res.n_accept = st.n_accept; res.status = st.status; res.handoffs = (int)gen;
+    prof[5] = (long long)wall_clock64() - tk_epi;
+    for (int i = 0; i < 6; ++i) res.prof[i] = prof[i];
+    (void)tk_begin;
     const long long* src = (const long long*)&res;
     long long* dst = (long long*)A.res;
     for (int i = 0; i < (int)(sizeof(AdjResult) / sizeof(long long)); ++i)

@@ -1,6 +1,8 @@
 // Host side of the fused backward segment of odeint_adjoint (include/mi_ode.h section A', csrc/mi_ode_adjoint.h).
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include "mi_ode_host.h"
 #include "mi_ode_adjoint.h"
@@ -171,6 +173,10 @@ static int adj_launch(mi_ode_adjoint* h, const mi_ode_rhs* rhs, int mode, const 
   A.th_in = (const float*)th; A.th_out = (float*)th_out; A.adjt_in = (const float*)adjt; A.adjt_out = (float*)adjt_out;
   A.planes = h->planes; A.theta = h->theta; A.act = h->act; A.wpart = h->wpart; A.res = h->res;
   A.mode = mode; A.P = h->P; A.Ppad = h->Ppad; A.SL = h->SL;
+  if (const char* be = getenv("MI_ODE_ADJOINT_BENCH")) {     // "mode,iterations": segment calls time one pass instead (tuning aid)
+    int bm = 0, bi = 0;
+    if (mode == 0 && sscanf(be, "%d,%d", &bm, &bi) == 2 && (bm == 2 || bm == 3) && bi > 0) { A.mode = bm; A.bench_iters = bi; }
+  }
   MI_HIP(hipMemcpyAsync(h->args_dev, h->args_host, sizeof(AdjArgs), hipMemcpyHostToDevice, st));
   const AdjArgs* dev_args = h->args_dev;
   void* args[] = {(void*)&dev_args};
@@ -181,6 +187,15 @@ static int adj_launch(mi_ode_adjoint* h, const mi_ode_rhs* rhs, int mode, const 
   const AdjResult r = *h->res;
   h->seq += (unsigned)r.handoffs + 16u;
   if (h->seq >= 0xE0000000u) h->seq = 0;
+  if (A.mode >= 2) {
+    fprintf(stderr, "[adjoint bench] %s pass: %.1f us each (%d iterations, grid %d)\n", A.mode == 2 ? "tile (one attempt, 6 evaluations per tile)" : "weight-gradient (6 slots, 2 combinations)",
+            0.01 * (double)(r.prof[0] + r.prof[1]) / A.bench_iters, A.bench_iters, h->grid);
+    if (stats != nullptr) memset(stats, 0, sizeof(*stats));
+    return 0;
+  }
+  if (getenv("MI_ODE_ADJOINT_PROF") != nullptr && mode == 0)
+    fprintf(stderr, "[adjoint prof] attempts %lld  us: tile passes %.1f  weight-gradient passes %.1f  hand-off 1 %.1f  theta slices %.1f  hand-off 2 %.1f  epilogue %.1f\n",
+            r.n_attempt, 0.01 * r.prof[0], 0.01 * r.prof[1], 0.01 * r.prof[2], 0.01 * r.prof[3], 0.01 * r.prof[4], 0.01 * r.prof[5]);
   if (stats != nullptr) {
     memset(stats, 0, sizeof(*stats));
     stats->n_attempts = r.n_attempt; stats->n_accepted = r.n_accept; stats->n_rejected = r.n_attempt - r.n_accept;
