@@ -21,6 +21,7 @@ from .odeint import odeint
 # The backward solve of the ODEFunc tanh MLP runs as ONE kernel launch per output interval (csrc/mi_ode_adjoint.h) when the
 # problem qualifies (`_fused_plan`); FUSED = False (or TFDIFFEQ_AMD_FUSED_ADJOINT=0) keeps every case on the plane kernels.
 FUSED = os.environ.get('TFDIFFEQ_AMD_FUSED_ADJOINT', '1') != '0'
+FUSED_FORWARD = True          # the forward solve under odeint_adjoint also takes the fused kernels of a network that has them
 _ENGINES = {}
 
 
@@ -181,7 +182,17 @@ class _OdeintAdjointMethod(torch.autograd.Function):
     def forward(ctx, func, n_tensors, cfg, t, flat_params, *y0):
         ctx.func, ctx.cfg, ctx.n_tensors = func, cfg, n_tensors
         with torch.no_grad():
-            ans = odeint(func, tuple(y0), t, rtol=cfg['rtol'], atol=cfg['atol'], method=cfg['method'], options=cfg['options'])
+            fwd, state = func, tuple(y0)
+            if FUSED and FUSED_FORWARD and n_tensors == 1 and isinstance(func, _TupleModule):
+                # a network with a device descriptor (models.ODEFunc) takes the fused forward kernels here too: a training
+                # step then is one launch forward and one per interval backward
+                get = getattr(func.base_func, 'device_rhs', None)
+                mlp = get() if get is not None else None
+                if mlp is not None and y0[0].is_cuda and mlp.supports(y0[0]):
+                    fwd, state = mlp, y0[0]
+            ans = odeint(fwd, state, t, rtol=cfg['rtol'], atol=cfg['atol'], method=cfg['method'], options=cfg['options'])
+            if isinstance(ans, torch.Tensor):
+                ans = (ans,)
         ctx.save_for_backward(t, flat_params, *ans)
         return ans
 
