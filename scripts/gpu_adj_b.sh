@@ -9,7 +9,7 @@ MI_ODE_ADJOINT_BENCH=3,10 timeout 300 python scripts/adj_bench.py 2
 } > gpurun_out/adj_bench.log 2>&1
 grep bench gpurun_out/adj_bench.log
 rm -f gpurun_out/adj_pmc.jsonl
-for m in 2 3; do
+for m in ${ADJ_MODES:-2 3}; do
   for SET in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR" "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_WRREQ_sum" "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_SCA SQ_INSTS_FLAT"; do
     TAG=${m}_$(echo $SET | tr ' ' '_' | cut -c1-30)
     rm -rf gpurun_out/adjpmc_$TAG

@@ -345,7 +345,7 @@ struct AdjShared {
   float h0;
   double ymax, amax, thmax;    // max |.| of the current state (the accepted y1 of the previous step)
   float adjt;
-  int s0_cur, th_cur;
+  int s0_cur, th_cur, skip_initb;
 };
 typedef MI_LDS AdjShared lds_AdjShared;
 
@@ -514,86 +514,125 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
   const MI_LDS AdjWList& L = ash->wl[list];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
   const int d = A.p.s.dim, hd = A.p.s.rhs.hidden;
-  (void)smem;
-  if (w < G::NW12) {
-    adj_f4 g1[NC][CB], g2[NC][HB], g3[NC][CB];
-    float s1[NC], s2[NC], s3[NC][CB];
+  // The planes every wave needs - x, a, h1 of a (tile, slot) item, contiguous at the start of the slot - go through LDS, one
+  // HALF item (the 16 rows {8 lg + 4 half + j}) at a time, double buffered: read straight from L2 by all 8 waves they were
+  // fetched from HBM 2.5 times (the waves drift apart, L2 is 128 KB per workgroup) and 63 % of the wave-cycles were s_waitcnt.
+  // The activation tiles' LDS is free between the tile passes.  Column stride 20 floats: the 16 lanes of a 4 x f32 read cover
+  // all 64 banks.  One barrier per half item.
+  constexpr int SHC = 2 * DP + HP, LDC = 20, NT = 64 * G::NW;
+  constexpr int NCH = (SHC * 4 + NT - 1) / NT;              // 16-byte chunks a thread stages per half item
+  lds_float* const stg = (lds_float*)(size_t)smem + (DP * G::LW1 + HP * G::LW3);
+  const bool mm = w < G::NW12;                              // waves that own output columns
+  adj_f4 g1[NC][CB], g2[NC][HB], g3[NC][CB];
+  float s1[NC], s2[NC], s3[NC][CB];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      s1[c] = s2[c] = 0.f;
+  for (int c = 0; c < NC; ++c) {
+    s1[c] = s2[c] = 0.f;
 #pragma unroll
-      for (int b = 0; b < CB; ++b) { g1[c][b] = adj_f4{0, 0, 0, 0}; g3[c][b] = adj_f4{0, 0, 0, 0}; s3[c][b] = 0.f; }
+    for (int b = 0; b < CB; ++b) { g1[c][b] = adj_f4{0, 0, 0, 0}; g3[c][b] = adj_f4{0, 0, 0, 0}; s3[c][b] = 0.f; }
 #pragma unroll
-      for (int b = 0; b < HB; ++b) g2[c][b] = adj_f4{0, 0, 0, 0};
+    for (int b = 0; b < HB; ++b) g2[c][b] = adj_f4{0, 0, 0, 0};
+  }
+  const long long ntiles = (A.p.s.batch + G::R - 1) / G::R;
+  const int colw = 16 * w + li;                             // this lane's column inside the wave's 16-column block
+  const int nlist = uniform_i(L.n);
+  const long long my_tiles = (long long)blockIdx.x < ntiles ? (ntiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
+  const int nsteps = (int)(my_tiles * nlist * 2);           // (tile, listed slot, half) in this order
+  const g_float* const act_base = (const g_float*)A.act;
+  auto step_ptr = [&](int step) -> const g_float* {         // + 4 half: MFMA k slot lg of sub-step j <-> tile row 8 lg + 4 half + j
+    const int half = step & 1, q = (step >> 1) % nlist;
+    const long long tile_i = blockIdx.x + (long long)((step >> 1) / nlist) * gridDim.x;
+    return act_base + (tile_i * G::NSLOT + uniform_i(L.slot[q])) * (long long)G::SLOT + 4 * half;
+  };
+  // (keeping the list in scalar registers and stepping (tile, entry, half) cursors instead of dividing was tried: the SGPRs
+  // spill to VGPR lanes and the pass loses 15 %)
+  adj_f4 sx[NCH];                                           // staged chunks in flight
+  adj_f4 nb1, nb2, nh2;                                     // this wave's own operands (its g1, g2, h2 columns) of the next step
+  auto fetch_shared = [&](int step) {
+    const g_float* act = step_ptr(step);
+#pragma unroll
+    for (int u = 0; u < NCH; ++u) {
+      const unsigned ch = threadIdx.x + u * NT;             // column ch >> 2, rows 8 (ch & 3) + 4 half ..
+      if (NCH * NT == SHC * 4 || ch < SHC * 4) sx[u] = *(const g_f4*)(act + ((ch >> 2) * G::R + 8 * (ch & 3)));
     }
-    const long long ntiles = (A.p.s.batch + G::R - 1) / G::R;
-    const int colw = 16 * w + li;                           // this lane's column inside the wave's 16-column block
-    const int nlist = uniform_i(L.n);
-    const long long my_tiles = (long long)blockIdx.x < ntiles ? (ntiles - 1 - blockIdx.x) / gridDim.x + 1 : 0;
-    const int nsteps = (int)(my_tiles * nlist * 2);         // (tile, listed slot, half tile) in this order
-    const g_float* const act_base = (const g_float*)A.act;
-    // Operands of one step.  MFMA k slot lg of sub-step j <-> tile row 8 lg + 4 half + j: a lane reads 4 consecutive rows of
-    // its column at once.  Group "2": layer 2 (g2, h1); group "13": layers 1 and 3 (g1, x; a, h2).
-    // (Staging the planes all waves share - x, a, h1 - through LDS was tried: two more barriers per item, slower.)
-    auto step_ptr = [&](int step) -> const g_float* {
-      const int half = step & 1, q = (step >> 1) % nlist;
-      const long long tile_i = blockIdx.x + (long long)((step >> 1) / nlist) * gridDim.x;
-      return act_base + (tile_i * G::NSLOT + uniform_i(L.slot[q])) * (long long)G::SLOT + 4 * half;
-    };
-    adj_f4 bg2, ah1[HB], bg1, ah2, ba[CB], ax[CB];
-    auto load2 = [&](int step) {
-      const g_float* act = step_ptr(step);
-      bg2 = *(const g_f4*)(act + (unsigned)(G::OFF_G2 + colw * G::R + 8 * lg));
+  };
+  auto put_shared = [&](int step) {
+    lds_float* dst = stg + (step & 1) * (SHC * LDC);
 #pragma unroll
-      for (int b = 0; b < HB; ++b) ah1[b] = *(const g_f4*)(act + (unsigned)(G::OFF_H1 + (16 * b + li) * G::R + 8 * lg));
-    };
-    auto load13 = [&](int step) {
+    for (int u = 0; u < NCH; ++u) {
+      const unsigned ch = threadIdx.x + u * NT;
+      if (NCH * NT == SHC * 4 || ch < SHC * 4) *(lds_f4*)(dst + (ch >> 2) * LDC + 4 * (ch & 3)) = sx[u];
+    }
+  };
+  auto fetch_own = [&](int step) {
+    if (mm) {
       const g_float* act = step_ptr(step);
-      bg1 = *(const g_f4*)(act + (unsigned)(G::OFF_G1 + colw * G::R + 8 * lg));
-      ah2 = *(const g_f4*)(act + (unsigned)(G::OFF_H2 + colw * G::R + 8 * lg));
-#pragma unroll
-      for (int b = 0; b < CB; ++b) {
-        ba[b] = *(const g_f4*)(act + (unsigned)(G::OFF_A + (16 * b + li) * G::R + 8 * lg));
-        ax[b] = *(const g_f4*)(act + (unsigned)(G::OFF_X + (16 * b + li) * G::R + 8 * lg));
-      }
-    };
-    if (nsteps > 0) load2(0);
-    for (int step = 0; step < nsteps; ++step) {             // software pipeline: the loads of one group fly during the MFMAs of the other
+      nb1 = *(const g_f4*)(act + (unsigned)(G::OFF_G1 + colw * G::R + 8 * lg));
+      nb2 = *(const g_f4*)(act + (unsigned)(G::OFF_G2 + colw * G::R + 8 * lg));
+      nh2 = *(const g_f4*)(act + (unsigned)(G::OFF_H2 + colw * G::R + 8 * lg));
+    }
+  };
+  if (nsteps > 0) {
+    fetch_shared(0);
+    fetch_own(0);
+    put_shared(0);
+    if (nsteps > 1) fetch_shared(1);
+  }
+  __syncthreads();
+  for (int step = 0; step < nsteps; ++step) {
+    const adj_f4 bg1 = nb1, bg2 = nb2, ah2 = nh2;
+    if (step + 1 < nsteps) fetch_own(step + 1);             // flies during this step's MFMAs
+    if (mm) {
       const int q = (step >> 1) % nlist;
       float cf[NC];
 #pragma unroll
       for (int c = 0; c < NC; ++c) cf[c] = uniform_f(L.c[c][q]);
-      load13(step);
-      __builtin_amdgcn_sched_barrier(0);
+      const lds_float* src = stg + (step & 1) * (SHC * LDC) + 4 * lg;
+      {                                                     // layer 2: W2 += h1^T (c g2)
+        adj_f4 ah1[HB];
 #pragma unroll
-      for (int j = 0; j < 4; ++j)                           // layer 2: W2 += h1^T (c g2)
+        for (int b = 0; b < HB; ++b) ah1[b] = *(const lds_f4*)(src + (2 * DP + 16 * b + li) * LDC);
 #pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const float sb2 = cf[c] * bg2[j];
-          s2[c] += sb2;
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int b = 0; b < HB; ++b) g2[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah1[b][j], sb2, g2[c][b], 0, 0, 0);
-        }
-      __builtin_amdgcn_sched_barrier(0);
-      if (step + 1 < nsteps) load2(step + 1);
-      __builtin_amdgcn_sched_barrier(0);
+          for (int c = 0; c < NC; ++c) {
+            const float sb2 = cf[c] * bg2[j];
+            s2[c] += sb2;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)                           // layer 1: W1 += x^T (c g1);  layer 3: W3 += h2^T (c a)
-#pragma unroll
-        for (int c = 0; c < NC; ++c) {
-          const float sb1 = cf[c] * bg1[j];
-          s1[c] += sb1;
-#pragma unroll
-          for (int b = 0; b < CB; ++b) g1[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[b][j], sb1, g1[c][b], 0, 0, 0);
-#pragma unroll
-          for (int b = 0; b < CB; ++b) {
-            const float sa = cf[c] * ba[b][j];
-            s3[c][b] += sa;
-            g3[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah2[j], sa, g3[c][b], 0, 0, 0);
+            for (int b = 0; b < HB; ++b) g2[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah1[b][j], sb2, g2[c][b], 0, 0, 0);
           }
+      }
+      {                                                     // layer 1: W1 += x^T (c g1);  layer 3: W3 += h2^T (c a)
+        adj_f4 ba[CB], ax[CB];
+#pragma unroll
+        for (int b = 0; b < CB; ++b) {
+          ax[b] = *(const lds_f4*)(src + (16 * b + li) * LDC);
+          ba[b] = *(const lds_f4*)(src + (DP + 16 * b + li) * LDC);
         }
-      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int c = 0; c < NC; ++c) {
+            const float sb1 = cf[c] * bg1[j];
+            s1[c] += sb1;
+#pragma unroll
+            for (int b = 0; b < CB; ++b) g1[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[b][j], sb1, g1[c][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < CB; ++b) {
+              const float sa = cf[c] * ba[b][j];
+              s3[c][b] += sa;
+              g3[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah2[j], sa, g3[c][b], 0, 0, 0);
+            }
+          }
+      }
     }
+    if (step + 1 < nsteps) {
+      put_shared(step + 1);                                 // (its buffer was last read in step - 1, before the previous barrier)
+      if (step + 2 < nsteps) fetch_shared(step + 2);
+    }
+    __syncthreads();
+  }
+  if (mm) {
     // canonical order: W1 [d][hd], b1 [hd], W2 [hd][hd], b2 [hd], W3 [hd][d], b3 [d]
     const int oW1 = 0, oB1 = d * hd, oW2 = oB1 + hd, oB2 = oW2 + hd * hd, oW3 = oB2 + hd, oB3 = oW3 + hd * d;
 #pragma unroll
@@ -717,7 +756,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
   }
   lds_float* const slice_scratch = (lds_float*)(size_t)smem + (DP * AdjGeom<DP, HP>::LW1 + HP * AdjGeom<DP, HP>::LW3);   // the activation tiles' LDS
   CtrlParams cp = SA.cp;
-  if (threadIdx.x == 0) { sh.tout[0] = A.t_end; persist_init_ctl(s_c, A.p); sh.ok = 1; ash.s0_cur = 0; ash.th_cur = 0; ash.adjt = *A.adjt_in; }
+  if (threadIdx.x == 0) { sh.tout[0] = A.t_end; persist_init_ctl(s_c, A.p); sh.ok = 1; ash.s0_cur = 0; ash.th_cur = 0; ash.skip_initb = 0; ash.adjt = *A.adjt_in; }
   cp.t_out = sh.tout;
   __syncthreads();
   const long long npl = SA.batch * (long long)SA.dim;
@@ -821,10 +860,22 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
       }
       ash.h0 = h0;
       s_c.h0 = h0; s_c.d0 = ash.d0[0]; s_c.d1 = ash.d1[0];
+      // h0 = +inf is the NORMAL case of this tuple: adj_t has d1 = 0, so d0/d1 = x/0 (misc.py:233) unless adj_t = 0.  The
+      // second half of _select_initial_step then evaluates f at y0 + inf f0: every d2 = ||f1 - f0|| / inf is 0 (finite norm)
+      // or NaN (inf / inf, NaN), never positive, so python's max() over d1 + d2 (misc.py:243) is the max over d1 and
+      // min(100 h0, h1) = h1: the evaluation cannot change the result and is skipped - unless max(d1) <= 1e-15, where the
+      // branch of misc.py:239 depends on whether d2 is 0 or NaN.
+      ash.skip_initb = (isinf(h0) && h0 > 0.f && adj_pymax(ash.d1, 4) > 1e-15f) ? 1 : 0;
     }
     __syncthreads();
   }
-  if (ok) {                                                 // misc.py:235-245
+  const bool skip_initb = ok && uniform_i(ash.skip_initb) != 0;
+  if (skip_initb) {
+    if (threadIdx.x == 0) {
+      s_c.nfe += 1;
+      s_c.dt = (double)powf(0.01f / adj_pymax(ash.d1, 4), (float)(1.0 / (double)(cp.init_order + 1)));
+    }
+  } else if (ok) {                                          // misc.py:235-245
     if (threadIdx.x == 0) {
       AdjPlanes& P = ash.P;
       P.y0 = A.y_in; P.a0 = A.a_in; P.fy0 = fypl[0]; P.fa0 = fapl[0]; P.y1 = nullptr; P.a1 = nullptr; P.fy1 = nullptr; P.fa1 = nullptr;
