@@ -133,6 +133,71 @@ int main() {
   }
   printf("lincomb: max diff %.3e\n", md3);
   if (md3 != 0.0) { printf("FAIL lincomb not bit-exact\n"); return 1; }
+  // ---- 4. fused backward interval of odeint_adjoint (tanh MLP 3 -> 8 -> 8 -> 3, fp32) -----------------------------
+  {
+    const int AB = 50, AD = 3, AH = 8;
+    const int P = AD * AH + AH + AH * AH + AH + AH * AD + AD;
+    std::vector<float> W1(AD * AH), b1(AH), W2(AH * AH), b2(AH), W3(AH * AD), b3(AD), ya(AB * AD), aa(AB * AD);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+    for (auto* v : {&W1, &b1, &W2, &b2, &W3, &b3, &ya, &aa}) for (float& x : *v) x = rnd();
+    float *dW1, *db1, *dW2, *db2, *dW3, *db3, *dy, *da, *df, *dvy, *dvp, *dth, *dth1, *dat, *dat1, *da1;
+    auto up = [&](float** d, const std::vector<float>& h) { if (hipMalloc(d, h.size() * 4) != hipSuccess) return 1; return (int)hipMemcpy(*d, h.data(), h.size() * 4, hipMemcpyHostToDevice); };
+    if (up(&dW1, W1) || up(&db1, b1) || up(&dW2, W2) || up(&db2, b2) || up(&dW3, W3) || up(&db3, b3) || up(&dy, ya) || up(&da, aa)) return 1;
+    CK(hipMalloc(&df, AB * AD * 4)); CK(hipMalloc(&dvy, AB * AD * 4)); CK(hipMalloc(&da1, AB * AD * 4));
+    CK(hipMalloc(&dvp, P * 4)); CK(hipMalloc(&dth, P * 4)); CK(hipMalloc(&dth1, P * 4)); CK(hipMalloc(&dat, 4)); CK(hipMalloc(&dat1, 4));
+    CK(hipMemset(dth, 0, P * 4));
+    const float at0 = 0.25f;
+    CK(hipMemcpy(dat, &at0, 4, hipMemcpyHostToDevice));
+    mi_ode_adjoint_desc ad;
+    memset(&ad, 0, sizeof(ad));
+    ad.batch = AB; ad.dim = AD; ad.hidden = AH; ad.tableau = d.tableau;
+    ad.rtol = 1e-4; ad.atol = 1e-4; ad.safety = (double)0.9f; ad.ifactor = 10.0; ad.dfactor = (double)0.2f; ad.order = 5; ad.init_order = 4;
+    ad.max_num_steps = 1000;
+    mi_ode_rhs r;
+    memset(&r, 0, sizeof(r));
+    r.kind = MI_ODE_RHS_MLP_TANH; r.hidden = AH; r.sign = 1.0;
+    r.w[0] = dW1; r.w[1] = dW2; r.w[2] = dW3; r.b[0] = db1; r.b[1] = db2; r.b[2] = db3;
+    mi_ode_adjoint_handle ah = nullptr;
+    MI(mi_ode_adjoint_create(&ad, &ah));
+    if (mi_ode_adjoint_num_params(ah) != P) { printf("FAIL adjoint parameter count\n"); return 1; }
+    MI(mi_ode_adjoint_dynamics(ah, &r, dy, da, df, dvy, dvp, nullptr));
+    std::vector<float> f(AB * AD), vy(AB * AD), vp(P);
+    CK(hipMemcpy(f.data(), df, f.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(vy.data(), dvy, vy.size() * 4, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(vp.data(), dvp, vp.size() * 4, hipMemcpyDeviceToHost));
+    // host: f, -a^T df/dy, -a^T df/dtheta in double
+    std::vector<double> rvp(P, 0.0);
+    double mf = 0, mv = 0, mp = 0, sp = 0;
+    for (int b = 0; b < AB; ++b) {
+      double h1[AH], h2[AH], g2[AH], g1[AH];
+      for (int j = 0; j < AH; ++j) { double z = b1[j]; for (int i = 0; i < AD; ++i) z += ya[b * AD + i] * W1[i * AH + j]; h1[j] = tanh(z); }
+      for (int j = 0; j < AH; ++j) { double z = b2[j]; for (int i = 0; i < AH; ++i) z += h1[i] * W2[i * AH + j]; h2[j] = tanh(z); }
+      for (int k = 0; k < AD; ++k) { double z = b3[k]; for (int j = 0; j < AH; ++j) z += h2[j] * W3[j * AD + k]; mf = fmax(mf, fabs(z - f[b * AD + k])); }
+      for (int j = 0; j < AH; ++j) { double z = 0; for (int k = 0; k < AD; ++k) z += aa[b * AD + k] * W3[j * AD + k]; g2[j] = z * (1 - h2[j] * h2[j]); }
+      for (int i = 0; i < AH; ++i) { double z = 0; for (int j = 0; j < AH; ++j) z += g2[j] * W2[i * AH + j]; g1[i] = z * (1 - h1[i] * h1[i]); }
+      for (int i = 0; i < AD; ++i) { double z = 0; for (int j = 0; j < AH; ++j) z += g1[j] * W1[i * AH + j]; mv = fmax(mv, fabs(-z - vy[b * AD + i])); }
+      int o = 0;
+      for (int i = 0; i < AD; ++i) for (int j = 0; j < AH; ++j) rvp[o++] -= ya[b * AD + i] * g1[j];
+      for (int j = 0; j < AH; ++j) rvp[o++] -= g1[j];
+      for (int i = 0; i < AH; ++i) for (int j = 0; j < AH; ++j) rvp[o++] -= h1[i] * g2[j];
+      for (int j = 0; j < AH; ++j) rvp[o++] -= g2[j];
+      for (int j = 0; j < AH; ++j) for (int k = 0; k < AD; ++k) rvp[o++] -= h2[j] * aa[b * AD + k];
+      for (int k = 0; k < AD; ++k) rvp[o++] -= aa[b * AD + k];
+    }
+    for (int i = 0; i < P; ++i) { mp = fmax(mp, fabs(rvp[i] - vp[i])); sp = fmax(sp, fabs(rvp[i])); }
+    printf("adjoint dynamics: max |f - host| %.2e, |vjp_y - host| %.2e, |vjp_params - host| %.2e (scale %.2e)\n", mf, mv, mp, sp);
+    if (!(mf < 2e-6 && mv < 2e-6 && mp < 1e-5 * fmax(sp, 1.0))) { printf("FAIL adjoint dynamics\n"); return 1; }
+    mi_ode_stats ast;
+    bits = mi_ode_adjoint_segment(ah, &r, dy, da, dat, dth, 1.0, 0.0, nullptr, da1, dat1, dth1, &ast, nullptr);
+    if (bits != 0) { printf("FAIL adjoint interval status %d %s\n", bits, mi_ode_last_error()); return 1; }
+    float at1 = 0;
+    CK(hipMemcpy(&at1, dat1, 4, hipMemcpyDeviceToHost));
+    printf("adjoint interval 1 -> 0: attempts %lld accepted %lld launches %lld, adj_t %g -> %g\n", (long long)ast.n_attempts,
+           (long long)ast.n_accepted, (long long)ast.n_launches, at0, at1);
+    if (ast.n_launches != 1 || ast.n_accepted < 1 || at1 != at0) { printf("FAIL adjoint interval\n"); return 1; }
+    MI(mi_ode_adjoint_destroy(ah));
+  }
   printf("C-ABI OK (abi %d)\n", mi_ode_abi_version());
   return 0;
 }

@@ -558,3 +558,53 @@ def test_fixed_grid_with_step_size_runs_in_one_launch_and_interpolates_like_the_
     assert np.abs(got.cpu().numpy() - ref).max() < 1e-12
     with pytest.raises(ValueError, match='exclusive'):                 # solvers.py:49-56: the reference rejects ANY grid_constructor
         odeint(rhs.LotkaVolterra(1.5, 1., 3., 1.), to_dev(y0), torch.tensor(t), method=method, options={'grid_constructor': lambda f, y, tt_: tt_})
+
+
+# ---------------------------------------------------------------------------------------------
+# dopri8 (13 rows) on the MFMA tile kernels of the linear RHS ("widen the MFMA family")
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dim,batch', [(128, 4096), (20, 1000), (64, 333)])
+def test_dopri8_on_the_linear_tile_kernels(dim, batch):
+    """dopri8.py:12-77 with f = y @ W + b: the whole-call and whole-attempt tile kernels are instantiated for the 13-row
+    tableau too (14 stage derivatives of a 16-row tile in registers).  Against the oracle's dopri8, against the plane-kernel
+    engine (the path this case took before), and schedule against schedule (same bits).
+    Sharp comparison: a regime where every engine takes EXACTLY the same steps (first_step given, tolerance so loose that the
+    step factor sits on its 1/ifactor clamp): the 13-stage arithmetic and the dense output then agree to roundoff.  At
+    rtol = 1e-10 the error estimate is a 128-term cancellation at 1e-15: its noise moves dt by 1e-4 relative between
+    accumulation orders (MFMA / rocBLAS / numpy), and dopri8's dense output is only the 4th-order quartic of interp.py,
+    so interpolated values move by ~1e-7 - the plane-kernel engine differs from the oracle by as much."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(500 + dim)
+    S = rng.standard_normal((dim, dim))
+    A = -0.5 * np.eye(dim) + 0.5 * (S - S.T) / np.sqrt(dim)
+    b = 0.1 * rng.standard_normal(dim)
+    y0 = rng.standard_normal((batch, dim))
+    f = rhs.Linear(torch.tensor(A.T.copy()), torch.tensor(b))
+    fn = lambda t_, y: y @ A.T + b          # noqa: E731
+    # (a) identical step sequences by construction: dt = 0.01, then 0.1
+    t = np.array([0., 0.005, 0.05, 0.1])
+    loose = dict(rtol=1e-3, atol=1e-3)
+    ref = O.odeint(fn, y0, t, method='dopri8', options={'first_step': 0.01}, **loose)
+    outs = {}
+    for fusion in ('auto', 'step'):
+        outs[fusion] = odeint(f, to_dev(y0), torch.tensor(t), method='dopri8', options={'fusion': fusion, 'first_step': 0.01}, **loose)
+        st = dict(odeint.last_stats)
+        assert st['status'] == 0 and st['n_attempts'] == 2 and (st['n_launches'] == 1) == (fusion == 'auto'), (fusion, st)
+    assert torch.equal(outs['auto'], outs['step'])
+    assert np.abs(outs['auto'].cpu().numpy() - ref).max() < 1e-13
+    # (b) a demanding tolerance: same attempt sequence as the oracle and the plane-kernel engine, values within the band above
+    t = np.array([0., 0.4, 1.0])
+    tol = dict(rtol=1e-10, atol=1e-12)
+    ref, rst = O.odeint(fn, y0, t, method='dopri8', return_stats=True, **tol)
+    for fusion in ('auto', 'step'):
+        outs[fusion] = odeint(f, to_dev(y0), torch.tensor(t), method='dopri8', options={'fusion': fusion}, **tol)
+        st = dict(odeint.last_stats)
+        assert st['status'] == 0 and (st['n_launches'] == 1) == (fusion == 'auto'), (fusion, st)
+        assert (st['n_attempts'], st['n_accepted']) == (rst.n_attempts, rst.n_accepted)
+    assert torch.equal(outs['auto'], outs['step'])
+    planes = odeint(f, to_dev(y0), torch.tensor(t), method='dopri8', options={'force_plane_kernels': True}, **tol)
+    assert odeint.last_stats.get('engine') == 'plane kernels'
+    assert np.abs(outs['auto'].cpu().numpy() - ref).max() < 1e-6
+    assert float((outs['auto'] - planes).abs().max()) < 1e-6
+    odeint(f, to_dev(y0), torch.tensor(t), method='dopri8', options={'fusion': 'stage'}, **tol)     # no per-stage kernels for 13 rows:
+    assert odeint.last_stats.get('engine') == 'plane kernels'                                      # the generic engine takes it

@@ -44,7 +44,11 @@ struct AdjGeom {
   static constexpr int SLOT = R * (2 * DP + 4 * HP);        // floats per (tile, slot)
   static constexpr int OFF_X = 0, OFF_A = R * DP, OFF_H1 = 2 * R * DP, OFF_H2 = OFF_H1 + R * HP, OFF_G2 = OFF_H2 + R * HP,
                        OFF_G1 = OFF_G2 + R * HP;
-  static constexpr size_t lds_bytes() { return (size_t)(DP * LW1 + HP * LW3 + 2 * R * LDX + 2 * R * LDH) * sizeof(float); }
+  // dynamic LDS: W1, W3, then a region that holds the activation tiles of a tile pass, the double-buffered staging area of a
+  // weight-gradient pass (2 x (2 DP + HP) columns x 20) or the scratch of a theta slice (4 x 3 x 128), whichever is largest
+  static constexpr int TILES = 2 * R * LDX + 2 * R * LDH, STAGING = 2 * (2 * DP + HP) * 20, SLICE = 4 * 3 * 128;
+  static constexpr int REGION = TILES > STAGING ? (TILES > SLICE ? TILES : SLICE) : (STAGING > SLICE ? STAGING : SLICE);
+  static constexpr size_t lds_bytes() { return (size_t)(DP * LW1 + HP * LW3 + REGION) * sizeof(float); }
 };
 
 // k index held by lane group lg at slot s of a product whose lane groups hold KS values each: chunks of <= 16 consecutive

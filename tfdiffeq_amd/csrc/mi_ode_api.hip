@@ -393,7 +393,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   if (tb.n_stages < 0 || tb.n_stages > MI_ODE_MAX_STAGES) { mi_set_error("bad n_stages"); return MI_ODE_E_INVALID; }
   if (desc->adaptive) {
     // kernels are instantiated for: 3 and 6 rows, FSAL shaped (bosh3, dopri5, tsit5; every family and schedule);
-    // 13 rows FSAL shaped (dopri8) and 1 row not FSAL shaped (adaptive_heun): row-local families, schedules 2-4 only
+    // 13 rows FSAL shaped (dopri8): row-local families and the MFMA-linear tile kernels; 1 row not FSAL shaped (adaptive_heun):
+    // row-local families; schedules 2-4 only
     const bool classic = tb.fsal && (tb.n_stages == 3 || tb.n_stages == 6);
     const bool wide = (tb.fsal && tb.n_stages == 13) || (!tb.fsal && tb.n_stages == 1);
     if (!classic && !wide) { mi_set_error("fused adaptive engine: no kernels for a %d-row %s tableau", tb.n_stages, tb.fsal ? "FSAL-shaped" : "non-FSAL"); return MI_ODE_E_INVALID; }
@@ -426,8 +427,9 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   if (desc->adaptive && tb.n_stages != 3 && tb.n_stages != 6) {
     const bool rowlocal_fam = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
                               h->family == FAM_PLUGIN;
-    if (!rowlocal_fam || desc->fusion == 1) {
-      mi_set_error("%d-row tableaus run on the row-local whole-attempt / whole-call kernels only (no per-stage, MFMA or MLP kernels)", tb.n_stages);
+    const bool mfma13 = h->family == FAM_LINEAR_MFMA && tb.fsal && tb.n_stages == 13;     // dopri8 on the linear tile kernels
+    if (!(rowlocal_fam || mfma13) || desc->fusion == 1) {
+      mi_set_error("%d-row tableaus run on the whole-attempt / whole-call kernels of the row-local families and (13 rows) of the MFMA-linear family only (no per-stage or MLP kernels)", tb.n_stages);
       delete h; return MI_ODE_E_INVALID;
     }
   }

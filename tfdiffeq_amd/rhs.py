@@ -89,6 +89,7 @@ class _MatRHS(DeviceRHS):
         self.b = None if b is None else torch.as_tensor(b)
         self.dim = int(W.shape[0])
         self.row_local = self.dim == 2 and self.b is None       # 2x2 systems travel by value to the row-local kernels
+        self.tile_dopri8 = isinstance(self, Linear) and 3 <= self.dim <= 128    # the MFMA tile kernels also exist for the 13-row tableau
 
     def fill(self, rhs, dtype, device):
         keep = super(_MatRHS, self).fill(rhs, dtype, device)
