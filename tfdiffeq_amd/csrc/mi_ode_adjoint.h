@@ -522,7 +522,8 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
   // HALF item (the 16 rows {8 lg + 4 half + j}) at a time, double buffered: read straight from L2 by all 8 waves they were
   // fetched from HBM 2.5 times (the waves drift apart, L2 is 128 KB per workgroup) and 63 % of the wave-cycles were s_waitcnt.
   // The activation tiles' LDS is free between the tile passes.  Column stride 20 floats: the 16 lanes of a 4 x f32 read cover
-  // all 64 banks.  One barrier per half item.
+  // all 64 banks.  One barrier per half item.  (One barrier per whole item - the pass then takes the W1 / W3 part of the
+  // segment too and the tile passes re-stage the weights - was measured: the same 330 us, and 20 us more per tile pass.)
   constexpr int SHC = 2 * DP + HP, LDC = 20, NT = 64 * G::NW;
   constexpr int NCH = (SHC * 4 + NT - 1) / NT;              // 16-byte chunks a thread stages per half item
   lds_float* const stg = (lds_float*)(size_t)smem + (DP * G::LW1 + HP * G::LW3);
@@ -969,8 +970,8 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     const long long tk2 = (long long)wall_clock64();
     const Acc h1 = adj_record(ash.blk[0][1], ash.blk[1][1], ash.blk[0][2], ash.blk[1][2], 0);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
-    __threadfence();
     const long long tk3 = (long long)wall_clock64();
+    __threadfence();
     Acc accT;
     if (ok) {
       const float* th0p = thp[thc];
@@ -1024,21 +1025,25 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     const double dt_l = uniform_d(sh.st.emit_dt), ts_l = uniform_d(sh.st.emit_t0), tn_l = uniform_d(sh.st.emit_t1);
     const int s0c = uniform_i(ash.s0_cur), thc = uniform_i(ash.th_cur);      // after the swap: s0c holds stage S, 1 - s0c stage 0
     const float hs = (float)dt_l;
+    // y_mid needs every stage, f_1 and f_0 one slot each: three single-combination passes
     if (threadIdx.x == 0) {
       AdjWList& L = ash.wl[0];
       L.n = 0;
       for (int j = 0; j <= S; ++j) {
-        const float cm = (hs * A.cm[j]) * msign, c1 = j == S ? msign : 0.f;
-        if (cm == 0.f && c1 == 0.f) continue;
+        const float cm = (hs * A.cm[j]) * msign;
+        if (cm == 0.f) continue;
         L.slot[L.n] = j == 0 ? 1 - s0c : (j == S ? s0c : j);
-        L.c[0][L.n] = cm; L.c[1][L.n] = c1;
+        L.c[0][L.n] = cm; L.c[1][L.n] = 0.f;
         ++L.n;
       }
-      AdjWList& L0 = ash.wl[1];
-      L0.n = 1; L0.slot[0] = 1 - s0c; L0.c[0][0] = msign; L0.c[1][0] = 0.f;
+      AdjWList& L1 = ash.wl[1];
+      L1.n = 1; L1.slot[0] = s0c; L1.c[0][0] = msign; L1.c[1][0] = 0.f;
     }
     __syncthreads();
-    adj_wgrad_pass<DP, HP, 2>(Ap, smem, ash_off, 0, 0);
+    adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 0, 0);
+    adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 1, 1);
+    if (threadIdx.x == 0) { AdjWList& L0 = ash.wl[1]; L0.n = 1; L0.slot[0] = 1 - s0c; L0.c[0][0] = msign; L0.c[1][0] = 0.f; }
+    __syncthreads();
     adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 1, 2);
     Acc h1;
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
