@@ -85,6 +85,7 @@ struct AdjArgs {
   int mode;                    // 0: segment, 1: one evaluation of the augmented dynamics; 2 / 3: time `bench_iters` tile passes /
                                // weight-gradient passes of one attempt (no hand-offs; tuning aid, MI_ODE_ADJOINT_BENCH)
   int bench_iters;
+  int bench_flags;             // ablations for the pass micro-benchmarks: 1 no MFMAs, 2 no global fetches after the first, 4 no barriers, 8 no partial stores
   int P, Ppad, SL;             // parameters, padded, slice per workgroup
 };
 
@@ -502,6 +503,12 @@ __device__ __attribute__((noinline)) void adj_tile_pass(const AdjArgs* A_, unsig
   __syncthreads();
 }
 
+// The partials cross workgroups (and XCDs) inside the kernel.  They are written with agent-scope (sc1, write-through) stores
+// and read with agent-scope loads, the recipe of the hand-off records: a release fence per workgroup instead would write back
+// every dirty line of the XCD's L2 - the activation scratch - and cost 90 us per pass.
+__device__ __forceinline__ void adj_store_agent(g_float* p, float v) { __hip_atomic_store((float*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float adj_load_agent(const g_float* p) { return __hip_atomic_load((const float*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // ---- weight-gradient pass -----------------------------------------------------------------------------------------
 // sum over this workgroup's tiles and the listed activation slots of  coef * X^T Delta  for the three layers (+ column
 // sums for the biases), NC coefficient sets at once; the result goes to this workgroup's block of A.wpart, combinations
@@ -551,93 +558,105 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
   };
   // (keeping the list in scalar registers and stepping (tile, entry, half) cursors instead of dividing was tried: the SGPRs
   // spill to VGPR lanes and the pass loses 15 %)
-  adj_f4 sx[NCH];                                           // staged chunks in flight
-  adj_f4 nb1, nb2, nh2;                                     // this wave's own operands (its g1, g2, h2 columns) of the next step
-  auto fetch_shared = [&](int step) {
+  // Software pipeline, prefetch distance TWO half items (one was measured latency bound: a step took ~6 us whatever its
+  // MFMA count): two register sets each for the staged chunks and for this wave's own operands (its g1, g2, h2 columns),
+  // the loop body is two steps so that no set is ever copied while its loads fly.
+  const int abl = A.bench_flags;
+  struct Own { adj_f4 b1, b2, h2; };
+  adj_f4 sx[2][NCH];
+  Own own[2];
+  auto fetch_shared = [&](int step, adj_f4* dst) {
     const g_float* act = step_ptr(step);
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
       const unsigned ch = threadIdx.x + u * NT;             // column ch >> 2, rows 8 (ch & 3) + 4 half ..
-      if (NCH * NT == SHC * 4 || ch < SHC * 4) sx[u] = *(const g_f4*)(act + ((ch >> 2) * G::R + 8 * (ch & 3)));
+      if (NCH * NT == SHC * 4 || ch < SHC * 4) dst[u] = *(const g_f4*)(act + ((ch >> 2) * G::R + 8 * (ch & 3)));
     }
   };
-  auto put_shared = [&](int step) {
+  auto put_shared = [&](int step, const adj_f4* src) {
     lds_float* dst = stg + (step & 1) * (SHC * LDC);
 #pragma unroll
     for (int u = 0; u < NCH; ++u) {
       const unsigned ch = threadIdx.x + u * NT;
-      if (NCH * NT == SHC * 4 || ch < SHC * 4) *(lds_f4*)(dst + (ch >> 2) * LDC + 4 * (ch & 3)) = sx[u];
+      if (NCH * NT == SHC * 4 || ch < SHC * 4) *(lds_f4*)(dst + (ch >> 2) * LDC + 4 * (ch & 3)) = src[u];
     }
   };
-  auto fetch_own = [&](int step) {
+  auto fetch_own = [&](int step, Own& o) {
     if (mm) {
       const g_float* act = step_ptr(step);
-      nb1 = *(const g_f4*)(act + (unsigned)(G::OFF_G1 + colw * G::R + 8 * lg));
-      nb2 = *(const g_f4*)(act + (unsigned)(G::OFF_G2 + colw * G::R + 8 * lg));
-      nh2 = *(const g_f4*)(act + (unsigned)(G::OFF_H2 + colw * G::R + 8 * lg));
+      o.b1 = *(const g_f4*)(act + (unsigned)(G::OFF_G1 + colw * G::R + 8 * lg));
+      o.b2 = *(const g_f4*)(act + (unsigned)(G::OFF_G2 + colw * G::R + 8 * lg));
+      o.h2 = *(const g_f4*)(act + (unsigned)(G::OFF_H2 + colw * G::R + 8 * lg));
+    }
+  };
+  auto compute = [&](int step, const adj_f4 bg1, const adj_f4 bg2, const adj_f4 ah2) {
+    if (!mm || (abl & 1)) return;
+    const int q = (step >> 1) % nlist;
+    float cf[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) cf[c] = uniform_f(L.c[c][q]);
+    const lds_float* src = stg + (step & 1) * (SHC * LDC) + 4 * lg;
+    {                                                       // layer 2: W2 += h1^T (c g2)
+      adj_f4 ah1[HB];
+#pragma unroll
+      for (int b = 0; b < HB; ++b) ah1[b] = *(const lds_f4*)(src + (2 * DP + 16 * b + li) * LDC);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float sb2 = cf[c] * bg2[j];
+          s2[c] += sb2;
+#pragma unroll
+          for (int b = 0; b < HB; ++b) g2[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah1[b][j], sb2, g2[c][b], 0, 0, 0);
+        }
+    }
+    {                                                       // layer 1: W1 += x^T (c g1);  layer 3: W3 += h2^T (c a)
+      adj_f4 ba[CB], ax[CB];
+#pragma unroll
+      for (int b = 0; b < CB; ++b) {
+        ax[b] = *(const lds_f4*)(src + (16 * b + li) * LDC);
+        ba[b] = *(const lds_f4*)(src + (DP + 16 * b + li) * LDC);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          const float sb1 = cf[c] * bg1[j];
+          s1[c] += sb1;
+#pragma unroll
+          for (int b = 0; b < CB; ++b) g1[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[b][j], sb1, g1[c][b], 0, 0, 0);
+#pragma unroll
+          for (int b = 0; b < CB; ++b) {
+            const float sa = cf[c] * ba[b][j];
+            s3[c][b] += sa;
+            g3[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah2[j], sa, g3[c][b], 0, 0, 0);
+          }
+        }
     }
   };
   if (nsteps > 0) {
-    fetch_shared(0);
-    fetch_own(0);
-    put_shared(0);
-    if (nsteps > 1) fetch_shared(1);
+    fetch_shared(0, sx[0]);
+    fetch_own(0, own[0]);
+    if (nsteps > 1) { fetch_shared(1, sx[1]); fetch_own(1, own[1]); }
+    put_shared(0, sx[0]);
+    if (nsteps > 2) fetch_shared(2, sx[0]);
   }
   __syncthreads();
-  for (int step = 0; step < nsteps; ++step) {
-    const adj_f4 bg1 = nb1, bg2 = nb2, ah2 = nh2;
-    if (step + 1 < nsteps) fetch_own(step + 1);             // flies during this step's MFMAs
-    if (mm) {
-      const int q = (step >> 1) % nlist;
-      float cf[NC];
+  for (int step = 0; step < nsteps; step += 2) {             // nsteps is even (two halves per item)
 #pragma unroll
-      for (int c = 0; c < NC; ++c) cf[c] = uniform_f(L.c[c][q]);
-      const lds_float* src = stg + (step & 1) * (SHC * LDC) + 4 * lg;
-      {                                                     // layer 2: W2 += h1^T (c g2)
-        adj_f4 ah1[HB];
-#pragma unroll
-        for (int b = 0; b < HB; ++b) ah1[b] = *(const lds_f4*)(src + (2 * DP + 16 * b + li) * LDC);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const float sb2 = cf[c] * bg2[j];
-            s2[c] += sb2;
-#pragma unroll
-            for (int b = 0; b < HB; ++b) g2[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah1[b][j], sb2, g2[c][b], 0, 0, 0);
-          }
+    for (int par = 0; par < 2; ++par) {
+      const int st = step + par;
+      const adj_f4 bg1 = own[par].b1, bg2 = own[par].b2, ah2 = own[par].h2;
+      if (st + 2 < nsteps && !(abl & 2)) fetch_own(st + 2, own[par]);     // two steps ahead
+      compute(st, bg1, bg2, ah2);
+      if (st + 1 < nsteps) {
+        put_shared(st + 1, sx[1 - par]);                    // (its buffer was last read in step st - 1, before the previous barrier)
+        if (st + 3 < nsteps && !(abl & 2)) fetch_shared(st + 3, sx[1 - par]);
       }
-      {                                                     // layer 1: W1 += x^T (c g1);  layer 3: W3 += h2^T (c a)
-        adj_f4 ba[CB], ax[CB];
-#pragma unroll
-        for (int b = 0; b < CB; ++b) {
-          ax[b] = *(const lds_f4*)(src + (16 * b + li) * LDC);
-          ba[b] = *(const lds_f4*)(src + (DP + 16 * b + li) * LDC);
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int c = 0; c < NC; ++c) {
-            const float sb1 = cf[c] * bg1[j];
-            s1[c] += sb1;
-#pragma unroll
-            for (int b = 0; b < CB; ++b) g1[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[b][j], sb1, g1[c][b], 0, 0, 0);
-#pragma unroll
-            for (int b = 0; b < CB; ++b) {
-              const float sa = cf[c] * ba[b][j];
-              s3[c][b] += sa;
-              g3[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ah2[j], sa, g3[c][b], 0, 0, 0);
-            }
-          }
-      }
+      if (!(abl & 4)) __syncthreads();
     }
-    if (step + 1 < nsteps) {
-      put_shared(step + 1);                                 // (its buffer was last read in step - 1, before the previous barrier)
-      if (step + 2 < nsteps) fetch_shared(step + 2);
-    }
-    __syncthreads();
   }
-  if (mm) {
+  if (mm && !(abl & 8)) {
     // canonical order: W1 [d][hd], b1 [hd], W2 [hd][hd], b2 [hd], W3 [hd][d], b3 [d]
     const int oW1 = 0, oB1 = d * hd, oW2 = oB1 + hd, oB2 = oW2 + hd * hd, oW3 = oB2 + hd, oB3 = oW3 + hd * d;
 #pragma unroll
@@ -649,36 +668,36 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int m = 16 * b + 4 * lg + i;
-          if (m < d && colw < hd) out[(unsigned)(oW1 + m * hd + colw)] = g1[c][b][i];
+          if (m < d && colw < hd) adj_store_agent(out + (unsigned)(oW1 + m * hd + colw), g1[c][b][i]);
         }
 #pragma unroll
       for (int b = 0; b < HB; ++b)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int m = 16 * b + 4 * lg + i;
-          if (m < hd && colw < hd) out[(unsigned)(oW2 + m * hd + colw)] = g2[c][b][i];
+          if (m < hd && colw < hd) adj_store_agent(out + (unsigned)(oW2 + m * hd + colw), g2[c][b][i]);
         }
 #pragma unroll
       for (int b = 0; b < CB; ++b)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int m = 16 * w + 4 * lg + i, n = 16 * b + li;
-          if (m < hd && n < d) out[(unsigned)(oW3 + m * d + n)] = g3[c][b][i];
+          if (m < hd && n < d) adj_store_agent(out + (unsigned)(oW3 + m * d + n), g3[c][b][i]);
         }
       // bias gradients: a lane summed rows 8 lg .. 8 lg + 7 of every tile; fold the four lane groups
       float t1 = s1[c], t2 = s2[c];
       t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
       t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
-      if (lg == 0 && colw < hd) { out[(unsigned)(oB1 + colw)] = t1; out[(unsigned)(oB2 + colw)] = t2; }
+      if (lg == 0 && colw < hd) { adj_store_agent(out + (unsigned)(oB1 + colw), t1); adj_store_agent(out + (unsigned)(oB2 + colw), t2); }
 #pragma unroll
       for (int b = 0; b < CB; ++b) {
         float t3 = s3[c][b];
         t3 += __shfl_xor(t3, 16, 64); t3 += __shfl_xor(t3, 32, 64);
-        if (w == 0 && lg == 0 && 16 * b + li < d) out[(unsigned)(oB3 + 16 * b + li)] = t3;
+        if (w == 0 && lg == 0 && 16 * b + li < d) adj_store_agent(out + (unsigned)(oB3 + 16 * b + li), t3);
       }
     }
   }
-  __threadfence();                                          // the partials must be in memory before this workgroup's next record says so
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the partials are written through before this workgroup's next record says so
   __syncthreads();
 }
 
@@ -701,7 +720,7 @@ __device__ __forceinline__ void adj_slice(const AdjArgs& A, lds_float* scratch, 
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
-          for (int c = 0; c < NCOMB; ++c) v[u][c] = (wp + ((long long)(g + u * ngroups) * 3 + c) * A.Ppad)[(unsigned)p];
+          for (int c = 0; c < NCOMB; ++c) v[u][c] = adj_load_agent(wp + ((long long)(g + u * ngroups) * 3 + c) * A.Ppad + (unsigned)p);
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -709,7 +728,7 @@ __device__ __forceinline__ void adj_slice(const AdjArgs& A, lds_float* scratch, 
       }
       for (; g < G_; g += ngroups)
 #pragma unroll
-        for (int c = 0; c < NCOMB; ++c) s[c] += (wp + ((long long)g * 3 + c) * A.Ppad)[(unsigned)p];
+        for (int c = 0; c < NCOMB; ++c) s[c] += adj_load_agent(wp + ((long long)g * 3 + c) * A.Ppad + (unsigned)p);
     }
     __syncthreads();                                        // (scratch may still be read by the previous chunk)
 #pragma unroll
@@ -796,7 +815,6 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 0, 0);
     const Acc h1 = adj_record(ash.blk[0][0], ash.blk[1][0], ash.blk[0][2], ash.blk[0][3], (int)ash.blk[0][4]);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
-    __threadfence();
     Acc accT;
     if (ok) {
       adj_slice<1>(A, slice_scratch, [&](int p, const float* s) {
@@ -893,7 +911,6 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 0, 0);
     const Acc h1 = adj_record(0.0, 0.0, ash.blk[0][2], ash.blk[1][2], 0);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
-    __threadfence();
     Acc accT;
     if (ok) {
       adj_slice<1>(A, slice_scratch, [&](int p, const float* s) {
@@ -971,7 +988,6 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     const Acc h1 = adj_record(ash.blk[0][1], ash.blk[1][1], ash.blk[0][2], ash.blk[1][2], 0);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
     const long long tk3 = (long long)wall_clock64();
-    __threadfence();
     Acc accT;
     if (ok) {
       const float* th0p = thp[thc];
@@ -1047,7 +1063,6 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 1, 2);
     Acc h1;
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
-    __threadfence();
     if (ok) {
       const float x = interp_x<float>(ts_l, tn_l, A.t_end);
       const float* th0p = thp[1 - thc];

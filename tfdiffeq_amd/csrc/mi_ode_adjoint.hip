@@ -174,8 +174,8 @@ static int adj_launch(mi_ode_adjoint* h, const mi_ode_rhs* rhs, int mode, const 
   A.planes = h->planes; A.theta = h->theta; A.act = h->act; A.wpart = h->wpart; A.res = h->res;
   A.mode = mode; A.P = h->P; A.Ppad = h->Ppad; A.SL = h->SL;
   if (const char* be = getenv("MI_ODE_ADJOINT_BENCH")) {     // "mode,iterations": segment calls time one pass instead (tuning aid)
-    int bm = 0, bi = 0;
-    if (mode == 0 && sscanf(be, "%d,%d", &bm, &bi) == 2 && (bm == 2 || bm == 3) && bi > 0) { A.mode = bm; A.bench_iters = bi; }
+    int bm = 0, bi = 0, bf = 0;
+    if (mode == 0 && sscanf(be, "%d,%d,%d", &bm, &bi, &bf) >= 2 && (bm == 2 || bm == 3) && bi > 0) { A.mode = bm; A.bench_iters = bi; A.bench_flags = bf; }
   }
   MI_HIP(hipMemcpyAsync(h->args_dev, h->args_host, sizeof(AdjArgs), hipMemcpyHostToDevice, st));
   const AdjArgs* dev_args = h->args_dev;
