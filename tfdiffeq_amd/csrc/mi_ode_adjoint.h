@@ -85,7 +85,7 @@ struct AdjArgs {
   int mode;                    // 0: segment, 1: one evaluation of the augmented dynamics; 2 / 3: time `bench_iters` tile passes /
                                // weight-gradient passes of one attempt (no hand-offs; tuning aid, MI_ODE_ADJOINT_BENCH)
   int bench_iters;
-  int bench_flags;             // ablations for the pass micro-benchmarks: 1 no MFMAs, 2 no global fetches after the first, 4 no barriers, 8 no partial stores
+  int bench_flags;             // ablations for the pass micro-benchmarks: 1 no MFMAs, 2 no global fetches after the first, 4 no barriers, 8 no partial stores, 32 (tile pass) no activation stores
   int P, Ppad, SL;             // parameters, padded, slice per workgroup
 };
 
@@ -459,7 +459,7 @@ __device__ __attribute__((noinline)) void adj_tile_pass(const AdjArgs* A_, unsig
         }
         // stage 1 (c_sol = c_err = c_mid = 0 there for the FSAL pairs in use) leaves no activations; stage S is stage 0 of
         // the next step if this one is accepted
-        g_float* act = SG == 1 ? nullptr : act_tile + (long long)(SG == S ? 1 - P.s0_cur : SG) * G::SLOT;
+        g_float* act = (SG == 1 || (A.bench_flags & 32)) ? nullptr : act_tile + (long long)(SG == S ? 1 - P.s0_cur : SG) * G::SLOT;
         cx.eval(ys, as, fn, vn, act);
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ky[SG][i] = sign * fn[i]; ka[SG][i] = -(sign * vn[i]); }
