@@ -269,3 +269,24 @@ def test_config5_size_backward_is_one_launch_per_interval():
     assert _rel(gx_f, gx_p) < 1e-4
     for a, b in zip(gp_f, gp_p):
         assert _rel(a, b) < 1e-4
+
+
+def test_hand_off_time_out_falls_back_to_the_generic_path(monkeypatch):
+    """A grid hand-off that times out (the GPU shared with another persistent kernel; forced here by a spin limit of one poll)
+    must not fail the training step: nothing has been committed, the backward pass is redone on the plane-kernel engine."""
+    from tfdiffeq_amd import adjoint as ADJ
+    from tfdiffeq_amd import models, odeint_adjoint
+    torch.manual_seed(20)
+    block = models.ODEBlock(models.ODEFunc(8, 16, non_linearity='tanh'), tol=1e-3, adjoint=True).to(dev())
+    x = torch.randn(4096, 8, generator=torch.Generator().manual_seed(21)).to(dev())          # 128 workgroups
+    ref = _grads(block, x, False)
+    monkeypatch.setenv('MI_ODE_PERSIST_SPIN_FIRST', '1')
+    monkeypatch.setenv('MI_ODE_PERSIST_SPIN_LIMIT', '1')
+    ADJ.clear_adjoint_engines()
+    try:
+        with pytest.warns(UserWarning, match='fused adjoint kernel unavailable'):
+            got = _grads(block, x, True)
+    finally:
+        ADJ.clear_adjoint_engines()
+    assert got[3]['engine'] == 'plane kernels'
+    assert torch.equal(got[1], ref[1]) and all(torch.equal(a, b) for a, b in zip(got[2], ref[2]))

@@ -203,7 +203,18 @@ class _OdeintAdjointMethod(torch.autograd.Function):
         f_params = tuple(p for p in func.parameters() if p.requires_grad)
         like = ans[0]
         grad_output = tuple(g if g is not None else torch.zeros_like(a) for g, a in zip(grad_output, ans))
+        plan = _fused_plan(func, n_tensors, cfg, like, f_params)
+        if plan is not None:
+            try:
+                return _OdeintAdjointMethod._fused_backward(plan, func, t, flat_params, ans, grad_output, like)
+            except RuntimeError as e:                    # the in-kernel hand-off timed out (the GPU is shared with another
+                import warnings                          # persistent kernel): nothing was committed, take the generic path
+                warnings.warn('fused adjoint kernel unavailable (%s): falling back to the plane-kernel path' % e)
+        odeint_adjoint.last_backward_stats = {'engine': 'plane kernels'}
+        return _OdeintAdjointMethod._generic_backward(func, cfg, n_tensors, t, flat_params, ans, grad_output, f_params, like)
 
+    @staticmethod
+    def _augmented_dynamics(func, n_tensors, f_params, like):
         def augmented_dynamics(tt, y_aug):
             # dynamics of the original system augmented with the adjoint wrt y, t and the parameters (adjoint.py:69-105)
             y, adj_y = y_aug[:n_tensors], y_aug[n_tensors:2 * n_tensors]
@@ -227,32 +238,38 @@ class _OdeintAdjointMethod(torch.autograd.Function):
                 vjp_params = torch.zeros((), dtype=like.dtype, device=like.device)
             return (*[f.detach() for f in func_eval], *vjp_y, vjp_t.to(like.dtype), vjp_params.to(like.dtype))
 
+        return augmented_dynamics
+
+    @staticmethod
+    def _fused_backward(plan, func, t, flat_params, ans, grad_output, like):
+        eng, mlp, base = plan
         T = ans[0].shape[0]
-        plan = _fused_plan(func, n_tensors, cfg, like, f_params)
-        if plan is not None:
-            eng, mlp, base = plan
-            segs = []
-            with torch.no_grad():
-                g_out = grad_output[0]
-                adj_y = g_out[-1].contiguous()
-                theta = torch.zeros(eng.n_params, dtype=torch.float32, device=like.device)
-                adj_time = torch.zeros((), dtype=torch.float32, device=like.device)
-                time_vjps = []
-                t_dev = t.to(device=like.device)
-                for i in range(T - 1, 0, -1):
-                    func_i = func(t_dev[i].to(like.dtype), (ans[0][i],))[0]
-                    dLd_cur_t = torch.dot(func_i.reshape(-1), g_out[i].reshape(-1))              # adjoint.py:134-140
-                    adj_time = adj_time - dLd_cur_t
-                    time_vjps.append(dLd_cur_t.reshape(1))
-                    adj_y, adj_time, theta = eng.segment(mlp, ans[0][i], adj_y, adj_time, theta, float(t[i]), float(t[i - 1]))
-                    segs.append(eng.stats.as_dict())
-                    adj_y = adj_y + g_out[i - 1]
-                time_vjps.append(adj_time.reshape(1))
-                time_vjps = torch.cat(time_vjps[::-1]).to(dtype=t.dtype, device=t.device)
-                grad_params = canonical_to_module_order(base, theta).to(flat_params.dtype)
-            odeint_adjoint.last_backward_stats = {'engine': 'fused adjoint kernel (one launch per interval)', 'segments': segs}
-            return (None, None, None, time_vjps, grad_params, adj_y)
-        odeint_adjoint.last_backward_stats = {'engine': 'plane kernels'}
+        segs = []
+        with torch.no_grad():
+            g_out = grad_output[0]
+            adj_y = g_out[-1].contiguous()
+            theta = torch.zeros(eng.n_params, dtype=torch.float32, device=like.device)
+            adj_time = torch.zeros((), dtype=torch.float32, device=like.device)
+            time_vjps = []
+            t_dev = t.to(device=like.device)
+            for i in range(T - 1, 0, -1):
+                func_i = func(t_dev[i].to(like.dtype), (ans[0][i],))[0]
+                dLd_cur_t = torch.dot(func_i.reshape(-1), g_out[i].reshape(-1))              # adjoint.py:134-140
+                adj_time = adj_time - dLd_cur_t
+                time_vjps.append(dLd_cur_t.reshape(1))
+                adj_y, adj_time, theta = eng.segment(mlp, ans[0][i], adj_y, adj_time, theta, float(t[i]), float(t[i - 1]))
+                segs.append(eng.stats.as_dict())
+                adj_y = adj_y + g_out[i - 1]
+            time_vjps.append(adj_time.reshape(1))
+            time_vjps = torch.cat(time_vjps[::-1]).to(dtype=t.dtype, device=t.device)
+            grad_params = canonical_to_module_order(base, theta).to(flat_params.dtype)
+        odeint_adjoint.last_backward_stats = {'engine': 'fused adjoint kernel (one launch per interval)', 'segments': segs}
+        return (None, None, None, time_vjps, grad_params, adj_y)
+
+    @staticmethod
+    def _generic_backward(func, cfg, n_tensors, t, flat_params, ans, grad_output, f_params, like):
+        T = ans[0].shape[0]
+        augmented_dynamics = _OdeintAdjointMethod._augmented_dynamics(func, n_tensors, f_params, like)
         with torch.no_grad():
             adj_y = tuple(g[-1] for g in grad_output)
             adj_params = torch.zeros_like(flat_params, dtype=like.dtype) if flat_params.numel() > 0 else \
