@@ -28,10 +28,10 @@ def _canon(func, tensors):
     return torch.cat([w1.t().reshape(-1), b1, w2.t().reshape(-1), b2, w3.t().reshape(-1), b3])
 
 
-def _func(dim, hidden, seed):
+def _func(dim, hidden, seed, non_linearity='tanh'):
     from tfdiffeq_amd.models import ODEFunc
     torch.manual_seed(seed)
-    return ODEFunc(dim, hidden, non_linearity='tanh').to(dev())
+    return ODEFunc(dim, hidden, non_linearity=non_linearity).to(dev())
 
 
 def _engine(batch, dim, hidden, tol=1e-3, max_num_steps=1000):
@@ -243,8 +243,8 @@ def test_cases_the_fused_kernel_does_not_cover_stay_on_the_plane_engine():
     blk.odefunc.fc2.bias.requires_grad_(False)
     blk(x.clone().requires_grad_(True)).sum().backward()
     assert odeint_adjoint.last_backward_stats['engine'] == 'plane kernels'
-    # relu network, time dependent network, float64 state
-    for kw, dt in ((dict(non_linearity='relu'), torch.float32), (dict(non_linearity='tanh', time_dependent=True), torch.float32),
+    # a non-linearity the kernels do not know, time dependent network, float64 state
+    for kw, dt in ((dict(non_linearity='ELU'), torch.float32), (dict(non_linearity='tanh', time_dependent=True), torch.float32),
                    (dict(non_linearity='tanh'), torch.float64)):
         blk = models.ODEBlock(models.ODEFunc(8, 16, **kw), adjoint=True).to(dev()).to(dt)
         blk(x.to(dt).clone().requires_grad_(True)).sum().backward()
@@ -290,3 +290,56 @@ def test_hand_off_time_out_falls_back_to_the_generic_path(monkeypatch):
         ADJ.clear_adjoint_engines()
     assert got[3]['engine'] == 'plane kernels'
     assert torch.equal(got[1], ref[1]) and all(torch.equal(a, b) for a, b in zip(got[2], ref[2]))
+
+
+# ---------------------------------------------------------------------------------------------
+# the reference's other non-linearities: relu (ODEFunc's default, dense_odenet.py:14) and softplus
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('act', ['relu', 'softplus'])
+def test_other_activations_dynamics_and_segment(act):
+    func = _func(10, 48, 30, act)
+    g = torch.Generator(device='cpu').manual_seed(31)
+    y = torch.randn(500, 10, generator=g).to(dev())
+    a = (torch.randn(500, 10, generator=g) / 500).to(dev())
+    eng = _engine(500, 10, 48, 1e-4)
+    try:
+        f, vy, vp = eng.dynamics(func.device_rhs(), y, a)
+        yr = y.clone().requires_grad_(True)
+        fr = func(torch.tensor(0.), yr)
+        grads = torch.autograd.grad(fr, (yr,) + tuple(func.parameters()), -a)
+        assert _rel(f, fr.detach()) < 3e-6 and _rel(vy, grads[0]) < 3e-6 and _rel(vp, _canon(func, grads[1:])) < 1e-5
+        theta = torch.zeros(eng.n_params, device=dev())
+        adj_t = torch.tensor(0.1, device=dev())
+        a1, t_1, p1 = eng.segment(func.device_rhs(), y, a, adj_t, theta, 1.0, 0.0)
+        st = eng.stats.as_dict()
+    finally:
+        eng.close()
+    ref, rs = _plane_segment(func, y, a, adj_t, theta, 1.0, 0.0, 1e-4)
+    assert (st['n_attempts'], st['n_accepted']) == (rs['n_attempts'], rs['n_accepted'])
+    assert _rel(a1, ref[1][1]) < 2e-5 and _rel(p1, ref[3][1]) < 2e-5
+
+
+@pytest.mark.parametrize('act', ['relu', 'softplus'])
+def test_default_odenet_trains_on_the_fused_kernels(act):
+    """ODENet with the reference's default non-linearity: forward on the whole-call MLP kernel (against the torch-CPU
+    restatement), backward on the fused adjoint kernel (against float64 autograd through the restatement)."""
+    from tfdiffeq_amd import models, odeint, odeint_adjoint
+    from oracle import ode_torch_cpu as TC
+    torch.manual_seed(32)
+    block = models.ODEBlock(models.ODEFunc(12, 40, non_linearity=act), tol=1e-5, adjoint=True).to(dev())
+    x = torch.randn(300, 12, generator=torch.Generator().manual_seed(33))
+    with torch.no_grad():
+        got = block(x.to(dev()))
+    assert odeint.last_stats.get('n_launches') == 1
+    cpu = copy.deepcopy(block.odefunc).cpu()
+    ref, _ = TC.odeint_dopri5(lambda t_, y_: cpu(t_, y_), x, [0., 1.], rtol=1e-5, atol=1e-5)
+    assert _rel(got.cpu(), ref[1].detach()) < 2e-4
+    out = block(x.to(dev()).requires_grad_(True))
+    out.pow(2).sum().backward()
+    assert odeint_adjoint.last_backward_stats['engine'].startswith('fused')
+    cpu64 = copy.deepcopy(cpu).double()
+    ref64, _ = TC.odeint_dopri5(lambda t_, y_: cpu64(t_, y_), x.double(), [0., 1.], rtol=1e-9, atol=1e-11)
+    ref64[1].pow(2).sum().backward()
+    band = 1e-2 if act == 'relu' else 2e-3        # relu: the kinks cap what an adaptive solve of tolerance 1e-5 delivers (either path)
+    for pg, pc in zip(block.odefunc.parameters(), cpu64.parameters()):
+        assert _rel(pg.grad.cpu().double(), pc.grad) < band

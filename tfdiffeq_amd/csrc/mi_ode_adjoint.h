@@ -1,5 +1,5 @@
 // One backward segment of odeint_adjoint (/root/reference/tfdiffeq/adjoint.py:57-178) in ONE launch, for the ODEFunc
-// MLP  f(y) = W3^T tanh(W2^T tanh(W1^T y + b1) + b2) + b3  (tfdiffeq/models/dense_odenet.py:41-92), fp32.
+// MLP  f(y) = W3^T act(W2^T act(W1^T y + b1) + b2) + b3  (tfdiffeq/models/dense_odenet.py:41-92; act = tanh, relu or softplus), fp32.
 //
 // The reference integrates the heterogeneous tuple (y, adj_y, adj_t, adj_params) over [t_i, t_{i-1}] with odeint, i.e.
 // with the dopri5 step of rk_common.py:22-61 per component, the per-component error ratios of misc.py:250-264, their
@@ -107,7 +107,7 @@ struct AdjCtx {
   lds_float *s_w1, *s_w3, *s_x, *s_a, *s_hA, *s_hB;
   float w2f[G::KS2], w2t[G::KS2];                           // W2[k][col] and W2[col][k] of this wave's 16 hidden columns
   float b1v, b2v, b3v, sign;
-  int lane, wave, li, lg, d, hd, col, col12, rbase;
+  int lane, wave, li, lg, d, hd, col, col12, rbase, actk;
   bool owner;
 
   // pointers, lane roles, biases (every pass); `smem`: LDS address of the dynamic segment
@@ -125,6 +125,7 @@ struct AdjCtx {
     const g_float* B2 = (const g_float*)rhs.b[1];
     const g_float* B3 = (const g_float*)rhs.b[2];
     sign = (float)rhs.sign;
+    actk = __builtin_amdgcn_readfirstlane((int)rhs.s[0]);    // hidden activation (mi_ode_mlp.h: tanh / relu / softplus)
     col12 = 16 * wave + li;
     b1v = (B1 != nullptr && wave < G::NW12 && col12 < hd) ? B1[col12] : 0.f;
     b2v = (B2 != nullptr && wave < G::NW12 && col12 < hd) ? B2[col12] : 0.f;
@@ -196,8 +197,8 @@ struct AdjCtx {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        h1k[i] = mlp_tanh(c0[i] + b1v);
-        h1k[4 + i] = mlp_tanh(c1[i] + b1v);
+        h1k[i] = mlp_act(c0[i] + b1v, actk);
+        h1k[4 + i] = mlp_act(c1[i] + b1v, actk);
         s_hA[(4 * lg + i) * G::LDH + col12] = h1k[i];
         s_hA[(16 + 4 * lg + i) * G::LDH + col12] = h1k[4 + i];
       }
@@ -221,8 +222,8 @@ struct AdjCtx {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        h2k[i] = mlp_tanh(c0[i] + b2v);
-        h2k[4 + i] = mlp_tanh(c1[i] + b2v);
+        h2k[i] = mlp_act(c0[i] + b2v, actk);
+        h2k[4 + i] = mlp_act(c1[i] + b2v, actk);
         s_hB[(4 * lg + i) * G::LDH + col12] = h2k[i];
         s_hB[(16 + 4 * lg + i) * G::LDH + col12] = h2k[4 + i];
       }
@@ -261,8 +262,8 @@ struct AdjCtx {
       float g[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        g[i] = c0[i] * (1.0f - h2k[i] * h2k[i]);
-        g[4 + i] = c1[i] * (1.0f - h2k[4 + i] * h2k[4 + i]);
+        g[i] = c0[i] * mlp_act_deriv(h2k[i], actk);
+        g[4 + i] = c1[i] * mlp_act_deriv(h2k[4 + i], actk);
         s_hA[(4 * lg + i) * G::LDH + col12] = g[i];         // (h1's tile was last read before the previous barrier)
         s_hA[(16 + 4 * lg + i) * G::LDH + col12] = g[4 + i];
       }
@@ -287,8 +288,8 @@ struct AdjCtx {
       float g[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        g[i] = c0[i] * (1.0f - h1k[i] * h1k[i]);
-        g[4 + i] = c1[i] * (1.0f - h1k[4 + i] * h1k[4 + i]);
+        g[i] = c0[i] * mlp_act_deriv(h1k[i], actk);
+        g[4 + i] = c1[i] * mlp_act_deriv(h1k[4 + i], actk);
         s_hB[(4 * lg + i) * G::LDH + col12] = g[i];         // (h2's tile was last read before the previous barrier)
         s_hB[(16 + 4 * lg + i) * G::LDH + col12] = g[4 + i];
       }

@@ -40,11 +40,26 @@ __device__ __forceinline__ float mlp_tanh(float x) {
   return fabsf(x) < 0.25f ? small : big;
 }
 
+// The hidden activation: mi_ode_rhs.scalars[0] (wave-uniform).  0 = tanh (above); 1 = relu - the DEFAULT of the reference's
+// ODEFunc (dense_odenet.py:14, 46-47); 2 = softplus (dense_odenet.py:48-49).  mlp_act_deriv: d act / d z from the activation's
+// OUTPUT h (what the adjoint kernel keeps): tanh 1 - h^2, relu [h > 0], softplus sigmoid(z) = 1 - exp(-h).
+enum { MLP_ACT_TANH = 0, MLP_ACT_RELU = 1, MLP_ACT_SOFTPLUS = 2 };
+__device__ __forceinline__ float mlp_act(float x, int kind) {
+  if (kind == MLP_ACT_TANH) return mlp_tanh(x);
+  if (kind == MLP_ACT_RELU) return x > 0.f ? x : (x != x ? x : 0.f);            // NaN stays NaN
+  return x > 20.f ? x : log1pf(expf(x));                                       // log(1 + e^x); the overflow guard of every framework
+}
+__device__ __forceinline__ float mlp_act_deriv(float h, int kind) {
+  if (kind == MLP_ACT_TANH) return 1.0f - h * h;
+  if (kind == MLP_ACT_RELU) return h > 0.f ? 1.0f : 0.f;
+  return 1.0f - expf(-h);
+}
+
 // One evaluation of the MLP for the tile whose input rows sit in s_x.  Every thread of the workgroup must call it.
 // Owner threads (wave < NW3) receive their 4 output elements (rows rb*16 + 4*(lane>>4) + i, column 16*cb + (lane&15)).
 template <int DP, int HP>
 __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, const float* w1f, const float* w2f,
-                                         const float* w3f, float b1v, float b2v, float b3v, float* out4) {
+                                         const float* w3f, float b1v, float b2v, float b3v, float* out4, int act = MLP_ACT_TANH) {
   using G = MlpGeom<DP, HP>;
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -67,8 +82,8 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s_h1[(4 * lg + i) * G::LDH + col] = mlp_tanh(c0[i] + b1v);
-      s_h1[(16 + 4 * lg + i) * G::LDH + col] = mlp_tanh(c1[i] + b1v);
+      s_h1[(4 * lg + i) * G::LDH + col] = mlp_act(c0[i] + b1v, act);
+      s_h1[(16 + 4 * lg + i) * G::LDH + col] = mlp_act(c1[i] + b1v, act);
     }
   }
   __syncthreads();
@@ -88,8 +103,8 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s_h2[(4 * lg + i) * G::LDH + col] = mlp_tanh(c0[i] + b2v);
-      s_h2[(16 + 4 * lg + i) * G::LDH + col] = mlp_tanh(c1[i] + b2v);
+      s_h2[(4 * lg + i) * G::LDH + col] = mlp_act(c0[i] + b2v, act);
+      s_h2[(16 + 4 * lg + i) * G::LDH + col] = mlp_act(c1[i] + b2v, act);
     }
   }
   __syncthreads();
@@ -126,10 +141,11 @@ struct MlpCtx {
   float *s_x, *s_h1, *s_h2;
   float w1f[KS1], w2f[KS2], w3f[KS2];
   float b1v, b2v, b3v, sign;
-  int lane, wave, li, lg, d, hd, col, rbase;
+  int lane, wave, li, lg, d, hd, col, rbase, act;
   bool owner;
 
   __device__ __forceinline__ void init(const RhsParams& rhs, int dim, char* smem) {
+    act = __builtin_amdgcn_readfirstlane((int)rhs.s[0]);
     s_x = (float*)smem;
     s_h1 = s_x + G::R * G::LDX;
     s_h2 = s_h1 + G::R * G::LDH;
@@ -175,7 +191,7 @@ struct MlpCtx {
     }
   }
   __device__ __forceinline__ void eval(float* out4) {
-    mlp_eval<DP, HP>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v, b2v, b3v, out4);
+    mlp_eval<DP, HP>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v, b2v, b3v, out4, act);
   }
 };
 

@@ -9,7 +9,7 @@ Workload definitions follow the reference's examples:
   CubicLinear     f = (y**3) @ W               examples/ode_demo.py:33-35 (spiral)
   LotkaVolterra   examples/ode_usage.ipynb cells 39-42 / README.md:67-82, batched on the last axis
   Lorenz          examples/lorenz_attractor.py:20-37, batched on the last axis
-  MLPTanh         tfdiffeq/models/dense_odenet.py:41-92 (ODEFunc, time independent, tanh)
+  MLP / MLPTanh   tfdiffeq/models/dense_odenet.py:41-92 (ODEFunc, time independent; tanh, relu or softplus)
 """
 import torch
 
@@ -177,13 +177,17 @@ class Lorenz(DeviceRHS):
         return keep
 
 
-class MLPTanh(DeviceRHS):
-    """ODEFunc-shaped MLP dim -> hidden -> hidden -> dim with tanh, time independent
-    (tfdiffeq/models/dense_odenet.py:41-92).  Weights are [in, out] (Keras Dense layout)."""
+class MLP(DeviceRHS):
+    """ODEFunc-shaped MLP dim -> hidden -> hidden -> dim, time independent (tfdiffeq/models/dense_odenet.py:41-92).
+    Weights are [in, out] (Keras Dense layout).  activation: 'tanh', 'relu' (the reference's default) or 'softplus'."""
     kind = N.RHS_MLP_TANH
+    ACTIVATIONS = {'tanh': 0, 'relu': 1, 'softplus': 2}
 
-    def __init__(self, W1, b1, W2, b2, W3, b3):
-        super(MLPTanh, self).__init__()
+    def __init__(self, W1, b1, W2, b2, W3, b3, activation='tanh'):
+        super(MLP, self).__init__()
+        if activation not in self.ACTIVATIONS:
+            raise ValueError('the fused MLP kernels know %s, not %r' % (sorted(self.ACTIVATIONS), activation))
+        self.activation = activation
         self.Ws = [torch.as_tensor(w) for w in (W1, W2, W3)]
         self.bs = [None if b is None else torch.as_tensor(b) for b in (b1, b2, b3)]
         self.dim = int(self.Ws[0].shape[0])
@@ -191,13 +195,14 @@ class MLPTanh(DeviceRHS):
         assert self.Ws[1].shape == (self.hidden, self.hidden) and self.Ws[2].shape == (self.hidden, self.dim)
 
     def forward(self, t, y):
+        act = {'tanh': torch.tanh, 'relu': torch.relu, 'softplus': torch.nn.functional.softplus}[self.activation]
         h = y
         for i in range(3):
             h = torch.matmul(h, self._dev(self.Ws[i], y.dtype, y.device))
             if self.bs[i] is not None:
                 h = h + self._dev(self.bs[i], y.dtype, y.device)
             if i < 2:
-                h = torch.tanh(h)
+                h = act(h)
         return h
 
     fixed_grid_fused = False     # the fused MLP kernel is the whole-attempt (adaptive) kernel only
@@ -207,8 +212,9 @@ class MLPTanh(DeviceRHS):
                 and self.dim <= 64 and self.hidden <= 128)
 
     def fill(self, rhs, dtype, device):
-        keep = super(MLPTanh, self).fill(rhs, dtype, device)
+        keep = super(MLP, self).fill(rhs, dtype, device)
         rhs.hidden = self.hidden
+        rhs.scalars[0] = float(self.ACTIVATIONS[self.activation])
         for i in range(3):
             Wd = self._dev(self.Ws[i], dtype, device)
             rhs.w[i] = Wd.data_ptr()
@@ -218,6 +224,13 @@ class MLPTanh(DeviceRHS):
                 rhs.b[i] = bd.data_ptr()
                 keep.append(bd)
         return keep
+
+
+class MLPTanh(MLP):
+    """The tanh network (BASELINE config 5)."""
+
+    def __init__(self, W1, b1, W2, b2, W3, b3):
+        super(MLPTanh, self).__init__(W1, b1, W2, b2, W3, b3, activation='tanh')
 
 
 # ---------------------------------------------------------------------------------------------
