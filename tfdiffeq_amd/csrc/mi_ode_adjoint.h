@@ -101,13 +101,13 @@ typedef MI_GLOBAL adj_f4 g_f4;
 typedef MI_LDS float lds_float;
 typedef MI_LDS adj_f4 lds_f4;
 
-template <int DP, int HP>
+template <int DP, int HP, int ACT>
 struct AdjCtx {
   using G = AdjGeom<DP, HP>;
   lds_float *s_w1, *s_w3, *s_x, *s_a, *s_hA, *s_hB;
   float w2f[G::KS2], w2t[G::KS2];                           // W2[k][col] and W2[col][k] of this wave's 16 hidden columns
   float b1v, b2v, b3v, sign;
-  int lane, wave, li, lg, d, hd, col, col12, rbase, actk;
+  int lane, wave, li, lg, d, hd, col, col12, rbase;
   bool owner;
 
   // pointers, lane roles, biases (every pass); `smem`: LDS address of the dynamic segment
@@ -125,7 +125,6 @@ struct AdjCtx {
     const g_float* B2 = (const g_float*)rhs.b[1];
     const g_float* B3 = (const g_float*)rhs.b[2];
     sign = (float)rhs.sign;
-    actk = __builtin_amdgcn_readfirstlane((int)rhs.s[0]);    // hidden activation (mi_ode_mlp.h: tanh / relu / softplus)
     col12 = 16 * wave + li;
     b1v = (B1 != nullptr && wave < G::NW12 && col12 < hd) ? B1[col12] : 0.f;
     b2v = (B2 != nullptr && wave < G::NW12 && col12 < hd) ? B2[col12] : 0.f;
@@ -197,8 +196,8 @@ struct AdjCtx {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        h1k[i] = mlp_act(c0[i] + b1v, actk);
-        h1k[4 + i] = mlp_act(c1[i] + b1v, actk);
+        h1k[i] = mlp_act<ACT>(c0[i] + b1v);
+        h1k[4 + i] = mlp_act<ACT>(c1[i] + b1v);
         s_hA[(4 * lg + i) * G::LDH + col12] = h1k[i];
         s_hA[(16 + 4 * lg + i) * G::LDH + col12] = h1k[4 + i];
       }
@@ -222,8 +221,8 @@ struct AdjCtx {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        h2k[i] = mlp_act(c0[i] + b2v, actk);
-        h2k[4 + i] = mlp_act(c1[i] + b2v, actk);
+        h2k[i] = mlp_act<ACT>(c0[i] + b2v);
+        h2k[4 + i] = mlp_act<ACT>(c1[i] + b2v);
         s_hB[(4 * lg + i) * G::LDH + col12] = h2k[i];
         s_hB[(16 + 4 * lg + i) * G::LDH + col12] = h2k[4 + i];
       }
@@ -262,8 +261,8 @@ struct AdjCtx {
       float g[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        g[i] = c0[i] * mlp_act_deriv(h2k[i], actk);
-        g[4 + i] = c1[i] * mlp_act_deriv(h2k[4 + i], actk);
+        g[i] = c0[i] * mlp_act_deriv<ACT>(h2k[i]);
+        g[4 + i] = c1[i] * mlp_act_deriv<ACT>(h2k[4 + i]);
         s_hA[(4 * lg + i) * G::LDH + col12] = g[i];         // (h1's tile was last read before the previous barrier)
         s_hA[(16 + 4 * lg + i) * G::LDH + col12] = g[4 + i];
       }
@@ -288,8 +287,8 @@ struct AdjCtx {
       float g[8];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        g[i] = c0[i] * mlp_act_deriv(h1k[i], actk);
-        g[4 + i] = c1[i] * mlp_act_deriv(h1k[4 + i], actk);
+        g[i] = c0[i] * mlp_act_deriv<ACT>(h1k[i]);
+        g[4 + i] = c1[i] * mlp_act_deriv<ACT>(h1k[4 + i]);
         s_hB[(4 * lg + i) * G::LDH + col12] = g[i];         // (h2's tile was last read before the previous barrier)
         s_hB[(16 + 4 * lg + i) * G::LDH + col12] = g[4 + i];
       }
@@ -360,14 +359,14 @@ __device__ __forceinline__ float uniform_f(float v) { return __builtin_bit_cast(
 // ---- tile passes ---------------------------------------------------------------------------------------------------
 // Block records (thread 0 -> ash->blk[0] for y, blk[1] for a).  F0: {max |y0|, -, sum (y0/sc)^2, sum (f0/sc)^2, non-finite};
 // INITB: {-, -, sum ((f1-f0)/sc)^2}; STEP: {-, max |y1|, sum err^2}.
-template <int DP, int HP, int MODE, int S>
+template <int DP, int HP, int ACT, int MODE, int S>
 __device__ __attribute__((noinline)) void adj_tile_pass(const AdjArgs* A_, unsigned smem, unsigned ash_off) {
   using G = AdjGeom<DP, HP>;
   const MI_CONST AdjArgs& A = *(const MI_CONST AdjArgs*)uniform_p(A_);     // scalar loads
   lds_AdjShared* ash = (lds_AdjShared*)(size_t)__builtin_amdgcn_readfirstlane((int)ash_off);
   smem = (unsigned)__builtin_amdgcn_readfirstlane((int)smem);
   const MI_CONST StepArgs& SA = A.p.s;
-  AdjCtx<DP, HP> cx;
+  AdjCtx<DP, HP, ACT> cx;
   cx.bind(SA.rhs, SA.dim, smem);
   struct {
     const g_float *y0, *a0, *fy0, *fa0;
@@ -763,7 +762,7 @@ __device__ __forceinline__ Acc adj_record(double m0, double m1, double s0, doubl
   return a;
 }
 
-template <int DP, int HP, int S>
+template <int DP, int HP, int ACT, int S>
 __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(const AdjArgs* __restrict__ Ap) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ PersistShared sh;
@@ -775,7 +774,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
   Ctl& s_c = sh.c;
   const StepArgs& SA = A.p.s;
   {
-    AdjCtx<DP, HP> cx;
+    AdjCtx<DP, HP, ACT> cx;
     cx.bind(SA.rhs, SA.dim, smem);
     cx.stage_weights(SA.rhs);
   }
@@ -812,7 +811,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
       L.n = 1; L.slot[0] = 0; L.c[0][0] = msign; L.c[1][0] = 0.f;
     }
     __syncthreads();
-    adj_tile_pass<DP, HP, ADJ_F0, S>(Ap, smem, ash_off);
+    adj_tile_pass<DP, HP, ACT, ADJ_F0, S>(Ap, smem, ash_off);
     adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 0, 0);
     const Acc h1 = adj_record(ash.blk[0][0], ash.blk[1][0], ash.blk[0][2], ash.blk[0][3], (int)ash.blk[0][4]);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
@@ -848,7 +847,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
       __syncthreads();
       const long long tb0 = (long long)wall_clock64();
       for (int it = 0; it < A.bench_iters; ++it) {
-        if (A.mode == 2) adj_tile_pass<DP, HP, ADJ_STEP, S>(Ap, smem, ash_off);
+        if (A.mode == 2) adj_tile_pass<DP, HP, ACT, ADJ_STEP, S>(Ap, smem, ash_off);
         else adj_wgrad_pass<DP, HP, 2>(Ap, smem, ash_off, 0, 0);
       }
       if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -908,7 +907,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
       L.n = 1; L.slot[0] = 2; L.c[0][0] = msign; L.c[1][0] = 0.f;
     }
     __syncthreads();
-    adj_tile_pass<DP, HP, ADJ_INITB, S>(Ap, smem, ash_off);
+    adj_tile_pass<DP, HP, ACT, ADJ_INITB, S>(Ap, smem, ash_off);
     adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 0, 0);
     const Acc h1 = adj_record(0.0, 0.0, ash.blk[0][2], ash.blk[1][2], 0);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
@@ -982,7 +981,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     }
     __syncthreads();
     const long long tk0 = (long long)wall_clock64();
-    adj_tile_pass<DP, HP, ADJ_STEP, S>(Ap, smem, ash_off);
+    adj_tile_pass<DP, HP, ACT, ADJ_STEP, S>(Ap, smem, ash_off);
     const long long tk1 = (long long)wall_clock64();
     adj_wgrad_pass<DP, HP, 2>(Ap, smem, ash_off, 0, 0);
     const long long tk2 = (long long)wall_clock64();

@@ -15,7 +15,7 @@ struct mi_ode_adjoint {
   int P, Ppad, SL;
   int grid, block;
   size_t lds;
-  const void* fn;
+  const void* fn[3];           // the kernel for each hidden activation (mi_ode_rhs.scalars[0])
   long long ntiles;
   float *planes, *theta, *act, *wpart;
   double* partials;            // hand-off records (2 parities)
@@ -30,10 +30,21 @@ struct mi_ode_adjoint {
 
 namespace {
 template <int DP, int HP>
-const void* adj_fn(size_t* lds, int* block) {
+const void* adj_fn(int act, size_t* lds, int* block) {
   *lds = AdjGeom<DP, HP>::lds_bytes();
   *block = 64 * AdjGeom<DP, HP>::NW;
-  return (const void*)k_adjoint_mlp<DP, HP, 6>;
+  switch (act) {
+    case MLP_ACT_TANH: return (const void*)k_adjoint_mlp<DP, HP, MLP_ACT_TANH, 6>;
+    case MLP_ACT_RELU: return (const void*)k_adjoint_mlp<DP, HP, MLP_ACT_RELU, 6>;
+    case MLP_ACT_SOFTPLUS: return (const void*)k_adjoint_mlp<DP, HP, MLP_ACT_SOFTPLUS, 6>;
+    default: return nullptr;
+  }
+}
+const void* adj_fn_dims(int dp, int hp, int act, size_t* lds, int* block) {
+  if (dp == 16 && hp == 16) return adj_fn<16, 16>(act, lds, block);
+  if (dp == 16 && hp == 128) return adj_fn<16, 128>(act, lds, block);
+  if (dp == 64 && hp == 16) return adj_fn<64, 16>(act, lds, block);
+  return adj_fn<64, 128>(act, lds, block);
 }
 int pad16(int v, int lo, int hi) { return v <= lo ? lo : hi; }
 }  // namespace
@@ -73,10 +84,7 @@ extern "C" int mi_ode_adjoint_create(const mi_ode_adjoint_desc* desc, mi_ode_adj
   h->d = *desc;
   h->dp = pad16(desc->dim, 16, 64);
   h->hp = pad16(desc->hidden, 16, 128);
-  if (h->dp == 16 && h->hp == 16) h->fn = adj_fn<16, 16>(&h->lds, &h->block);
-  else if (h->dp == 16 && h->hp == 128) h->fn = adj_fn<16, 128>(&h->lds, &h->block);
-  else if (h->dp == 64 && h->hp == 16) h->fn = adj_fn<64, 16>(&h->lds, &h->block);
-  else h->fn = adj_fn<64, 128>(&h->lds, &h->block);
+  for (int act = 0; act < 3; ++act) h->fn[act] = adj_fn_dims(h->dp, h->hp, act, &h->lds, &h->block);
   const int d = desc->dim, hd = desc->hidden;
   h->P = d * hd + hd + hd * hd + hd + hd * d + d;
   h->Ppad = (h->P + 63) / 64 * 64;
@@ -84,8 +92,9 @@ extern "C" int mi_ode_adjoint_create(const mi_ode_adjoint_desc* desc, mi_ode_adj
   int dev = 0, cus = 0, per_cu = 0;
   MI_HIP(hipGetDevice(&dev));
   MI_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
-  if (hipFuncSetAttribute(h->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) (void)hipGetLastError();
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->fn, h->block, h->lds) != hipSuccess || per_cu < 1) {
+  for (int act = 0; act < 3; ++act)
+    if (hipFuncSetAttribute(h->fn[act], hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) (void)hipGetLastError();
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->fn[0], h->block, h->lds) != hipSuccess || per_cu < 1) {
     (void)hipGetLastError();
     mi_set_error("fused adjoint kernel does not fit a compute unit (LDS %zu bytes, %d threads)", h->lds, h->block);
     delete h; return MI_ODE_E_HIP;
@@ -180,7 +189,9 @@ static int adj_launch(mi_ode_adjoint* h, const mi_ode_rhs* rhs, int mode, const 
   MI_HIP(hipMemcpyAsync(h->args_dev, h->args_host, sizeof(AdjArgs), hipMemcpyHostToDevice, st));
   const AdjArgs* dev_args = h->args_dev;
   void* args[] = {(void*)&dev_args};
-  hipError_t e = hipLaunchKernel(h->fn, dim3((unsigned)h->grid), dim3((unsigned)h->block), args, h->lds, st);
+  const int act = (int)rhs->scalars[0];
+  if (act < 0 || act > 2) { mi_set_error("fused adjoint: unknown activation code %d", act); return MI_ODE_E_INVALID; }
+  hipError_t e = hipLaunchKernel(h->fn[act], dim3((unsigned)h->grid), dim3((unsigned)h->block), args, h->lds, st);
   if (e != hipSuccess) { mi_set_error("fused adjoint kernel launch failed: %s", hipGetErrorString(e)); (void)hipGetLastError(); return MI_ODE_E_HIP; }
   h->n_launches += 1;
   MI_HIP(hipStreamSynchronize(st));              // the kernel's last act was the zero-copy store of its result record

@@ -40,26 +40,41 @@ __device__ __forceinline__ float mlp_tanh(float x) {
   return fabsf(x) < 0.25f ? small : big;
 }
 
-// The hidden activation: mi_ode_rhs.scalars[0] (wave-uniform).  0 = tanh (above); 1 = relu - the DEFAULT of the reference's
+// The hidden activation: mi_ode_rhs.scalars[0], a TEMPLATE parameter of the kernels (a run-time switch made the compiler evaluate
+// every branch and select: config 5 went from 0.42 to 0.54 ms).  0 = tanh (above); 1 = relu - the DEFAULT of the reference's
 // ODEFunc (dense_odenet.py:14, 46-47); 2 = softplus (dense_odenet.py:48-49).  mlp_act_deriv: d act / d z from the activation's
 // OUTPUT h (what the adjoint kernel keeps): tanh 1 - h^2, relu [h > 0], softplus sigmoid(z) = 1 - exp(-h).
 enum { MLP_ACT_TANH = 0, MLP_ACT_RELU = 1, MLP_ACT_SOFTPLUS = 2 };
-__device__ __forceinline__ float mlp_act(float x, int kind) {
-  if (kind == MLP_ACT_TANH) return mlp_tanh(x);
-  if (kind == MLP_ACT_RELU) return x > 0.f ? x : (x != x ? x : 0.f);            // NaN stays NaN
-  return x > 20.f ? x : log1pf(expf(x));                                       // log(1 + e^x); the overflow guard of every framework
+// (the softplus arithmetic is built from the transcendental unit's exp2 / log2 like mlp_tanh - ocml's expf / log1pf inlined at
+// sixteen call sites cost the tanh path registers.  log1p(u) = log(w) u / (w - 1) with w = fl(1 + u): the classic correction
+// for the rounding of 1 + u.)
+__device__ __forceinline__ float mlp_softplus(float x) {
+  const float u = __builtin_amdgcn_exp2f(x * 1.4426950408889634f);              // e^x
+  const float w = 1.0f + u, dw = w - 1.0f;
+  const float l1p = dw == 0.f ? u : (__builtin_amdgcn_logf(w) * 0.6931471805599453f) * (u * __builtin_amdgcn_rcpf(dw));   // v_log_f32 is log2
+  return x > 20.f ? x : l1p;                                                    // x > 20: log(1 + e^x) = x in fp32 (every framework's guard)
 }
-__device__ __forceinline__ float mlp_act_deriv(float h, int kind) {
-  if (kind == MLP_ACT_TANH) return 1.0f - h * h;
-  if (kind == MLP_ACT_RELU) return h > 0.f ? 1.0f : 0.f;
-  return 1.0f - expf(-h);
+template <int ACT>
+__device__ __forceinline__ float mlp_act(float x) {
+  if constexpr (ACT == MLP_ACT_TANH) return mlp_tanh(x);
+  else if constexpr (ACT == MLP_ACT_RELU) return x > 0.f ? x : (x != x ? x : 0.f);            // NaN stays NaN
+  else return mlp_softplus(x);
+}
+template <int ACT>
+__device__ __forceinline__ float mlp_act_deriv(float h) {
+  if constexpr (ACT == MLP_ACT_TANH) return 1.0f - h * h;
+  else if constexpr (ACT == MLP_ACT_RELU) return h > 0.f ? 1.0f : 0.f;
+  else {
+    const float small = h * (1.0f - h * (0.5f - h * 0.16666667f));                // 1 - e^-h without the cancellation, h < 2^-6
+    return h < 0.015625f ? small : 1.0f - __builtin_amdgcn_exp2f(h * -1.4426950408889634f);
+  }
 }
 
 // One evaluation of the MLP for the tile whose input rows sit in s_x.  Every thread of the workgroup must call it.
 // Owner threads (wave < NW3) receive their 4 output elements (rows rb*16 + 4*(lane>>4) + i, column 16*cb + (lane&15)).
-template <int DP, int HP>
+template <int DP, int HP, int ACT>
 __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, const float* w1f, const float* w2f,
-                                         const float* w3f, float b1v, float b2v, float b3v, float* out4, int act = MLP_ACT_TANH) {
+                                         const float* w3f, float b1v, float b2v, float b3v, float* out4) {
   using G = MlpGeom<DP, HP>;
   typedef float f4 __attribute__((ext_vector_type(4)));
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -82,8 +97,8 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s_h1[(4 * lg + i) * G::LDH + col] = mlp_act(c0[i] + b1v, act);
-      s_h1[(16 + 4 * lg + i) * G::LDH + col] = mlp_act(c1[i] + b1v, act);
+      s_h1[(4 * lg + i) * G::LDH + col] = mlp_act<ACT>(c0[i] + b1v);
+      s_h1[(16 + 4 * lg + i) * G::LDH + col] = mlp_act<ACT>(c1[i] + b1v);
     }
   }
   __syncthreads();
@@ -103,8 +118,8 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s_h2[(4 * lg + i) * G::LDH + col] = mlp_act(c0[i] + b2v, act);
-      s_h2[(16 + 4 * lg + i) * G::LDH + col] = mlp_act(c1[i] + b2v, act);
+      s_h2[(4 * lg + i) * G::LDH + col] = mlp_act<ACT>(c0[i] + b2v);
+      s_h2[(16 + 4 * lg + i) * G::LDH + col] = mlp_act<ACT>(c1[i] + b2v);
     }
   }
   __syncthreads();
@@ -134,18 +149,17 @@ struct MlpArgs {
 };
 
 // Per-thread context of the MLP tile kernels: resident weight slices (zero padded), biases, LDS tiles, element map.
-template <int DP, int HP>
+template <int DP, int HP, int ACT>
 struct MlpCtx {
   using G = MlpGeom<DP, HP>;
   static constexpr int KS1 = DP / 4, KS2 = HP / 4;
   float *s_x, *s_h1, *s_h2;
   float w1f[KS1], w2f[KS2], w3f[KS2];
   float b1v, b2v, b3v, sign;
-  int lane, wave, li, lg, d, hd, col, rbase, act;
+  int lane, wave, li, lg, d, hd, col, rbase;
   bool owner;
 
   __device__ __forceinline__ void init(const RhsParams& rhs, int dim, char* smem) {
-    act = __builtin_amdgcn_readfirstlane((int)rhs.s[0]);
     s_x = (float*)smem;
     s_h1 = s_x + G::R * G::LDX;
     s_h2 = s_h1 + G::R * G::LDH;
@@ -191,15 +205,15 @@ struct MlpCtx {
     }
   }
   __device__ __forceinline__ void eval(float* out4) {
-    mlp_eval<DP, HP>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v, b2v, b3v, out4, act);
+    mlp_eval<DP, HP, ACT>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v, b2v, b3v, out4);
   }
 };
 
 // One pass over this workgroup's tiles: MODE F0 (f0 + the norms of misc._select_initial_step, seeds copy_a / copy_b),
 // INITB (second half of _select_initial_step), STEP (one adaptive attempt).  SC0 as in the linear kernels.
-template <int DP, int HP, int MODE, int S, bool TS, bool SC0>
+template <int DP, int HP, int ACT, int MODE, int S, bool TS, bool SC0>
 __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<float, S>& P, void* copy_a, void* copy_b,
-                                         MlpCtx<DP, HP>& cx, Acc& acc, const double* t_out) {
+                                         MlpCtx<DP, HP, ACT>& cx, Acc& acc, const double* t_out) {
   using G = MlpGeom<DP, HP>;
   const int d = cx.d, col = cx.col, rbase = cx.rbase;
   const bool owner = cx.owner;
@@ -294,7 +308,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
   }
 }
 
-template <int DP, int HP, int MODE, int S, bool TS>
+template <int DP, int HP, int ACT, int MODE, int S, bool TS>
 __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
   using G = MlpGeom<DP, HP>;
   const StepArgs& A = M.step;
@@ -308,11 +322,11 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
     if (MODE == MLP_INITB) P.hs = (float)A.ctl->h0;
   }
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  MlpCtx<DP, HP> cx;
+  MlpCtx<DP, HP, ACT> cx;
   cx.init(A.rhs, A.dim, smem_raw);
   double* red = (double*)(cx.s_h2 + G::R * G::LDH);
   Acc acc;
-  mlp_pass<DP, HP, MODE, S, TS, false>(A, P, M.copy_a, M.copy_b, cx, acc, A.t_out);
+  mlp_pass<DP, HP, ACT, MODE, S, TS, false>(A, P, M.copy_a, M.copy_b, cx, acc, A.t_out);
   if constexpr (MODE == MLP_STEP) finish_attempt(A, acc, red);
   else block_reduce_store(acc, red, A.partials + (long long)blockIdx.x * kRec);
 }
@@ -320,12 +334,12 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
 // The whole call in one launch (see mi_ode_persist.h): before_integrate, every attempt, controller and dense output on
 // the persistent tile grid; weights are loaded once per call.  Same planes / hand-off / redundant controller as
 // k_persist_linear_mfma.
-template <int DP, int HP, int S, bool TS>
+template <int DP, int HP, int ACT, int S, bool TS>
 __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(PersistArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ PersistShared sh;
   Ctl& s_c = sh.c;
-  MlpCtx<DP, HP> cx;
+  MlpCtx<DP, HP, ACT> cx;
   cx.init(A.s.rhs, A.s.dim, smem_raw);
   CtrlParams cp = A.s.cp;
   cp.t_out = persist_stage_tout(A, sh.tout);
@@ -346,7 +360,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
     StepPlanes<float, S> P;
     P.y0 = y_user; P.f0 = nullptr; P.y1 = nullptr; P.f1 = fa; P.hs = 0.f; P.t0 = 0.f; P.j_lo = P.j_hi = 0;
     Acc acc;
-    mlp_pass<DP, HP, MLP_F0, S, TS, true>(A.s, P, nullptr, A.out0, cx, acc, t_out);
+    mlp_pass<DP, HP, ACT, MLP_F0, S, TS, true>(A.s, P, nullptr, A.out0, cx, acc, t_out);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
     __syncthreads();
@@ -355,7 +369,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
     StepPlanes<float, S> P;
     P.y0 = y_user; P.f0 = fa; P.y1 = nullptr; P.f1 = nullptr; P.hs = (float)uniform_d(s_c.h0); P.t0 = 0.f; P.j_lo = P.j_hi = 0;
     Acc acc;
-    mlp_pass<DP, HP, MLP_INITB, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
+    mlp_pass<DP, HP, ACT, MLP_INITB, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
   }
@@ -389,7 +403,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
     P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
     P.j_lo = uniform_i(sh.pub.emit_lo); P.j_hi = uniform_i(sh.pub.emit_hi);
     Acc acc;
-    mlp_pass<DP, HP, MLP_STEP, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
+    mlp_pass<DP, HP, ACT, MLP_STEP, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
     if (threadIdx.x == 0) {
       AttemptState st = sh.st;
