@@ -20,6 +20,10 @@
 #include "mi_ode_stage_linear.h"
 #include "mi_ode_stage_rowlocal.h"
 
+#ifndef MI_ABL
+#define MI_ABL 0               // tuning aid (scripts/build_ablations.sh): 1 no MFMAs, 2 one-term stage combinations, 4 no barriers, 8 no plane loads / stores
+#endif
+
 namespace mi {
 
 struct StepArgs {
@@ -359,22 +363,26 @@ struct LinCtx {
   __device__ __forceinline__ void rhs_eval(const T (&ys)[4], T (&kn)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_ys[TR::acc_row(lane, i) * LD + col] = ys[i];
-    lds_barrier();
+    if (!(MI_ABL & 4)) lds_barrier();
     acc_t c0 = {0, 0, 0, 0};
     const T* ap = s_ys + li * LD + lg * KS;
+#if (MI_ABL & 1)
+    c0[0] = ap[0] * bf[0]; c0[1] = ap[1] * bf[1]; c0[2] = ap[2] * bf[2]; c0[3] = ap[3] * bf[3];
+#else
 #pragma unroll
     for (int m = 0; m < KS / VEC; ++m) {
       const CH a0 = *(const CH*)(ap + m * VEC);
 #pragma unroll
       for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], bf[m * VEC + v], c0);
     }
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       T k_ = c0[i];
       if (has_bias) k_ = k_ + bias_v;
       kn[i] = sign * k_;
     }
-    lds_barrier();
+    if (!(MI_ABL & 4)) lds_barrier();
   }
 };
 
@@ -397,7 +405,7 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = t_i * R_ + cx.row_of(i);
-      const bool ok = row < A.batch && cx.colok;
+      const bool ok = row < A.batch && cx.colok && !(MI_ABL & 8);
       y0n[i] = ok ? stream_load<SC0>(P.y0 + row * cx.d + cx.col) : (T)0;
       f0n[i] = ok ? stream_load<SC0>(P.f0 + row * cx.d + cx.col) : (T)0;
     }
@@ -422,7 +430,7 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
         T kk[SG];
 #pragma unroll
         for (int j = 0; j < SG; ++j) kk[j] = k[j][i];
-        ys[i] = step_combine<T, SG>(y0e[i], kk, hs, A);
+        ys[i] = (MI_ABL & 2) ? y0e[i] + hs * kk[SG - 1] : step_combine<T, SG>(y0e[i], kk, hs, A);
       }
       cx.rhs_eval(ys, k[SG]);
     };
@@ -437,8 +445,10 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
         T err, ymid;
         step_finish<T, S>(y0e[i], kk, hs, A, err, ymid, !TS && P.j_hi > P.j_lo);
         const long long idx = row * cx.d + cx.col;
-        P.y1[idx] = ys[i];
-        P.f1[idx] = k[S][i];
+        if (!(MI_ABL & 8) || err == (T)123.456) {
+          P.y1[idx] = ys[i];
+          P.f1[idx] = k[S][i];
+        }
         step_emit<T, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, t_out);
         acc.maxa = fmax(acc.maxa, (double)fabs(y0e[i]));
         acc.maxb = fmax(acc.maxb, (double)fabs(ys[i]));
