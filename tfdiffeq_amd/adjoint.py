@@ -159,9 +159,16 @@ def _fused_plan(func, n_tensors, cfg, like, f_params):
     if mlp is None or not mlp.supports(y1):
         return None
     batch = y1.numel() // y1.shape[-1]
+    if batch < 1:
+        return None
     f32 = lambda v: float(np.float32(v))                 # noqa: E731  (misc.py:137-144: python float -> float32 -> float64)
-    eng = _cached_adjoint_engine(batch, int(y1.shape[-1]), int(mlp.hidden), float(cfg['adjoint_rtol']), float(cfg['adjoint_atol']),
-                                 f32(0.9), f32(10.0), f32(0.2), int(max_num_steps), str(like.device))
+    try:
+        eng = _cached_adjoint_engine(batch, int(y1.shape[-1]), int(mlp.hidden), float(cfg['adjoint_rtol']), float(cfg['adjoint_atol']),
+                                     f32(0.9), f32(10.0), f32(0.2), int(max_num_steps), str(like.device))
+    except N.NativeError as e:                           # e.g. no memory for the activation scratch (15 KB per row): the generic path
+        import warnings                                  # needs none
+        warnings.warn('fused adjoint engine unavailable (%s): using the plane-kernel path' % e)
+        return None
     return eng, mlp, base
 
 
