@@ -43,10 +43,11 @@
 extern "C" {
 #endif
 
-#define MI_ODE_ABI_VERSION 6
+#define MI_ODE_ABI_VERSION 7
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
+#define MI_ODE_MAX_SEGMENTS 8        /* components of a tuple state packed into one buffer (mi_ode_desc.n_segments) */
 
 /* ---- status bits (also the bits of mi_ode_stats.status) --------------------------------- */
 #define MI_ODE_OK 0
@@ -152,7 +153,18 @@ typedef struct mi_ode_desc {
    * the one-launch-per-call schedule.  The allgather hook stays the fallback (mi_ode_xrank_enable). */
   void* xrank_host;
   int64_t xrank_bytes;
+  /* Tuple states (odeint.py:28-81: y0 may be a tuple of tensors; the RHS is applied to every component).  The components -
+   * each [rows_k, dim] - travel in ONE buffer with a segment table: component k starts at a multiple of MI_ODE_SEGMENT_ALIGN
+   * rows (the caller pads; padding rows are never read or written) and has seg_rows[k] rows; `batch` = the padded total.  The
+   * scalar decisions run per component exactly as in the reference: one error ratio each (misc.py:250-264), accepted if all
+   * are <= 1 (dopri5.py:108), python max() of them for the next step (misc.py:270) and over the per-component norms of the
+   * initial step (misc.py:227-245).  n_segments <= 1: a single tensor.  Row-local right-hand sides (catalogue and plugins),
+   * adaptive tableaus with the misc controller, one rank, whole-call schedule. */
+  int32_t n_segments;
+  int32_t reserved2;
+  int64_t seg_rows[MI_ODE_MAX_SEGMENTS];
 } mi_ode_desc;
+#define MI_ODE_SEGMENT_ALIGN 256
 
 typedef struct mi_ode_stats {
   int64_t n_attempts, n_accepted, n_rejected, nfe;

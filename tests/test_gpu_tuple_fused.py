@@ -1,0 +1,108 @@
+"""GPU tests of tuple states on the fused engine (mi_ode_desc.n_segments: components packed into one buffer with a segment
+table; per-component error ratios, all <= 1 to accept, python max() for the step size and over the initial-step norms -
+odeint.py:28-81, misc.py:183-287, dopri5.py:103-121).  Checkers: the oracle (numpy restatement, tuple-aware), the
+reference's own tuple fixture, and the plane-kernel engine running the same tuple."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ode_numpy as O
+from tests.golden_util import load
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+def _lorenz_np(t, y):
+    return np.stack([10. * (y[..., 1] - y[..., 0]), y[..., 0] * (28. - y[..., 2]) - y[..., 1], y[..., 0] * y[..., 1] - 8. / 3. * y[..., 2]], axis=-1)
+
+
+@pytest.mark.parametrize('dtype,method', [(np.float64, 'dopri5'), (np.float32, 'dopri5'), (np.float64, 'bosh3'), (np.float64, 'dopri8')])
+def test_tuple_of_lorenz_states_runs_as_one_launch(dtype, method):
+    """Three components of different shapes ([300, 3], [5, 7, 3], [1000, 3]); each has its own error ratio.  Same attempt
+    sequence as the oracle and the plane-kernel engine."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(7)
+    comps = [(np.array([1., 1., 1.]) + s * rng.standard_normal(shape)).astype(dtype)
+             for s, shape in ((1e-2, (300, 3)), (3.0, (5, 7, 3)), (1e-1, (1000, 3)))]
+    t = np.array([0., 0.15, 0.4])
+    f64 = dtype == np.float64
+    tol = dict(rtol=1e-7, atol=1e-9) if f64 else dict(rtol=1e-4, atol=1e-6)
+    f = rhs.PerComponent(rhs.Lorenz())
+    y0 = tuple(torch.tensor(c, device=dev()) for c in comps)
+    sol = odeint(f, y0, torch.tensor(t), method=method, **tol)
+    st = dict(odeint.last_stats)
+    assert st.get('components') == 3 and st['n_launches'] == 1 and st['status'] == 0, st
+    planes = odeint(f, y0, torch.tensor(t), method=method, options={'force_plane_kernels': True}, **tol)
+    ps = dict(odeint.last_stats)
+    assert ps.get('engine') == 'plane kernels'
+    ref, rst = O.odeint(lambda t_, ys: tuple(_lorenz_np(t_, y) for y in ys), tuple(comps), t, method=method, return_stats=True, **tol)
+    assert (st['n_attempts'], st['n_accepted']) == (rst.n_attempts, rst.n_accepted) == (ps['n_attempts'], ps['n_accepted'])
+    for got, pl, rf, c in zip(sol, planes, ref, comps):
+        assert tuple(got.shape) == (3,) + c.shape and got.dtype == (torch.float64 if f64 else torch.float32)
+        band = 1e-9 if f64 else 2e-4
+        scale = np.abs(rf).max()
+        assert np.abs(got.cpu().numpy() - rf).max() < band * scale
+        assert float((got - pl).abs().max()) < band * scale
+
+
+def test_a_component_with_a_large_error_decides():
+    """The accept test is per component: a stiff-ish component (far from the attractor) forces rejections / small steps that
+    the same system WITHOUT that component does not need - and a single concatenated tensor (one pooled tolerance) steps
+    differently from the tuple (the reference's F3 semantics: tol is one scalar per component)."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(8)
+    a = np.array([1., 1., 1.]) + 1e-3 * rng.standard_normal((400, 3))
+    b = np.array([30., -40., 90.]) + rng.standard_normal((50, 3))
+    t = torch.tensor([0., 0.3])
+    kw = dict(rtol=1e-6, atol=1e-9, method='dopri5')
+    f = rhs.PerComponent(rhs.Lorenz())
+    both = odeint(f, (torch.tensor(a, device=dev()), torch.tensor(b, device=dev())), t, **kw)
+    n_both = odeint.last_stats['n_attempts']
+    alone = odeint(rhs.Lorenz(), torch.tensor(a, device=dev()), t, **kw)
+    n_alone = odeint.last_stats['n_attempts']
+    assert n_both > n_alone
+    ref, rst = O.odeint(lambda t_, ys: tuple(_lorenz_np(t_, y) for y in ys), (a, b), np.array([0., 0.3]), rtol=1e-6, atol=1e-9,
+                        method='dopri5', return_stats=True)
+    assert n_both == rst.n_attempts
+    # (the two pow() implementations move dt by ulps; 20 steps of a chaotic system amplify that)
+    assert np.abs(both[0].cpu().numpy() - ref[0]).max() < 1e-4 and np.abs(both[1].cpu().numpy() - ref[1]).max() < 1e-4
+    assert float((both[0][1] - alone[1]).abs().max()) < 1e-3           # same trajectories, different step sequences (tolerance 1e-6, chaotic)
+
+
+def test_reference_tuple_fixture_through_the_fused_engine():
+    """tests/golden/run_constant_dopri5_tuple.npz: the reference's own tuple run (tests/problems.py `constant`, two scalar
+    components) - here as a one-dimensional CustomRowLocal system lifted with PerComponent: one launch, the reference's step
+    trace and values."""
+    from tfdiffeq_amd import odeint, rhs
+    d, meta = load('run_constant_dopri5_tuple')
+    p = meta['rhs_params']
+    const = rhs.CustomRowLocal(1, 'const T d_ = y[0] - (p[0] * t + p[1]); k[0] = p[0] + d_ * d_ * d_ * d_ * d_;', params=[p['a'], p['b']],
+                               torch_fn=lambda t_, y: p['a'] + (y - (p['a'] * t_ + p['b'])) ** 5)
+    y0 = tuple(torch.tensor(np.asarray(d['y0_%d' % i], dtype=np.float64).reshape(1, 1), device=dev()) for i in range(2))
+    sol = odeint(rhs.PerComponent(const), y0, torch.tensor(np.asarray(d['t'], dtype=np.float64)), method='dopri5')
+    st = dict(odeint.last_stats)
+    assert st.get('components') == 2 and st['n_launches'] == 1, st
+    trace = d['trace']
+    assert st['n_attempts'] == trace.shape[0] and st['n_accepted'] == int(trace[:, 2].sum())
+    assert abs(st['dt'] - trace[-1, 3]) <= 1e-9 * abs(trace[-1, 3])
+    for i in range(2):
+        np.testing.assert_allclose(sol[i].cpu().numpy().reshape(-1), d['y_%d' % i], rtol=1e-9, atol=1e-12)
+
+
+def test_what_the_segmented_engine_does_not_take_stays_generic():
+    from tfdiffeq_amd import odeint, rhs
+    y = tuple(torch.randn(10, 3, dtype=torch.float64, device=dev()) for _ in range(2))
+    f = rhs.PerComponent(rhs.Lorenz())
+    t = torch.tensor([0., 0.05])
+    odeint(f, y, t, method='tsit5')                                   # pooled ratio (tsit5.py:126-138): one mean over all components
+    assert odeint.last_stats.get('engine') == 'plane kernels'
+    odeint(f, y, t, method='dopri5', rtol=[1e-6, 1e-4], atol=[1e-9, 1e-7])     # per-component tolerances
+    assert odeint.last_stats.get('engine') == 'plane kernels'
+    odeint(f, y + tuple(torch.randn(4, 3, dtype=torch.float64, device=dev()) for _ in range(7)), t, method='dopri5')   # 9 components
+    assert odeint.last_stats.get('engine') == 'plane kernels'
+    with pytest.raises(TypeError):
+        rhs.PerComponent(lambda t_, y_: y_)

@@ -433,6 +433,25 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       delete h; return MI_ODE_E_INVALID;
     }
   }
+  h->nseg = desc->n_segments > 1 ? desc->n_segments : 0;
+  if (h->nseg > 1) {                               // tuple state (include/mi_ode.h): row-local kernels, whole-call schedule
+    const bool rowlocal_fam = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
+                              h->family == FAM_PLUGIN;
+    long long rows = 0;
+    bool ok = h->nseg <= MI_ODE_MAX_SEGMENTS && rowlocal_fam && desc->adaptive && desc->controller == MI_ODE_CTRL_MISC &&
+              h->d.world_size <= 1 && desc->allgather == nullptr && (desc->fusion == 0 || desc->fusion == 4);
+    for (int k = 0; ok && k < h->nseg; ++k) {
+      if (desc->seg_rows[k] < 1) ok = false;
+      h->seg_blk[k] = (int)(rows / MI_ODE_SEGMENT_ALIGN);
+      rows += (desc->seg_rows[k] + MI_ODE_SEGMENT_ALIGN - 1) / MI_ODE_SEGMENT_ALIGN * MI_ODE_SEGMENT_ALIGN;
+    }
+    if (ok) h->seg_blk[h->nseg] = (int)(rows / MI_ODE_SEGMENT_ALIGN);
+    if (!ok || rows != desc->batch) {
+      mi_set_error("tuple states: 2..%d components of >= 1 row each, every component padded to %d rows (batch = the padded total), a row-local RHS, an "
+                   "adaptive tableau with the misc controller, one rank, fusion 0 or 4", MI_ODE_MAX_SEGMENTS, MI_ODE_SEGMENT_ALIGN);
+      delete h; return MI_ODE_E_INVALID;
+    }
+  }
   rc = h->is_f32 ? mi_stage_geometry_f32(h) : mi_stage_geometry_f64(h);
   if (rc != 0) { delete h; return rc; }
   {   // whole-attempt fusion: row-local families and the MFMA linear family, adaptive FSAL tableaus
@@ -487,6 +506,10 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     const bool can = capable && (single || h->xrank_dev != nullptr);
     if (desc->fusion == 4 && !can && single) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local or MFMA-linear RHS, single rank, every workgroup co-resident)"); delete h; return MI_ODE_E_INVALID; }
     h->persist = (can && (desc->fusion == 4 || desc->fusion == 0)) ? 1 : 0;
+    if (h->nseg > 1 && !h->persist) {
+      mi_set_error("tuple states run on the whole-call kernel only, and its grid (%lld workgroups) is not co-resident on this device", g);
+      delete h; return MI_ODE_E_INVALID;
+    }
     h->persist_grid = (int)g;
     h->persist_sleep_first = g <= 32 ? 16 : 32;
     h->persist_sleep_poll = 2;
@@ -582,6 +605,7 @@ extern "C" int mi_ode_begin(mi_ode_handle h, const void* y0_dev, double t0, void
 static int begin_impl(mi_ode_handle h, const void* y0_dev, double t0, void* first_out_dev, void* stream) {
   if (h == nullptr || y0_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
   if (!h->d.adaptive) { mi_set_error("mi_ode_begin on a fixed-grid handle"); return MI_ODE_E_INVALID; }
+  if (h->nseg > 1) { mi_set_error("tuple states: mi_ode_integrate with at least two times only (whole-call kernel)"); return MI_ODE_E_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   MI_HIP(hipStreamSynchronize(st));            // the pinned staging record may still be in flight from a previous call
   Ctl* c = h->ctl_host;
@@ -741,6 +765,9 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   if (h->xrank_on) {
     A.xrank = h->xrank_dev; A.xpeers = h->xpeer_tab_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank;
   } else { A.world = 1; }
+  A.nseg = h->nseg;
+  for (int k = 0; k < h->nseg; ++k) { A.seg_blk[k] = h->seg_blk[k]; A.seg_rows[k] = h->d.seg_rows[k]; }
+  if (h->nseg > 1) A.seg_blk[h->nseg] = h->seg_blk[h->nseg];
   A.spin_limit = h->persist_spin_limit;
   A.spin_first = h->persist_spin_first < h->persist_spin_limit ? h->persist_spin_first : h->persist_spin_limit;
   // back-off before the first poll (units of 64 clocks): a failed poll round costs G x G record loads on the fabric, so
@@ -791,7 +818,8 @@ extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const doubl
   const bool multi = h->d.world_size > 1 || h->d.allgather != nullptr || h->nccl_comm != nullptr;
   if (h->persist && T > 1 && h->d.adaptive && (!multi || h->xrank_on)) {
     const int prc = integrate_persist(h, y0_dev, t_host, T, out_dev, stats, st);
-    if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4 || multi) return prc;   // (a rank must not change schedule alone)
+    if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4 || multi || h->nseg > 1) return prc;   // (a rank must not change schedule
+                                                                                                            // alone; tuple states have no other)
     h->persist = 0;        // the grid hand-off timed out (co-residency lost to another persistent kernel?): this
   }                        // handle goes back to one launch per attempt, starting with this call
   int rc = begin_impl(h, y0_dev, t_host[0], out_dev, stream);   // before_integrate runs even when T == 1 (solvers.py:31);

@@ -122,6 +122,88 @@ __device__ __forceinline__ void attempt_core(AttemptState& c, const double* rec,
   attempt_tail(c, ratio, ratio <= 1.0, P);                 // NaN -> rejected (dopri5.py:108)
 }
 
+// ---- tuple states: one record per component ("segment") -------------------------------------------------------------
+// The reference keeps a tuple of tensors as the state (odeint.py:28-81; adjoint.py:148 builds one).  Every scalar decision
+// then runs over the components: _select_initial_step takes python max() over the per-component norms (misc.py:227-245),
+// _compute_error_ratio returns one ratio per component (misc.py:250-264), the step is accepted if ALL are <= 1
+// (dopri5.py:108) and _optimal_step_size uses max() of them (misc.py:270).  python max(): first maximal element.
+constexpr int kMaxSeg = MI_ODE_MAX_SEGMENTS;
+struct SegState { double d1[kMaxSeg]; };                     // what the second half of the initial step keeps from the first
+
+__device__ __forceinline__ double py_max(const double* v, int n) {
+  double best = v[0];
+  for (int i = 1; i < n; ++i)
+    if (v[i] > best) best = v[i];
+  return best;
+}
+
+// rec[k]: the combined record of component k, rec[k][R_N] = its element count
+__device__ __forceinline__ void controller_apply_seg(Ctl* c, SegState* ss, const double (*rec)[kRec], int nseg, int phase, const CtrlParams& P) {
+  if (phase == PH_F0) {                                      // misc.py:227-233
+    c->nfe += 1;
+    double d0[kMaxSeg], d1[kMaxSeg], q[kMaxSeg];
+    bool nonfinite = false;
+    for (int k = 0; k < nseg; ++k) {
+      const double N = rec[k][R_N];
+      nonfinite = nonfinite || rec[k][R_FLAG] != 0.0;
+      if (P.is_f32) {
+        d0[k] = (double)(sqrtf((float)rec[k][R_SUMA]) / powf((float)N, 0.5f));
+        d1[k] = (double)(sqrtf((float)rec[k][R_SUMB]) / powf((float)N, 0.5f));
+        q[k] = (double)((float)d0[k] / (float)d1[k]);
+      } else {
+        d0[k] = sqrt(rec[k][R_SUMA]) / pow(N, 0.5);
+        d1[k] = sqrt(rec[k][R_SUMB]) / pow(N, 0.5);
+        q[k] = d0[k] / d1[k];
+      }
+      ss->d1[k] = d1[k];
+    }
+    c->y0_nonfinite = nonfinite;
+    const double m0 = py_max(d0, nseg), m1 = py_max(d1, nseg);
+    double h0;
+    if (P.is_f32) h0 = ((float)m0 < 1e-5f || (float)m1 < 1e-5f) ? (double)1e-6f : (double)(0.01f * (float)py_max(q, nseg));
+    else h0 = (m0 < 1e-5 || m1 < 1e-5) ? 1e-6 : 0.01 * py_max(q, nseg);
+    c->d0 = d0[0]; c->d1 = d1[0]; c->h0 = h0;
+    return;
+  }
+  if (phase == PH_INITB) {                                   // misc.py:236-245
+    c->nfe += 1;
+    double both[2 * kMaxSeg], d2[kMaxSeg];
+    for (int k = 0; k < nseg; ++k) {
+      const double N = rec[k][R_N];
+      if (P.is_f32) d2[k] = (double)((sqrtf((float)rec[k][R_SUMA]) / powf((float)N, 0.5f)) / (float)c->h0);
+      else d2[k] = (sqrt(rec[k][R_SUMA]) / pow(N, 0.5)) / c->h0;
+      both[k] = ss->d1[k]; both[nseg + k] = d2[k];
+    }
+    double first;
+    if (P.is_f32) {
+      const float h0 = (float)c->h0;
+      float h1;
+      if ((float)py_max(ss->d1, nseg) <= 1e-15f && (float)py_max(d2, nseg) <= 1e-15f) h1 = (float)nan_max((double)1e-6f, (double)(h0 * 1e-3f));
+      else h1 = powf(0.01f / (float)py_max(both, 2 * nseg), (float)(1.0 / (double)(P.init_order + 1)));
+      first = nan_min((double)(100.0f * h0), (double)h1);
+    } else {
+      const double h0 = c->h0;
+      double h1;
+      if (py_max(ss->d1, nseg) <= 1e-15 && py_max(d2, nseg) <= 1e-15) h1 = nan_max(1e-6, h0 * 1e-3);
+      else h1 = pow(0.01 / py_max(both, 2 * nseg), 1.0 / (double)(P.init_order + 1));
+      first = nan_min(100.0 * h0, h1);
+    }
+    c->dt = first;
+    return;
+  }
+}
+
+// dopri5.py:103-121 over the components
+__device__ __forceinline__ void attempt_core_seg(AttemptState& c, const double (*rec)[kRec], int nseg, const CtrlParams& P) {
+  double ratios[kMaxSeg];
+  bool accept = true;
+  for (int k = 0; k < nseg; ++k) {
+    ratios[k] = error_ratio(rec[k], P);
+    accept = accept && (ratios[k] <= 1.0);
+  }
+  attempt_tail(c, py_max(ratios, nseg), accept, P);
+}
+
 // One thread: apply the phase logic to the combined record `rec` with exactly the reference's scalar arithmetic.
 __device__ __forceinline__ void controller_apply(Ctl* c, const double* rec, int phase, const CtrlParams& P) {
   const double N = rec[R_N];

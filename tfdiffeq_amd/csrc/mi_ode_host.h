@@ -82,6 +82,8 @@ struct mi_ode_solver {
   unsigned seq;               // hand-off sequence numbers already used on this handle (identical on every rank)
   int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)
   int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation
+  int nseg;                   // tuple state: components packed into the one buffer (mi_ode_desc.n_segments), 0 / 1: a single tensor
+  int seg_blk[MI_ODE_MAX_SEGMENTS + 1];   // first workgroup of every component in the whole-call kernel's grid
   int lin_dp;                 // FAM_LINEAR_MFMA: tile width the kernels are instantiated for (16 / 32 / 64 / 128 >= dim, zero padded)
   // bookkeeping
   long long n_launches;

@@ -53,6 +53,10 @@ struct PersistArgs {
   int spin_limit;              // bound on the spin iterations of one hand-off
   int spin_first;              // ... of the FIRST grid hand-off of a launch: the residency check (see grid_reduce_rank)
   int sleep_first, sleep_poll; // back-off (units of 64 clocks): before the first poll / between polls
+  // tuple states (mi_ode_desc.n_segments > 1): component k owns workgroups seg_blk[k] .. seg_blk[k + 1] - 1 and seg_rows[k] rows
+  int nseg;
+  int seg_blk[kMaxSeg + 1];
+  long long seg_rows[kMaxSeg];
 };
 
 // thread 0: the scalar state mi_ode_begin would have uploaded
@@ -180,6 +184,8 @@ struct PersistShared {
   double vals[5][kPersistMaxGrid];                            // every workgroup's record, staged for the fixed-order fold
   double tout[kPersistTout];                                  // the requested output times, when they fit
   double xr[6][kXMaxWorld + 1];                               // cross-rank hand-off: every rank's record (+ one staging column)
+  double seg_rec[kMaxSeg][kRec];                              // tuple states: the combined record of every component
+  SegState seg;
   int ok;                                                     // 1 until a hand-off times out
 };
 
@@ -324,6 +330,24 @@ __device__ __forceinline__ bool grid_reduce_rank(const PersistArgs& A, const Acc
   }
   __syncthreads();
   const bool ok = sh.ok != 0;
+  if (A.nseg > 1) {                                           // one fold per component: sh.seg_rec (grid_reduce_seg)
+    if (threadIdx.x < 64 && ok) {
+      for (int k = 0; k < A.nseg; ++k) {
+        const int b0 = A.seg_blk[k], b1 = A.seg_blk[k + 1];
+        double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
+        for (int b = b0 + (int)threadIdx.x; b < b1; b += 64) {
+          v0 = fmax(v0, sh.vals[R_MAXA][b]); v1 = fmax(v1, sh.vals[R_MAXB][b]);
+          v2 += sh.vals[R_SUMA][b]; v3 += sh.vals[R_SUMB][b]; v4 = fmax(v4, sh.vals[R_FLAG][b]);
+        }
+        v0 = wave_max(v0); v1 = wave_max(v1); v2 = wave_sum(v2); v3 = wave_sum(v3); v4 = wave_max(v4);
+        if (threadIdx.x == 0) {
+          double* o = sh.seg_rec[k];
+          o[R_MAXA] = v0; o[R_MAXB] = v1; o[R_SUMA] = v2; o[R_SUMB] = v3; o[R_FLAG] = v4; o[6] = 0; o[7] = 0;
+        }
+      }
+    }
+    return ok;
+  }
   if (threadIdx.x < 64 && ok) {
     double v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0;
     for (int b = threadIdx.x; b < G; b += 64) {
@@ -365,7 +389,17 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
   cp.t_out = persist_stage_tout(A, sh.tout);                  // the output cursor and the dense output read t from LDS
   const double* t_out = cp.t_out;
   const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = row < A.s.batch;
+  const int nseg = A.nseg;                                    // > 1: tuple state, one component per range of workgroups
+  bool live = row < A.s.batch;
+  if (nseg > 1) {
+    int sg = 0;
+    for (int k = 1; k < nseg; ++k)
+      if ((int)blockIdx.x >= A.seg_blk[k]) sg = k;
+    live = (long long)((int)blockIdx.x - A.seg_blk[sg]) * blockDim.x + threadIdx.x < A.seg_rows[sg];
+  }
+  auto seg_counts = [&]() {                                   // thread 0: element counts into the components' records
+    for (int k = 0; k < nseg; ++k) sh.seg_rec[k][R_N] = (double)(A.seg_rows[k] * (long long)D);
+  };
   unsigned gen = 0;
   double r[5], rec[kRec], n_tot = 0.0;
 
@@ -407,7 +441,10 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
       }
     }
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
+    if (threadIdx.x == 0 && ok) {
+      if (nseg > 1) { seg_counts(); controller_apply_seg(&s_c, &sh.seg, sh.seg_rec, nseg, PH_F0, cp); }
+      else { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
+    }
     __syncthreads();
   }
   if (cp.auto_first_step && ok) {                             // k_stage_rowlocal<M_INITB> (misc.py:235-245)
@@ -427,7 +464,10 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
       }
     }
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
+    if (threadIdx.x == 0 && ok) {
+      if (nseg > 1) { seg_counts(); controller_apply_seg(&s_c, &sh.seg, sh.seg_rec, nseg, PH_INITB, cp); }
+      else { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
+    }
   }
   // thread 0 keeps the scalar state of the loop in registers from here on and publishes what the others need
   AttemptState st;
@@ -484,6 +524,7 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
     MI_TICK(tk2);
     if (threadIdx.x == 0) {
       if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
+      else if (nseg > 1) { seg_counts(); attempt_core_seg(st, sh.seg_rec, nseg, cp); }
       else { fill_record(rec, r, n_tot); attempt_core(st, rec, cp); }
       sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.emit_t0 = st.emit_t0; sh.pub.emit_t1 = st.emit_t1;
       sh.pub.emit_dt = st.emit_dt; sh.pub.accepted = st.accepted; sh.pub.emit_lo = st.emit_lo;

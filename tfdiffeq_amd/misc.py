@@ -330,6 +330,7 @@ class _ReverseFunc(object):
         self.base = base
         rhs = getattr(base, 'device_rhs', None)
         self.device_rhs = rhs.reversed() if rhs is not None else None
+        self.per_component = getattr(base, 'per_component', False)
 
     def __call__(self, t, y):
         return tuple(-f_ for f_ in self.base(-t, y))

@@ -233,6 +233,25 @@ class MLPTanh(MLP):
         super(MLPTanh, self).__init__(W1, b1, W2, b2, W3, b3, activation='tanh')
 
 
+class PerComponent(object):
+    """Lift of a row-local DeviceRHS to TUPLE states: func(t, (y_1, .., y_K)) = (f(t, y_1), .., f(t, y_K)) - what the reference's
+    own tuple tests do (tests/problems.py `construct_problem(tuple_state=True)`), K <= 8 components of shape [..., dim] each.
+    With a row-local `base` (catalogue or CustomRowLocal) and an adaptive non-pooled method the components travel in one
+    buffer with a segment table and the whole integration is one kernel launch: one error ratio per component, all must be
+    <= 1, python max() drives the step size (misc.py:250-287) - exactly the reference's tuple semantics.  Otherwise (and on the
+    plane-kernel path) it is an ordinary callable."""
+
+    def __init__(self, base):
+        if not getattr(base, 'kind', 0):
+            raise TypeError('PerComponent wraps a DeviceRHS')
+        self.base = base
+        self.device_rhs = base
+        self.per_component = True
+
+    def __call__(self, t, ys):
+        return tuple(self.base(t, y) for y in ys)
+
+
 # ---------------------------------------------------------------------------------------------
 # user-defined device right-hand sides
 # ---------------------------------------------------------------------------------------------

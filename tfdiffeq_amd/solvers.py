@@ -97,7 +97,7 @@ class _FusedEngine(object):
     def __init__(self, device_rhs, y0, adaptive, tableau, c_mid=None, rtol=1e-7, atol=1e-9, controller=N.CTRL_MISC,
                  interp=N.INTERP_QUARTIC_MID, order=5, init_order=4, safety=0.9, ifactor=10.0, dfactor=0.2,
                  first_step=None, max_num_steps=2 ** 31 - 1, process_group=None, linear_variant=0, chunk_attempts=0,
-                 profile=False, fusion=0):
+                 profile=False, fusion=0, seg_rows=None):
         N.require_gpu_tensor(y0, 'y0')
         self.lib = N.load()
         self.y0 = y0.contiguous()
@@ -121,6 +121,10 @@ class _FusedEngine(object):
         d.chunk_attempts = int(chunk_attempts)
         d.profile = 1 if profile else 0
         d.fusion = {'auto': 0, 'stage': 1, 'step': 2, 'step_split': 3, 'whole': 4}.get(fusion, fusion)
+        if seg_rows is not None:               # tuple state: y0 is the packed buffer (_pack_components), one segment per component
+            d.n_segments = len(seg_rows)
+            for k, r in enumerate(seg_rows):
+                d.seg_rows[k] = int(r)
         self._hook = None
         if process_group is not None:
             import torch.distributed as dist
@@ -350,6 +354,35 @@ def _tableau_key(tb, c_mid):
             None if c_mid is None else tuple(c_mid))
 
 
+def _fusable_tuple(func, y0):
+    """The row-local DeviceRHS behind a `rhs.PerComponent` lift if this tuple state can travel as one segmented buffer."""
+    rhs = getattr(func, 'device_rhs', None)
+    if rhs is None or not getattr(func, 'per_component', False) or not getattr(rhs, 'row_local', False):
+        return None
+    if not 2 <= len(y0) <= N.MAX_SEGMENTS:
+        return None
+    y = y0[0]
+    for c in y0:
+        if not (isinstance(c, torch.Tensor) and c.is_cuda and c.dim() >= 1 and c.numel() > 0 and c.dtype == y.dtype and
+                c.device == y.device and rhs.supports(c)):
+            return None
+    return rhs
+
+
+def _pack_components(y0, dim):
+    """(packed [rows, dim] buffer, rows per component, row offset per component): every component starts on a multiple of
+    _native.SEGMENT_ALIGN rows (include/mi_ode.h: mi_ode_desc.n_segments); padding rows are never touched by the kernels."""
+    rows = [int(c.numel() // dim) for c in y0]
+    offs, total = [], 0
+    for r in rows:
+        offs.append(total)
+        total += (r + N.SEGMENT_ALIGN - 1) // N.SEGMENT_ALIGN * N.SEGMENT_ALIGN
+    packed = torch.zeros((total, dim), dtype=y0[0].dtype, device=y0[0].device)
+    for c, r, o in zip(y0, rows, offs):
+        packed[o:o + r].copy_(c.reshape(r, dim))
+    return packed, rows, offs
+
+
 def _fusable(func, y0):
     """The DeviceRHS behind `func` if the fused engine can run this problem, else None."""
     rhs = getattr(func, 'device_rhs', None)
@@ -556,6 +589,11 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
     # -- fused engine ----------------------------------------------------------------------------
     def _make_engine(self):
         rhs = None if self._force_planes else _fusable(self.func, self.y0)
+        self._packed = None
+        if rhs is None and not self._force_planes and not self.pooled_ratio and self._pg is None and self._fusion in (0, 'auto', 4, 'whole'):
+            rhs = _fusable_tuple(self.func, self.y0)            # tuple state of a row-local RHS: one segmented buffer
+            if rhs is not None:
+                self._packed = _pack_components(self.y0, rhs.dim)
         if rhs is None:
             return None
         from .rk_common import _is_fsal_shaped
@@ -572,15 +610,25 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         if self.first_step is not None:
             from .misc import _convert_to_tensor
             first = float(_convert_to_tensor(self.first_step, dtype=np.float64))   # dopri5.py:77: float32 detour
-        y = self.y0[0]
+        y = self.y0[0] if self._packed is None else self._packed[0]
+        seg_rows = None if self._packed is None else tuple(self._packed[1])
+        if seg_rows is not None and any(float(r_) != float(rtol0) or float(a_) != float(atol0) for r_, a_ in zip(self.rtol, self.atol)):
+            self._packed = None                                  # per-component tolerances: the generic path
+            return None
         args = (float(rtol0), float(atol0), self.controller, self.interp, self.order, self.init_order, float(self.safety),
                 float(self.ifactor), float(self.dfactor), first, self.max_num_steps)
         key = ('adaptive', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
                _tableau_key(self.tableau, self.c_mid), args, id(self._pg) if self._pg is not None else None,
-               self._linear_variant, self._chunk_attempts, bool(self._profile), self._fusion)
-        return _cached_engine(key, lambda: _FusedEngine(
-            rhs, y, True, self.tableau, self.c_mid, *args, process_group=self._pg, linear_variant=self._linear_variant,
-            chunk_attempts=self._chunk_attempts, profile=self._profile, fusion=self._fusion))
+               self._linear_variant, self._chunk_attempts, bool(self._profile), self._fusion, seg_rows)
+        try:
+            return _cached_engine(key, lambda: _FusedEngine(
+                rhs, y, True, self.tableau, self.c_mid, *args, process_group=self._pg, linear_variant=self._linear_variant,
+                chunk_attempts=self._chunk_attempts, profile=self._profile, fusion=self._fusion, seg_rows=seg_rows))
+        except N.NativeError:
+            if seg_rows is None:
+                raise
+            self._packed = None                                  # e.g. more workgroups than are co-resident: the generic path
+            return None
 
     def integrate(self, t):
         _assert_increasing(t)
@@ -592,12 +640,16 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             return out
         prof0 = eng.profile() if self._profile else None
         try:
-            out = eng.integrate(t.to(torch.float64).numpy(), self.y0[0])
+            out = eng.integrate(t.to(torch.float64).numpy(), self.y0[0] if self._packed is None else self._packed[0])
         finally:
             self.stats = eng.stats.as_dict()
             self.stats['cross_rank'] = eng.transport
             if self._profile:
                 self.stats['profile'] = [a - b for a, b in zip(eng.profile(), prof0)]
+        if self._packed is not None:                             # [T, padded rows, dim] -> one [T, *shape] tensor per component
+            _, rows, offs = self._packed
+            self.stats['components'] = len(rows)
+            return tuple(out[:, o:o + r].reshape((out.shape[0],) + tuple(c.shape)) for c, r, o in zip(self.y0, rows, offs))
         return (out,)
 
     # -- plane-kernel path (any callable, tuple states) -------------------------------------------
