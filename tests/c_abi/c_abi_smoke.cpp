@@ -133,6 +133,42 @@ int main() {
   }
   printf("lincomb: max diff %.3e\n", md3);
   if (md3 != 0.0) { printf("FAIL lincomb not bit-exact\n"); return 1; }
+  // ---- 3b. tuple state: two components (the same 1000 rows twice, the second scaled by 1e-3 in its perturbation) -------
+  {
+    const int AL = MI_ODE_SEGMENT_ALIGN;
+    const long long pad = ((long long)B + AL - 1) / AL * AL;           // rows per padded component
+    std::vector<double> packed((size_t)2 * pad * D, 0.0);
+    memcpy(packed.data(), y0.data(), n * sizeof(double));
+    memcpy(packed.data() + pad * D, y0.data(), n * sizeof(double));
+    double *d_p, *d_po, *d_single;
+    CK(hipMalloc(&d_p, packed.size() * sizeof(double)));
+    CK(hipMalloc(&d_po, 2 * packed.size() * sizeof(double)));
+    CK(hipMalloc(&d_single, 2 * n * sizeof(double)));
+    CK(hipMemcpy(d_p, packed.data(), packed.size() * sizeof(double), hipMemcpyHostToDevice));
+    const double t3[2] = {0.0, 0.5};
+    mi_ode_desc dt_ = d;                                                // the dopri5 descriptor of section 2
+    dt_.batch = 2 * pad; dt_.n_segments = 2; dt_.seg_rows[0] = B; dt_.seg_rows[1] = B;
+    mi_ode_handle ht = nullptr, hs = nullptr;
+    MI(mi_ode_create(&dt_, &ht));
+    bits = mi_ode_integrate(ht, d_p, t3, 2, d_po, &st, nullptr);
+    if (bits != 0) { printf("FAIL tuple state status %d %s\n", bits, mi_ode_last_error()); return 1; }
+    const long long tuple_attempts = st.n_attempts, tuple_launches = st.n_launches;
+    MI(mi_ode_create(&d, &hs));                                          // the single tensor of the same rows
+    bits = mi_ode_integrate(hs, d_y0, t3, 2, d_single, &st, nullptr);
+    if (bits != 0) { printf("FAIL single state status %d\n", bits); return 1; }
+    std::vector<double> a(n), b2(n), c(n);
+    CK(hipMemcpy(a.data(), d_po + packed.size(), n * sizeof(double), hipMemcpyDeviceToHost));                 // t = 0.5, component 0
+    CK(hipMemcpy(b2.data(), d_po + packed.size() + pad * D, n * sizeof(double), hipMemcpyDeviceToHost));      // component 1
+    CK(hipMemcpy(c.data(), d_single + n, n * sizeof(double), hipMemcpyDeviceToHost));
+    double md = 0;
+    for (long long i = 0; i < n; ++i) md = fmax(md, fmax(fabs(a[i] - c[i]), fabs(b2[i] - c[i])));
+    printf("tuple state (2 components, segment table): attempts %lld (single tensor: %lld), launches %lld, max |component - single| = %.3e\n",
+           tuple_attempts, (long long)st.n_attempts, tuple_launches, md);
+    // two identical components have identical error ratios: the max() over them is the single tensor's ratio - same steps, same bits
+    if (md != 0.0 || tuple_attempts != st.n_attempts || tuple_launches != 1) { printf("FAIL tuple state\n"); return 1; }
+    MI(mi_ode_destroy(ht)); MI(mi_ode_destroy(hs));
+  }
+
   // ---- 4. fused backward interval of odeint_adjoint (tanh MLP 3 -> 8 -> 8 -> 3, fp32) -----------------------------
   {
     const int AB = 50, AD = 3, AH = 8;

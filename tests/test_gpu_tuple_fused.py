@@ -106,3 +106,19 @@ def test_what_the_segmented_engine_does_not_take_stays_generic():
     assert odeint.last_stats.get('engine') == 'plane kernels'
     with pytest.raises(TypeError):
         rhs.PerComponent(lambda t_, y_: y_)
+
+
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_fixed_grid_tuple_state_on_the_one_launch_kernel(method):
+    """No norms on a fixed grid: the components share one buffer; bit-exact against the oracle (elementwise arithmetic)."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(9)
+    comps = [np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal(shape) for shape in ((40, 3), (3, 5, 3))]
+    t = np.linspace(0., 0.2, 21)
+    sol = odeint(rhs.PerComponent(rhs.Lorenz()), tuple(torch.tensor(c, device=dev()) for c in comps), torch.tensor(t), method=method)
+    st = dict(odeint.last_stats)
+    assert st.get('components') == 2 and st['n_launches'] == 1, st
+    ref = O.odeint(lambda t_, ys: tuple(_lorenz_np(t_, y) for y in ys), tuple(comps), t, method=method)
+    for got, rf, c in zip(sol, ref, comps):
+        assert tuple(got.shape) == (21,) + c.shape
+        assert np.abs(got.cpu().numpy() - rf).max() < 1e-12

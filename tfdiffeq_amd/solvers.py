@@ -479,6 +479,22 @@ class FixedGridODESolver(object):
         rhs = _fusable(self.func, self.y0)
         default_grid = getattr(self, '_default_grid', False)
         time_grid = None
+        if rhs is None and default_grid and self.eps == 0.0 and self._fused_tableau is not None:
+            # a tuple state of a row-local RHS (rhs.PerComponent): a fixed grid has no norms, so the components simply share one
+            # buffer (rows are independent trajectories) and the one-launch kernel
+            trhs = _fusable_tuple(self.func, self.y0)
+            if trhs is not None and trhs.fixed_grid_fused:
+                dim = trhs.dim
+                rows = [int(c.numel() // dim) for c in self.y0]
+                y = torch.cat([c.reshape(-1, dim) for c in self.y0], dim=0).contiguous()
+                key = ('fixed', trhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
+                       _tableau_key(self._fused_tableau, None), self._fusion)
+                eng = _cached_engine(key, lambda: _FusedEngine(trhs, y, False, self._fused_tableau, fusion=self._fusion))
+                out = eng.integrate(t.to(torch.float64).numpy(), y)
+                self.stats = eng.stats.as_dict()
+                self.stats['components'] = len(rows)
+                offs = np.concatenate([[0], np.cumsum(rows)])
+                return tuple(out[:, int(o):int(o) + r].reshape((out.shape[0],) + tuple(c.shape)) for c, r, o in zip(self.y0, rows, offs[:-1]))
         if rhs is not None and rhs.fixed_grid_fused and self._fused_tableau is not None:
             y = self.y0[0]
             key = ('fixed', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
