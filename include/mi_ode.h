@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI_ODE_ABI_VERSION 7
+#define MI_ODE_ABI_VERSION 8
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -158,11 +158,13 @@ typedef struct mi_ode_desc {
    * rows (the caller pads; padding rows are never read or written) and has seg_rows[k] rows; `batch` = the padded total.  The
    * scalar decisions run per component exactly as in the reference: one error ratio each (misc.py:250-264), accepted if all
    * are <= 1 (dopri5.py:108), python max() of them for the next step (misc.py:270) and over the per-component norms of the
-   * initial step (misc.py:227-245).  n_segments <= 1: a single tensor.  Row-local right-hand sides (catalogue and plugins),
-   * adaptive tableaus with the misc controller, one rank, whole-call schedule. */
+   * initial step (misc.py:227-245); with the tsit5 controller ONE ratio pooled over all components (tsit5.py:126-138).
+   * n_segments <= 1: a single tensor.  Row-local right-hand sides (catalogue and plugins), adaptive tableaus, one rank,
+   * whole-call schedule. */
   int32_t n_segments;
-  int32_t reserved2;
+  int32_t seg_tolerances;     /* 1: seg_rtol / seg_atol hold one pair per component (dopri5.py:60-61 accepts lists); 0: rtol / atol for all */
   int64_t seg_rows[MI_ODE_MAX_SEGMENTS];
+  double seg_rtol[MI_ODE_MAX_SEGMENTS], seg_atol[MI_ODE_MAX_SEGMENTS];   /* (the initial step uses rtol / atol = the first pair, dopri5.py:74) */
 } mi_ode_desc;
 #define MI_ODE_SEGMENT_ALIGN 256
 

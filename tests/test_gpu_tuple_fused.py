@@ -93,16 +93,46 @@ def test_reference_tuple_fixture_through_the_fused_engine():
         np.testing.assert_allclose(sol[i].cpu().numpy().reshape(-1), d['y_%d' % i], rtol=1e-9, atol=1e-12)
 
 
+def test_per_component_tolerances_and_the_pooled_tsit5_ratio():
+    """dopri5.py:60-61 accepts one (rtol, atol) pair per component; tsit5 pools all components into ONE mean with scalar
+    tolerances (tsit5.py:126-138).  Both on the segmented engine, against the oracle and the plane-kernel engine."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(11)
+    comps = [np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((200, 3)), np.array([5., -3., 20.]) + rng.standard_normal((40, 3))]
+    y0 = tuple(torch.tensor(c, device=dev()) for c in comps)
+    f = rhs.PerComponent(rhs.Lorenz())
+    t = np.array([0., 0.2])
+    fn = lambda t_, ys: tuple(_lorenz_np(t_, y) for y in ys)          # noqa: E731
+    kw = dict(method='dopri5', rtol=[1e-7, 1e-4], atol=[1e-9, 1e-6])
+    sol = odeint(f, y0, torch.tensor(t), **kw)
+    st = dict(odeint.last_stats)
+    assert st.get('components') == 2 and st['n_launches'] == 1
+    ref, rst = O.odeint(fn, tuple(comps), t, return_stats=True, **kw)
+    assert (st['n_attempts'], st['n_accepted']) == (rst.n_attempts, rst.n_accepted)
+    uniform = odeint(f, y0, torch.tensor(t), method='dopri5', rtol=1e-4, atol=1e-6)
+    assert odeint.last_stats['n_attempts'] < st['n_attempts']          # the tight component costs steps
+    for got, rf in zip(sol, ref):
+        assert np.abs(got.cpu().numpy() - rf).max() < 1e-5
+    del uniform
+    sol = odeint(f, y0, torch.tensor(t), method='tsit5', rtol=1e-6, atol=1e-9)
+    st = dict(odeint.last_stats)
+    assert st.get('components') == 2 and st['n_launches'] == 1
+    planes = odeint(f, y0, torch.tensor(t), method='tsit5', rtol=1e-6, atol=1e-9, options={'force_plane_kernels': True})
+    ps = dict(odeint.last_stats)
+    assert ps.get('engine') == 'plane kernels' and (st['n_attempts'], st['n_accepted']) == (ps['n_attempts'], ps['n_accepted'])
+    for got, pl in zip(sol, planes):
+        assert float((got - pl).abs().max()) < 1e-6
+
+
 def test_what_the_segmented_engine_does_not_take_stays_generic():
     from tfdiffeq_amd import odeint, rhs
     y = tuple(torch.randn(10, 3, dtype=torch.float64, device=dev()) for _ in range(2))
     f = rhs.PerComponent(rhs.Lorenz())
     t = torch.tensor([0., 0.05])
-    odeint(f, y, t, method='tsit5')                                   # pooled ratio (tsit5.py:126-138): one mean over all components
-    assert odeint.last_stats.get('engine') == 'plane kernels'
-    odeint(f, y, t, method='dopri5', rtol=[1e-6, 1e-4], atol=[1e-9, 1e-7])     # per-component tolerances
-    assert odeint.last_stats.get('engine') == 'plane kernels'
     odeint(f, y + tuple(torch.randn(4, 3, dtype=torch.float64, device=dev()) for _ in range(7)), t, method='dopri5')   # 9 components
+    assert odeint.last_stats.get('engine') == 'plane kernels'
+    odeint(rhs.PerComponent(rhs.Linear(torch.eye(16, dtype=torch.float64, device=dev()))),
+           tuple(torch.randn(10, 16, dtype=torch.float64, device=dev()) for _ in range(2)), t, method='dopri5')       # not a row-local system
     assert odeint.last_stats.get('engine') == 'plane kernels'
     with pytest.raises(TypeError):
         rhs.PerComponent(lambda t_, y_: y_)

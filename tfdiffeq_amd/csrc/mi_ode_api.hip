@@ -438,7 +438,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     const bool rowlocal_fam = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
                               h->family == FAM_PLUGIN;
     long long rows = 0;
-    bool ok = h->nseg <= MI_ODE_MAX_SEGMENTS && rowlocal_fam && desc->adaptive && desc->controller == MI_ODE_CTRL_MISC &&
+    bool ok = h->nseg <= MI_ODE_MAX_SEGMENTS && rowlocal_fam && desc->adaptive &&
+              !(desc->controller == MI_ODE_CTRL_TSIT5 && desc->seg_tolerances) &&       // tsit5 takes scalar tolerances (tsit5.py:81-82)
               h->d.world_size <= 1 && desc->allgather == nullptr && (desc->fusion == 0 || desc->fusion == 4);
     for (int k = 0; ok && k < h->nseg; ++k) {
       if (desc->seg_rows[k] < 1) ok = false;
@@ -448,7 +449,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     if (ok) h->seg_blk[h->nseg] = (int)(rows / MI_ODE_SEGMENT_ALIGN);
     if (!ok || rows != desc->batch) {
       mi_set_error("tuple states: 2..%d components of >= 1 row each, every component padded to %d rows (batch = the padded total), a row-local RHS, an "
-                   "adaptive tableau with the misc controller, one rank, fusion 0 or 4", MI_ODE_MAX_SEGMENTS, MI_ODE_SEGMENT_ALIGN);
+                   "adaptive tableau, one rank, fusion 0 or 4", MI_ODE_MAX_SEGMENTS, MI_ODE_SEGMENT_ALIGN);
       delete h; return MI_ODE_E_INVALID;
     }
   }
@@ -768,6 +769,8 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   A.nseg = h->nseg;
   for (int k = 0; k < h->nseg; ++k) { A.seg_blk[k] = h->seg_blk[k]; A.seg_rows[k] = h->d.seg_rows[k]; }
   if (h->nseg > 1) A.seg_blk[h->nseg] = h->seg_blk[h->nseg];
+  A.seg_tol = h->nseg > 1 && h->d.seg_tolerances ? 1 : 0;
+  for (int k = 0; k < h->nseg; ++k) { A.seg_rtol[k] = h->d.seg_rtol[k]; A.seg_atol[k] = h->d.seg_atol[k]; }
   A.spin_limit = h->persist_spin_limit;
   A.spin_first = h->persist_spin_first < h->persist_spin_limit ? h->persist_spin_first : h->persist_spin_limit;
   // back-off before the first poll (units of 64 clocks): a failed poll round costs G x G record loads on the fabric, so

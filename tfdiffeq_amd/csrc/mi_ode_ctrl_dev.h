@@ -193,12 +193,28 @@ __device__ __forceinline__ void controller_apply_seg(Ctl* c, SegState* ss, const
   }
 }
 
-// dopri5.py:103-121 over the components
-__device__ __forceinline__ void attempt_core_seg(AttemptState& c, const double (*rec)[kRec], int nseg, const CtrlParams& P) {
+// dopri5.py:103-121 over the components; tol: {rtol_k, atol_k} per component, or null for P.rtol / P.atol
+__device__ __forceinline__ void attempt_core_seg(AttemptState& c, const double (*rec)[kRec], int nseg, const CtrlParams& P,
+                                                 const double* seg_rtol, const double* seg_atol) {
+  if (P.controller == MI_ODE_CTRL_TSIT5) {                   // tsit5.py:126-138: ONE mean over every element of every component
+    double num = 0.0, den = 0.0;
+    for (int k = 0; k < nseg; ++k) {
+      double tol;
+      if (P.is_f32) tol = (double)((float)P.atol + (float)P.rtol * (float)fmax(rec[k][R_MAXA], rec[k][R_MAXB]));
+      else tol = P.atol + P.rtol * fmax(rec[k][R_MAXA], rec[k][R_MAXB]);
+      num += rec[k][R_SUMA] / (tol * tol);
+      den += rec[k][R_N];
+    }
+    const double ratio = P.is_f32 ? (double)(float)(num / den) : num / den;
+    attempt_tail(c, ratio, ratio <= 1.0, P);
+    return;
+  }
   double ratios[kMaxSeg];
   bool accept = true;
   for (int k = 0; k < nseg; ++k) {
-    ratios[k] = error_ratio(rec[k], P);
+    CtrlParams Pk = P;
+    if (seg_rtol != nullptr) { Pk.rtol = seg_rtol[k]; Pk.atol = seg_atol[k]; }
+    ratios[k] = error_ratio(rec[k], Pk);
     accept = accept && (ratios[k] <= 1.0);
   }
   attempt_tail(c, py_max(ratios, nseg), accept, P);

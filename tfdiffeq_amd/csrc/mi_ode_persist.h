@@ -57,6 +57,8 @@ struct PersistArgs {
   int nseg;
   int seg_blk[kMaxSeg + 1];
   long long seg_rows[kMaxSeg];
+  int seg_tol;                 // 1: per-component tolerances below
+  double seg_rtol[kMaxSeg], seg_atol[kMaxSeg];
 };
 
 // thread 0: the scalar state mi_ode_begin would have uploaded
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
     MI_TICK(tk2);
     if (threadIdx.x == 0) {
       if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
-      else if (nseg > 1) { seg_counts(); attempt_core_seg(st, sh.seg_rec, nseg, cp); }
+      else if (nseg > 1) { seg_counts(); attempt_core_seg(st, sh.seg_rec, nseg, cp, A.seg_tol ? A.seg_rtol : nullptr, A.seg_atol); }
       else { fill_record(rec, r, n_tot); attempt_core(st, rec, cp); }
       sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.emit_t0 = st.emit_t0; sh.pub.emit_t1 = st.emit_t1;
       sh.pub.emit_dt = st.emit_dt; sh.pub.accepted = st.accepted; sh.pub.emit_lo = st.emit_lo;

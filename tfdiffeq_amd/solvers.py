@@ -97,7 +97,7 @@ class _FusedEngine(object):
     def __init__(self, device_rhs, y0, adaptive, tableau, c_mid=None, rtol=1e-7, atol=1e-9, controller=N.CTRL_MISC,
                  interp=N.INTERP_QUARTIC_MID, order=5, init_order=4, safety=0.9, ifactor=10.0, dfactor=0.2,
                  first_step=None, max_num_steps=2 ** 31 - 1, process_group=None, linear_variant=0, chunk_attempts=0,
-                 profile=False, fusion=0, seg_rows=None):
+                 profile=False, fusion=0, seg_rows=None, seg_tols=None):
         N.require_gpu_tensor(y0, 'y0')
         self.lib = N.load()
         self.y0 = y0.contiguous()
@@ -125,6 +125,10 @@ class _FusedEngine(object):
             d.n_segments = len(seg_rows)
             for k, r in enumerate(seg_rows):
                 d.seg_rows[k] = int(r)
+            if seg_tols is not None:               # one (rtol, atol) pair per component (dopri5.py:60-61)
+                d.seg_tolerances = 1
+                for k, (r_, a_) in enumerate(seg_tols):
+                    d.seg_rtol[k], d.seg_atol[k] = float(r_), float(a_)
         self._hook = None
         if process_group is not None:
             import torch.distributed as dist
@@ -606,7 +610,7 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
     def _make_engine(self):
         rhs = None if self._force_planes else _fusable(self.func, self.y0)
         self._packed = None
-        if rhs is None and not self._force_planes and not self.pooled_ratio and self._pg is None and self._fusion in (0, 'auto', 4, 'whole'):
+        if rhs is None and not self._force_planes and self._pg is None and self._fusion in (0, 'auto', 4, 'whole'):
             rhs = _fusable_tuple(self.func, self.y0)            # tuple state of a row-local RHS: one segmented buffer
             if rhs is not None:
                 self._packed = _pack_components(self.y0, rhs.dim)
@@ -628,18 +632,19 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             first = float(_convert_to_tensor(self.first_step, dtype=np.float64))   # dopri5.py:77: float32 detour
         y = self.y0[0] if self._packed is None else self._packed[0]
         seg_rows = None if self._packed is None else tuple(self._packed[1])
-        if seg_rows is not None and any(float(r_) != float(rtol0) or float(a_) != float(atol0) for r_, a_ in zip(self.rtol, self.atol)):
-            self._packed = None                                  # per-component tolerances: the generic path
-            return None
+        seg_tols = None
+        if seg_rows is not None and not self.pooled_ratio and \
+                any(float(r_) != float(rtol0) or float(a_) != float(atol0) for r_, a_ in zip(self.rtol, self.atol)):
+            seg_tols = tuple((float(r_), float(a_)) for r_, a_ in zip(self.rtol, self.atol))
         args = (float(rtol0), float(atol0), self.controller, self.interp, self.order, self.init_order, float(self.safety),
                 float(self.ifactor), float(self.dfactor), first, self.max_num_steps)
         key = ('adaptive', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
                _tableau_key(self.tableau, self.c_mid), args, id(self._pg) if self._pg is not None else None,
-               self._linear_variant, self._chunk_attempts, bool(self._profile), self._fusion, seg_rows)
+               self._linear_variant, self._chunk_attempts, bool(self._profile), self._fusion, seg_rows, seg_tols)
         try:
             return _cached_engine(key, lambda: _FusedEngine(
                 rhs, y, True, self.tableau, self.c_mid, *args, process_group=self._pg, linear_variant=self._linear_variant,
-                chunk_attempts=self._chunk_attempts, profile=self._profile, fusion=self._fusion, seg_rows=seg_rows))
+                chunk_attempts=self._chunk_attempts, profile=self._profile, fusion=self._fusion, seg_rows=seg_rows, seg_tols=seg_tols))
         except N.NativeError:
             if seg_rows is None:
                 raise
