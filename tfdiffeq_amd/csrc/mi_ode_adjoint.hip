@@ -117,6 +117,7 @@ extern "C" int mi_ode_adjoint_create(const mi_ode_adjoint_desc* desc, mi_ode_adj
   if (e == hipSuccess) e = hipMalloc((void**)&h->args_dev, sizeof(AdjArgs));
   if (e == hipSuccess) e = hipMemset(h->partials, 0, (size_t)kMaxBlocks * kRec * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->wpart, 0, (size_t)h->grid * 3 * (size_t)h->Ppad * sizeof(float));
+  if (e == hipSuccess) e = hipMemset(h->theta, 0, 3 * (size_t)h->Ppad * sizeof(float));   // (mi_ode_adjoint_dynamics reads a dummy adj_t from it)
   if (e != hipSuccess) {
     mi_set_error("fused adjoint workspace: %s", hipGetErrorString(e));
     (void)hipGetLastError();
