@@ -18,7 +18,7 @@ import torch
 from . import _native as N
 from .odeint import odeint
 
-# The backward solve of the ODEFunc tanh MLP runs as ONE kernel launch per output interval (csrc/mi_ode_adjoint.h) when the
+# The backward solve of the ODEFunc MLP (relu, softplus or tanh) runs as ONE kernel launch per output interval (csrc/mi_ode_adjoint.h) when the
 # problem qualifies (`_fused_plan`); FUSED = False (or TFDIFFEQ_AMD_FUSED_ADJOINT=0) keeps every case on the plane kernels.
 FUSED = os.environ.get('TFDIFFEQ_AMD_FUSED_ADJOINT', '1') != '0'
 FUSED_FORWARD = True          # the forward solve under odeint_adjoint also takes the fused kernels of a network that has them
@@ -32,7 +32,7 @@ def _flatten(seq):
 
 class _FusedAdjointEngine(object):
     """Owns one mi_ode_adjoint handle: the augmented system (y, adj_y, adj_t, adj_params) of adjoint.py:57-178 for a
-    [batch, dim] float32 state and the dim -> hidden -> hidden -> dim tanh MLP."""
+    [batch, dim] float32 state and the dim -> hidden -> hidden -> dim MLP (rhs.MLP: relu, softplus or tanh)."""
 
     def __init__(self, batch, dim, hidden, rtol, atol, safety, ifactor, dfactor, max_num_steps, device):
         from .dopri5 import _DORMAND_PRINCE_SHAMPINE_TABLEAU, DPS_C_MID
