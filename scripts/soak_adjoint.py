@@ -1,0 +1,64 @@
+"""Soak of the fused adjoint kernel: random ODEFunc shapes, activations, batch sizes, tolerances and time grids.  Every
+gradient is measured against a float64 adjoint solve at tolerance 1e-9 of the same loss; the fused kernel's error must not
+exceed max(3 x the generic (plane-kernel) fp32 adjoint's error at the same tolerance, 10 x tolerance) - both are
+O(tolerance) approximations with their own step sequences (the generic path's error ratio carries the roundoff of its
+full-batch parameter-gradient planes, so it tends to take smaller steps than the tolerance asks for), so they are not
+compared with each other; the outliers of the first soak were re-run at tolerance / 10 and converged with it.
+usage: python scripts/soak_adjoint.py [n] [seed]"""
+import copy
+import sys
+import time
+
+import numpy as np
+import torch
+
+from tfdiffeq_amd import adjoint as ADJ
+from tfdiffeq_amd import models, odeint_adjoint
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = 'cuda'
+worst, fails, t_start = 0.0, 0, time.time()
+for it in range(n):
+    dim = int(rng.integers(1, 65))
+    hidden = int(rng.integers(1, 129))
+    batch = int(rng.choice([1, 7, 32, 33, 100, 257, 1000, 4096]))
+    act = str(rng.choice(['tanh', 'relu', 'softplus']))
+    tol = float(10.0 ** rng.uniform(-5.0, -2.5))
+    T = int(rng.integers(2, 5))
+    ts = np.sort(rng.uniform(0.0, 2.0, size=T))
+    if rng.random() < 0.3:
+        ts = ts[::-1].copy()                                   # decreasing time grid
+    if np.min(np.abs(np.diff(ts))) < 1e-3:
+        continue
+    torch.manual_seed(int(rng.integers(1 << 30)))
+    func = models.ODEFunc(dim, hidden, non_linearity=act).to(dev)
+    y0 = torch.randn(batch, dim, device=dev)
+    w = torch.randn(T, batch, dim, device=dev)
+    res = {}
+    for key in ('fused', 'generic', 'f64'):
+        ADJ.FUSED, ADJ.FUSED_FORWARD = key == 'fused', False
+        f = func if key != 'f64' else copy.deepcopy(func).double()
+        dt = torch.float64 if key == 'f64' else torch.float32
+        tl = 1e-9 if key == 'f64' else tol
+        for p in f.parameters():
+            p.grad = None
+        yi = y0.to(dt).clone().requires_grad_(True)
+        sol = odeint_adjoint(f, yi, torch.tensor(ts), rtol=tl, atol=tl, method='dopri5', options={'max_num_steps': 100000})
+        (sol * w.to(dt)).sum().backward()
+        res[key] = ([yi.grad.double()] + [p.grad.double() for p in f.parameters()], dict(odeint_adjoint.last_backward_stats))
+    ADJ.FUSED, ADJ.FUSED_FORWARD = True, True
+    assert res['fused'][1]['engine'].startswith('fused'), res['fused'][1]
+
+    def err(key):
+        return max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-30)) for a, b in zip(res[key][0], res['f64'][0]))
+    ef, eg = err('fused'), err('generic')
+    band = max(3.0 * eg, 10.0 * tol, 2e-5)
+    worst = max(worst, ef / band)
+    if it % 10 == 0:
+        print('it %d: fused %.2e generic %.2e  (%.0f s)' % (it, ef, eg, time.time() - t_start), flush=True)
+    if not (ef < band) or not np.isfinite(ef):
+        fails += 1
+        print('MISMATCH it %d: dim %d hidden %d batch %d act %s tol %.1e T %d ts %s: fused %.2e generic %.2e' % (it, dim, hidden, batch, act, tol, T, ts, ef, eg))
+print('soak: %d problems, %d outside the band, worst error / band %.2f, %.0f s' % (n, fails, worst, time.time() - t_start))
+sys.exit(1 if fails else 0)
