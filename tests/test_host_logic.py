@@ -186,3 +186,66 @@ def test_rhs_plugin_builds_and_exports_its_table():
     assert not lib.mi_ode_plugin_get(N.dtype_code(torch.float32))                      # built for one dtype only
     with pytest.raises(ValueError):
         rhs.CustomRowLocal(9, "k[0] = 0;")
+
+
+# ---------------------------------------------------------------------------------------------
+# round 2 host logic: tuple packing, adjoint parameter order, eligibility checks (no GPU needed)
+# ---------------------------------------------------------------------------------------------
+def test_tuple_components_are_packed_on_workgroup_boundaries():
+    import torch
+    from tfdiffeq_amd import _native as N
+    from tfdiffeq_amd import solvers
+    comps = (torch.arange(6.).reshape(3, 2), torch.arange(10.).reshape(5, 2) + 100., torch.arange(600.).reshape(300, 2) - 7.)
+    packed, rows, offs = solvers._pack_components(comps, 2)
+    assert rows == [3, 5, 300]
+    assert offs == [0, N.SEGMENT_ALIGN, 2 * N.SEGMENT_ALIGN]
+    assert packed.shape == (2 * N.SEGMENT_ALIGN + 2 * N.SEGMENT_ALIGN, 2)          # 300 rows round up to 512
+    for c, r, o in zip(comps, rows, offs):
+        assert torch.equal(packed[o:o + r], c)
+    used = torch.zeros(packed.shape[0], dtype=torch.bool)
+    for r, o in zip(rows, offs):
+        used[o:o + r] = True
+    assert float(packed[~used].abs().max()) == 0.0                                    # padding rows are zero
+    # a trailing-shape component ([batch, k, dim]) is flattened row-wise
+    packed3, rows3, _ = solvers._pack_components((torch.ones(4, 3, 2), torch.ones(1, 2)), 2)
+    assert rows3 == [12, 1] and packed3.shape[0] == 2 * N.SEGMENT_ALIGN
+
+
+def test_adjoint_parameter_order_round_trip():
+    """The fused adjoint kernel returns adj_params as (W1 [in, out], b1, W2, b2, W3, b3); torch.nn.Linear keeps [out, in]."""
+    import torch
+    from tfdiffeq_amd import adjoint, models
+    f = models.ODEFunc(3, 5, non_linearity='tanh')
+    with torch.no_grad():
+        for p in f.parameters():
+            p.copy_(torch.randn_like(p))
+    canonical = torch.cat([f.fc1.weight.t().reshape(-1), f.fc1.bias, f.fc2.weight.t().reshape(-1), f.fc2.bias,
+                           f.fc3.weight.t().reshape(-1), f.fc3.bias]).detach()
+    want = torch.cat([p.reshape(-1) for p in f.parameters()]).detach()
+    assert torch.equal(adjoint.canonical_to_module_order(f, canonical), want)
+
+
+def test_fused_paths_are_not_chosen_for_host_tensors_or_uncovered_functions():
+    import torch
+    from tfdiffeq_amd import adjoint, models, rhs, solvers
+    f = models.ODEFunc(3, 5, non_linearity='tanh')
+    cfg = dict(adjoint_method=None, adjoint_options=None, adjoint_rtol=1e-6, adjoint_atol=1e-9)
+    wrapped = adjoint._TupleModule(f)
+    like = torch.zeros(2, 4, 3)                                                       # CPU tensor: never the fused kernel
+    assert adjoint._fused_plan(wrapped, 1, cfg, like, list(f.parameters())) is None
+    assert adjoint._fused_plan(f, 1, cfg, like, list(f.parameters())) is None         # not the adjoint's own wrapper
+    assert adjoint._fused_plan(wrapped, 2, cfg, like, list(f.parameters())) is None   # tuple state
+    assert adjoint._fused_plan(wrapped, 1, dict(cfg, adjoint_method='rk4'), like, list(f.parameters())) is None
+    # descriptors: time dependence and activations outside the kernel's set have none
+    assert models.ODEFunc(3, 5, time_dependent=True).device_rhs() is None
+    assert models.ODEFunc(3, 5, non_linearity='ELU').device_rhs() is None
+    assert models.ODEFunc(3, 5).device_rhs().activation == 'relu'
+    # tuple lift: only row-local systems, 2..8 components, device tensors
+    lift = rhs.PerComponent(rhs.Lorenz())
+    assert solvers._fusable_tuple(lift, (torch.zeros(4, 3), torch.zeros(2, 3))) is None          # host tensors
+    assert solvers._fusable_tuple(rhs.Lorenz(), (torch.zeros(4, 3), torch.zeros(2, 3))) is None  # not lifted
+    dense = rhs.PerComponent(rhs.Linear.from_matrix(torch.eye(4)))                               # not row-local: a plain callable
+    assert solvers._fusable_tuple(dense, (torch.zeros(4, 4), torch.zeros(2, 4))) is None
+    import pytest
+    with pytest.raises(TypeError):
+        rhs.PerComponent(lambda t, y: y)                                                         # not a DeviceRHS
