@@ -608,3 +608,60 @@ def test_dopri8_on_the_linear_tile_kernels(dim, batch):
     assert float((outs['auto'] - planes).abs().max()) < 1e-6
     odeint(f, to_dev(y0), torch.tensor(t), method='dopri8', options={'fusion': 'stage'}, **tol)     # no per-stage kernels for 13 rows:
     assert odeint.last_stats.get('engine') == 'plane kernels'                                      # the generic engine takes it
+
+
+# ---------------------------------------------------------------------------------------------
+# time-dependent ODEFunc (dense_odenet.py:79-84: fc1 sees concat([t, x])) on the fused MLP kernels
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize('act,method', [('tanh', 'dopri5'), ('relu', 'dopri5'), ('softplus', 'tsit5'), ('tanh', 'bosh3')])
+def test_time_dependent_odefunc_on_the_fused_kernel(act, method):
+    """The stage time only shifts the first layer's bias by t * W1[0, :]: the network stays on the one-launch MFMA kernel.
+    Checks: (a) the same solve through the plane-kernel engine with the torch module as a callable (same step sequence),
+    (b) the torch-CPU restatement of the reference's Dopri5 path, (c) decreasing times (f <- -f(-t, y), misc.py:318-321),
+    (d) the time dependence is real (a t-shifted solve differs)."""
+    import copy
+    from tfdiffeq_amd import models, odeint, odeint_adjoint
+    from oracle import ode_torch_cpu as TC
+    torch.manual_seed(41)
+    func = models.ODEFunc(10, 48, time_dependent=True, non_linearity=act).to(dev())
+    with torch.no_grad():
+        func.fc1.weight[:, 0].mul_(3.0)                          # make the time column matter
+    d = func.device_rhs()
+    assert d is not None and d.time_dependent and d.dim == 10
+    y0 = torch.randn(777, 10, generator=torch.Generator().manual_seed(42)).to(dev())
+    t = torch.tensor([0.25, 0.9, 1.6])
+    kw = dict(rtol=1e-5, atol=1e-6, method=method)
+    with torch.no_grad():
+        a = odeint(d, y0, t, **kw)
+        sa = dict(odeint.last_stats)
+        assert sa['status'] == 0 and sa['n_launches'] == 1
+        b = odeint(func, y0, t, **kw)                             # python callable: plane kernels
+        sb = dict(odeint.last_stats)
+        assert abs(sa['n_attempts'] - sb['n_attempts']) <= 1
+        assert (a - b).abs().max().item() < 3e-5 * max(1.0, b.abs().max().item())
+        if method == 'dopri5':
+            cpu = copy.deepcopy(func).cpu()
+            ref, _ = TC.odeint_dopri5(lambda t_, y_: cpu(t_, y_), y0.cpu(), [0.25, 0.9, 1.6], rtol=1e-5, atol=1e-6)
+            assert (a.cpu() - torch.stack([r.detach() for r in ref])).abs().max().item() < 5e-5 * max(1.0, b.abs().max().item())
+        # launch per attempt == whole call, bit for bit
+        c = odeint(d, y0, t, options={'fusion': 'step'}, **kw)
+        assert torch.equal(a, c)
+        # decreasing times
+        tr = torch.tensor([1.6, 0.9, 0.25])
+        ar = odeint(d, y0, tr, **kw)
+        br = odeint(func, y0, tr, **kw)
+        assert (ar - br).abs().max().item() < 3e-5 * max(1.0, br.abs().max().item())
+        # a shifted time grid gives another answer
+        shifted = odeint(d, y0, t + 1.0, **kw)
+        assert (shifted[-1] - a[-1]).abs().max().item() > 1e-3
+    # ODEBlock: inference on the fused kernel, training through the generic adjoint (adj_t has a real derivative there)
+    block = models.ODEBlock(func, tol=1e-4, adjoint=True, solver='dopri5')
+    with torch.no_grad():
+        out = block(y0)
+    assert odeint.last_stats.get('n_launches') == 1
+    x = y0.clone().requires_grad_(True)
+    block(x).pow(2).sum().backward()
+    assert not odeint_adjoint.last_backward_stats['engine'].startswith('fused')
+    assert x.grad is not None and all(p.grad is not None and torch.isfinite(p.grad).all() for p in func.parameters())
+    assert float(func.fc1.weight.grad[:, 0].abs().max()) > 0.0

@@ -156,8 +156,8 @@ def _fused_plan(func, n_tensors, cfg, like, f_params):
         return None                                      # first_step / safety / ... : not wired into the fused controller
     mlp = get()
     y1 = like[0]
-    if mlp is None or not mlp.supports(y1):
-        return None
+    if mlp is None or mlp.time_dependent or not mlp.supports(y1):
+        return None                                      # time dependence: adj_t has a real derivative, generic path
     batch = y1.numel() // y1.shape[-1]
     if batch < 1:
         return None

@@ -156,6 +156,7 @@ struct MlpCtx {
   float *s_x, *s_h1, *s_h2;
   float w1f[KS1], w2f[KS2], w3f[KS2];
   float b1v, b2v, b3v, sign;
+  float wtv;                  // time-dependent first layer (rhs.s[1] != 0): W1 is [d + 1, hd], row 0 multiplies t; else 0
   int lane, wave, li, lg, d, hd, col, rbase;
   bool owner;
 
@@ -174,10 +175,12 @@ struct MlpCtx {
     sign = (float)rhs.sign;
     // resident weight slices, zero padded: lane (col = li, group lg) holds W[k = lg*KS + s][16*block + li]
     const int c12 = 16 * wave + li;
+    const int td = rhs.s[1] != 0.0 ? 1 : 0;                   // dense_odenet.py:79-84: fc1 sees concat([t, x])
+    wtv = (td && wave < G::NW12 && c12 < hd) ? W1[c12] : 0.f;
 #pragma unroll
     for (int s = 0; s < KS1; ++s) {
       const int k = lg * KS1 + s;
-      w1f[s] = (wave < G::NW12 && k < d && c12 < hd) ? W1[(long long)k * hd + c12] : 0.f;
+      w1f[s] = (wave < G::NW12 && k < d && c12 < hd) ? W1[(long long)(k + td) * hd + c12] : 0.f;
     }
 #pragma unroll
     for (int s = 0; s < KS2; ++s) {
@@ -204,8 +207,9 @@ struct MlpCtx {
       for (int i = 0; i < 4; ++i) s_x[(rbase + i) * G::LDX + col] = (col < d) ? v4[i] : 0.f;
     }
   }
-  __device__ __forceinline__ void eval(float* out4) {
-    mlp_eval<DP, HP, ACT>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v, b2v, b3v, out4);
+  // ts: the time the network sees (already multiplied by the direction sign); it only shifts the first layer's bias
+  __device__ __forceinline__ void eval(float* out4, float ts) {
+    mlp_eval<DP, HP, ACT>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v + ts * wtv, b2v, b3v, out4);
   }
 };
 
@@ -237,7 +241,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
     }
     if (MODE == MLP_F0) {
       cx.put_x(y0e);
-      cx.eval(kn);
+      cx.eval(kn, sign * P.t0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const long long row = row0 + rbase + i;
@@ -257,7 +261,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
 #pragma unroll
       for (int i = 0; i < 4; ++i) ys[i] = y0e[i] + hs * k[0][i];               // misc.py:235
       cx.put_x(ys);
-      cx.eval(kn);
+      cx.eval(kn, sign * (P.t0 + hs));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const long long row = row0 + rbase + i;
@@ -281,7 +285,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
         ys[i] = step_combine<float, SG>(y0e[i], kk, hs, A);
       }
       cx.put_x(ys);
-      cx.eval(kn);
+      cx.eval(kn, sign * (P.t0 + (float)A.alpha[SG - 1] * hs));                 // rk_common.py:50, in the state dtype
 #pragma unroll
       for (int i = 0; i < 4; ++i) k[SG][i] = sign * kn[i];
     };
@@ -315,7 +319,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
   StepPlanes<float, S> P;
   if (MODE == MLP_F0) {
     P.y0 = (const float*)M.x_y0;
-    P.f0 = nullptr; P.y1 = nullptr; P.hs = 0.f; P.t0 = 0.f; P.j_lo = P.j_hi = 0;
+    P.f0 = nullptr; P.y1 = nullptr; P.hs = 0.f; P.t0 = (float)A.ctl->t1; P.j_lo = P.j_hi = 0;
     P.f1 = (float*)(A.planes + 2 * A.stride);               // F0 writes f0 into idx_k[0] of a fresh handle
   } else {
     if (!resolve_step<float, S>(A, P)) return;
@@ -358,7 +362,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
   bool ok;
   {
     StepPlanes<float, S> P;
-    P.y0 = y_user; P.f0 = nullptr; P.y1 = nullptr; P.f1 = fa; P.hs = 0.f; P.t0 = 0.f; P.j_lo = P.j_hi = 0;
+    P.y0 = y_user; P.f0 = nullptr; P.y1 = nullptr; P.f1 = fa; P.hs = 0.f; P.t0 = (float)A.t0; P.j_lo = P.j_hi = 0;
     Acc acc;
     mlp_pass<DP, HP, ACT, MLP_F0, S, TS, true>(A.s, P, nullptr, A.out0, cx, acc, t_out);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
@@ -367,7 +371,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
   }
   if (cp.auto_first_step && ok) {
     StepPlanes<float, S> P;
-    P.y0 = y_user; P.f0 = fa; P.y1 = nullptr; P.f1 = nullptr; P.hs = (float)uniform_d(s_c.h0); P.t0 = 0.f; P.j_lo = P.j_hi = 0;
+    P.y0 = y_user; P.f0 = fa; P.y1 = nullptr; P.f1 = nullptr; P.hs = (float)uniform_d(s_c.h0); P.t0 = (float)A.t0; P.j_lo = P.j_hi = 0;
     Acc acc;
     mlp_pass<DP, HP, ACT, MLP_INITB, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);

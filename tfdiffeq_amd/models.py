@@ -1,10 +1,10 @@
 """Mirror of tfdiffeq/models/dense_odenet.py for torch: ODEFunc, ODEBlock, ODENet.
 
 `ODEBlock` is config 5's real caller: t = [0, 1], rtol = atol = tol (1e-3), `max_num_steps = 1000`, optional zero
-augmentation, returns the state at t = 1 (dense_odenet.py:131-191).  When the ODEFunc is the plain
-(time-independent) MLP with a relu (the reference's default), softplus or tanh non-linearity, inference runs on the fused
-MFMA kernel (`rhs.MLP`, csrc/mi_ode_mlp.h) and training on it plus the fused adjoint kernel (csrc/mi_ode_adjoint.h);
-otherwise the plane-kernel engine (and the generic `odeint_adjoint`) take over.
+augmentation, returns the state at t = 1 (dense_odenet.py:131-191).  When the ODEFunc has a relu (the reference's default),
+softplus or tanh non-linearity, inference runs on the fused MFMA kernel (`rhs.MLP`, csrc/mi_ode_mlp.h; `time_dependent=True`
+included: the stage time only shifts the first layer's bias) and training of the time-independent network on it plus the
+fused adjoint kernel (csrc/mi_ode_adjoint.h); otherwise the plane-kernel engine (and the generic `odeint_adjoint`) take over.
 """
 import torch
 from torch import nn
@@ -50,7 +50,7 @@ class ODEFunc(nn.Module):
         """The fused-kernel descriptor of this network, or None if the fused MLP kernel does not cover it.
         ONE descriptor per module: its [in, out] weight copies are refreshed in place when a parameter changed
         (optimizer step, load_state_dict, .to()), so the cached engine - keyed on those buffers - keeps being hit."""
-        if self.time_dependent or self.non_linearity_name not in _rhs.MLP.ACTIVATIONS:
+        if self.non_linearity_name not in _rhs.MLP.ACTIVATIONS:
             return None
         layers = (self.fc1, self.fc2, self.fc3)
         stamp = tuple((l.weight._version, l.bias._version, l.weight.data_ptr(), l.bias.data_ptr(), l.weight.device, l.weight.dtype)
@@ -69,7 +69,7 @@ class ODEFunc(nn.Module):
                 desc = _rhs.MLP(self.fc1.weight.detach().t().contiguous(), self.fc1.bias.detach().clone(),
                                 self.fc2.weight.detach().t().contiguous(), self.fc2.bias.detach().clone(),
                                 self.fc3.weight.detach().t().contiguous(), self.fc3.bias.detach().clone(),
-                                activation=self.non_linearity_name)
+                                activation=self.non_linearity_name, time_dependent=self.time_dependent)
         object.__setattr__(self, '_fused_rhs', (stamp, desc))
         return desc
 

@@ -178,25 +178,30 @@ class Lorenz(DeviceRHS):
 
 
 class MLP(DeviceRHS):
-    """ODEFunc-shaped MLP dim -> hidden -> hidden -> dim, time independent (tfdiffeq/models/dense_odenet.py:41-92).
-    Weights are [in, out] (Keras Dense layout).  activation: 'tanh', 'relu' (the reference's default) or 'softplus'."""
+    """ODEFunc-shaped MLP dim -> hidden -> hidden -> dim (tfdiffeq/models/dense_odenet.py:41-92).
+    Weights are [in, out] (Keras Dense layout).  activation: 'tanh', 'relu' (the reference's default) or 'softplus'.
+    time_dependent: the first layer sees concat([t, x]) (dense_odenet.py:79-84): W1 is [dim + 1, hidden], row 0 for t."""
     kind = N.RHS_MLP_TANH
     ACTIVATIONS = {'tanh': 0, 'relu': 1, 'softplus': 2}
 
-    def __init__(self, W1, b1, W2, b2, W3, b3, activation='tanh'):
+    def __init__(self, W1, b1, W2, b2, W3, b3, activation='tanh', time_dependent=False):
         super(MLP, self).__init__()
         if activation not in self.ACTIVATIONS:
             raise ValueError('the fused MLP kernels know %s, not %r' % (sorted(self.ACTIVATIONS), activation))
         self.activation = activation
+        self.time_dependent = bool(time_dependent)
         self.Ws = [torch.as_tensor(w) for w in (W1, W2, W3)]
         self.bs = [None if b is None else torch.as_tensor(b) for b in (b1, b2, b3)]
-        self.dim = int(self.Ws[0].shape[0])
+        self.dim = int(self.Ws[0].shape[0]) - (1 if self.time_dependent else 0)
         self.hidden = int(self.Ws[0].shape[1])
         assert self.Ws[1].shape == (self.hidden, self.hidden) and self.Ws[2].shape == (self.hidden, self.dim)
 
     def forward(self, t, y):
         act = {'tanh': torch.tanh, 'relu': torch.relu, 'softplus': torch.nn.functional.softplus}[self.activation]
         h = y
+        if self.time_dependent:
+            t_vec = torch.ones(y.shape[:-1] + (1,), dtype=y.dtype, device=y.device) * torch.as_tensor(t, dtype=y.dtype, device=y.device)
+            h = torch.cat([t_vec, y], dim=-1)
         for i in range(3):
             h = torch.matmul(h, self._dev(self.Ws[i], y.dtype, y.device))
             if self.bs[i] is not None:
@@ -215,6 +220,7 @@ class MLP(DeviceRHS):
         keep = super(MLP, self).fill(rhs, dtype, device)
         rhs.hidden = self.hidden
         rhs.scalars[0] = float(self.ACTIVATIONS[self.activation])
+        rhs.scalars[1] = 1.0 if self.time_dependent else 0.0
         for i in range(3):
             Wd = self._dev(self.Ws[i], dtype, device)
             rhs.w[i] = Wd.data_ptr()
