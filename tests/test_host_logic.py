@@ -236,8 +236,13 @@ def test_fused_paths_are_not_chosen_for_host_tensors_or_uncovered_functions():
     assert adjoint._fused_plan(f, 1, cfg, like, list(f.parameters())) is None         # not the adjoint's own wrapper
     assert adjoint._fused_plan(wrapped, 2, cfg, like, list(f.parameters())) is None   # tuple state
     assert adjoint._fused_plan(wrapped, 1, dict(cfg, adjoint_method='rk4'), like, list(f.parameters())) is None
-    # descriptors: time dependence and activations outside the kernel's set have none
-    assert models.ODEFunc(3, 5, time_dependent=True).device_rhs() is None
+    # descriptors: activations outside the kernel's set have none; a time-dependent network has one (forward kernel only)
+    td = models.ODEFunc(3, 5, time_dependent=True, non_linearity='tanh')
+    d = td.device_rhs()
+    assert d.time_dependent and d.dim == 3 and tuple(d.Ws[0].shape) == (4, 5)
+    y = torch.randn(6, 3)
+    assert torch.allclose(d(torch.tensor(0.7), y), td(torch.tensor(0.7), y).detach(), atol=1e-6)
+    assert torch.allclose(d.reversed()(torch.tensor(-0.7), y), -td(torch.tensor(0.7), y).detach(), atol=1e-6)   # misc.py:318-321
     assert models.ODEFunc(3, 5, non_linearity='ELU').device_rhs() is None
     assert models.ODEFunc(3, 5).device_rhs().activation == 'relu'
     # tuple lift: only row-local systems, 2..8 components, device tensors
