@@ -72,12 +72,12 @@ __device__ __forceinline__ void persist_init_ctl(Ctl& c, const PersistArgs& A) {
 }
 
 // every thread: output times into LDS when they fit (kernel arguments for tiny T, else the uploaded array)
-__device__ __forceinline__ const double* persist_stage_tout(const PersistArgs& A, double* lds_tout) {
+__device__ __forceinline__ const double* persist_stage_tout(const PersistArgs& A, double* lds_tout, int lds_cap = kPersistTout) {
   if (A.n_out <= kPersistTSmall) {
     if ((int)threadIdx.x < A.n_out) lds_tout[threadIdx.x] = A.t_small[threadIdx.x];
     return lds_tout;
   }
-  if (A.n_out <= kPersistTout) {
+  if (A.n_out <= lds_cap) {
     for (int i = threadIdx.x; i < A.n_out; i += blockDim.x) lds_tout[i] = A.s.t_out[i];
     return lds_tout;
   }
@@ -178,18 +178,23 @@ struct PersistPub {
 constexpr int kXRec = 16;                                       // 8-byte words per rank record in the host segment (12 used)
 constexpr int kXMaxWorld = 64;
 
-struct PersistShared {
+// MAXG: workgroups whose records are staged for the fold, TOUT: output times cached in LDS - parameters because a kernel that
+// fills the LDS with weights (mi_ode_mlp_wt.h) cannot afford the 50 KB of the general case
+template <int MAXG, int TOUT>
+struct PersistSharedT {
+  static constexpr int kMaxGrid = MAXG, kTout = TOUT;
   Ctl c;                                                      // prologue (before_integrate) and the final write-back
   PersistPub pub;
   AttemptState st;                                            // MFMA kernel: the loop's scalar state rests here between attempts
   double red[80];
-  double vals[5][kPersistMaxGrid];                            // every workgroup's record, staged for the fixed-order fold
-  double tout[kPersistTout];                                  // the requested output times, when they fit
+  double vals[5][MAXG];                                       // every workgroup's record, staged for the fixed-order fold
+  double tout[TOUT];                                          // the requested output times, when they fit
   double xr[6][kXMaxWorld + 1];                               // cross-rank hand-off: every rank's record (+ one staging column)
   double seg_rec[kMaxSeg][kRec];                              // tuple states: the combined record of every component
   SegState seg;
   int ok;                                                     // 1 until a hand-off times out
 };
+using PersistShared = PersistSharedT<kPersistMaxGrid, kPersistTout>;
 
 // ---- cross-rank hand-off through host memory ------------------------------------------------------------------
 // Encoding (the "LL" idea of collective libraries): every 8-byte word carries 4 bytes of payload and a 4-byte
@@ -224,7 +229,8 @@ __device__ __forceinline__ bool ll_load_record(const unsigned long long* p, unsi
 //     stream over the xGMI link to that peer - and then polls slot q of its OWN mailbox, i.e. local memory.  No poll
 //     ever crosses a link, no host memory, no PCIe;
 //   * a host segment shared by the ranks (A.xrank): one slot per rank, written once, polled by everybody over PCIe.
-__device__ __forceinline__ void cross_rank(const PersistArgs& A, PersistShared& sh, unsigned gen, double (&r)[5], double& n_tot,
+template <class SH>
+__device__ __forceinline__ void cross_rank(const PersistArgs& A, SH& sh, unsigned gen, double (&r)[5], double& n_tot,
                                            double n_local) {
   const int W = A.world;
   const unsigned seq = A.seq_base + gen + 1u;
@@ -297,7 +303,8 @@ __device__ __forceinline__ void cross_rank(const PersistArgs& A, PersistShared& 
 // Returns false (to every thread) on a hand-off timeout.  `gen` counts hand-offs (uniform over the grid).  Thread i
 // polls record i (one round trip once the slowest workgroup has published), wavefront 0 folds in
 // reduce_block_records' fixed order.
-__device__ __forceinline__ bool grid_reduce_rank(const PersistArgs& A, const Acc& acc, PersistShared& sh, unsigned gen,
+template <class SH>
+__device__ __forceinline__ bool grid_reduce_rank(const PersistArgs& A, const Acc& acc, SH& sh, unsigned gen,
                                                  double (&r)[5]) {
   const int G = (int)gridDim.x;
   block_reduce_thread0(acc, sh.red, r);
@@ -362,7 +369,8 @@ __device__ __forceinline__ bool grid_reduce_rank(const PersistArgs& A, const Acc
 }
 
 // ... and over all ranks when the run is batch-sharded.  n_tot (thread 0): elements behind the combined record.
-__device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc, PersistShared& sh, unsigned gen,
+template <class SH>
+__device__ __forceinline__ bool grid_reduce(const PersistArgs& A, const Acc& acc, SH& sh, unsigned gen,
                                             double (&r)[5], double& n_tot) {
   bool ok = grid_reduce_rank(A, acc, sh, gen, r);
   n_tot = (double)A.s.cp.n_local;

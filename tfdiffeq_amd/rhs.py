@@ -11,6 +11,8 @@ Workload definitions follow the reference's examples:
   Lorenz          examples/lorenz_attractor.py:20-37, batched on the last axis
   MLP / MLPTanh   tfdiffeq/models/dense_odenet.py:41-92 (ODEFunc, time independent; tanh, relu or softplus)
 """
+import os
+
 import torch
 
 from . import _native as N
@@ -190,6 +192,8 @@ class MLP(DeviceRHS):
             raise ValueError('the fused MLP kernels know %s, not %r' % (sorted(self.ACTIVATIONS), activation))
         self.activation = activation
         self.time_dependent = bool(time_dependent)
+        # 'wave': the experimental barrier-free layout of the whole-call kernel (csrc/mi_ode_mlp_wt.h), opt-in
+        self.layout = os.environ.get('TFDIFFEQ_AMD_MLP_LAYOUT', 'workgroup')
         self.Ws = [torch.as_tensor(w) for w in (W1, W2, W3)]
         self.bs = [None if b is None else torch.as_tensor(b) for b in (b1, b2, b3)]
         self.dim = int(self.Ws[0].shape[0]) - (1 if self.time_dependent else 0)
@@ -221,6 +225,7 @@ class MLP(DeviceRHS):
         rhs.hidden = self.hidden
         rhs.scalars[0] = float(self.ACTIVATIONS[self.activation])
         rhs.scalars[1] = 1.0 if self.time_dependent else 0.0
+        rhs.scalars[2] = 1.0 if self.layout == 'wave' else 0.0
         for i in range(3):
             Wd = self._dev(self.Ws[i], dtype, device)
             rhs.w[i] = Wd.data_ptr()
