@@ -22,7 +22,9 @@ typedef const __attribute__((address_space(3))) wt_f4* wt_lds4;
 
 template <int DP, int HP>
 struct WtGeom {
-  static constexpr int NW = 4;                               // waves per workgroup = 1 per SIMD: the 7 x 16 stage derivatives of a lane need the 512-register budget
+  static constexpr int NW = 4;                               // waves per workgroup = 1 per SIMD: 374 registers per lane (7 x 16 stage derivatives + activations).
+                                                             // NW = 8 (2 per SIMD, 128 + 128 registers, ~40 scratch accesses per evaluation) measured the
+                                                             // same 0.474 ms at config 5 and is slower on small batches (fewer, longer workgroups)
   static constexpr int R = 16 * NW;                          // rows per workgroup tile
   static constexpr int KB1 = DP / 16, MB1 = HP / 16, MB3 = DP / 16;
   static constexpr int LW1 = DP + 4, LW2 = HP + 4, LW3 = HP + 4;   // row strides = 4 (mod 64 banks): ds_read_b128 conflict-free
