@@ -108,9 +108,29 @@ struct WtCtx {
     const float* B3 = (const float*)rhs.b[2];
     const int td = rhs.s[1] != 0.0 ? 1 : 0;                   // time-dependent first layer: W1 is [d + 1, hd], row 0 for t
     const int nt = blockDim.x, tid = threadIdx.x;
-    for (int i = tid; i < DP * HP; i += nt) { const int k = i / HP, o = i % HP; w[G::OFF_W1 + o * G::LW1 + k] = (k < d && o < hd) ? W1[(long long)(k + td) * hd + o] : 0.f; }
-    for (int i = tid; i < HP * HP; i += nt) { const int k = i / HP, o = i % HP; w[G::OFF_W2 + o * G::LW2 + k] = (k < hd && o < hd) ? W2[(long long)k * hd + o] : 0.f; }
-    for (int i = tid; i < HP * DP; i += nt) { const int k = i / DP, o = i % DP; w[G::OFF_W3 + o * G::LW3 + k] = (k < hd && o < d) ? W3[(long long)k * d + o] : 0.f; }
+    // [in][out] in memory -> zero-padded [out][in] in LDS.  Branch-free with eight loads in flight per thread: written as a
+    // guarded element loop the compiler waited for every single load (128 round trips to L2 = ~0.1 ms per launch).
+    auto stage = [&](float* dst, const float* W, int K, int O, int LW, int kreal, int oreal, int ld, int koff) {
+      const int N = K * O;
+      for (int base = 0; base < N; base += 8 * nt) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * nt + tid, k = i / O, o = i - k * O;
+          const bool in = i < N && k < kreal && o < oreal;
+          const float x = W[in ? (long long)(k + koff) * ld + o : 0];
+          v[u] = in ? x : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * nt + tid, k = i / O, o = i - k * O;
+          if (i < N) dst[o * LW + k] = v[u];
+        }
+      }
+    };
+    stage(w + G::OFF_W1, W1, DP, HP, G::LW1, d, hd, hd, td);
+    stage(w + G::OFF_W2, W2, HP, HP, G::LW2, hd, hd, hd, 0);
+    stage(w + G::OFF_W3, W3, HP, DP, G::LW3, hd, d, d, 0);
     for (int i = tid; i < HP; i += nt) {
       w[G::OFF_B1 + i] = (B1 != nullptr && i < hd) ? B1[i] : 0.f;
       w[G::OFF_B2 + i] = (B2 != nullptr && i < hd) ? B2[i] : 0.f;
@@ -185,13 +205,26 @@ __device__ __forceinline__ void wt_pass(const StepArgs& A, const StepPlanes<floa
     float y0e[E], k[S + 1][E], ys[E], kn[E];
 #pragma unroll
     for (int i = 0; i < E; ++i) {
+      // branch-free (clamped address + select): as guarded loads every element got its own branch and its own s_waitcnt - 32
+      // serialized round trips per tile and pass
       const int col = cx.col(i);
       const bool oki = rowok && col < d;
-      y0e[i] = oki ? stream_load<true>(P.y0 + row * d + col) : 0.f;
-      k[0][i] = (oki && MODE != MLP_F0) ? stream_load<true>(P.f0 + row * d + col) : 0.f;
-      if (MODE == MLP_F0 && oki && copy_b != nullptr) ((float*)copy_b)[row * d + col] = y0e[i];
+      const long long off = oki ? row * d + col : 0;
+      const float yv = stream_load<true>(P.y0 + off);
+      y0e[i] = oki ? yv : 0.f;
+      if constexpr (MODE != MLP_F0) {
+        const float fv = stream_load<true>(P.f0 + off);
+        k[0][i] = oki ? fv : 0.f;
+      } else {
+        k[0][i] = 0.f;
+      }
     }
     if (MODE == MLP_F0) {
+      if (copy_b != nullptr) {                                                       // solution[0] (after all loads were issued)
+#pragma unroll
+        for (int i = 0; i < E; ++i)
+          if (rowok && cx.col(i) < d) ((float*)copy_b)[row * d + cx.col(i)] = y0e[i];
+      }
       cx.eval(y0e, kn, sign * P.t0);
 #pragma unroll
       for (int i = 0; i < E; ++i) {
