@@ -34,6 +34,38 @@ struct WtGeom {
   static constexpr size_t lds_bytes() { return (size_t)FLOATS * sizeof(float) + 80 * sizeof(double); }
 };
 
+
+// ---- packed fp32 arithmetic (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per lane and instruction, same roundings as the
+// scalar forms; contraction is off for the whole library) for the VALU share of an evaluation: the hidden activations and the
+// stage combinations.  The transcendental v_exp_f32 / v_rcp_f32 have no packed form.
+typedef float wt_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ wt_f2 wt_tanh2(wt_f2 x) {                  // mlp_tanh on two values, operation for operation
+  const wt_f2 a = x * 2.8853900817779268f;
+  wt_f2 e;
+  e[0] = __builtin_amdgcn_exp2f(a[0]); e[1] = __builtin_amdgcn_exp2f(a[1]);
+  const wt_f2 ep = e + 1.0f;
+  wt_f2 rc;
+  rc[0] = __builtin_amdgcn_rcpf(ep[0]); rc[1] = __builtin_amdgcn_rcpf(ep[1]);
+  const wt_f2 big = 1.0f - 2.0f * rc;
+  const wt_f2 x2 = x * x;
+  const wt_f2 small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.053968254f)));
+  wt_f2 out;
+  out[0] = fabsf(x[0]) < 0.25f ? small[0] : big[0];
+  out[1] = fabsf(x[1]) < 0.25f ? small[1] : big[1];
+  return out;
+}
+template <int ACT>
+__device__ __forceinline__ void wt_act4(wt_f4& c) {
+  if constexpr (ACT == MLP_ACT_TANH) {
+    wt_f2 lo = {c[0], c[1]}, hi = {c[2], c[3]};
+    lo = wt_tanh2(lo); hi = wt_tanh2(hi);
+    c[0] = lo[0]; c[1] = lo[1]; c[2] = hi[0]; c[3] = hi[1];
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c[r] = mlp_act<ACT>(c[r]);
+  }
+}
+
 // one layer on a 16-row tile: out[mb] = act(bias + ts * tw + sum_k Wt[16 mb + .][k] * in[.][k]), weights transposed [out][in] in
 // LDS; two output blocks at a time = two independent accumulator chains (a dependent MFMA issues every 64 cycles, its latency is 40)
 template <int MB, int KB, int LW, int ACT, bool TW>
@@ -71,8 +103,7 @@ __device__ __forceinline__ void wt_layer(wt_lds wt, wt_lds bias, wt_lds tw, floa
       __builtin_amdgcn_sched_barrier(0);
     }
     if constexpr (ACT >= 0) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) { c0[r] = mlp_act<ACT>(c0[r]); c1[r] = mlp_act<ACT>(c1[r]); }
+      wt_act4<ACT>(c0); wt_act4<ACT>(c1);
     }
     out[mb] = c0; out[mb + 1] = c1;
     __builtin_amdgcn_sched_barrier(0);     // keeps the scheduler from hoisting every block's LDS reads to the top (hundreds of spills)
@@ -260,11 +291,15 @@ __device__ __forceinline__ void wt_pass(const StepArgs& A, const StepPlanes<floa
 #pragma unroll
       for (int j = 0; j < SG; ++j) bc[j] = brow[j];
 #pragma unroll
-      for (int i = 0; i < E; ++i) {
-        float kk[SG];
+      for (int i = 0; i < E; i += 2) {                                               // two elements per packed operation
+        wt_f2 acc = {k[0][i], k[0][i + 1]};
+        acc = (hs * bc[0]) * acc;
 #pragma unroll
-        for (int j = 0; j < SG; ++j) kk[j] = k[j][i];
-        ys[i] = wt_combine<SG>(y0e[i], kk, hs, bc);
+        for (int j = 1; j < SG; ++j) {
+          const wt_f2 kj = {k[j][i], k[j][i + 1]};
+          acc = acc + (hs * bc[j]) * kj;
+        }
+        ys[i] = y0e[i] + acc[0]; ys[i + 1] = y0e[i + 1] + acc[1];
       }
       cx.eval(ys, kn, sign * (P.t0 + (float)A.alpha[SG - 1] * hs));                  // rk_common.py:50, in the state dtype
 #pragma unroll
