@@ -333,7 +333,6 @@ __device__ __forceinline__ void wt_pass(const StepArgs& A, const StepPlanes<floa
 // The whole call in one launch on the wave-tile layout; control flow identical to k_persist_mlp.
 template <int DP, int HP, int ACT, int S, bool TS>
 __global__ __launch_bounds__((64 * WtGeom<DP, HP>::NW)) void k_persist_mlp_wt(PersistArgs A) {
-  using G = WtGeom<DP, HP>;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ PersistSharedT<256, 64> sh;                       // grid <= one workgroup per CU; more than 64 output times are read from memory
   Ctl& s_c = sh.c;
