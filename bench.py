@@ -63,6 +63,20 @@ def pmc_traffic(kernel_substr):
     return None, None
 
 
+def rocprof_avg_us(kernel_substr):
+    """Average duration (us) of a kernel in the newest committed rocprofv3 kernel trace of this command (profiles/r*_summary.json)."""
+    import glob
+    for f in sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_summary.json')), reverse=True):
+        try:
+            ku = json.load(open(f)).get('kernel_us', {})
+        except Exception:
+            continue
+        for k, v in ku.items():
+            if kernel_substr in k and 'avg_real_us' in v:
+                return v['avg_real_us'], os.path.relpath(f, ROOT)
+    return None, None
+
+
 def config4(batch, dim, seed_y):
     g2 = torch.Generator().manual_seed(2)
     S = torch.randn(dim, dim, generator=g2, dtype=torch.float64)
@@ -112,10 +126,9 @@ def cpu_baseline(gpu_result):
                 'state_elements_per_s': CPU_SAMPLE_BATCH * DIM / wall, 'element_steps_per_s': CPU_SAMPLE_BATCH * DIM * st_.n_attempts / wall}, st_
     try:
         res['1_thread'], st = timed(1, CPU_RUNS)
-        res['all_cores'], _ = timed(n_all, CPU_RUNS)       # (warmup_runs = 0: the first run alone exceeded 3 s and is the figure reported)
-        for nt in (8, 32):                                 # the thread counts such a port is actually run with
-            if nt < n_all:
-                res['%d_threads' % nt], _ = timed(nt, CPU_RUNS)
+        for nt in (8, 32):                                 # the thread counts such a port is actually run with.  (All %d logical CPUs of
+            if nt <= n_all:                                # the GPU box were measured once, in round 2: 81 s per call - eager ops of this
+                res['%d_threads' % nt], _ = timed(nt, CPU_RUNS)   # size do not scale to hundreds of threads; not repeated in every run.)
     finally:
         torch.set_num_threads(old)
     # numpy oracle, one core, the full shard: the parity check at BASELINE size rides on it
@@ -136,7 +149,7 @@ def cpu_baseline(gpu_result):
     return {'value': best['state_elements_per_s'], 'unit': 'state-elements/s', 'cores': best['threads'], 'kind': 'port',
             'sample': 'config 4 at batch %d x dim %d (1/%d of one GPU shard), whole odeint call, torch-CPU eager restatement of the '
                       'reference path (one tensor op per reference op, same host syncs), 1 warm-up + %d runs, median %.2f s at %d thread(s) (the '
-                      'fastest of 1 / 8 / 32 / all %d), %d attempts' % (CPU_SAMPLE_BATCH, DIM, BATCH // CPU_SAMPLE_BATCH, CPU_RUNS, best['median_s'],
+                      'fastest of 1 / 8 / 32 threads; the host has %d logical CPUs), %d attempts' % (CPU_SAMPLE_BATCH, DIM, BATCH // CPU_SAMPLE_BATCH, CPU_RUNS, best['median_s'],
                                                                        best['threads'], n_all, st.n_attempts),
             'cpu_model': cpu_model(), 'host_cpus': n_all, 'torch_threads': res,
             'numpy_oracle': {'threads': 1, 'batch': BATCH, 'wall_s': wall_np, 'state_elements_per_s': BATCH * DIM / wall_np,
@@ -212,10 +225,16 @@ def main():
     ap.add_argument('--config', type=int, default=4, choices=[1, 2, 3, 4, 5], help='BASELINE.json configuration (default: the headline, 4)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--linear-variant', type=int, default=0)
+    ap.add_argument('--transport', default='auto', choices=['auto', 'peer', 'host', 'rccl', 'hook'],
+                    help="N > 1: how the per-attempt record crosses ranks - 'peer' mailboxes in peer device memory (xGMI, one launch per "
+                         "call), 'host' a shared host segment (one launch per call), 'rccl' ncclAllGather enqueued by libmi_ode per attempt, "
+                         "'hook' torch.distributed through the callback; 'auto' tries them in that order.  What ran is in config.cross_rank")
     ap.add_argument('--fusion', default='auto', choices=['auto', 'stage', 'step', 'whole'],
                     help="'stage': one kernel per RK stage (34 planes/attempt, HBM-bound); 'step': whole attempt in one kernel; "
                          "'whole'/'auto': the whole call in one launch")
     args = ap.parse_args()
+    if args.transport != 'auto':
+        os.environ['TFDIFFEQ_AMD_XRANK'] = args.transport          # (read when the engine is created, on every rank)
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         respawn(args)
     # stdout carries exactly ONE line (the JSON result): libraries that print to file descriptor 1 (RCCL's start-up
@@ -284,6 +303,7 @@ def main():
         prof_all_ms += p[2]
         prof_n += int(p[1])
     torch.cuda.synchronize()
+    my_elapsed = time.perf_counter() - t_start                # this rank's own clock, before the closing barrier (config.per_rank)
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
@@ -293,8 +313,12 @@ def main():
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
         per_rank = [None] * world
+        att = max(int(stats.get('n_attempts', 0)), 1)
         dist.all_gather_object(per_rank, {'rank': rank, 'rows': int(y0.shape[0]), 'attempts': int(stats.get('n_attempts', 0)),
-                                          'launches': int(stats.get('n_launches', 0)), 'cross_rank': stats.get('cross_rank', '?')})
+                                          'launches': int(stats.get('n_launches', 0)), 'cross_rank': stats.get('cross_rank', '?'),
+                                          'ms_per_step': 1e3 * my_elapsed / args.steps,
+                                          'us_per_attempt': 1e6 * my_elapsed / args.steps / att,
+                                          'kernel_ms_per_step': prof_last_ms / max(prof_n, 1)})
 
     if rank == 0:
         n_elem_rank = int(y0.numel())
@@ -309,7 +333,7 @@ def main():
         all_ms = prof_all_ms / max(prof_n, 1)
         cfg = {'workload': desc + '; one odeint call per step; rows per GPU %d, global %d' % (int(y0.shape[0]), rows_global),
                'parallelism': 'batch-sharded x%d (%s scaling)' % (n_gpus, args.scaling) if args.config == 4 else 'single GPU',
-               'rccl_ranks': n_gpus if use_dist else 0, 'cross_rank': stats.get('cross_rank', 'single rank'),
+               'rccl_ranks': n_gpus if use_dist else 0, 'cross_rank': stats.get('cross_rank', 'single rank'), 'transport_requested': args.transport,
                'preheat_calls': PREHEAT_CALLS, 'attempts_per_step': attempts, 'accepted': int(stats.get('n_accepted', 0)),
                'nfe': int(stats.get('nfe', 0)), 'host_polls': int(stats.get('n_polls', 0)), 'kernel_launches': launches,
                'element_steps_per_s': n_elem_global * max(attempts, 1) * args.steps / elapsed,
@@ -341,7 +365,13 @@ def main():
                                   'v_mfma_f64_16x16x4_f64, error norms, in-kernel controller and dense output)' % nfe,
                         'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': planes * n_elem_rank * 8,
                         'hbm_GBps_at_algorithmic_bytes': (planes * n_elem_rank * 8) / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0,
-                        'avg_launch_ms': last_ms, 'launches_timed': prof_n, 'peak_source': peak_src}
+                        'avg_launch_ms': last_ms, 'launches_timed': prof_n, 'peak_source': peak_src,
+                        'frac_source': 'HIP events around the launch, inside this run (achieved = algorithmic flops / avg_launch_ms)'}
+                rp_us, rp_src = rocprof_avg_us('k_persist_linear_mfma<double, 128, 6')
+                if rp_us:                                       # the committed profiler pass of the same command (clocks ~2.5 % lower under the profiler)
+                    roof['frac_rocprof'] = flops / (rp_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS
+                    roof['rocprof_avg_launch_ms'] = rp_us * 1e-3
+                    roof['rocprof_source'] = rp_src
             elif step_fused:
                 flops = 6 * 2 * DIM * n_elem_rank
                 ach = flops / (last_ms * 1e-3) / 1e12 if last_ms > 0 else 0.0
@@ -388,6 +418,7 @@ def main():
                 stage_roof = {'bound': 'hbm', 'achieved': s_ach, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s', 'frac': s_ach / HBM_PEAK_GBS,
                               'traffic': traffic, 'traffic_source': src,
                               'kernel': 'k_stage_linear_mfma<double,128,6,LAST_FSAL> (Dopri5 stage 6 + error norms), options fusion=stage',
+                              'measured': 'OUTSIDE the timed region: 2 + 5 extra odeint calls with the per-stage schedule after the timed steps',
                               'algorithmic_bytes_per_launch': bytes_last, 'avg_launch_ms': s_last_ms, 'launches_timed': s_n,
                               'all_stage_kernels_GBps': (bytes_attempt / (s_all_ms * 1e-3) / 1e9) if s_all_ms > 0 else 0.0,
                               'ms_per_step_with_this_schedule': 1e3 * t_s / 5}

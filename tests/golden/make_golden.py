@@ -583,7 +583,26 @@ def gen_detest():
     print('detest: %d problems captured, skipped: %s' % (len([k for k in out if k.endswith('_runs')]), skipped))
 
 
+def gen_f32_runs():
+    """Round 3: float32 whole runs of the catalogue systems (the fp64 fixtures' inputs, cast) - the fp32 parity bands of
+    tests/golden/fp32_bands.json are anchored on these."""
+    def inputs(name):
+        d = np.load(os.path.join(HERE, name + '.npz'), allow_pickle=False)
+        return d['y0'].astype(np.float32), d['t']
+    y0, t = inputs('run_lorenz_b64_dopri5')
+    run_case('run_lorenz_b64_dopri5_f32', rhs_lorenz(), y0, t, 'dopri5', rtol=1e-4, atol=1e-6)
+    y0, t = inputs('run_lv_b32_dopri5')
+    run_case('run_lv_b32_dopri5_f32', rhs_lv(), y0, t, 'dopri5', rtol=1e-4, atol=1e-6)
+    d = np.load(os.path.join(HERE, 'run_linear_b48_d16_dopri5.npz'), allow_pickle=False)
+    W = np.asarray(json.loads(str(d['meta']))['rhs_params']['W'], dtype=np.float32)
+    run_case('run_linear_b48_d16_dopri5_f32', rhs_linear(W), d['y0'].astype(np.float32), d['t'], 'dopri5', rtol=1e-4, atol=1e-6)
+    run_case('run_lv_b32_bosh3_f32', rhs_lv(), inputs('run_lv_b32_dopri5')[0], np.array([0., 0.25]), 'bosh3', rtol=1e-3, atol=1e-5)
+
+
 if __name__ == '__main__':
+    if '--f32-only' in sys.argv:
+        gen_f32_runs()
+        sys.exit(0)
     if '--detest-only' in sys.argv:
         gen_detest()
         sys.exit(0)
@@ -599,3 +618,4 @@ if __name__ == '__main__':
     gen_adams()
     gen_fixed_grids()
     gen_detest()
+    gen_f32_runs()

@@ -25,6 +25,11 @@ FUSED_FORWARD = True          # the forward solve under odeint_adjoint also take
 _ENGINES = {}
 
 
+class HandoffTimeout(RuntimeError):
+    """The fused adjoint kernel's in-kernel grid hand-off timed out (the GPU is shared with another persistent kernel).  Nothing
+    was committed: the caller may take the generic path.  Every other native failure propagates."""
+
+
 def _flatten(seq):
     flat = [p.reshape(-1) for p in seq]
     return torch.cat(flat) if len(flat) > 0 else torch.tensor([])
@@ -87,7 +92,7 @@ class _FusedAdjointEngine(object):
         del keep
         if rc != 0:
             if rc & N.ST_SYNC_TIMEOUT:
-                raise RuntimeError(N.status_message(rc))
+                raise HandoffTimeout(N.status_message(rc))
             msg = N.status_message(rc)
             if rc & N.ST_MAX_STEPS:
                 msg = 'max_num_steps exceeded ({}>={})'.format(self.desc.max_num_steps, self.desc.max_num_steps)
@@ -183,6 +188,16 @@ class _TupleModule(torch.nn.Module):
         return (self.base_func(t, y[0]),)
 
 
+def _count_nfe(func, n):
+    """Add kernel-side evaluations of f to the wrapped module's `nfe` counter, when it keeps one (models.ODEFunc)."""
+    base = getattr(func, 'base_func', func)
+    if hasattr(base, 'nfe'):
+        try:
+            base.nfe += int(n)
+        except Exception:
+            pass
+
+
 class _OdeintAdjointMethod(torch.autograd.Function):
 
     @staticmethod
@@ -198,6 +213,8 @@ class _OdeintAdjointMethod(torch.autograd.Function):
                 if mlp is not None and y0[0].is_cuda and mlp.supports(y0[0]):
                     fwd, state = mlp, y0[0]
             ans = odeint(fwd, state, t, rtol=cfg['rtol'], atol=cfg['atol'], method=cfg['method'], options=cfg['options'])
+            if fwd is not func:                          # f ran inside the kernel: keep the module's evaluation counter honest
+                _count_nfe(func, odeint.last_stats.get('nfe', 0))       # (dense_odenet.py:38, 78: users log odefunc.nfe)
             if isinstance(ans, torch.Tensor):
                 ans = (ans,)
         ctx.save_for_backward(t, flat_params, *ans)
@@ -214,8 +231,9 @@ class _OdeintAdjointMethod(torch.autograd.Function):
         if plan is not None:
             try:
                 return _OdeintAdjointMethod._fused_backward(plan, func, t, flat_params, ans, grad_output, like)
-            except RuntimeError as e:                    # the in-kernel hand-off timed out (the GPU is shared with another
-                import warnings                          # persistent kernel): nothing was committed, take the generic path
+            except HandoffTimeout as e:                  # the in-kernel hand-off timed out (the GPU is shared with another
+                import warnings                          # persistent kernel): nothing was committed, take the generic path.
+                                                         # (Only that: any other native / HIP failure propagates.)
                 warnings.warn('fused adjoint kernel unavailable (%s): falling back to the plane-kernel path' % e)
         odeint_adjoint.last_backward_stats = {'engine': 'plane kernels'}
         return _OdeintAdjointMethod._generic_backward(func, cfg, n_tensors, t, flat_params, ans, grad_output, f_params, like)
@@ -266,6 +284,7 @@ class _OdeintAdjointMethod(torch.autograd.Function):
                 time_vjps.append(dLd_cur_t.reshape(1))
                 adj_y, adj_time, theta = eng.segment(mlp, ans[0][i], adj_y, adj_time, theta, float(t[i]), float(t[i - 1]))
                 segs.append(eng.stats.as_dict())
+                _count_nfe(func, segs[-1].get('nfe', 0))
                 adj_y = adj_y + g_out[i - 1]
             time_vjps.append(adj_time.reshape(1))
             time_vjps = torch.cat(time_vjps[::-1]).to(dtype=t.dtype, device=t.device)

@@ -143,6 +143,11 @@ static int adj_launch(mi_ode_adjoint* h, const mi_ode_rhs* rhs, int mode, const 
       rhs->w[2] == nullptr) {
     mi_set_error("fused adjoint: rhs must be the MLP-tanh descriptor the handle was created for"); return MI_ODE_E_INVALID;
   }
+  if (rhs->scalars[1] != 0.0) {                  // (mi_ode_rhs carries no dim: this is the one shape mismatch the descriptor can show)
+    mi_set_error("fused adjoint: the kernel covers the time-independent network only (rhs.scalars[1] != 0: w[0] is [dim + 1, hidden] - "
+                 "adj_t has a real derivative there); use the generic adjoint");
+    return MI_ODE_E_INVALID;
+  }
   MI_HIP(hipStreamSynchronize(st));              // the pinned argument block may still be in flight from a previous call
   AdjArgs& A = *h->args_host;
   memset(&A, 0, sizeof(A));

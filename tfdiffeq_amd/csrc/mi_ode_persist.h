@@ -187,6 +187,7 @@ struct PersistSharedT {
   PersistPub pub;
   AttemptState st;                                            // MFMA kernel: the loop's scalar state rests here between attempts
   double red[80];
+  double coef[kLinCoefMax];                                   // linear tile kernels: dt * tableau products of the attempt (LinCoef)
   double vals[5][MAXG];                                       // every workgroup's record, staged for the fixed-order fold
   double tout[TOUT];                                          // the requested output times, when they fit
   double xr[6][kXMaxWorld + 1];                               // cross-rank hand-off: every rank's record (+ one staging column)
@@ -661,7 +662,18 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     P.j_lo = uniform_i(sh.pub.emit_lo); P.j_hi = uniform_i(sh.pub.emit_hi);
     Acc acc;
     MI_TICK(ta0);
-    lin_attempt_pass<T, D, S, TS, true>(A.s, P, cx, acc, t_out);
+#ifdef MI_TRACE
+    if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256) && gen == 3u) { cx.tr = (long long*)(A.s.partials + 8192) + (threadIdx.x ? 256 : 0); cx.tn = 0; }
+    else cx.tr = nullptr;
+#endif
+    lin_attempt_pass<T, D, S, TS, true>(A.s, P, cx, acc, t_out, (T*)sh.coef);
+#ifdef MI_TRACE
+    if (cx.tr != nullptr) {
+      for (int q = 0; q + 3 < cx.tn && q < 4 * 14; q += 4)
+        printf("[trace] wave %d eval %2d: write+barrier %5lld  mfma %5lld  barrier2 %5lld  | since prev eval end %5lld\n", (int)threadIdx.x >> 6, q / 4,
+               cx.tr[q + 1] - cx.tr[q], cx.tr[q + 2] - cx.tr[q + 1], cx.tr[q + 3] - cx.tr[q + 2], q ? cx.tr[q] - cx.tr[q - 1] : 0LL);
+    }
+#endif
     MI_TICK(ta1);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);                   // (its barriers also fence the reads of sh.pub above)
     MI_TICK(ta2);

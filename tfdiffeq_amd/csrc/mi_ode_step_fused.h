@@ -340,7 +340,17 @@ struct LinCtx {
   T bf[KS];                                                  // are never loaded or stored; W rows / columns >= d are zero, so the padding
   T bias_v, sign;                                            // contributes exact zeros to every product, sum and norm)
   bool has_bias;
+  bool plain;                                                // no bias, forward time: k is the accumulator as it is (the bias add and
+                                                             // the sign product are exact no-ops then; skipping them saves 16 vector
+                                                             // instructions per evaluation that the matrix pipe would wait for)
   T* s_ys;                                                   // [R_][LD]
+#ifdef MI_TRACE
+  long long* tr = nullptr;                                   // timeline of rhs_eval (tuning aid): 4 stamps per evaluation
+  int tn = 0;
+  __device__ __forceinline__ void stamp() { if (tr != nullptr && tn < 256) tr[tn++] = (long long)__builtin_readcyclecounter(); }
+#else
+  __device__ __forceinline__ void stamp() {}
+#endif
 
   __device__ __forceinline__ void init(const RhsParams& rhs, T* lds, int dim) {
     const int tid = threadIdx.x;
@@ -354,6 +364,7 @@ struct LinCtx {
     has_bias = bias != nullptr;
     bias_v = (has_bias && colok) ? bias[col] : (T)0;
     sign = (T)rhs.sign;
+    plain = bias == nullptr && rhs.sign == 1.0;
     s_ys = lds;
   }
   __device__ __forceinline__ int row_of(int i) const { return TR::acc_row(lane, i); }
@@ -361,9 +372,11 @@ struct LinCtx {
   // f(ys) for the tile: ys (this thread's 4 accumulator-layout elements) -> LDS -> barrier -> KS MFMA steps against
   // the resident W slice -> k (same layout, reversed-time sign applied) -> barrier (every wave is done with the tile)
   __device__ __forceinline__ void rhs_eval(const T (&ys)[4], T (&kn)[4]) {
+    stamp();
 #pragma unroll
     for (int i = 0; i < 4; ++i) s_ys[TR::acc_row(lane, i) * LD + col] = ys[i];
     if (!(MI_ABL & 4)) lds_barrier();
+    stamp();
     acc_t c0 = {0, 0, 0, 0};
     const T* ap = s_ys + li * LD + lg * KS;
 #if (MI_ABL & 1)
@@ -376,15 +389,48 @@ struct LinCtx {
       for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], bf[m * VEC + v], c0);
     }
 #endif
+    stamp();
+    if (plain) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      T k_ = c0[i];
-      if (has_bias) k_ = k_ + bias_v;
-      kn[i] = sign * k_;
+      for (int i = 0; i < 4; ++i) kn[i] = c0[i];
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        T k_ = c0[i];
+        if (has_bias) k_ = k_ + bias_v;
+        kn[i] = sign * k_;
+      }
     }
-    if (!(MI_ABL & 4)) lds_barrier();
+    if (!(MI_ABL & 4)) lds_barrier();    stamp();
   }
 };
+
+// dt * coefficient products of an attempt, staged in LDS once per pass: (T)dt * (T)c, the very products step_combine /
+// step_finish form.  Rows of beta back to back (row s at s(s-1)/2, s = 1..S), then c_error, then c_mid.  Reading one back is
+// an LDS instruction; forming it in place is a v_mul_f64 plus the scalar-register traffic of the tableau (the ~35 entries do
+// not fit the SGPR file next to everything else: v_readlane reloads) per use and tile - and on this part every vector
+// instruction of either wavefront of a SIMD takes its issue time away from the matrix pipe (scripts/micro/mfma_pair.hip).
+template <int S>
+struct LinCoef {
+  static constexpr int kErr = S * (S + 1) / 2, kMid = kErr + S + 1, kCount = kMid + S + 1;
+  static constexpr int row(int s) { return s * (s - 1) / 2; }
+};
+constexpr int kLinCoefMax = 128;                             // >= LinCoef<13>::kCount = 119
+
+template <typename T, int S>
+__device__ __forceinline__ void lin_fill_coef(const StepArgs& A, T hs, T* coef) {
+  using CF = LinCoef<S>;
+  for (int q = threadIdx.x; q < CF::kCount; q += blockDim.x) {
+    double c;
+    if (q < CF::kErr) {
+      int s_ = 1;
+      while (CF::row(s_ + 1) <= q) ++s_;
+      c = A.beta[s_ - 1][q - CF::row(s_)];
+    } else if (q < CF::kMid) c = A.e[q - CF::kErr];
+    else c = A.cmid[q - CF::kMid];
+    coef[q] = hs * (T)c;
+  }
+}
 
 // SC0: read the streamed state with workgroup-scope (sc0, L1-bypassing) loads - needed when the kernel outlives an
 // attempt (whole-integration kernel: a plane is rewritten and re-read inside one launch)
@@ -397,9 +443,12 @@ __device__ __forceinline__ T stream_load(const T* p) {
 // One adaptive attempt over this workgroup's tiles (tile = blockIdx.x, + gridDim.x, ...).
 template <typename T, int D, int S, bool TS, bool SC0>
 __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPlanes<T, S>& P, LinCtx<T, D>& cx, Acc& acc,
-                                                 const double* t_out) {
+                                                 const double* t_out, T* coef /* LDS, kLinCoefMax */) {
   constexpr int R_ = LinCtx<T, D>::R_;
+  using CF = LinCoef<S>;
   const long long ntiles = (A.batch + R_ - 1) / R_;
+  lin_fill_coef<T, S>(A, P.hs, coef);
+  lds_barrier();
   T y0n[4], f0n[4];                                          // prefetched next tile (accumulator layout)
   auto fetch = [&](long long t_i) {
 #pragma unroll
@@ -414,10 +463,6 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
 
   for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
     const long long row0 = tile_i * R_;
-    // keep the ~35 dt*coefficient products out of the register file: without this LICM hoists them out of the
-    // tile loop (fp64 has no scalar ALU, so each product would pin a VGPR pair for the whole kernel)
-    T hs = P.hs;
-    asm volatile("" : "+v"(hs));
     T y0e[4], k[S + 1][4], ys[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { y0e[i] = y0n[i]; k[0][i] = f0n[i]; }
@@ -425,16 +470,35 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
 
     auto stage = [&](auto sg_c) {
       constexpr int SG = decltype(sg_c)::value;
+      T cb[SG];                                              // dt * beta_{SG, j}: step_combine's products, from the table
+#pragma unroll
+      for (int j = 0; j < SG; ++j) cb[j] = coef[CF::row(SG) + j];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        T kk[SG];
+        T a_ = cb[0] * k[0][i];                              // misc._scaled_dot_product order (rk_common.py:51)
 #pragma unroll
-        for (int j = 0; j < SG; ++j) kk[j] = k[j][i];
-        ys[i] = (MI_ABL & 2) ? y0e[i] + hs * kk[SG - 1] : step_combine<T, SG>(y0e[i], kk, hs, A);
+        for (int j = 1; j < SG; ++j) a_ = a_ + cb[j] * k[j][i];
+        ys[i] = y0e[i] + a_;
       }
       cx.rhs_eval(ys, k[SG]);
     };
     for_stages<1, S>(stage);
+    const bool need_mid = !TS && P.j_hi > P.j_lo;            // (wave-uniform: an output time falls into this attempt)
+    T err4[4], ym4[4];                                       // rk_common.py:60 / dopri5.py:42: step_finish's operations, one table
+#pragma unroll                                               // entry at a time (the coefficients are vector registers now)
+    for (int j = 0; j <= S; ++j) {
+      const T ce = coef[CF::kErr + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) err4[i] = (j == 0) ? ce * k[0][i] : err4[i] + ce * k[j][i];
+    }
+    if (need_mid) {
+#pragma unroll
+      for (int j = 0; j <= S; ++j) {
+        const T cm = coef[CF::kMid + j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ym4[i] = (j == 0) ? cm * k[0][i] : ym4[i] + cm * k[j][i];
+      }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = row0 + cx.row_of(i);
@@ -442,8 +506,8 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
         T kk[S + 1];
 #pragma unroll
         for (int j = 0; j <= S; ++j) kk[j] = k[j][i];
-        T err, ymid;
-        step_finish<T, S>(y0e[i], kk, hs, A, err, ymid, !TS && P.j_hi > P.j_lo);
+        const T err = err4[i];
+        const T ymid = need_mid ? y0e[i] + ym4[i] : y0e[i];
         const long long idx = row * cx.d + cx.col;
         if (!(MI_ABL & 8) || err == (T)123.456) {
           P.y1[idx] = ys[i];
@@ -543,7 +607,7 @@ __global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
   LinCtx<T, D> cx;
   cx.init(A.rhs, s_ys, A.dim);
   Acc acc;
-  lin_attempt_pass<T, D, S, TS, false>(A, P, cx, acc, A.t_out);
+  lin_attempt_pass<T, D, S, TS, false>(A, P, cx, acc, A.t_out, (T*)(red + 80));
   finish_attempt(A, acc, red);
 }
 
@@ -638,7 +702,7 @@ __global__ __launch_bounds__(D * 4) void k_fixed_linear_mfma(FixedArgs A) {
 
 template <typename T, int D>
 constexpr size_t step_linear_lds_bytes() {
-  return (size_t)16 * (D + MfmaTraits<T>::VEC) * sizeof(T) + 80 * sizeof(double);
+  return (size_t)16 * (D + MfmaTraits<T>::VEC) * sizeof(T) + (80 + kLinCoefMax) * sizeof(double);     // stage tile | red | coefficient table
 }
 
 }  // namespace mi

@@ -48,29 +48,26 @@ class ODEFunc(nn.Module):
 
     def device_rhs(self):
         """The fused-kernel descriptor of this network, or None if the fused MLP kernel does not cover it.
-        ONE descriptor per module: its [in, out] weight copies are refreshed in place when a parameter changed
-        (optimizer step, load_state_dict, .to()), so the cached engine - keyed on those buffers - keeps being hit."""
+        ONE descriptor per module; its [in, out] weight copies are refreshed IN PLACE on every call (six small device copies), so
+        the cached engine - keyed on those buffers - keeps being hit and the kernels never see stale weights.  (A version stamp
+        cannot decide "unchanged": `p.data -= lr * p.grad`, `p.data.clamp_()` and friends bump no version counter and keep
+        data_ptr - hand-written SGD and weight clipping look exactly like that.)"""
         if self.non_linearity_name not in _rhs.MLP.ACTIVATIONS:
             return None
         layers = (self.fc1, self.fc2, self.fc3)
-        stamp = tuple((l.weight._version, l.bias._version, l.weight.data_ptr(), l.bias.data_ptr(), l.weight.device, l.weight.dtype)
-                      for l in layers)
         cached = getattr(self, '_fused_rhs', None)
-        if cached is not None and cached[0] == stamp:
-            return cached[1]
         with torch.no_grad():
             if cached is not None and all(w.device == l.weight.device and w.dtype == l.weight.dtype and w.shape == l.weight.t().shape
-                                          for w, l in zip(cached[1].Ws, layers)):
-                for w, b, l in zip(cached[1].Ws, cached[1].bs, layers):      # same storage: engines created on it stay valid
+                                          for w, l in zip(cached.Ws, layers)):
+                for w, b, l in zip(cached.Ws, cached.bs, layers):            # same storage: engines created on it stay valid
                     w.copy_(l.weight.t())
                     b.copy_(l.bias)
-                desc = cached[1]
-            else:
-                desc = _rhs.MLP(self.fc1.weight.detach().t().contiguous(), self.fc1.bias.detach().clone(),
-                                self.fc2.weight.detach().t().contiguous(), self.fc2.bias.detach().clone(),
-                                self.fc3.weight.detach().t().contiguous(), self.fc3.bias.detach().clone(),
-                                activation=self.non_linearity_name, time_dependent=self.time_dependent)
-        object.__setattr__(self, '_fused_rhs', (stamp, desc))
+                return cached
+            desc = _rhs.MLP(self.fc1.weight.detach().t().contiguous(), self.fc1.bias.detach().clone(),
+                            self.fc2.weight.detach().t().contiguous(), self.fc2.bias.detach().clone(),
+                            self.fc3.weight.detach().t().contiguous(), self.fc3.bias.detach().clone(),
+                            activation=self.non_linearity_name, time_dependent=self.time_dependent)
+        object.__setattr__(self, '_fused_rhs', desc)
         return desc
 
 
@@ -114,6 +111,8 @@ class ODEBlock(nn.Module):
             func = fused if (fused is not None and fused.supports(x_aug)) else self.odefunc
             with torch.no_grad():
                 out = odeint(func, x_aug, integration_time, **kw)                           # :184-186
+            if func is fused:                                    # f ran inside the kernel: the counter the reference exposes
+                self.odefunc.nfe += int(odeint.last_stats.get('nfe', 0))                    # (:38, :78, :147) stays meaningful
         if eval_times is None:
             return out[1]                                        # :188-189
         return out

@@ -182,11 +182,14 @@ class _FusedEngine(object):
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=process_group)
                 return int(flag.item()) == 1
 
-            def selftest_and_enable():
+            def selftest_and_enable(have=True):
                 # every rank tests the hand-off; it is used only if ALL ranks saw all peers (a rank on another node, or a failed
-                # mapping, turns it off for everybody)
-                with torch.cuda.device(self.device):
-                    ok = self.lib.mi_ode_xrank_selftest(self.h, self._stream()) == 0
+                # mapping, turns it off for everybody).  `have` False: this rank has nothing to test (no segment) - it still
+                # takes part in the vote, with "no": the all-reduce below is a collective, every rank of the group must enter it.
+                ok = False
+                if have:
+                    with torch.cuda.device(self.device):
+                        ok = self.lib.mi_ode_xrank_selftest(self.h, self._stream()) == 0
                 if all_agree(ok):
                     N.check(self.lib.mi_ode_xrank_enable(self.h, 1), 'mi_ode_xrank_enable')
                     return True
@@ -222,8 +225,8 @@ class _FusedEngine(object):
                 if all_agree(ok) and selftest_and_enable():
                     self.xrank = True
                     self.transport = 'in-kernel hand-off through peer device memory (xGMI mailboxes), one launch per call'
-            if adaptive and not self.xrank and self._xr is not None and 'host' in allow:
-                if selftest_and_enable():
+            if adaptive and not self.xrank and 'host' in allow:   # (group-uniform condition: self._xr may be None on ONE rank only)
+                if selftest_and_enable(self._xr is not None):
                     self.xrank = True
                     self.transport = 'in-kernel hand-off through a shared host segment, one launch per call'
 
