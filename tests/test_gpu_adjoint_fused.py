@@ -15,6 +15,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.bands import assert_scalar
+
 pytestmark = pytest.mark.gpu
 
 
@@ -229,9 +231,9 @@ def test_fused_adjoint_gradients_against_autograd_through_the_restatement():
     sol = odeint_adjoint(func, yi, torch.tensor([0.0, 1.0]), rtol=1e-6, atol=1e-6, method='dopri5')
     (sol[1] * w.to(dev())).sum().backward()
     assert odeint_adjoint.last_backward_stats['engine'].startswith('fused')
-    assert _rel(yi.grad.cpu().double(), y64.grad) < 2e-4
-    for pg, pc in zip(func.parameters(), cpu64.parameters()):
-        assert _rel(pg.grad.cpu().double(), pc.grad) < 2e-4
+    assert_scalar(_rel(yi.grad.cpu().double(), y64.grad), 'fused_adjoint_vs_fp64_autograd/tol1e-6/dL_dy0')
+    for i, (pg, pc) in enumerate(zip(func.parameters(), cpu64.parameters())):
+        assert_scalar(_rel(pg.grad.cpu().double(), pc.grad), 'fused_adjoint_vs_fp64_autograd/tol1e-6/dL_dparam%d' % i)
 
 
 def test_cases_the_fused_kernel_does_not_cover_stay_on_the_plane_engine():
@@ -333,13 +335,13 @@ def test_default_odenet_trains_on_the_fused_kernels(act):
     assert odeint.last_stats.get('n_launches') == 1
     cpu = copy.deepcopy(block.odefunc).cpu()
     ref, _ = TC.odeint_dopri5(lambda t_, y_: cpu(t_, y_), x, [0., 1.], rtol=1e-5, atol=1e-5)
-    assert _rel(got.cpu(), ref[1].detach()) < 2e-4
+    assert_scalar(_rel(got.cpu(), ref[1].detach()), 'default_odenet_forward/%s' % act)
     out = block(x.to(dev()).requires_grad_(True))
     out.pow(2).sum().backward()
     assert odeint_adjoint.last_backward_stats['engine'].startswith('fused')
     cpu64 = copy.deepcopy(cpu).double()
     ref64, _ = TC.odeint_dopri5(lambda t_, y_: cpu64(t_, y_), x.double(), [0., 1.], rtol=1e-9, atol=1e-11)
     ref64[1].pow(2).sum().backward()
-    band = 1e-2 if act == 'relu' else 2e-3        # relu: the kinks cap what an adaptive solve of tolerance 1e-5 delivers (either path)
-    for pg, pc in zip(block.odefunc.parameters(), cpu64.parameters()):
-        assert _rel(pg.grad.cpu().double(), pc.grad) < band
+    # (relu: the kinks cap what an adaptive solve of tolerance 1e-5 delivers, on either path - its recorded bands are wider)
+    for i, (pg, pc) in enumerate(zip(block.odefunc.parameters(), cpu64.parameters())):
+        assert_scalar(_rel(pg.grad.cpu().double(), pc.grad), 'default_odenet_grads/%s/param%d' % (act, i))

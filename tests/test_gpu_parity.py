@@ -13,7 +13,8 @@ import torch
 
 from oracle import ode_numpy as O
 from oracle.rhs_numpy import make_rhs
-from tests.golden_util import load, mlp_weights, run_cases
+from tests.bands import assert_f32                  # per-case float32 bands, tests/golden/fp32_bands.json
+from tests.golden_util import load, mlp_weights, run_cases, traces_touching_the_threshold
 from tests.rhs_util import device_rhs, sine_exact, torch_rhs
 
 pytestmark = pytest.mark.gpu
@@ -227,6 +228,7 @@ def _run_product(name, engine, fusion=None):
 
 
 FUSED_RHS = ('cubic_linear', 'linear', 'lotka_volterra', 'lorenz', 'mlp_tanh')
+TRACES_TOUCHING_THE_THRESHOLD = set(traces_touching_the_threshold())     # (none of the committed fixtures, as it happens)
 
 
 def _cases(engine):
@@ -244,34 +246,47 @@ def _cases(engine):
     return out
 
 
-@pytest.mark.parametrize('fusion', ['step', 'stage', 'whole'])
-@pytest.mark.parametrize('name', _cases('fused'))
+def _fused_schedules():
+    """(fixture, schedule) pairs that have a kernel: 'whole' = the row-local whole-integration kernel (adaptive solvers on the
+    catalogue systems; for the fixed-grid linear cases 'step' already is the one-launch kernel); the MLP family has no per-stage
+    kernels.  (Round 2 parametrised the full product and skipped 14 combinations at run time.)"""
+    out = []
+    for name in _cases('fused'):
+        _, m = load(name)
+        for fusion in ('step', 'stage', 'whole'):
+            if fusion == 'whole' and (m['rhs'] not in ('cubic_linear', 'lotka_volterra', 'lorenz') or
+                                      m['method'] not in ('dopri5', 'bosh3', 'tsit5', 'dopri8', 'adaptive_heun') or
+                                      (m['rhs'] == 'cubic_linear' and len(m['rhs_params']['W']) != 2)):
+                continue
+            if m['rhs'] == 'mlp_tanh' and fusion == 'stage':
+                continue
+            out.append((name, fusion))
+    return out
+
+
+@pytest.mark.parametrize('name,fusion', _fused_schedules())
 def test_fused_engine_reproduces_reference_runs(name, fusion):
     """fusion='stage': one kernel per RK stage (34 planes per attempt); 'step': whole attempt in one kernel;
     'whole': the whole adaptive integration in one launch (tiny row-local systems)."""
     _, meta0 = load(name)
-    if fusion == 'whole' and (meta0['rhs'] not in ('cubic_linear', 'lotka_volterra', 'lorenz') or
-                              meta0['method'] not in ('dopri5', 'bosh3', 'tsit5', 'dopri8', 'adaptive_heun') or
-                              (meta0['rhs'] == 'cubic_linear' and len(meta0['rhs_params']['W']) != 2)):
-        pytest.skip('whole-integration kernel: adaptive solvers on the row-local catalogue systems')
     if fusion == 'step' and meta0['rhs'] == 'linear' and len(meta0['rhs_params']['W']) not in (2, 16, 32, 64, 128):
         fusion = 'auto'                                 # no whole-attempt kernel for the VALU fallback family
-    if meta0['method'] not in ('dopri5', 'bosh3', 'tsit5') and meta0['rhs'] == 'linear' and fusion == 'whole':
-        pytest.skip("fixed grid: 'step' already is the one-launch kernel")
-    if meta0['rhs'] == 'mlp_tanh' and fusion == 'stage':
-        pytest.skip('the MLP family only has the whole-attempt kernel')
     d, meta, sol, stats = _run_product(name, 'fused', fusion)
     f32 = d['y0'].dtype == np.float32
     assert tuple(sol.shape) == d['y'].shape and sol.dtype == (torch.float32 if f32 else torch.float64)
     if f32:
-        assert_band(sol.cpu(), d['y'], 2e-3, 2e-4, name)      # fp32 state: roundoff-limited
+        assert_f32(sol.cpu(), d['y'], 'fused/%s/%s' % (name, fusion))
     else:
         assert_band(sol.cpu(), d['y'], RTOL, ATOL, name)
     if 'trace' in d.files and not f32:
         ref_att, ref_acc = len(d['trace']), int(d['trace'][:, 2].sum())
-        # step sequences may fork where ratio ~ 1 (reduction order differs); they must stay close
-        assert abs(stats['n_attempts'] - ref_att) <= max(2, ref_att // 20), (stats, ref_att)
-        assert abs(stats['n_accepted'] - ref_acc) <= max(2, ref_acc // 20), (stats, ref_acc)
+        if name in TRACES_TOUCHING_THE_THRESHOLD:
+            # the reference's own trace passes through ratio == 1 +- 1e-9: a last-bit difference of the reduction order may flip
+            # that decision, the sequences must stay close (the only fixtures that keep this allowance)
+            assert abs(stats['n_attempts'] - ref_att) <= max(2, ref_att // 20), (stats, ref_att)
+            assert abs(stats['n_accepted'] - ref_acc) <= max(2, ref_acc // 20), (stats, ref_acc)
+        elif meta['method'] != 'tsit5':                 # (tsit5: only `refcompat` follows the reference's defective tableau, F6)
+            assert (stats['n_attempts'], stats['n_accepted']) == (ref_att, ref_acc), (stats, ref_att, ref_acc)
     assert stats['status'] == 0
 
 
@@ -285,7 +300,7 @@ def test_plane_kernel_engine_reproduces_reference_runs(name):
     f32 = d['y0'].dtype == np.float32
     assert tuple(sol.shape) == d['y'].shape
     if f32:
-        assert_band(sol.cpu(), d['y'], 2e-3, 2e-4, name)
+        assert_f32(sol.cpu(), d['y'], 'planes/%s' % name)
     elif name == 'run_sine_adams':
         # the reference's own run is 6.7e-5 off the exact solution here (its test bar is 1e-4, odeint_tests.py:86-92):
         # a step sequence that forks on a 1-ulp pow() difference moves the answer by that much
@@ -947,7 +962,7 @@ def test_wide_and_non_fsal_tableaus_on_the_row_local_kernels(problem, method):
                 assert abs(sc['n_attempts'] - sa['n_attempts']) <= 1, (sa, sc)
                 assert (a - c).abs().max().item() <= 1e-9 * scale
             else:
-                assert (a - c).abs().max().item() <= 2e-3 * scale
+                assert_f32(a.cpu(), c.cpu(), 'wide_tableau/%s/%s/%s/fused_vs_planes' % (problem, method, 'fwd' if float(tt[-1]) > 0 else 'rev'))
 
 
 _TIMEOUT_SCRIPT = r"""
@@ -1062,14 +1077,14 @@ def test_config5_mlp_fused_kernel_full_size():
     sa = dict(odeint.last_stats)
     assert sa['status'] == 0 and sa['n_launches'] == 1           # the whole call is one launch
     b = odeint(f, y0, t, rtol=1e-3, atol=1e-3, method='dopri5', options={'force_plane_kernels': True})
-    assert (a - b).abs().max().item() < 2e-4 * max(1.0, b.abs().max().item())
+    assert_f32(a.cpu(), b.cpu(), 'config5_full/fused_vs_planes')
     # tight tolerance on a slice against the numpy oracle (fp32 arithmetic on both sides)
     w = {'W1': Ws[0].numpy(), 'b1': bs[0].numpy(), 'W2': Ws[1].numpy(), 'b2': bs[1].numpy(), 'W3': Ws[2].numpy(), 'b3': bs[2].numpy()}
     fo = make_rhs('mlp_tanh', {}, dtype=np.float32, weights=w)
     ys = y0[:512]
     c = odeint(f, ys, t, rtol=1e-5, atol=1e-6, method='dopri5')
     ref = O.odeint(fo, ys.cpu().numpy(), t.numpy().astype(np.float64), rtol=1e-5, atol=1e-6, method='dopri5')
-    assert_band(c.cpu(), ref, 2e-4, 2e-5, 'fused MLP vs oracle')
+    assert_f32(c.cpu(), ref, 'config5_slice/fused_vs_oracle_tol1e-5')
     # ragged batch (not a multiple of the 32-row tile) and tsit5 (all k planes written)
     d1 = odeint(f, y0[:1000], t, rtol=1e-3, atol=1e-3, method='tsit5')
     d2 = odeint(f, y0[:1000], t, rtol=1e-3, atol=1e-3, method='tsit5', options={'force_plane_kernels': True})

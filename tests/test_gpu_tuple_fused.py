@@ -7,6 +7,7 @@ import pytest
 import torch
 
 from oracle import ode_numpy as O
+from tests.bands import assert_f32
 from tests.golden_util import load
 
 pytestmark = pytest.mark.gpu
@@ -43,10 +44,14 @@ def test_tuple_of_lorenz_states_runs_as_one_launch(dtype, method):
     assert (st['n_attempts'], st['n_accepted']) == (rst.n_attempts, rst.n_accepted) == (ps['n_attempts'], ps['n_accepted'])
     for got, pl, rf, c in zip(sol, planes, ref, comps):
         assert tuple(got.shape) == (3,) + c.shape and got.dtype == (torch.float64 if f64 else torch.float32)
-        band = 1e-9 if f64 else 2e-4
-        scale = np.abs(rf).max()
-        assert np.abs(got.cpu().numpy() - rf).max() < band * scale
-        assert float((got - pl).abs().max()) < band * scale
+        if f64:
+            scale = np.abs(rf).max()
+            assert np.abs(got.cpu().numpy() - rf).max() < 1e-9 * scale
+            assert float((got - pl).abs().max()) < 1e-9 * scale
+        else:
+            comp = 'comp%dx%d' % (c.size // 3, 3)
+            assert_f32(got.cpu(), rf, 'tuple_lorenz/%s/%s/fused_vs_oracle' % (method, comp))
+            assert_f32(got.cpu(), pl.cpu(), 'tuple_lorenz/%s/%s/fused_vs_planes' % (method, comp))
 
 
 def test_a_component_with_a_large_error_decides():
