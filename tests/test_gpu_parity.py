@@ -658,6 +658,84 @@ def test_cross_rank_handoff_two_processes_share_the_gpu(world, mode, needle):
             assert needle in r_.get('transport', needle), (o['rank'], method, r_)
 
 
+_SKEW_SCRIPT = r"""
+import os, sys, json, time
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, os.environ['REPO'])
+from tfdiffeq_amd import odeint, rhs
+rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+torch.cuda.set_device(0)
+dist.init_process_group('gloo', rank=rank, world_size=world)
+g2 = torch.Generator().manual_seed(2)
+S = torch.randn(128, 128, generator=g2, dtype=torch.float64)
+A = -0.5 * torch.eye(128, dtype=torch.float64) + 0.5 * (S - S.t()) / np.sqrt(128)
+full = torch.randn(812, 128, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+cut = [round(812 * q / world) for q in range(world + 1)]
+y = full[cut[rank]:cut[rank + 1]].cuda()
+t = torch.tensor([0., 0.4, 1.0])
+f = rhs.Linear.from_matrix(A)
+opts = {'process_group': dist.group.WORLD}
+ref = odeint(f, full.cuda(), t, rtol=1e-6, atol=1e-9, method='dopri5')[:, cut[rank]:cut[rank + 1]]
+odeint(f, y, t, rtol=1e-6, atol=1e-9, method='dopri5', options=opts)        # engine + transport set-up (collectives) happen here
+res = []
+for late in range(world):                       # every rank takes its turn at being 50 ms late with its launch
+    torch.cuda.synchronize(); dist.barrier()
+    if rank == late:
+        time.sleep(float(os.environ['SKEW_S']))
+    t0 = time.perf_counter()
+    b = odeint(f, y, t, rtol=1e-6, atol=1e-9, method='dopri5', options=opts)
+    torch.cuda.synchronize()
+    st = dict(odeint.last_stats)
+    res.append({'late': late, 'diff': float((b - ref).abs().max()), 'status': st['status'], 'launches': st['n_launches'],
+                'transport': st['cross_rank'], 'wall_ms': 1e3 * (time.perf_counter() - t0)})
+print('RESULT' + json.dumps({'rank': rank, 'res': res}), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.parametrize('mode,needle', [('peer', 'peer device memory'), ('host', 'host segment')])
+@pytest.mark.parametrize('world', [2, 4])
+def test_cross_rank_handoff_tolerates_a_late_launch(world, mode, needle):
+    """First contact with a multi-GPU node must be boring: launches of the ranks of a job are never
+    simultaneous.  Each rank in turn starts its whole-call kernel 50 ms after the others; the early ranks' persistent kernels
+    spin in the cross-rank hand-off meanwhile.  Every call must end with status 0, on the SAME one-launch transport (no time-out,
+    no fallback to a collective), with the single-rank result."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for rank in range(world):
+        env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                   REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY='0',
+                   TFDIFFEQ_AMD_XRANK=mode, SKEW_S='0.05')
+        procs.append(subprocess.Popen([sys.executable, '-c', _SKEW_SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p_ in procs:
+        try:
+            so, se = p_.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p_.returncode == 0, se[-3000:]
+        line = [ln for ln in so.splitlines() if ln.startswith('RESULT')]
+        assert line, (so[-1500:], se[-1500:])
+        outs.append(json.loads(line[-1][6:]))
+    for o in outs:
+        for r_ in o['res']:
+            assert r_['status'] == 0 and r_['launches'] == 1 and needle in r_['transport'], (o['rank'], r_)
+            assert r_['diff'] < 1e-10, (o['rank'], r_)
+            if r_['late'] != o['rank']:
+                assert r_['wall_ms'] > 25.0, ('an early rank did not wait for the late one?', o['rank'], r_)
+
+
 # ---------------------------------------------------------------------------------------------
 # whole integration in ONE launch (tiny row-local systems) vs one launch per attempt: identical bits
 # ---------------------------------------------------------------------------------------------

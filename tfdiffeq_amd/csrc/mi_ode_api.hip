@@ -525,6 +525,10 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     h->persist_spin_first = 1 << 12;              // first hand-off of a launch = residency check: ~5 ms (a poll round is ~1 us)
     if (const char* e3 = getenv("MI_ODE_PERSIST_SPIN_FIRST")) h->persist_spin_first = atoi(e3);
     if (const char* e2 = getenv("MI_ODE_PERSIST_SPIN_LIMIT")) h->persist_spin_limit = atoi(e2);  // tests: force the time-out path
+    h->persist_xspin_limit = 1 << 22;             // cross-rank part: ~10 s (a poll round is ~2.5 us) - launch skew between the ranks of a job is
+                                                  // normal (measured tolerance test: tests/test_gpu_parity.py, 50 ms per rank); a dead peer still ends the wait
+    if (const char* e4 = getenv("MI_ODE_PERSIST_XSPIN_LIMIT")) h->persist_xspin_limit = atoi(e4);
+    if (getenv("MI_ODE_PERSIST_SPIN_LIMIT") && !getenv("MI_ODE_PERSIST_XSPIN_LIMIT")) h->persist_xspin_limit = h->persist_spin_limit;
   }
   // controller / dense-output parameters
   h->cp.rtol = desc->rtol; h->cp.atol = desc->atol;
@@ -777,6 +781,7 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   A.seg_tol = h->nseg > 1 && h->d.seg_tolerances ? 1 : 0;
   for (int k = 0; k < h->nseg; ++k) { A.seg_rtol[k] = h->d.seg_rtol[k]; A.seg_atol[k] = h->d.seg_atol[k]; }
   A.spin_limit = h->persist_spin_limit;
+  A.xspin_limit = h->persist_xspin_limit;
   A.spin_first = h->persist_spin_first < h->persist_spin_limit ? h->persist_spin_first : h->persist_spin_limit;
   // back-off before the first poll (units of 64 clocks): a failed poll round costs G x G record loads on the fabric, so
   // wait about as long as the publish needs to become visible (measured: G=16 best at <= 24, G=256 best at 32)
@@ -856,6 +861,7 @@ extern "C" int mi_ode_xrank_selftest(mi_ode_handle h, void* stream) {
   memset(&A, 0, sizeof(A));
   A.xrank = h->xrank_dev; A.xpeers = h->xpeer_tab_dev; A.gbuf = h->gbuf; A.world = (int)h->d.world_size; A.rank = (int)h->d.rank;
   A.spin_limit = A.spin_first = 1 << 20;        // several seconds: covers module-load skew between the ranks
+  A.xspin_limit = 1 << 22;
   h->xrank_tests += 64u;
   A.seq_base = 0xF0000000u + (h->xrank_tests & 0x0FFFFFFu);   // disjoint from the numbers of real calls
   int* res_dev = (int*)h->ticket + 8;

@@ -67,6 +67,7 @@ struct mi_ode_solver {
   int persist_grid;
   int persist_sleep_first, persist_sleep_poll;   // hand-off back-off (units of 64 clocks)
   int persist_spin_limit;     // bound on the polls of one hand-off
+  int persist_xspin_limit;    // ... of its cross-rank part (seconds: a rank that launches late is normal)
   int persist_spin_first;     // ... of the first hand-off of a launch (residency check)
   int init_tiles16;           // 1: before_integrate runs on the 16-row tile kernels (k_init_linear_mfma), grid = step_grid
   double* xrank_dev;          // device view of desc.xrank_host (registered), or null

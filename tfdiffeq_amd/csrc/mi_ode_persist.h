@@ -51,6 +51,8 @@ struct PersistArgs {
   unsigned seq_base;           // sequence numbers of this call's hand-offs are seq_base + 1, + 2, ... (never 0)
   int n_out;                   // T - 1
   int spin_limit;              // bound on the spin iterations of one hand-off
+  int xspin_limit;             // ... of the CROSS-RANK part of a hand-off: ranks of a job never launch at the same instant (a late rank is
+                               // normal, not a fault), so this bound is seconds, not the fraction of a second workgroups of ONE device get
   int spin_first;              // ... of the FIRST grid hand-off of a launch: the residency check (see grid_reduce_rank)
   int sleep_first, sleep_poll; // back-off (units of 64 clocks): before the first poll / between polls
   // tuple states (mi_ode_desc.n_segments > 1): component k owns workgroups seg_blk[k] .. seg_blk[k + 1] - 1 and seg_rows[k] rows
@@ -267,7 +269,7 @@ __device__ __forceinline__ void cross_rank(const PersistArgs& A, SH& sh, unsigne
       int spins = 0;
       while (!ll_load_record(poll, seq, v)) {
         for (int i = 0; i < 4; ++i) __builtin_amdgcn_s_sleep(1);
-        if (++spins > A.spin_limit) { sh.ok = 0; break; }
+        if (++spins > A.xspin_limit) { sh.ok = 0; break; }
       }
 #pragma unroll
       for (int i = 0; i < 6; ++i) sh.xr[i][threadIdx.x] = v[i];
@@ -286,13 +288,13 @@ __device__ __forceinline__ void cross_rank(const PersistArgs& A, SH& sh, unsigne
   }
   if (threadIdx.x == 0) {
     double v[5], nv = 0.0;
-    int spins = 0;
+    long long spins = 0;
     for (;;) {
       if (load_record_sc1(g, seq, v) && load_ll_sc1(g + 10, seq, nv)) { n_tot = nv; break; }
       double dummy;
       if (load_ll_sc1(g, bad, dummy)) { sh.ok = 0; break; }
       __builtin_amdgcn_s_sleep(2);
-      if (++spins > 8 * A.spin_limit) { sh.ok = 0; break; }    // (outlasts the gateway's own bounded wait: it reports failures)
+      if (++spins > 8LL * A.xspin_limit) { sh.ok = 0; break; }  // (outlasts the gateway's own bounded wait: it reports failures)
     }
 #pragma unroll
     for (int i = 0; i < 5; ++i) r[i] = v[i];
