@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI_ODE_ABI_VERSION 8
+#define MI_ODE_ABI_VERSION 9
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -169,6 +169,20 @@ typedef struct mi_ode_desc {
   int32_t seg_tolerances;     /* 1: seg_rtol / seg_atol hold one pair per component (dopri5.py:60-61 accepts lists); 0: rtol / atol for all */
   int64_t seg_rows[MI_ODE_MAX_SEGMENTS];
   double seg_rtol[MI_ODE_MAX_SEGMENTS], seg_atol[MI_ODE_MAX_SEGMENTS];   /* (the initial step uses rtol / atol = the first pair, dopri5.py:74) */
+  /* Fixed-grid multistep solvers (adaptive = 0; the tableau is ignored): the reference's AdamsBashforth / AdamsBashforthMoulton
+   * (fixed_adams.py:152-212) as ONE launch per mi_ode_fixed_grid_integrate[_on] call, for the row-local catalogue systems.
+   * ms_ab / ms_am / ms_am0 are HOST arrays, copied at create, holding the coefficients as the reference forms them in Python
+   * floats: ms_ab[o * 12 + j] = (1 / DIVISOR[o]) * BASHFORTH[o][j], ms_am[o * 12 + j] = (1 / DIVISOR[o + 1]) * MOULTON[o + 1][j + 1],
+   * ms_am0[o] = MOULTON[o + 1][0] / DIVISOR[o + 1], o = 0 .. 12 (rows of unused orders: zeros).  rtol / atol: the corrector's
+   * convergence test (misc.py:129-134; odeint passes ITS rtol / atol).  stats.n_rejected = steps whose corrector did not converge
+   * (the reference prints a warning for each and drops its oldest history entry, fixed_adams.py:197-200). */
+  int32_t multistep;          /* 0: none, 1: Adams-Bashforth ('explicit_adams'), 2: Adams-Bashforth-Moulton ('fixed_adams') */
+  int32_t ms_max_order;       /* <= 12 (fixed_adams.py:89) */
+  int32_t ms_max_iters;       /* corrector iterations (fixed_adams.py:90: 4) */
+  int32_t ms_min_order;       /* below it the start-up RK4 3/8 step runs (fixed_adams.py:88: 4) */
+  const double* ms_ab;
+  const double* ms_am;
+  const double* ms_am0;
 } mi_ode_desc;
 #define MI_ODE_SEGMENT_ALIGN 256
 

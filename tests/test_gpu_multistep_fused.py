@@ -1,0 +1,92 @@
+"""The fixed-grid Adams family ('explicit_adams', 'fixed_adams'; fixed_adams.py:152-212) as ONE launch for the row-local catalogue
+systems (csrc/mi_ode_adams.h) - against the fixtures captured from the reference, the numpy oracle and the per-step host loop over
+plane kernels."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import adams_numpy as OA
+from tests.golden_util import load
+from tests.rhs_util import device_rhs
+
+pytestmark = pytest.mark.gpu
+
+
+def dev():
+    return torch.device('cuda:0')
+
+
+@pytest.mark.parametrize('name', ['run_spiral_b64_explicit_adams', 'run_spiral_b64_fixed_adams'])
+def test_reference_fixtures_in_one_launch(name):
+    from tfdiffeq_amd import odeint
+    d, meta = load(name)
+    f = device_rhs(meta['rhs'], meta['rhs_params'])
+    kw = {k: meta[k] for k in ('rtol', 'atol') if meta.get(k) is not None}
+    if meta.get('options'):
+        kw['options'] = dict(meta['options'])
+    y0 = torch.tensor(d['y0'], device=dev())
+    sol = odeint(f, y0, torch.as_tensor(d['t']), method=meta['method'], **kw)
+    st = dict(odeint.last_stats)
+    assert st.get('engine', '').startswith('fused multistep') and st['n_launches'] == 1 and st['status'] == 0, st
+    assert np.abs(sol.cpu().numpy() - d['y']).max() <= 1e-12 * max(1.0, np.abs(d['y']).max())
+    # the same call on the per-step loop over plane kernels (the path every other right-hand side takes)
+    loop = odeint(f, y0, torch.as_tensor(d['t']), method=meta['method'], **dict(kw, options=dict(kw.get('options', {}), fusion='stage')))
+    assert dict(odeint.last_stats).get('engine', '') != 'fused multistep kernel (one launch)'
+    assert float((sol - loop).abs().max()) <= 1e-12 * max(1.0, float(loop.abs().max()))
+
+
+def _lv_np(t, y):
+    u, v = y[..., 0], y[..., 1]
+    return np.stack([1.5 * u - 1.0 * u * v, -3.0 * v + 1.0 * u * v], axis=-1)
+
+
+def _lorenz_np(t, y):
+    return np.stack([10. * (y[..., 1] - y[..., 0]), y[..., 0] * (28. - y[..., 2]) - y[..., 1], y[..., 0] * y[..., 1] - 8. / 3. * y[..., 2]], axis=-1)
+
+
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('method', ['explicit_adams', 'fixed_adams'])
+@pytest.mark.parametrize('problem,batch', [('lv', 1), ('lv', 5000), ('lorenz', 300), ('lorenz', 70000)])
+def test_against_the_numpy_oracle(problem, batch, method, dtype):
+    """Single and many workgroups (the implicit solver's convergence test is ONE decision for the whole batch: it crosses
+    workgroups through the grid hand-off), both dtypes, forward and reversed time."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(5)
+    if problem == 'lv':
+        f, fn, y0 = rhs.LotkaVolterra(1.5, 1.0, 3.0, 1.0), _lv_np, 1.0 + 0.5 * rng.uniform(size=(batch, 2))
+        t = np.linspace(0., 1.0, 41)
+    else:
+        f, fn, y0 = rhs.Lorenz(), _lorenz_np, np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((batch, 3))
+        t = np.linspace(0., 0.1, 41)
+    y0 = y0.astype(dtype)
+    tol = dict(rtol=1e-7, atol=1e-9) if dtype == np.float64 else dict(rtol=1e-4, atol=1e-6)
+    n_check = min(batch, 512)                                    # (the oracle is a Python loop: a slice of the batch is enough
+    for tt in (t, -t):                                           #  - unless the convergence decisions differ, which the counts show)
+        fo = fn if tt[-1] > 0 else (lambda t_, y_: -fn(-t_, y_))
+        sol = odeint(f, torch.tensor(y0, device=dev()), torch.tensor(tt), method=method, **tol)
+        st = dict(odeint.last_stats)
+        assert st.get('engine', '').startswith('fused multistep') and st['n_launches'] == 1 and st['status'] == 0, st
+        solver = OA.FixedAdams(lambda t_, ys: (fo(t_, ys[0]),), (y0,), implicit=(method == 'fixed_adams'), **tol)
+        ref = solver.integrate(np.abs(tt).astype(dtype))[0]
+        assert st['n_rejected'] == solver.n_not_converged, (st, solver.n_not_converged)
+        band = 1e-11 if dtype == np.float64 else 2e-5
+        got = sol.cpu().numpy()
+        assert np.abs(got[:, :n_check] - ref[:, :n_check]).max() <= band * max(1.0, np.abs(ref).max()), (problem, batch, method, dtype)
+
+
+def test_the_corrector_that_does_not_converge_is_reported_like_the_reference(capfd):
+    """max_iters = 1 with a tight tolerance: the reference prints a warning per step and drops its oldest history entry
+    (fixed_adams.py:197-200); the kernel counts the steps (stats.n_rejected), the solver prints the same warnings."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(6)
+    y0 = 1.0 + 0.5 * rng.uniform(size=(300, 2))
+    t = np.linspace(0., 1.0, 21)
+    opts = {'max_iters': 1}
+    sol = odeint(rhs.LotkaVolterra(1.5, 1.0, 3.0, 1.0), torch.tensor(y0, device=dev()), torch.tensor(t), method='fixed_adams',
+                 rtol=1e-13, atol=1e-15, options=opts)
+    st = dict(odeint.last_stats)
+    solver = OA.FixedAdams(lambda t_, ys: (_lv_np(t_, ys[0]),), (y0,), implicit=True, rtol=1e-13, atol=1e-15, max_iters=1)
+    ref = solver.integrate(t)[0]
+    assert solver.n_not_converged > 0 and st['n_rejected'] == solver.n_not_converged, (st, solver.n_not_converged)
+    assert capfd.readouterr().err.count('Functional iteration did not converge') >= st['n_rejected']
+    assert np.abs(sol.cpu().numpy() - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())

@@ -12,6 +12,7 @@
 #include "mi_ode_plane.h"
 #include "mi_ode_step_fused.h"
 #include "mi_ode_persist.h"
+#include "mi_ode_adams.h"
 #include "mi_ode_mlp.h"
 #include "mi_ode_plugin.h"
 
@@ -370,6 +371,8 @@ extern "C" int mi_ode_destroy(mi_ode_handle h) {
   if (h == nullptr) return 0;
   if (h->planes) (void)hipFree(h->planes);
   if (h->partials) (void)hipFree(h->partials);
+  if (h->adams_tab) (void)hipFree(h->adams_tab);
+  if (h->adams_res) (void)hipHostFree(h->adams_res);
   if (h->rank_rec && h->own_exchange) (void)hipFree(h->rank_rec);
   if (h->gathered && h->own_exchange) (void)hipFree(h->gathered);
   if (h->ctl) (void)hipFree(h->ctl);
@@ -455,6 +458,33 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   }
   rc = h->is_f32 ? mi_stage_geometry_f32(h) : mi_stage_geometry_f64(h);
   if (rc != 0) { delete h; return rc; }
+  if (desc->multistep != 0) {                      // fixed-grid Adams family in one launch (mi_ode_adams.h)
+    const bool rowlocal_cat = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ;
+    if (desc->adaptive || !rowlocal_cat || (desc->multistep != 1 && desc->multistep != 2) || desc->ms_ab == nullptr || desc->ms_am == nullptr ||
+        desc->ms_am0 == nullptr || desc->ms_max_order < 1 || desc->ms_max_order > kAdamsMaxOrder || desc->ms_max_iters < 1 ||
+        desc->ms_min_order < 1 || h->d.world_size > 1 || h->nseg > 1) {
+      mi_set_error("multistep: fixed grid, a row-local catalogue system, one rank, one tensor; 1 <= max_order <= %d, max_iters >= 1, coefficient tables", kAdamsMaxOrder);
+      delete h; return MI_ODE_E_INVALID;
+    }
+    const long long g = (desc->batch + 255) / 256;
+    if (desc->multistep == 2 && g > 1) {           // the corrector's convergence test couples the workgroups: they must be co-resident
+      const int cap = h->is_f32 ? mi_adams_capacity_f32(h) : mi_adams_capacity_f64(h);
+      if (g > cap || g > kPersistMaxGrid) {
+        mi_set_error("fixed_adams in one launch: %lld workgroups cannot be co-resident on this device (%d)", g, cap);
+        delete h; return MI_ODE_E_INVALID;
+      }
+    }
+    double tab[2 * 13 * 12 + 13];
+    memcpy(tab, desc->ms_ab, sizeof(double) * 13 * 12);
+    memcpy(tab + 13 * 12, desc->ms_am, sizeof(double) * 13 * 12);
+    memcpy(tab + 2 * 13 * 12, desc->ms_am0, sizeof(double) * 13);
+    hipError_t ea = hipMalloc((void**)&h->adams_tab, sizeof(tab));
+    if (ea == hipSuccess) ea = hipMemcpy(h->adams_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
+    if (ea == hipSuccess) ea = hipHostMalloc((void**)&h->adams_res, 2 * sizeof(long long), hipHostMallocDefault);
+    if (ea != hipSuccess) { mi_set_error("multistep tables: %s", hipGetErrorString(ea)); delete h; return MI_ODE_E_HIP; }
+    h->adams_res[0] = h->adams_res[1] = 0;
+    h->d.ms_ab = h->d.ms_am = h->d.ms_am0 = nullptr;   // (caller-owned host arrays: not kept)
+  }
   {   // whole-attempt fusion: row-local families and the MFMA linear family, adaptive FSAL tableaus
     const bool can = desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
                                         h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP ||
@@ -1015,7 +1045,7 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
   if (h->d.adaptive) { mi_set_error("fixed-grid call on an adaptive handle"); return MI_ODE_E_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   const bool euler = h->S == 0;
-  if (!euler && h->S != 3) { mi_set_error("fixed grid: tableau must be euler (0 rows) or rk4 3/8 (3 rows)"); return MI_ODE_E_INVALID; }
+  if (!euler && h->S != 3 && h->d.multistep == 0) { mi_set_error("fixed grid: tableau must be euler (0 rows) or rk4 3/8 (3 rows)"); return MI_ODE_E_INVALID; }
   for (int i = 1; i < T; ++i)
     if (!(t_host[i] > t_host[i - 1])) {
       if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = MI_ODE_ST_BAD_T; }
@@ -1047,6 +1077,35 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
     memset(&F, 0, sizeof(F));
     F.grid = own_grid ? h->t_out_dev + T : h->t_out_dev; F.M = (own_grid ? G : T) - 1; F.eps = eps;
     F.y0 = y0_dev; F.out = out_dev; F.t = h->t_out_dev; F.batch = h->d.batch; F.T = T; F.rk4 = euler ? 0 : 1; F.dim = (int)h->d.dim; F.rhs = h->rhs;
+    if (h->d.multistep != 0) {                     // Adams-Bashforth(-Moulton): one launch, the history in registers (mi_ode_adams.h)
+      AdamsArgs AA;
+      memset(&AA, 0, sizeof(AA));
+      AA.f = F;
+      AA.implicit = h->d.multistep == 2 ? 1 : 0; AA.max_iters = h->d.ms_max_iters; AA.max_order = h->d.ms_max_order; AA.min_order = h->d.ms_min_order;
+      AA.rtol = h->d.rtol; AA.atol = h->d.atol; AA.tab = h->adams_tab; AA.result = h->adams_res;
+      AA.p.s.partials = h->partials; AA.p.seq_base = h->seq; AA.p.nseg = 1; AA.p.world = 1;
+      AA.p.spin_limit = h->persist_spin_limit > 0 ? h->persist_spin_limit : (1 << 17);
+      AA.p.spin_first = 1 << 12; if (AA.p.spin_first > AA.p.spin_limit) AA.p.spin_first = AA.p.spin_limit;
+      AA.p.xspin_limit = AA.p.spin_limit;
+      AA.p.sleep_first = 16; AA.p.sleep_poll = 2;
+      const long long g = (h->d.batch + 255) / 256;
+      rcf = h->is_f32 ? mi_launch_adams_f32(h, AA, (int)g, st) : mi_launch_adams_f64(h, AA, (int)g, st);
+      if (rcf != 0) return rcf;
+      MI_HIP(hipStreamSynchronize(st));            // the kernel's last act: {steps without convergence, status} into pinned memory
+      h->seq += (unsigned)((long long)F.M * AA.max_iters + 16);
+      if (h->seq >= 0xE0000000u) h->seq = 0;
+      const long long steps = (own_grid ? G : T) - 1;
+      if (stats) {
+        memset(stats, 0, sizeof(*stats));
+        stats->n_attempts = stats->n_accepted = steps;
+        stats->n_rejected = h->adams_res[0];
+        stats->status = (uint32_t)h->adams_res[1];
+        stats->t = t_host[T - 1];
+        stats->n_launches = h->n_launches;
+        stats->n_polls = 1;
+      }
+      return (int)h->adams_res[1];
+    }
     if (h->family == FAM_PLUGIN) {
       rcf = h->plugin->launch_fixed(h, &F, st);
       if (rcf != 0) { mi_set_error("plugin fixed-grid kernel launch failed"); return rcf; }

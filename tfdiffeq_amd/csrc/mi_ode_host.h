@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mi_ode_dev.h"
+namespace mi { struct AdamsArgs; }
 
 namespace mi {
 struct StepArgs;
@@ -85,6 +86,8 @@ struct mi_ode_solver {
   int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation
   int nseg;                   // tuple state: components packed into the one buffer (mi_ode_desc.n_segments), 0 / 1: a single tensor
   int seg_blk[MI_ODE_MAX_SEGMENTS + 1];   // first workgroup of every component in the whole-call kernel's grid
+  double* adams_tab;          // device: the multistep coefficient tables of the descriptor (mi_ode_adams.h), or null
+  long long* adams_res;       // pinned host: {steps whose corrector did not converge, status}
   int lin_dp;                 // FAM_LINEAR_MFMA: tile width the kernels are instantiated for (16 / 32 / 64 / 128 >= dim, zero padded)
   // bookkeeping
   long long n_launches;
@@ -110,6 +113,10 @@ int mi_launch_stage_f32(mi_ode_solver* h, int mode, int nk, mi::StageArgs& A, hi
 int mi_launch_step_f64(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
 int mi_launch_step_f32(mi_ode_solver* h, mi::StepArgs& A, hipStream_t st);
 int mi_launch_fixed_f64(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
+int mi_launch_adams_f64(mi_ode_solver* h, mi::AdamsArgs& A, int grid, hipStream_t st);
+int mi_launch_adams_f32(mi_ode_solver* h, mi::AdamsArgs& A, int grid, hipStream_t st);
+int mi_adams_capacity_f64(mi_ode_solver* h);
+int mi_adams_capacity_f32(mi_ode_solver* h);
 int mi_launch_fixed_f32(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
 int mi_launch_persist_f64(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);
 int mi_launch_persist_f32(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);

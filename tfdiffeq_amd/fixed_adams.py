@@ -32,6 +32,21 @@ class AdamsBashforthMoulton(FixedGridODESolver):
         self.prev_f = collections.deque(maxlen=self.max_order - 1)
         self.prev_t = None
 
+    def _fused_multistep(self):
+        """The descriptor of the one-launch kernel (csrc/mi_ode_adams.h): the integer tables as the products the reference forms in
+        Python floats - (1 / divisor) * c_j for the predictor and for the corrector's delta, m_0 / divisor for its leading term."""
+        ab, am, am0 = [0.0] * (13 * 12), [0.0] * (13 * 12), [0.0] * 13
+        for o in range(1, 13):
+            if o < len(_BASHFORTH_COEFFICIENTS) and _DIVISOR[o] is not None:
+                for j, c in enumerate(_BASHFORTH_COEFFICIENTS[o][:12]):
+                    ab[o * 12 + j] = (1 / _DIVISOR[o]) * c
+            if o + 1 < len(_MOULTON_COEFFICIENTS) and _DIVISOR[o + 1] is not None:
+                mc = _MOULTON_COEFFICIENTS[o + 1]
+                for j, c in enumerate(mc[1:13]):
+                    am[o * 12 + j] = (1 / _DIVISOR[o + 1]) * c
+                am0[o] = mc[0] / _DIVISOR[o + 1]
+        return (2 if self.implicit else 1, self.max_order, self.max_iters, _MIN_ORDER, tuple(ab), tuple(am), tuple(am0))
+
     def _update_history(self, t, f):
         if self.prev_t is None or self.prev_t != t:
             self.prev_f.appendleft(f)

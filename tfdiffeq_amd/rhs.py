@@ -70,6 +70,11 @@ class DeviceRHS(object):
     fixed_grid_fused = True
     row_local = False             # True: runs on the one-trajectory-per-thread kernels (which also cover dopri8 / adaptive_heun)
 
+    @property
+    def multistep_fused(self):
+        """True: 'explicit_adams' / 'fixed_adams' run as one launch (csrc/mi_ode_adams.h: the row-local catalogue systems)."""
+        return bool(self.row_local) and self.kind != N.RHS_PLUGIN
+
     def supports(self, y0):
         """True when the fused kernels can take this state tensor."""
         return y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)

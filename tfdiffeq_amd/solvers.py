@@ -18,6 +18,7 @@ import os
 import collections
 import ctypes as C
 import math
+import sys
 
 import numpy as np
 import torch
@@ -97,7 +98,7 @@ class _FusedEngine(object):
     def __init__(self, device_rhs, y0, adaptive, tableau, c_mid=None, rtol=1e-7, atol=1e-9, controller=N.CTRL_MISC,
                  interp=N.INTERP_QUARTIC_MID, order=5, init_order=4, safety=0.9, ifactor=10.0, dfactor=0.2,
                  first_step=None, max_num_steps=2 ** 31 - 1, process_group=None, linear_variant=0, chunk_attempts=0,
-                 profile=False, fusion=0, seg_rows=None, seg_tols=None):
+                 profile=False, fusion=0, seg_rows=None, seg_tols=None, multistep=None):
         N.require_gpu_tensor(y0, 'y0')
         self.lib = N.load()
         self.y0 = y0.contiguous()
@@ -121,6 +122,11 @@ class _FusedEngine(object):
         d.chunk_attempts = int(chunk_attempts)
         d.profile = 1 if profile else 0
         d.fusion = {'auto': 0, 'stage': 1, 'step': 2, 'step_split': 3, 'whole': 4}.get(fusion, fusion)
+        if multistep is not None:              # fixed-grid Adams family in one launch (include/mi_ode.h: multistep): the coefficient
+            kind, max_order, max_iters, min_order, ab, am, am0 = multistep      # tables as host arrays, formed in Python floats
+            d.multistep, d.ms_max_order, d.ms_max_iters, d.ms_min_order = int(kind), int(max_order), int(max_iters), int(min_order)
+            self._ms_tabs = ((C.c_double * (13 * 12))(*ab), (C.c_double * (13 * 12))(*am), (C.c_double * 13)(*am0))
+            d.ms_ab, d.ms_am, d.ms_am0 = (C.cast(a_, C.POINTER(C.c_double)) for a_ in self._ms_tabs)
         if seg_rows is not None:               # tuple state: y0 is the packed buffer (_pack_components), one segment per component
             d.n_segments = len(seg_rows)
             for k, r in enumerate(seg_rows):
@@ -434,6 +440,10 @@ class AdaptiveStepsizeODESolver(object):
         return tuple(map(torch.stack, tuple(zip(*solution))))
 
 
+_EULER_SHAPE = collections.namedtuple('_T', 'alpha beta c_sol c_error')(alpha=[], beta=[], c_sol=[1.0], c_error=[0.0])   # (the tableau slot of a
+                                                                                       # multistep descriptor: unused by the kernel)
+
+
 class FixedGridODESolver(object):
     __metaclass__ = abc.ABCMeta
 
@@ -479,6 +489,10 @@ class FixedGridODESolver(object):
 
     _fused_tableau = None      # subclasses with a fused kernel set a _ButcherTableau here
 
+    def _fused_multistep(self):
+        """(kind, max_order, max_iters, min_order, ab, am, am0) for the one-launch multistep kernel, or None (fixed_adams.py sets it)."""
+        return None
+
     def integrate(self, t):
         """solvers.py:82-104."""
         _assert_increasing(t)
@@ -502,6 +516,28 @@ class FixedGridODESolver(object):
                 self.stats['components'] = len(rows)
                 offs = np.concatenate([[0], np.cumsum(rows)])
                 return tuple(out[:, int(o):int(o) + r].reshape((out.shape[0],) + tuple(c.shape)) for c, r, o in zip(self.y0, rows, offs[:-1]))
+        ms = self._fused_multistep() if rhs is not None else None
+        if ms is not None and getattr(rhs, 'multistep_fused', False) and self._fusion not in (1, 'stage') and not self._graph:
+            # the Adams family on a row-local catalogue system: the whole integration - history, predictor, corrector iterations and
+            # their batch-wide convergence test - in ONE launch (csrc/mi_ode_adams.h)
+            y = self.y0[0]
+            key = ('multistep', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device), ms[:4], float(self.rtol), float(self.atol))
+            try:
+                eng = _cached_engine(key, lambda: _FusedEngine(rhs, y, False, _EULER_SHAPE, rtol=self.rtol, atol=self.atol, multistep=ms))
+            except N.NativeError:
+                eng = None                            # (e.g. a batch whose workgroups cannot be co-resident): the per-step loop below
+            if eng is not None:
+                if default_grid and self.eps == 0.0:
+                    out = eng.integrate(t.to(torch.float64).numpy(), y)
+                else:
+                    time_grid = self.grid_constructor(self.func, self.y0, t)
+                    assert bool(time_grid[0] == t[0]) and bool(time_grid[-1] == t[-1])        # solvers.py:87
+                    out = eng.integrate(t.to(torch.float64).numpy(), y, grid=time_grid.to(torch.float64).numpy(), eps=float(self.eps))
+                self.stats = eng.stats.as_dict()
+                self.stats['engine'] = 'fused multistep kernel (one launch)'
+                for _ in range(int(self.stats.get('n_rejected', 0))):                         # fixed_adams.py:197-199
+                    print('Warning: Functional iteration did not converge. Solution may be incorrect.', file=sys.stderr)
+                return (out,)
         if rhs is not None and rhs.fixed_grid_fused and self._fused_tableau is not None:
             y = self.y0[0]
             key = ('fixed', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
