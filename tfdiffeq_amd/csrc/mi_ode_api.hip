@@ -512,11 +512,6 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     const bool mlp = h->family == FAM_MLP;
     h->init_tiles16 = mfma ? 1 : 0;
     long long g = (mfma || mlp) ? (long long)h->step_grid : (desc->batch + 255) / 256;
-    if (mlp && mi_mlp_wave_tile(h)) {              // 64-row workgroup tiles, one workgroup per CU (136 KB of LDS): the persistent grid walks them
-      const long long tiles = (desc->batch + 63) / 64;
-      const long long cap_wt = h->num_cus < 256 ? h->num_cus : 256;      // PersistSharedT<256, ...> stages at most 256 records
-      g = tiles < cap_wt ? tiles : cap_wt;
-    }
     const bool single = h->d.world_size <= 1 && desc->allgather == nullptr;
     if (desc->xrank_host != nullptr) {           // cross-rank hand-off segment: make it visible to this GPU
       if (h->d.world_size > kXMaxWorld || desc->xrank_bytes < mi_ode_xrank_bytes(h->d.world_size)) {

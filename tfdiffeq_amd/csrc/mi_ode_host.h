@@ -126,7 +126,6 @@ int mi_persist_capacity_f64(mi_ode_solver* h);
 int mi_persist_capacity_f32(mi_ode_solver* h);
 int mi_launch_persist_mlp_f32(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);
 int mi_persist_capacity_mlp_f32(mi_ode_solver* h);
-int mi_mlp_wave_tile(const mi_ode_solver* h);     // 1: the experimental wave-tile layout serves this handle (mi_ode_mlp_wt.h)
 int mi_launch_mlp_f32(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st);
 int mi_stage_geometry_f64(mi_ode_solver* h);
 int mi_stage_geometry_f32(mi_ode_solver* h);

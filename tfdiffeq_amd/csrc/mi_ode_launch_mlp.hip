@@ -4,9 +4,6 @@
 #include "mi_ode_host.h"
 // ---- fused MLP kernels (fp32 only) ---------------------------------------------------------------------------
 #include "mi_ode_mlp.h"
-#ifdef MI_ODE_EXPERIMENTAL_WT      // make WT=1: the experimental wave-tile layout of the whole-call kernel (opt-in at run time too)
-#include "mi_ode_mlp_wt.h"
-#endif
 
 namespace {
 int mlp_activation(const mi_ode_solver* h) { return (int)h->rhs.s[0]; }      // mi_ode_rhs.scalars[0]: 0 tanh, 1 relu, 2 softplus
@@ -67,31 +64,7 @@ const void* persist_mlp_fn(const mi_ode_solver* h) {
     default: return nullptr;
   }
 }
-#ifdef MI_ODE_EXPERIMENTAL_WT
-// experimental wave-tile layout (mi_ode_mlp_wt.h): opt-in through mi_ode_rhs.scalars[2], 64-128-128-64 padding, 6-row tableaus
-bool mlp_wave_tile(const mi_ode_solver* h) { return mi_mlp_wave_tile(h) != 0; }
-template <int ACT>
-const void* persist_mlp_wt_fn_act(const mi_ode_solver* h) {
-  return h->ts_dense ? (const void*)mi::k_persist_mlp_wt<64, 128, ACT, 6, true> : (const void*)mi::k_persist_mlp_wt<64, 128, ACT, 6, false>;
-}
-const void* persist_mlp_wt_fn(const mi_ode_solver* h) {
-  switch (mlp_activation(h)) {
-    case mi::MLP_ACT_TANH: return persist_mlp_wt_fn_act<mi::MLP_ACT_TANH>(h);
-    case mi::MLP_ACT_RELU: return persist_mlp_wt_fn_act<mi::MLP_ACT_RELU>(h);
-    case mi::MLP_ACT_SOFTPLUS: return persist_mlp_wt_fn_act<mi::MLP_ACT_SOFTPLUS>(h);
-    default: return nullptr;
-  }
-}
-#endif
 const void* persist_mlp_fn_any(const mi_ode_solver* h, size_t* lds, int* block) {
-#ifdef MI_ODE_EXPERIMENTAL_WT
-  if (mlp_wave_tile(h)) {
-    *lds = mi::WtGeom<64, 128>::lds_bytes(); *block = 64 * mi::WtGeom<64, 128>::NW;
-    const void* fn = persist_mlp_wt_fn(h);
-    if (fn != nullptr && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)*lds) != hipSuccess) (void)hipGetLastError();
-    return fn;
-  }
-#endif
   if (h->mlp_dp == 16 && h->mlp_hp == 16) { *lds = mi::MlpGeom<16, 16>::lds_bytes(); *block = 64 * mi::MlpGeom<16, 16>::NW; return persist_mlp_fn<16, 16>(h); }
   if (h->mlp_dp == 16 && h->mlp_hp == 128) { *lds = mi::MlpGeom<16, 128>::lds_bytes(); *block = 64 * mi::MlpGeom<16, 128>::NW; return persist_mlp_fn<16, 128>(h); }
   if (h->mlp_dp == 64 && h->mlp_hp == 16) { *lds = mi::MlpGeom<64, 16>::lds_bytes(); *block = 64 * mi::MlpGeom<64, 16>::NW; return persist_mlp_fn<64, 16>(h); }
@@ -99,15 +72,6 @@ const void* persist_mlp_fn_any(const mi_ode_solver* h, size_t* lds, int* block) 
   return nullptr;
 }
 }  // namespace
-
-int mi_mlp_wave_tile(const mi_ode_solver* h) {
-#ifdef MI_ODE_EXPERIMENTAL_WT
-  return (h->rhs.s[2] != 0.0 && h->mlp_dp == 64 && h->mlp_hp == 128 && h->S == 6) ? 1 : 0;
-#else
-  (void)h;
-  return 0;                                                  // not compiled in: mi_ode_rhs.scalars[2] is ignored
-#endif
-}
 
 int mi_persist_capacity_mlp_f32(mi_ode_solver* h) {
   size_t lds = 0; int block = 0;

@@ -181,7 +181,7 @@ constexpr int kXRec = 16;                                       // 8-byte words 
 constexpr int kXMaxWorld = 64;
 
 // MAXG: workgroups whose records are staged for the fold, TOUT: output times cached in LDS - parameters because a kernel that
-// fills the LDS with weights (mi_ode_mlp_wt.h) cannot afford the 50 KB of the general case
+// fills the LDS with its own data cannot afford the 50 KB of the general case
 template <int MAXG, int TOUT>
 struct PersistSharedT {
   static constexpr int kMaxGrid = MAXG, kTout = TOUT;

@@ -197,8 +197,6 @@ class MLP(DeviceRHS):
             raise ValueError('the fused MLP kernels know %s, not %r' % (sorted(self.ACTIVATIONS), activation))
         self.activation = activation
         self.time_dependent = bool(time_dependent)
-        # 'wave': the experimental barrier-free layout of the whole-call kernel (csrc/mi_ode_mlp_wt.h), opt-in
-        self.layout = os.environ.get('TFDIFFEQ_AMD_MLP_LAYOUT', 'workgroup')
         self.Ws = [torch.as_tensor(w) for w in (W1, W2, W3)]
         self.bs = [None if b is None else torch.as_tensor(b) for b in (b1, b2, b3)]
         self.dim = int(self.Ws[0].shape[0]) - (1 if self.time_dependent else 0)
@@ -230,7 +228,6 @@ class MLP(DeviceRHS):
         rhs.hidden = self.hidden
         rhs.scalars[0] = float(self.ACTIVATIONS[self.activation])
         rhs.scalars[1] = 1.0 if self.time_dependent else 0.0
-        rhs.scalars[2] = 1.0 if self.layout == 'wave' else 0.0
         for i in range(3):
             Wd = self._dev(self.Ws[i], dtype, device)
             rhs.w[i] = Wd.data_ptr()
