@@ -199,7 +199,8 @@ def workload(cfg, args, rank, world, dev):
         rng = np.random.default_rng(1)
         y0 = torch.tensor(np.array([1., 1., 1.]) + 1e-3 * rng.standard_normal((65536, 3)))
         return (rhs.Lorenz(), y0.to(dev), torch.tensor([0., 1.], dtype=torch.float64), dict(rtol=1e-6, atol=1e-9, method='tsit5'),
-                'config 3: Lorenz (10, 8/3, 28), batch 65536 x 3, Tsit5 (published coefficients) fp64, rtol 1e-6 atol 1e-9, t=[0,1]')
+                'config 3: Lorenz (10, 8/3, 28), batch 65536 x 3, Tsit5 (published coefficients - the reference\'s own tableau is defective, SURVEY F6, so '
+                'this configuration has NO reference anchor: parity is against the oracle\'s corrected tableau and DOP853) fp64, rtol 1e-6 atol 1e-9, t=[0,1]')
     if cfg == 5:
         gm = torch.Generator().manual_seed(4)
 

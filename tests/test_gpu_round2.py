@@ -280,7 +280,7 @@ def test_odenet_trains_the_ode_function_whatever_the_adjoint_flag(adjoint):
     assert net.linear_layer.weight.grad is not None
 
 
-def test_plain_odeint_with_grad_inputs_returns_gradients_or_refuses():
+def test_plain_odeint_with_grad_inputs_returns_gradients():
     from tfdiffeq_amd import odeint
     lin = torch.nn.Linear(3, 3).to(dev()).double()
 
@@ -294,8 +294,13 @@ def test_plain_odeint_with_grad_inputs_returns_gradients_or_refuses():
         out = odeint(f, y0, torch.tensor([0., 0.5]), rtol=1e-6, atol=1e-8)
     out[1].sum().backward()
     assert y0.grad is not None and float(y0.grad.abs().max()) > 0 and lin.weight.grad is not None
-    with pytest.raises(RuntimeError, match='requires grad'):
-        odeint(lambda t, y: -y, y0, torch.tensor([0., 0.5]))
+    # a plain callable: the reference back-propagates through it too (odeint.py:28-81 under a tape) - here dL/dy0 comes from the
+    # adjoint solve of the parameterless system; y' = -y: y(0.5) = y0 e^-0.5, so d sum(y(0.5)) / d y0 = e^-0.5 everywhere
+    y1 = torch.randn(8, 3, device=dev(), dtype=torch.float64, requires_grad=True)
+    with pytest.warns(UserWarning, match='plain callable'):
+        out = odeint(lambda t, y: -y, y1, torch.tensor([0., 0.5]), rtol=1e-9, atol=1e-11)
+    out[1].sum().backward()
+    assert float((y1.grad - np.exp(-0.5)).abs().max()) < 1e-7
 
 
 def test_adjoint_of_a_forcing_only_rhs_has_zero_gradients():

@@ -60,6 +60,38 @@ __device__ __forceinline__ float mlp_act(float x) {
   else if constexpr (ACT == MLP_ACT_RELU) return x > 0.f ? x : (x != x ? x : 0.f);            // NaN stays NaN
   else return mlp_softplus(x);
 }
+// Two activations at once (plus the bias add in front): for tanh the affine / polynomial parts run as PACKED fp32 instructions
+// (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two IEEE operations per lane and issue slot, same roundings - the results are
+// the bits mlp_tanh gives, element for element); v_exp_f32 / v_rcp_f32 and the final select stay scalar.  Vector instructions do
+// not overlap with the matrix pipe of their SIMD on this part (profiles/r03_mfma_pair_first.txt) and tanh is ~3/4 of the vector
+// work of an evaluation, so halving the issue slots of its arithmetic is worth more than anything a schedule can hide.
+typedef float mlp_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ mlp_f2 mlp_tanh2(mlp_f2 x) {
+  const mlp_f2 t = x * 2.8853900817779268f;
+  mlp_f2 e;
+  e.x = __builtin_amdgcn_exp2f(t.x); e.y = __builtin_amdgcn_exp2f(t.y);
+  const mlp_f2 d = e + 1.0f;
+  mlp_f2 r;
+  r.x = __builtin_amdgcn_rcpf(d.x); r.y = __builtin_amdgcn_rcpf(d.y);
+  const mlp_f2 big = 1.0f - 2.0f * r;                                          // (2 r is exact: the same value fused or not)
+  const mlp_f2 x2 = x * x;
+  const mlp_f2 small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.053968254f)));
+  mlp_f2 out;
+  out.x = fabsf(x.x) < 0.25f ? small.x : big.x;
+  out.y = fabsf(x.y) < 0.25f ? small.y : big.y;
+  return out;
+}
+template <int ACT>
+__device__ __forceinline__ void mlp_act_pair(float a, float b, float bias, float& oa, float& ob) {
+  if constexpr (ACT == MLP_ACT_TANH) {
+    mlp_f2 x = {a, b};
+    x = x + bias;
+    const mlp_f2 y = mlp_tanh2(x);
+    oa = y.x; ob = y.y;
+  } else {
+    oa = mlp_act<ACT>(a + bias); ob = mlp_act<ACT>(b + bias);
+  }
+}
 template <int ACT>
 __device__ __forceinline__ float mlp_act_deriv(float h) {
   if constexpr (ACT == MLP_ACT_TANH) return 1.0f - h * h;
@@ -97,8 +129,10 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s_h1[(4 * lg + i) * G::LDH + col] = mlp_act<ACT>(c0[i] + b1v);
-      s_h1[(16 + 4 * lg + i) * G::LDH + col] = mlp_act<ACT>(c1[i] + b1v);
+      float h0, h1;
+      mlp_act_pair<ACT>(c0[i], c1[i], b1v, h0, h1);
+      s_h1[(4 * lg + i) * G::LDH + col] = h0;
+      s_h1[(16 + 4 * lg + i) * G::LDH + col] = h1;
     }
   }
   __syncthreads();
@@ -118,8 +152,10 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      s_h2[(4 * lg + i) * G::LDH + col] = mlp_act<ACT>(c0[i] + b2v);
-      s_h2[(16 + 4 * lg + i) * G::LDH + col] = mlp_act<ACT>(c1[i] + b2v);
+      float h0, h1;
+      mlp_act_pair<ACT>(c0[i], c1[i], b2v, h0, h1);
+      s_h2[(4 * lg + i) * G::LDH + col] = h0;
+      s_h2[(16 + 4 * lg + i) * G::LDH + col] = h1;
     }
   }
   __syncthreads();
@@ -228,6 +264,8 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
     float hs = P.hs;
     asm volatile("" : "+v"(hs));                            // keep dt*coefficient products out of long-lived registers
     float y0e[4], k[S + 1][4], ys[4], kn[4];
+    // (measured in round 3: prefetching the next tile's y0 / f0 into registers, as the linear kernels do, changes nothing here -
+    // 0.3385 vs 0.3386 ms per config-5 call - and costs 12 more spilled registers: the loads stay where they are)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const long long row = row0 + rbase + i;

@@ -49,9 +49,13 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
             from .adjoint import odeint_adjoint
             _warn_once('odeint: inputs require grad - gradients are computed with the adjoint method (odeint_adjoint)')
             return odeint_adjoint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)
-        raise RuntimeError('odeint: y0 requires grad but `func` is not a torch.nn.Module, so no gradient can be returned '
-                           '(the kernels are not recorded by autograd). Wrap f in a torch.nn.Module (gradients then come '
-                           'from odeint_adjoint), or call under torch.no_grad() / detach y0.')
+        # A plain callable: the reference differentiates through it all the same (tf.GradientTape sees every op).  Its gradient with
+        # respect to y0 (and t) is what the adjoint solve delivers for a parameterless system, so wrap it.  What cannot be
+        # discovered is a tensor the callable closes over - it gets no gradient here, and the warning says so.
+        from .adjoint import odeint_adjoint
+        _warn_once('odeint: y0 requires grad and `func` is a plain callable - gradients w.r.t. y0 and t are computed with the adjoint '
+                   'method; tensors the callable closes over receive NO gradient (make it a torch.nn.Module with parameters for that)')
+        return odeint_adjoint(_CallableModule(func), y0, t, rtol=rtol, atol=atol, method=method, options=options)
     tensor_input, func, y0, t = _check_inputs(func, y0, t)
 
     if options is None:
@@ -71,6 +75,25 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
 
 odeint.last_stats = {}
 _warned = set()
+
+
+def _callable_module(func):
+    import torch
+
+    class _M(torch.nn.Module):
+        """A parameterless module around a plain callable (odeint_adjoint needs a module to look for parameters in)."""
+
+        def __init__(self, f):
+            super().__init__()
+            self._f = f
+
+        def forward(self, t, y):
+            return self._f(t, y)
+    return _M(func)
+
+
+def _CallableModule(func):
+    return _callable_module(func)
 
 
 def _warn_once(msg):
