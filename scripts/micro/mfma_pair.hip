@@ -25,6 +25,7 @@ __device__ __forceinline__ void blk_mf(d4& c, double a, double b, double (&f)[8]
 }
 
 enum Role { R_IDLE = 0, R_M1 = 1, R_M2 = 2, R_V = 3, R_L = 4, R_MV = 5 /* 32 MFMA then 64 VALU */, R_VM = 6 /* 64 VALU then 32 MFMA */,
+  R_MV16 = 20, R_VM16 = 21, R_MV32 = 22, R_VM32 = 23, R_MV48 = 24, R_VM48 = 25, R_MV96 = 26, R_VM96 = 27,
   R_MF1 = 7, R_MF2 = 8, R_MF4 = 9, R_MI1 = 10, R_MI2 = 11, R_MI4 = 12, R_ML1 = 13 };
 
 __device__ __forceinline__ void blk_m1(d4& c, double a, double b) {
@@ -41,6 +42,11 @@ __device__ __forceinline__ void blk_m2(d4& c, d4& e, double a, double b) {
 __device__ __forceinline__ void blk_v(double (&f)[8], double x) {
 #pragma unroll
   for (int i = 0; i < 64; ++i) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(f[i & 7]) : "v"(x));
+}
+template <int NV>
+__device__ __forceinline__ void blk_vn(double (&f)[8], double x) {
+#pragma unroll
+  for (int i = 0; i < NV; ++i) asm volatile("v_fma_f64 %0, %0, %1, %0" : "+v"(f[i & 7]) : "v"(x));
 }
 __device__ __forceinline__ void blk_l(f4 (&r)[4], const char* lds, int lane) {
 #pragma unroll
@@ -72,6 +78,14 @@ __global__ __launch_bounds__(512) void k(const int* roles, int nroles, int iters
       case R_L: blk_l(r, lds, lane); break;
       case R_MV: blk_m1(c, a, b); blk_v(f, b); break;
       case R_VM: blk_v(f, b); blk_m1(c, a, b); break;
+      case R_MV16: blk_m1(c, a, b); blk_vn<16>(f, b); break;
+      case R_VM16: blk_vn<16>(f, b); blk_m1(c, a, b); break;
+      case R_MV32: blk_m1(c, a, b); blk_vn<32>(f, b); break;
+      case R_VM32: blk_vn<32>(f, b); blk_m1(c, a, b); break;
+      case R_MV48: blk_m1(c, a, b); blk_vn<48>(f, b); break;
+      case R_VM48: blk_vn<48>(f, b); blk_m1(c, a, b); break;
+      case R_MV96: blk_m1(c, a, b); blk_vn<96>(f, b); break;
+      case R_VM96: blk_vn<96>(f, b); blk_m1(c, a, b); break;
       case R_MF1: blk_mf<1, 0>(c, a, b, f, q, lane); break;
       case R_MF2: blk_mf<2, 0>(c, a, b, f, q, lane); break;
       case R_MF4: blk_mf<4, 0>(c, a, b, f, q, lane); break;
@@ -116,6 +130,14 @@ int main() {
     {"2 waves/SIMD MV + VM (w,w+1) barrier  ", 8, 2, {R_MV, R_VM}, 1},
     {"2 waves/SIMD MV + VM (w,w+4) no barr. ", 8, 8, {R_MV, R_MV, R_MV, R_MV, R_VM, R_VM, R_VM, R_VM}, 0},
     {"2 waves/SIMD MV + MV  no barrier      ", 8, 1, {R_MV}, 0},
+    {"MV16 + MV16 (lockstep) barrier          ", 8, 1, {R_MV16}, 1},
+    {"MV16 + VM16 (w,w+4 opposite) barrier    ", 8, 8, {R_MV16, R_MV16, R_MV16, R_MV16, R_VM16, R_VM16, R_VM16, R_VM16}, 1},
+    {"MV32 + MV32 (lockstep) barrier          ", 8, 1, {R_MV32}, 1},
+    {"MV32 + VM32 (w,w+4 opposite) barrier    ", 8, 8, {R_MV32, R_MV32, R_MV32, R_MV32, R_VM32, R_VM32, R_VM32, R_VM32}, 1},
+    {"MV48 + MV48 (lockstep) barrier          ", 8, 1, {R_MV48}, 1},
+    {"MV48 + VM48 (w,w+4 opposite) barrier    ", 8, 8, {R_MV48, R_MV48, R_MV48, R_MV48, R_VM48, R_VM48, R_VM48, R_VM48}, 1},
+    {"MV96 + MV96 (lockstep) barrier          ", 8, 1, {R_MV96}, 1},
+    {"MV96 + VM96 (w,w+4 opposite) barrier    ", 8, 8, {R_MV96, R_MV96, R_MV96, R_MV96, R_VM96, R_VM96, R_VM96, R_VM96}, 1},
     {"1 wave  M1 + 1 fp64 FMA per MFMA      ", 4, 1, {R_MF1}, 0},
     {"1 wave  M1 + 2 fp64 FMA per MFMA      ", 4, 1, {R_MF2}, 0},
     {"1 wave  M1 + 4 fp64 FMA per MFMA      ", 4, 1, {R_MF4}, 0},

@@ -63,7 +63,7 @@ __device__ __forceinline__ float mlp_act(float x) {
 // Two activations at once (plus the bias add in front): for tanh the affine / polynomial parts run as PACKED fp32 instructions
 // (v_pk_mul_f32 / v_pk_add_f32 / v_pk_fma_f32: two IEEE operations per lane and issue slot, same roundings - the results are
 // the bits mlp_tanh gives, element for element); v_exp_f32 / v_rcp_f32 and the final select stay scalar.  Vector instructions do
-// not overlap with the matrix pipe of their SIMD on this part (profiles/r03_mfma_pair_first.txt) and tanh is ~3/4 of the vector
+// not overlap with the matrix pipe of their SIMD on this part (profiles/r03_mfma_pair.txt) and tanh is ~3/4 of the vector
 // work of an evaluation, so halving the issue slots of its arithmetic is worth more than anything a schedule can hide.
 typedef float mlp_f2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ mlp_f2 mlp_tanh2(mlp_f2 x) {
