@@ -368,6 +368,14 @@ struct LinCtx {
     s_ys = lds;
   }
   __device__ __forceinline__ int row_of(int i) const { return TR::acc_row(lane, i); }
+  // Element i of this thread inside a tile whose first row starts at `base` (a uniform pointer: tile * R_ * d elements into
+  // the plane): a 32-bit offset, so the access is "scalar base + vector offset" and costs no 64-bit vector arithmetic.
+  __device__ __forceinline__ unsigned off_of(int i) const { return (unsigned)(TR::acc_row(lane, i) * d + col); }
+  // rows of the tile that exist (the last tile of a batch may be ragged)
+  __device__ __forceinline__ int rows_here(long long tile_i, long long batch) const {
+    const long long left = batch - tile_i * R_;
+    return left < R_ ? (int)left : R_;
+  }
 
   // f(ys) for the tile: ys (this thread's 4 accumulator-layout elements) -> LDS -> barrier -> KS MFMA steps against
   // the resident W slice -> k (same layout, reversed-time sign applied) -> barrier (every wave is done with the tile)
@@ -451,12 +459,14 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
   lds_barrier();
   T y0n[4], f0n[4];                                          // prefetched next tile (accumulator layout)
   auto fetch = [&](long long t_i) {
+    const T* ty = P.y0 + t_i * R_ * cx.d;
+    const T* tf = P.f0 + t_i * R_ * cx.d;
+    const int nr = cx.rows_here(t_i, A.batch);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long row = t_i * R_ + cx.row_of(i);
-      const bool ok = row < A.batch && cx.colok && !(MI_ABL & 8);
-      y0n[i] = ok ? stream_load<SC0>(P.y0 + row * cx.d + cx.col) : (T)0;
-      f0n[i] = ok ? stream_load<SC0>(P.f0 + row * cx.d + cx.col) : (T)0;
+      const bool ok = cx.row_of(i) < nr && cx.colok && !(MI_ABL & 8);
+      y0n[i] = ok ? stream_load<SC0>(ty + cx.off_of(i)) : (T)0;
+      f0n[i] = ok ? stream_load<SC0>(tf + cx.off_of(i)) : (T)0;
     }
   };
   if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -499,19 +509,21 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
         for (int i = 0; i < 4; ++i) ym4[i] = (j == 0) ? cm * k[0][i] : ym4[i] + cm * k[j][i];
       }
     }
+    const int nr = cx.rows_here(tile_i, A.batch);
+    T* ty1 = P.y1 + row0 * cx.d;
+    T* tf1 = P.f1 + row0 * cx.d;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long row = row0 + cx.row_of(i);
-      if (row < A.batch && cx.colok) {
+      if (cx.row_of(i) < nr && cx.colok) {
         T kk[S + 1];
 #pragma unroll
         for (int j = 0; j <= S; ++j) kk[j] = k[j][i];
         const T err = err4[i];
         const T ymid = need_mid ? y0e[i] + ym4[i] : y0e[i];
-        const long long idx = row * cx.d + cx.col;
+        const long long idx = row0 * cx.d + cx.off_of(i);
         if (!(MI_ABL & 8) || err == (T)123.456) {
-          P.y1[idx] = ys[i];
-          P.f1[idx] = k[S][i];
+          ty1[cx.off_of(i)] = ys[i];
+          tf1[cx.off_of(i)] = k[S][i];
         }
         step_emit<T, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, t_out);
         acc.maxa = fmax(acc.maxa, (double)fabs(y0e[i]));
@@ -531,11 +543,10 @@ __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f
   const long long ntiles = (A.batch + R_ - 1) / R_;
   T y0n[4];
   auto fetch = [&](long long t_i) {
+    const T* ty = y0 + t_i * R_ * cx.d;
+    const int nr = cx.rows_here(t_i, A.batch);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const long long row = t_i * R_ + cx.row_of(i);
-      y0n[i] = (row < A.batch && cx.colok) ? stream_load<SC0>(y0 + row * cx.d + cx.col) : (T)0;
-    }
+    for (int i = 0; i < 4; ++i) y0n[i] = (cx.row_of(i) < nr && cx.colok) ? stream_load<SC0>(ty + cx.off_of(i)) : (T)0;
   };
   if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
   for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
@@ -544,14 +555,14 @@ __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f
     for (int i = 0; i < 4; ++i) y0e[i] = y0n[i];
     if (tile_i + gridDim.x < ntiles) fetch(tile_i + gridDim.x);
     cx.rhs_eval(y0e, kn);
+    const int nr = cx.rows_here(tile_i, A.batch);
+    const long long tb = tile_i * R_ * cx.d;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long row = tile_i * R_ + cx.row_of(i);
-      if (row < A.batch && cx.colok) {
-        const long long idx = row * cx.d + cx.col;
-        f0_out[idx] = kn[i];
-        if (copy_a != nullptr) copy_a[idx] = y0e[i];
-        if (copy_b != nullptr) copy_b[idx] = y0e[i];
+      if (cx.row_of(i) < nr && cx.colok) {
+        (f0_out + tb)[cx.off_of(i)] = kn[i];
+        if (copy_a != nullptr) (copy_a + tb)[cx.off_of(i)] = y0e[i];
+        if (copy_b != nullptr) (copy_b + tb)[cx.off_of(i)] = y0e[i];
         const T sc = (T)A.cp.atol + fabs(y0e[i]) * (T)A.cp.rtol;     // misc.py:225
         const double q0 = (double)(y0e[i] / sc);
         acc.suma += q0 * q0;
@@ -570,12 +581,14 @@ __device__ __forceinline__ void lin_initb_pass(const StepArgs& A, const T* y0, c
   const long long ntiles = (A.batch + R_ - 1) / R_;
   T y0n[4], f0n[4];
   auto fetch = [&](long long t_i) {
+    const T* ty = y0 + t_i * R_ * cx.d;
+    const T* tf = f0 + t_i * R_ * cx.d;
+    const int nr = cx.rows_here(t_i, A.batch);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long row = t_i * R_ + cx.row_of(i);
-      const bool ok = row < A.batch && cx.colok;
-      y0n[i] = ok ? stream_load<SC0>(y0 + row * cx.d + cx.col) : (T)0;
-      f0n[i] = ok ? stream_load<SC0>(f0 + row * cx.d + cx.col) : (T)0;
+      const bool ok = cx.row_of(i) < nr && cx.colok;
+      y0n[i] = ok ? stream_load<SC0>(ty + cx.off_of(i)) : (T)0;
+      f0n[i] = ok ? stream_load<SC0>(tf + cx.off_of(i)) : (T)0;
     }
   };
   if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
@@ -585,10 +598,10 @@ __device__ __forceinline__ void lin_initb_pass(const StepArgs& A, const T* y0, c
     for (int i = 0; i < 4; ++i) { y0e[i] = y0n[i]; f0e[i] = f0n[i]; ys[i] = y0e[i] + h0 * f0e[i]; }   // misc.py:235
     if (tile_i + gridDim.x < ntiles) fetch(tile_i + gridDim.x);
     cx.rhs_eval(ys, kn);
+    const int nr = cx.rows_here(tile_i, A.batch);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long row = tile_i * R_ + cx.row_of(i);
-      if (row < A.batch && cx.colok) {
+      if (cx.row_of(i) < nr && cx.colok) {
         const T sc = (T)A.cp.atol + fabs(y0e[i]) * (T)A.cp.rtol;
         const double q = (double)((kn[i] - f0e[i]) / sc);            // misc.py:237
         acc.suma += q * q;
