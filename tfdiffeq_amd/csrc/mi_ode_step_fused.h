@@ -333,6 +333,8 @@ struct LinCtx {
   static constexpr int R_ = 16;
   static constexpr int LD = D + VEC;
   static constexpr int KS = D / 4;
+  static constexpr int TILE = R_ * LD;                       // one stage tile; the kernels allocate kBufs of them
+  static constexpr int kBufs = 2;
   using CH = Chunk<T, VEC>;
   int lane, wave, li, lg, col;
   int d;                                                     // the state's true row length, d <= D: the tile kernels are instantiated
@@ -343,7 +345,8 @@ struct LinCtx {
   bool plain;                                                // no bias, forward time: k is the accumulator as it is (the bias add and
                                                              // the sign product are exact no-ops then; skipping them saves 16 vector
                                                              // instructions per evaluation that the matrix pipe would wait for)
-  T* s_ys;                                                   // [R_][LD]
+  T* s_ys;                                                   // [kBufs][R_][LD]: consecutive evaluations alternate between the two tiles,
+  int cur = 0;                                               // so ONE barrier per evaluation is enough (see rhs_eval)
 #ifdef MI_TRACE
   long long* tr = nullptr;                                   // timeline of rhs_eval (tuning aid): 4 stamps per evaluation
   int tn = 0;
@@ -377,16 +380,25 @@ struct LinCtx {
     return left < R_ ? (int)left : R_;
   }
 
-  // f(ys) for the tile: ys (this thread's 4 accumulator-layout elements) -> LDS -> barrier -> KS MFMA steps against
-  // the resident W slice -> k (same layout, reversed-time sign applied) -> barrier (every wave is done with the tile)
-  __device__ __forceinline__ void rhs_eval(const T (&ys)[4], T (&kn)[4]) {
+  // f(ys) for the tile: ys (this thread's 4 accumulator-layout elements) -> LDS tile `cur` -> barrier -> KS MFMA steps against
+  // the resident W slice -> k (same layout, reversed-time sign applied).  No closing barrier: the next evaluation writes the
+  // OTHER tile, and a wavefront that gets there has passed this evaluation's barrier, which every wavefront reaches only after
+  // it has finished reading that other tile (its previous evaluation's chain).
+  __device__ __forceinline__ void rhs_eval(const T (&ys)[4], T (&kn)[4]) { rhs_eval(ys, kn, [] {}); }
+  // `under_chain()` is issued between the first barrier and the MFMA chain: LDS reads that do not depend on the tile (the next
+  // combination's coefficients) complete while the matrix pipe works instead of after the closing barrier.
+  template <class F>
+  __device__ __forceinline__ void rhs_eval(const T (&ys)[4], T (&kn)[4], F&& under_chain) {
     stamp();
+    T* tile = s_ys + cur * TILE;
+    cur ^= 1;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s_ys[TR::acc_row(lane, i) * LD + col] = ys[i];
+    for (int i = 0; i < 4; ++i) tile[TR::acc_row(lane, i) * LD + col] = ys[i];
     if (!(MI_ABL & 4)) lds_barrier();
     stamp();
+    under_chain();
     acc_t c0 = {0, 0, 0, 0};
-    const T* ap = s_ys + li * LD + lg * KS;
+    const T* ap = tile + li * LD + lg * KS;
 #if (MI_ABL & 1)
     c0[0] = ap[0] * bf[0]; c0[1] = ap[1] * bf[1]; c0[2] = ap[2] * bf[2]; c0[3] = ap[3] * bf[3];
 #else
@@ -409,7 +421,7 @@ struct LinCtx {
         kn[i] = sign * k_;
       }
     }
-    if (!(MI_ABL & 4)) lds_barrier();    stamp();
+    stamp();
   }
 };
 
@@ -470,6 +482,8 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
     }
   };
   if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
+  const T c_first = coef[CF::row(1)];                        // dt * beta_{1,0}: the same for every tile
+  T cnx[S + 1];                                              // the coefficients of the NEXT combination (read under the MFMA chain)
 
   for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
     const long long row0 = tile_i * R_;
@@ -482,7 +496,7 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
       constexpr int SG = decltype(sg_c)::value;
       T cb[SG];                                              // dt * beta_{SG, j}: step_combine's products, from the table
 #pragma unroll
-      for (int j = 0; j < SG; ++j) cb[j] = coef[CF::row(SG) + j];
+      for (int j = 0; j < SG; ++j) cb[j] = (SG == 1) ? c_first : cnx[j];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         T a_ = cb[0] * k[0][i];                              // misc._scaled_dot_product order (rk_common.py:51)
@@ -490,14 +504,17 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
         for (int j = 1; j < SG; ++j) a_ = a_ + cb[j] * k[j][i];
         ys[i] = y0e[i] + a_;
       }
-      cx.rhs_eval(ys, k[SG]);
+      cx.rhs_eval(ys, k[SG], [&] {                           // next: row SG + 1 of beta, after the last stage c_error
+#pragma unroll
+        for (int j = 0; j <= SG; ++j) cnx[j] = coef[(SG < S ? CF::row(SG + 1) : CF::kErr) + j];
+      });
     };
     for_stages<1, S>(stage);
     const bool need_mid = !TS && P.j_hi > P.j_lo;            // (wave-uniform: an output time falls into this attempt)
     T err4[4], ym4[4];                                       // rk_common.py:60 / dopri5.py:42: step_finish's operations, one table
 #pragma unroll                                               // entry at a time (the coefficients are vector registers now)
     for (int j = 0; j <= S; ++j) {
-      const T ce = coef[CF::kErr + j];
+      const T ce = cnx[j];
 #pragma unroll
       for (int i = 0; i < 4; ++i) err4[i] = (j == 0) ? ce * k[0][i] : err4[i] + ce * k[j][i];
     }
@@ -616,7 +633,7 @@ __global__ __launch_bounds__(D * 4) void k_step_linear_mfma(StepArgs A) {
   if (!resolve_step<T, S>(A, P)) return;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* s_ys = (T*)smem_raw;
-  double* red = (double*)(s_ys + LinCtx<T, D>::R_ * LinCtx<T, D>::LD);
+  double* red = (double*)(s_ys + LinCtx<T, D>::kBufs * LinCtx<T, D>::TILE);
   LinCtx<T, D> cx;
   cx.init(A.rhs, s_ys, A.dim);
   Acc acc;
@@ -638,7 +655,7 @@ __global__ __launch_bounds__(D * 4) void k_init_linear_mfma(InitArgs I) {
   const Ctl* c = A.ctl;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* s_ys = (T*)smem_raw;
-  double* red = (double*)(s_ys + LinCtx<T, D>::R_ * LinCtx<T, D>::LD);
+  double* red = (double*)(s_ys + LinCtx<T, D>::kBufs * LinCtx<T, D>::TILE);
   LinCtx<T, D> cx;
   cx.init(A.rhs, s_ys, A.dim);
   Acc acc;
@@ -715,7 +732,7 @@ __global__ __launch_bounds__(D * 4) void k_fixed_linear_mfma(FixedArgs A) {
 
 template <typename T, int D>
 constexpr size_t step_linear_lds_bytes() {
-  return (size_t)16 * (D + MfmaTraits<T>::VEC) * sizeof(T) + (80 + kLinCoefMax) * sizeof(double);     // stage tile | red | coefficient table
+  return (size_t)2 * 16 * (D + MfmaTraits<T>::VEC) * sizeof(T) + (80 + kLinCoefMax) * sizeof(double);     // two stage tiles | red | coefficient table
 }
 
 }  // namespace mi
