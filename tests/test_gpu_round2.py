@@ -602,6 +602,59 @@ def test_dopri8_on_the_linear_tile_kernels(dim, batch):
     assert odeint.last_stats.get('engine') == 'plane kernels'                                      # the generic engine takes it
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize('shape,act', [((4096, 64, 128), 'tanh'), ((777, 10, 48), 'relu'), ((300, 16, 16), 'softplus'), ((1000, 40, 16), 'tanh')])
+def test_dopri8_on_the_mlp_tile_kernels(shape, act):
+    """dopri8.py:12-77 with the ODEFunc network (dense_odenet.py:41-92): the whole-call and whole-attempt MLP kernels are
+    instantiated for the 13-row tableau (VERDICT r02 "missing" 4).  (a) a regime where every engine takes EXACTLY the same steps
+    (first_step given, loose tolerance: the step factor sits on its clamp): against the fp32 numpy restatement of the network under
+    the oracle's dopri8, to a band set by fp32 roundoff of 13 stages; whole call == launch per attempt bit for bit;
+    (b) a tighter tolerance against the plane-kernel engine running the same network as a torch callable."""
+    from tfdiffeq_amd import odeint, rhs
+    batch, d_, h_ = shape
+    g = torch.Generator().manual_seed(77)
+
+    def glorot(i, o):
+        lim = (6.0 / (i + o)) ** 0.5
+        return (torch.rand(i, o, generator=g) * 2 - 1) * lim
+    Ws = [glorot(d_, h_), glorot(h_, h_), glorot(h_, d_)]
+    bs = [0.1 * torch.randn(h_, generator=g), 0.1 * torch.randn(h_, generator=g), 0.1 * torch.randn(d_, generator=g)]
+    f = rhs.MLP(Ws[0].to(dev()), bs[0].to(dev()), Ws[1].to(dev()), bs[1].to(dev()), Ws[2].to(dev()), bs[2].to(dev()), activation=act)
+    y0 = torch.randn(batch, d_, generator=g)
+    Wn = [w.numpy() for w in Ws]
+    bn = [b.numpy() for b in bs]
+    actn = {'tanh': np.tanh, 'relu': lambda x: np.maximum(x, np.float32(0)),
+            'softplus': lambda x: np.logaddexp(x, np.float32(0)).astype(np.float32)}[act]
+
+    def fn(t_, y):
+        h = actn(y @ Wn[0] + bn[0])
+        h = actn(h @ Wn[1] + bn[1])
+        return (h @ Wn[2] + bn[2]).astype(np.float32)
+    t = np.array([0., 0.005, 0.05, 0.1])
+    loose = dict(rtol=1e-2, atol=1e-2)
+    ref, rst = O.odeint(fn, y0.numpy(), t, method='dopri8', options={'first_step': 0.01}, return_stats=True, **loose)
+    outs = {}
+    for fusion in ('auto', 'step'):
+        outs[fusion] = odeint(f, y0.to(dev()), torch.tensor(t), method='dopri8', options={'fusion': fusion, 'first_step': 0.01}, **loose)
+        st = dict(odeint.last_stats)
+        assert st['status'] == 0 and (st['n_launches'] == 1) == (fusion == 'auto'), (fusion, st)
+        assert (st['n_attempts'], st['n_accepted']) == (rst.n_attempts, rst.n_accepted), (fusion, st, rst)
+    assert torch.equal(outs['auto'], outs['step'])
+    assert_f32(outs['auto'].cpu().numpy(), ref, 'dopri8_mlp_%s_%dx%dx%d' % (act, batch, d_, h_))
+    tt = torch.tensor([0., 0.4, 1.0])
+    tol = dict(rtol=1e-5, atol=1e-6)
+    a = odeint(f, y0.to(dev()), tt, method='dopri8', **tol)
+    sa = dict(odeint.last_stats)
+    assert sa['status'] == 0 and sa['n_launches'] == 1
+    b = odeint(f, y0.to(dev()), tt, method='dopri8', options={'force_plane_kernels': True}, **tol)
+    sb = dict(odeint.last_stats)
+    assert sb.get('engine') == 'plane kernels' and abs(sa['n_attempts'] - sb['n_attempts']) <= 1
+    assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
+    c = odeint(f, y0.to(dev()), -tt, method='dopri8', **tol)                # decreasing times
+    dref = odeint(f, y0.to(dev()), -tt, method='dopri8', options={'force_plane_kernels': True}, **tol)
+    assert (c - dref).abs().max().item() < 2e-5 * max(1.0, dref.abs().max().item())
+
+
 # ---------------------------------------------------------------------------------------------
 # time-dependent ODEFunc (dense_odenet.py:79-84: fc1 sees concat([t, x])) on the fused MLP kernels
 # ---------------------------------------------------------------------------------------------

@@ -430,9 +430,9 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   if (desc->adaptive && tb.n_stages != 3 && tb.n_stages != 6) {
     const bool rowlocal_fam = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
                               h->family == FAM_PLUGIN;
-    const bool mfma13 = h->family == FAM_LINEAR_MFMA && tb.fsal && tb.n_stages == 13;     // dopri8 on the linear tile kernels
+    const bool mfma13 = (h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP) && tb.fsal && tb.n_stages == 13;   // dopri8 on the tile kernels
     if (!(rowlocal_fam || mfma13) || desc->fusion == 1) {
-      mi_set_error("%d-row tableaus run on the whole-attempt / whole-call kernels of the row-local families and (13 rows) of the MFMA-linear family only (no per-stage or MLP kernels)", tb.n_stages);
+      mi_set_error("%d-row tableaus run on the whole-attempt / whole-call kernels of the row-local families and (13 rows) of the MFMA-linear and MLP families only (no per-stage kernels)", tb.n_stages);
       delete h; return MI_ODE_E_INVALID;
     }
   }

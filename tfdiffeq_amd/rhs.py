@@ -190,6 +190,7 @@ class MLP(DeviceRHS):
     time_dependent: the first layer sees concat([t, x]) (dense_odenet.py:79-84): W1 is [dim + 1, hidden], row 0 for t."""
     kind = N.RHS_MLP_TANH
     ACTIVATIONS = {'tanh': 0, 'relu': 1, 'softplus': 2}
+    tile_dopri8 = True            # the MFMA tile kernels are instantiated for the 13-row tableau as well (dopri8.py:12-77)
 
     def __init__(self, W1, b1, W2, b2, W3, b3, activation='tanh', time_dependent=False):
         super(MLP, self).__init__()
