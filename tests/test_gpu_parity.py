@@ -782,6 +782,55 @@ def test_whole_integration_kernel_equals_launch_per_attempt(problem, batch, meth
     assert torch.equal(a32, b32)
 
 
+@pytest.mark.parametrize('problem,batch,method', [('lorenz', 131073, 'dopri5'), ('lorenz', 400000, 'tsit5'), ('lv', 1000003, 'dopri5'),
+                                                  ('spiral', 140000, 'bosh3'), ('lorenz', 200000, 'dopri8'), ('lv', 150000, 'adaptive_heun')])
+def test_whole_integration_kernel_beyond_one_trajectory_per_thread(problem, batch, method):
+    """More than 131 072 trajectories ("missing" 5): the one-launch schedule continues with the state in HBM planes
+    and a co-resident grid walking the batch (k_persist_rowlocal_planes).  Same attempt sequence as one launch per attempt and as
+    the oracle; values against both.  (Not bit for bit against the per-attempt launches: their grid - hence the order in which the
+    error norm's partial sums are folded - is a different one.)"""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(19)
+    if problem == 'lorenz':
+        f, y0, t = rhs.Lorenz(), np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((batch, 3)), np.linspace(0., 0.5, 6)
+        fn = lambda t_, y: np.stack([10. * (y[:, 1] - y[:, 0]), y[:, 0] * (28. - y[:, 2]) - y[:, 1], y[:, 0] * y[:, 1] - (8. / 3.) * y[:, 2]], axis=1)   # noqa: E731
+    elif problem == 'lv':
+        f, y0, t = rhs.LotkaVolterra(), 1 + 0.5 * rng.uniform(size=(batch, 2)), np.linspace(0., 2.0, 5)
+        fn = lambda t_, y: np.stack([1.5 * y[:, 0] - 1.0 * y[:, 0] * y[:, 1], -3.0 * y[:, 1] + 1.0 * y[:, 0] * y[:, 1]], axis=1)   # noqa: E731
+    else:
+        Am = np.array([[-0.1, 2.0], [-2.0, -0.1]])
+        f = rhs.CubicLinear(torch.tensor(Am))
+        y0, t = rng.uniform(-2, 2, size=(batch, 2)), np.linspace(0., 2.0, 5)
+        fn = lambda t_, y: (y ** 3) @ Am                                       # noqa: E731
+    if method in ('bosh3', 'adaptive_heun'):
+        t = t[0] + (0.02 if method == 'bosh3' else 0.05) * (t - t[0])      # (the oracle has to follow in seconds)
+    tol = dict(rtol=1e-6, atol=1e-9)
+    yd, tt = to_dev(y0, torch.float64), torch.tensor(t, dtype=torch.float64)
+    a = odeint(f, yd, tt, method=method, options={'fusion': 'step'}, **tol)
+    sa = dict(odeint.last_stats)
+    b = odeint(f, yd, tt, method=method, **tol)                                # auto: the one-launch schedule
+    sb = dict(odeint.last_stats)
+    assert sb['n_launches'] == 1 and sa['n_launches'] > 1 and sb['status'] == 0, (sa, sb)
+    for k_ in ('n_attempts', 'n_accepted', 'nfe'):
+        assert sa[k_] == sb[k_], (k_, sa, sb)
+    scale = max(1.0, float(a.abs().max()))
+    assert float((a - b).abs().max()) <= 1e-11 * scale
+    oopt = {'tsit5_fixed': True} if method == 'tsit5' else None          # (the product integrates with the published tsit5 coefficients)
+    ref, rst = O.odeint(fn, y0, t, method=method, options=oopt, return_stats=True, **tol)
+    assert (sb['n_attempts'], sb['n_accepted']) == (rst.n_attempts, rst.n_accepted), (sb, rst)
+    assert np.abs(b.cpu().numpy() - ref).max() <= 1e-10 * scale
+    br = odeint(f, yd, torch.tensor(t[::-1].copy()), method=method, **tol) if problem == 'lv' else None   # reversed time
+    if br is not None:
+        assert dict(odeint.last_stats)['n_launches'] == 1
+        refr = O.odeint(fn, y0, t[::-1].copy(), method=method, options=oopt, **tol)
+        assert np.abs(br.cpu().numpy() - refr).max() <= 1e-9 * max(1.0, float(np.abs(refr).max()))
+    b32 = odeint(f, yd.float(), tt, method=method, rtol=1e-4, atol=1e-6)      # float32 state: the same kernel
+    s32 = dict(odeint.last_stats)
+    a32 = odeint(f, yd.float(), tt, method=method, options={'fusion': 'step'}, rtol=1e-4, atol=1e-6)
+    assert s32['n_launches'] == 1 and s32['n_attempts'] == dict(odeint.last_stats)['n_attempts']
+    assert float((a32 - b32).abs().max()) <= 2e-5 * scale
+
+
 @pytest.mark.parametrize('method', ['dopri5', 'bosh3', 'tsit5'])
 @pytest.mark.parametrize('problem', ['linear16', 'linear32_bias', 'linear128', 'linear64_f32', 'linear128_big'])
 def test_whole_integration_mfma_kernel_equals_launch_per_attempt(problem, method):
@@ -912,8 +961,11 @@ def test_custom_rhs_plugin_runs_the_catalogue_kernels_bit_for_bit():
     # too many trajectories for the co-resident grid: one launch per attempt, still the plugin's kernels
     big = to_dev(np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((200000, 3)), torch.float64)
     tb = torch.tensor([0., 0.1])
-    assert torch.equal(odeint(custom, big, tb, method='dopri5'), odeint(builtin, big, tb, method='dopri5'))
+    pb = odeint(custom, big, tb, method='dopri5')
     assert odeint.last_stats['n_launches'] > 1
+    bb = odeint(builtin, big, tb, method='dopri5')           # (the catalogue system continues on the plane-streaming whole-call kernel:
+    assert odeint.last_stats['n_launches'] == 1              #  another grid, so the error norm's partial sums fold in another order)
+    assert float((pb - bb).abs().max()) <= 1e-12
     with pytest.raises(Exception, match='per-stage'):
         odeint(custom, big[:10], tb, method='dopri5', options={'fusion': 'stage'})
 
@@ -1092,8 +1144,12 @@ def test_whole_integration_kernel_status_paths():
     bad = to_dev(np.array([[1., float('nan'), 1.]]), torch.float64)
     with pytest.raises(AssertionError, match='non-finite'):
         odeint(rhs.Lorenz(), bad, tt, method='dopri5', options={'fusion': 'whole'})
+    big = to_dev(np.ones((600000, 3)), torch.float64)        # beyond one trajectory per thread: the plane-streaming whole-call kernel
+    odeint(rhs.Lorenz(), big, torch.tensor([0., 0.1], dtype=torch.float64), method='dopri5', options={'fusion': 'whole'})
+    assert dict(odeint.last_stats)['n_launches'] == 1
+    from tfdiffeq_amd import plugin_examples                  # RHS plugins only have the one-trajectory-per-thread kernel
     with pytest.raises(Exception):
-        odeint(rhs.Lorenz(), to_dev(np.ones((600000, 3)), torch.float64), tt, method='dopri5', options={'fusion': 'whole'})
+        odeint(plugin_examples.lorenz(), big, tt, method='dopri5', options={'fusion': 'whole'})
 
 
 # ---------------------------------------------------------------------------------------------

@@ -64,6 +64,8 @@ struct mi_ode_solver {
   int step_fused;             // 1: whole-attempt kernel in use
   int step_grid, step_block;
   int persist;                // 1: whole integration in one launch (mi_ode_persist.h)
+  int persist_planes;         // 1: row-local system too large for one trajectory per thread: k_persist_rowlocal_planes (state in HBM planes)
+  int persist_planes_block;   // its workgroup size
   int persist_capable;        // 1: such a kernel exists for this problem and its grid is co-resident (transport aside)
   int persist_grid;
   int persist_sleep_first, persist_sleep_poll;   // hand-off back-off (units of 64 clocks)

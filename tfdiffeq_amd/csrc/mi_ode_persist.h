@@ -583,6 +583,202 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-local systems, ANY batch size: the whole call in one launch with the state in HBM planes.
+// k_persist_rowlocal keeps a trajectory in its thread's registers for the whole integration, so its grid is batch / 256
+// workgroups and stops where those are no longer co-resident (or the all-to-all hand-off no longer cheap): 131 072
+// trajectories.  Here a co-resident grid walks the batch with a grid-stride loop per pass (a thread always meets the same
+// rows), exactly the passes of k_step_rowlocal / k_stage_rowlocal<M_F0 / M_INITB>: y and f planes alternate on accept
+// like the linear tile kernel's below, dense output is emitted speculatively inside the attempt pass (the output cursor only
+// moves on accept, so a rejected attempt's rows are overwritten).  Traffic per attempt: y0, f0 in, y1, f1 out.
+// ------------------------------------------------------------------------------------------------
+template <typename T, int S, bool TS, class RHS, bool FSAL = true>
+__global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) {
+  constexpr int D = RHS::D;
+  using Row = RowVec<T, D>;
+  __shared__ PersistShared sh;
+  Ctl& s_c = sh.c;
+  const RHS rhs(A.s.rhs);
+  const T sign = (T)A.s.rhs.sign;
+  CtrlParams cp = A.s.cp;
+  cp.t_out = persist_stage_tout(A, sh.tout);
+  const double* t_out = cp.t_out;
+  unsigned gen = 0;
+  double r[5], rec[kRec], n_tot = 0.0;
+  if (threadIdx.x == 0) { persist_init_ctl(s_c, A); sh.ok = 1; }
+  __syncthreads();
+  const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x, pitch = (long long)gridDim.x * blockDim.x;
+  const long long batch = A.s.batch;
+
+  T* const ya = (T*)(A.s.planes);
+  T* const yb = (T*)(A.s.planes + A.s.stride);
+  T* const fa = (T*)(A.s.planes + 2 * A.s.stride);
+  T* const fb = (T*)(A.s.planes + (long long)(2 + S) * A.s.stride);
+  const T* const y_user = (const T*)A.y0;
+  auto load_row = [](const T* plane, long long row) {        // planes rewritten inside this launch: skip this CU's L1 (sc0)
+    Row v;
+#pragma unroll
+    for (int d = 0; d < D; ++d) v.v[d] = __hip_atomic_load(plane + row * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return v;
+  };
+
+  bool ok;
+  const T t_first = (T)uniform_d(s_c.t1);
+  {                                                           // before_integrate, first half (misc.py:225-233)
+    Acc acc;
+    for (long long row = first; row < batch; row += pitch) {
+      const Row y = *(const Row*)(y_user + row * D);
+      *(Row*)((T*)A.out0 + row * D) = y;                      // solution[0] = y0 (solvers.py:30)
+      T ys[D], f0[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) ys[d] = y.v[d];
+      rhs(sign * t_first, ys, f0);
+      Row f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) f.v[d] = sign * f0[d];
+      *(Row*)(fa + row * D) = f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const T sc = (T)cp.atol + fabs(y.v[d]) * (T)cp.rtol;  // misc.py:225
+        const double q0 = (double)(y.v[d] / sc);
+        acc.suma += q0 * q0;
+        if (!finite_(y.v[d])) acc.flag = 1;
+      }
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const T sc = (T)cp.atol + fabs(y.v[d]) * (T)cp.rtol;
+        const double q1 = (double)(f.v[d] / sc);
+        acc.sumb += q1 * q1;                                  // misc.py:228
+      }
+    }
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
+    __syncthreads();
+  }
+  if (cp.auto_first_step && ok) {                             // second half (misc.py:235-245)
+    Acc acc;
+    const T h0 = (T)uniform_d(s_c.h0);
+    for (long long row = first; row < batch; row += pitch) {
+      const Row y = *(const Row*)(y_user + row * D);
+      const Row f0 = load_row(fa, row);
+      T ys[D], f1[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) ys[d] = y.v[d] + h0 * f0.v[d];
+      rhs(sign * (t_first + (T)1.0 * h0), ys, f1);
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const T kn = sign * f1[d];
+        const T sc = (T)cp.atol + fabs(y.v[d]) * (T)cp.rtol;
+        const double q = (double)((kn - f0.v[d]) / sc);       // misc.py:237
+        acc.suma += q * q;
+      }
+    }
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
+  }
+  auto publish = [&](const AttemptState& st) {                // thread 0: what the next attempt needs
+    sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.accepted = st.accepted; sh.pub.done = st.done;
+    int j = st.next_out;                                      // speculative output range of the NEXT attempt (resolve_step)
+    const double t_new = st.t1 + st.dt;
+    while (j < st.n_out && !(t_out[j] > t_new)) ++j;
+    sh.pub.emit_lo = st.next_out; sh.pub.emit_hi = j;
+  };
+  if (threadIdx.x == 0) {
+    if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
+    else set_outputs_apply(&s_c, A.n_out);
+    AttemptState st;
+    st.load(s_c);
+    st.accepted = 0;
+    publish(st);
+    sh.st = st;
+  }
+  __syncthreads();
+
+  const T* cur_y = y_user;
+  T* cur_f = fa;
+  while (!uniform_i(sh.pub.done)) {                           // the adaptive loop (dopri5.py:82-121); the attempt is k_step_rowlocal's
+    StepPlanes<T, S> P;
+    const double dt_u = uniform_d(sh.pub.dt), t1_u = uniform_d(sh.pub.t1);
+    P.y0 = cur_y; P.f0 = cur_f;
+    P.y1 = (cur_y == ya) ? yb : ya;
+    P.f1 = (cur_f == fa) ? fb : fa;
+    P.hs = (T)dt_u; P.t0 = (T)t1_u;
+    P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
+    P.j_lo = uniform_i(sh.pub.emit_lo); P.j_hi = uniform_i(sh.pub.emit_hi);
+    Acc acc;
+    Row y0n, f0n;                                             // the next row of this thread, loaded one iteration ahead
+    auto fetch = [&](long long row) {
+      if (row < batch) { y0n = (cur_y == y_user) ? *(const Row*)(y_user + row * D) : load_row(P.y0, row); f0n = load_row(P.f0, row); }
+    };
+    fetch(first);
+    for (long long row = first; row < batch; row += pitch) {
+      const Row y0 = y0n;
+      T hs = P.hs;
+      asm volatile("" : "+v"(hs));                            // dt * coefficient products are formed per row, not kept (and spilled) across rows
+      T k[S + 1][D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) k[0][d] = f0n.v[d];
+      fetch(row + pitch);
+      T ys[D];
+      auto stage = [&](auto sg_c) {
+        constexpr int SG = decltype(sg_c)::value;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+          T kk[SG];
+#pragma unroll
+          for (int j = 0; j < SG; ++j) kk[j] = k[j][d];
+          ys[d] = step_combine<T, SG>(y0.v[d], kk, hs, A.s);
+        }
+        T kn[D];
+        rhs(sign * (P.t0 + (T)A.s.alpha[SG - 1] * hs), ys, kn);
+#pragma unroll
+        for (int d = 0; d < D; ++d) k[SG][d] = sign * kn[d];
+      };
+      for_stages<1, S>(stage);
+      Row y1, f1;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        T kk[S + 1];
+#pragma unroll
+        for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
+        T err, ymid;
+        step_finish<T, S>(y0.v[d], kk, hs, A.s, err, ymid, !TS && P.j_hi > P.j_lo);
+        if constexpr (!FSAL) ys[d] = step_y1_general<T, S>(y0.v[d], kk, hs, A.s);   // rk_common.py:55-56
+        y1.v[d] = ys[d];                                      // FSAL: y1 = y_S (rk_common.py:58)
+        f1.v[d] = k[S][d];
+        acc.maxa = fmax(acc.maxa, (double)fabs(y0.v[d]));
+        acc.maxb = fmax(acc.maxb, (double)fabs(ys[d]));
+        acc.suma += (double)err * (double)err;
+        step_emit<T, S, TS>(A.s, P, y0.v[d], ys[d], kk, ymid, row * D + d, t_out);
+      }
+      *(Row*)(P.y1 + row * D) = y1;
+      *(Row*)(P.f1 + row * D) = f1;
+    }
+    ok = grid_reduce(A, acc, sh, gen++, r, n_tot);            // (its barriers also fence the reads of sh.pub above)
+    if (threadIdx.x == 0) {
+      AttemptState st = sh.st;
+      if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
+      else { fill_record(rec, r, n_tot); attempt_core(st, rec, cp); }
+      publish(st);
+      sh.st = st;
+    }
+    __syncthreads();
+    if (uniform_i(sh.pub.accepted)) { cur_y = P.y1; cur_f = P.f1; }
+  }
+
+  // final state for mi_ode_get_state: plane indices as controller_apply's rotation would have left them
+  if (cur_y == y_user) {                                      // no accepted step (error exit): seed plane 0 with y0
+    const long long n = batch * D;
+    for (long long i = first; i < n; i += pitch) ya[i] = y_user[i];
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    sh.st.store(s_c);
+    s_c.idx_y0 = (cur_y == yb) ? 1 : 0; s_c.idx_y1 = (cur_y == yb) ? 0 : 1;
+    s_c.idx_k[0] = (cur_f == fa) ? 2 : 2 + S; s_c.idx_k[S] = (cur_f == fa) ? 2 + S : 2;
+    persist_write_back(A, s_c);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Linear RHS, dim in {16, 32, 64, 128}: the whole call in one launch on the persistent MFMA grid.
 // Same hand-off and redundant controller as above; the state stays in HBM planes (a workgroup only ever touches its own
 // tiles, so planes written in one attempt are re-read by the SAME workgroup in the next - sc0 loads skip its L1),
