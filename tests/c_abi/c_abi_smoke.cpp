@@ -2,6 +2,7 @@
 //   1. fixed grid RK4 (3/8 rule) on a Lorenz batch vs a scalar host loop written here   (bit-exact expected)
 //   2. adaptive Dopri5 on the same batch vs the fine RK4 solution                        (1e-6)
 //   3. the stateless plane kernel mi_ode_lincomb vs a host loop                          (bit-exact expected)
+//   3b. tuple state, 4. fused adjoint interval, 5. fixed-grid Adams-Bashforth in one launch vs a host loop, 6. 300000 trajectories in one launch
 // Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -I include tests/c_abi/c_abi_smoke.cpp -L tfdiffeq_amd -lmi_ode
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -233,6 +234,89 @@ int main() {
            (long long)ast.n_accepted, (long long)ast.n_launches, at0, at1);
     if (ast.n_launches != 1 || ast.n_accepted < 1 || at1 != at0) { printf("FAIL adjoint interval\n"); return 1; }
     MI(mi_ode_adjoint_destroy(ah));
+  }
+  // ---- 5. fixed-grid Adams-Bashforth in one launch (mi_ode_desc.multistep, ABI 9) vs a host loop ------------------
+  {
+    // tables as the reference forms them in Python floats: (1 / divisor) * c_j, orders 1..4 (fixed_adams.py:9-86)
+    static double ab[13 * 12], am[13 * 12], am0[13];
+    memset(ab, 0, sizeof(ab)); memset(am, 0, sizeof(am)); memset(am0, 0, sizeof(am0));
+    const double cab[5][4] = {{0}, {1}, {3, -1}, {23, -16, 5}, {55, -59, 37, -9}};
+    const double dab[5] = {0, 1, 2, 12, 24};
+    for (int o = 1; o <= 4; ++o) for (int j = 0; j < o; ++j) ab[o * 12 + j] = (1 / dab[o]) * cab[o][j];
+    const int MO = 5;                                                   // max_order 5: history of 4 derivatives -> AB4
+    mi_ode_desc dm;
+    memset(&dm, 0, sizeof(dm));
+    dm.dtype = MI_ODE_F64; dm.adaptive = 0; dm.batch = B; dm.dim = D; dm.tableau.n_stages = 3; dm.first_step = NAN;
+    dm.rhs = d.rhs;
+    dm.multistep = 1; dm.ms_max_order = MO; dm.ms_max_iters = 4; dm.ms_min_order = 4; dm.ms_ab = ab; dm.ms_am = am; dm.ms_am0 = am0;
+    dm.rtol = 1e-7; dm.atol = 1e-9;
+    mi_ode_handle hm = nullptr;
+    MI(mi_ode_create(&dm, &hm));
+    MI(mi_ode_fixed_grid_integrate(hm, d_y0, t.data(), T, d_out, &st, nullptr));
+    CK(hipMemcpy(out.data(), d_out, (size_t)T * n * sizeof(double), hipMemcpyDeviceToHost));
+    double md5 = 0;
+    for (int b = 0; b < B; ++b) {
+      double y[3] = {y0[3 * b], y0[3 * b + 1], y0[3 * b + 2]}, hist[4][3];
+      int len = 0;
+      for (int i = 0; i + 1 < T; ++i) {
+        const double dt = t[i + 1] - t[i];
+        double fn[3], dy[3];
+        lorenz(y, fn);
+        for (int j = 3; j > 0; --j) memcpy(hist[j], hist[j - 1], sizeof(fn));
+        memcpy(hist[0], fn, sizeof(fn));
+        len = len + 1 < MO - 1 ? len + 1 : MO - 1;
+        if (len < 4 - 1) {                                              // start-up: RK4 3/8 rule with k1 = history[0]
+          double k2[3], k3[3], k4[3], ys[3];
+          for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * fn[q] / 3;
+          lorenz(ys, k2);
+          for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * (fn[q] / -3 + k2[q]);
+          lorenz(ys, k3);
+          for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * (fn[q] - k2[q] + k3[q]);
+          lorenz(ys, k4);
+          for (int q = 0; q < 3; ++q) dy[q] = (fn[q] + 3 * k2[q] + 3 * k3[q] + k4[q]) * (dt / 8);
+        } else {
+          for (int q = 0; q < 3; ++q) {
+            double a_ = ab[len * 12] * hist[0][q];
+            for (int j = 1; j < len; ++j) a_ = a_ + ab[len * 12 + j] * hist[j][q];
+            dy[q] = dt * a_;
+          }
+        }
+        for (int q = 0; q < 3; ++q) { y[q] = y[q] + dy[q]; md5 = fmax(md5, fabs(out[(size_t)(i + 1) * n + 3 * b + q] - y[q])); }
+      }
+    }
+    printf("explicit Adams (one launch): max |gpu - host| = %.3e, launches %lld\n", md5, (long long)st.n_launches);
+    if (!(md5 <= 1e-12) || st.n_launches != 1) { printf("FAIL multistep\n"); return 1; }
+    MI(mi_ode_destroy(hm));
+  }
+
+  // ---- 6. more trajectories than one per thread keeps co-resident: the whole call is still one launch (state in HBM planes) --
+  {
+    const long long BB = 300000, nn = BB * D;
+    std::vector<double> yb((size_t)nn);
+    for (long long b = 0; b < BB; ++b) for (int q = 0; q < 3; ++q) yb[3 * b + q] = y0[3 * (b % B) + q];      // the 1000 rows, repeated
+    double *d_yb, *d_ob;
+    CK(hipMalloc(&d_yb, nn * sizeof(double))); CK(hipMalloc(&d_ob, 2 * nn * sizeof(double)));
+    CK(hipMemcpy(d_yb, yb.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    mi_ode_desc db_ = d;                                                 // the dopri5 descriptor of section 2
+    db_.batch = BB;
+    mi_ode_handle hb = nullptr, hs = nullptr;
+    MI(mi_ode_create(&db_, &hb));
+    const double t6[2] = {0.0, 0.5};
+    bits = mi_ode_integrate(hb, d_yb, t6, 2, d_ob, &st, nullptr);
+    if (bits != 0) { printf("FAIL large batch status %d %s\n", bits, mi_ode_last_error()); return 1; }
+    const long long big_launches = st.n_launches, big_attempts = st.n_attempts;
+    MI(mi_ode_create(&d, &hs));
+    bits = mi_ode_integrate(hs, d_y0, t6, 2, d_out, &st, nullptr);
+    if (bits != 0) { printf("FAIL status %d\n", bits); return 1; }
+    std::vector<double> a((size_t)nn), c(n);
+    CK(hipMemcpy(a.data(), d_ob + nn, nn * sizeof(double), hipMemcpyDeviceToHost));
+    CK(hipMemcpy(c.data(), d_out + n, n * sizeof(double), hipMemcpyDeviceToHost));
+    double md6 = 0;                                                      // 300 copies of the same rows: the norms are those of the 1000 -> same steps
+    for (long long i = 0; i < nn; ++i) md6 = fmax(md6, fabs(a[i] - c[i % n]));
+    printf("300000 trajectories: launches %lld, attempts %lld (1000 rows: %lld), max |row - its copy in the small run| = %.3e\n", big_launches,
+           big_attempts, (long long)st.n_attempts, md6);
+    if (big_launches != 1 || big_attempts != st.n_attempts || !(md6 <= 1e-12)) { printf("FAIL large batch\n"); return 1; }
+    MI(mi_ode_destroy(hb)); MI(mi_ode_destroy(hs));
   }
   printf("C-ABI OK (abi %d)\n", mi_ode_abi_version());
   return 0;
