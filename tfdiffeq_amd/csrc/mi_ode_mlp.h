@@ -104,6 +104,26 @@ __device__ __forceinline__ float mlp_act_deriv(float h) {
 
 // One evaluation of the MLP for the tile whose input rows sit in s_x.  Every thread of the workgroup must call it.
 // Owner threads (wave < NW3) receive their 4 output elements (rows rb*16 + 4*(lane>>4) + i, column 16*cb + (lane&15)).
+#ifndef MI_MLP_ABL
+#define MI_MLP_ABL 0
+#endif
+#ifdef MI_TRACE                                              // tuning aid: cycle stamps of the layer phases, workgroup 0, wavefronts 0 and 4
+__device__ long long mi_mlp_tr[2][1024];
+__device__ int mi_mlp_tn[2];
+__device__ __forceinline__ void mlp_stamp() {
+  if (blockIdx.x == 0 && (threadIdx.x == 0 || threadIdx.x == 256)) {
+    const int w = threadIdx.x ? 1 : 0;
+    const int n = mi_mlp_tn[w];
+    if (n < 1024) { mi_mlp_tr[w][n] = (long long)__builtin_readcyclecounter(); mi_mlp_tn[w] = n + 1; }
+  }
+}
+#else
+__device__ __forceinline__ void mlp_stamp() {}
+#endif
+// (Round 3: issuing the LDS reads of the NEXT group of MFMAs before the current group - explicit operand pipelining with
+// sched_group_barrier - changed nothing, 0.351 vs 0.343 ms at config 5: the two wavefronts of a SIMD interleave their fp32 chains and
+// cover each other's LDS round trips.  What the reads cost is the start of every chain after its barrier (profiles/r03_mlp_timeline.txt).
+// Two accumulators in the dependent chain of layer 3: no change either - 2816 vs 2812 cycles.)
 template <int DP, int HP, int ACT>
 __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, const float* w1f, const float* w2f,
                                          const float* w3f, float b1v, float b2v, float b3v, float* out4) {
@@ -112,20 +132,39 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int li = lane & 15, lg = lane >> 4;
   constexpr int KS1 = DP / 4, KS2 = HP / 4;
+#if (MI_MLP_ABL & 1)
+  f4 fake = {1.0f, 0.5f, 0.25f, 0.125f};
+  asm volatile("" : "+v"(fake));
+#define MI_MLP_LD(p) fake
+#elif (MI_MLP_ABL & 2)                                      // the reads are issued (and their results kept alive) but nothing waits for them
+  f4 fake = {1.0f, 0.5f, 0.25f, 0.125f};
+  asm volatile("" : "+v"(fake));
+  auto mi_mlp_ld2 = [&](const float* p_) {
+    f4 t_;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(t_) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const float*)p_));
+    return fake;
+  };
+#define MI_MLP_LD(p) mi_mlp_ld2(p)
+#else
+#define MI_MLP_LD(p) (*(const f4*)(p))
+#endif
+  mlp_stamp();
   __syncthreads();                                          // s_x is complete
+  mlp_stamp();
   if (wave < G::NW12) {                                     // layer 1: [32 x DP] @ [DP x 16]
     f4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
     const float* a0p = s_x + li * G::LDX + lg * KS1;
     const float* a1p = s_x + (16 + li) * G::LDX + lg * KS1;
 #pragma unroll
     for (int m = 0; m < KS1 / 4; ++m) {
-      const f4 a0 = *(const f4*)(a0p + 4 * m), a1 = *(const f4*)(a1p + 4 * m);
+      const f4 a0 = MI_MLP_LD(a0p + 4 * m), a1 = MI_MLP_LD(a1p + 4 * m);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[v], w1f[4 * m + v], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[v], w1f[4 * m + v], c1, 0, 0, 0);
       }
     }
+    mlp_stamp();
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -135,20 +174,23 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
       s_h1[(16 + 4 * lg + i) * G::LDH + col] = h1;
     }
   }
+  mlp_stamp();
   __syncthreads();
+  mlp_stamp();
   if (wave < G::NW12) {                                     // layer 2: [32 x HP] @ [HP x 16]
     f4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
     const float* a0p = s_h1 + li * G::LDH + lg * KS2;
     const float* a1p = s_h1 + (16 + li) * G::LDH + lg * KS2;
 #pragma unroll
     for (int m = 0; m < KS2 / 4; ++m) {
-      const f4 a0 = *(const f4*)(a0p + 4 * m), a1 = *(const f4*)(a1p + 4 * m);
+      const f4 a0 = MI_MLP_LD(a0p + 4 * m), a1 = MI_MLP_LD(a1p + 4 * m);
 #pragma unroll
       for (int v = 0; v < 4; ++v) {
         c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[v], w2f[4 * m + v], c0, 0, 0, 0);
         c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[v], w2f[4 * m + v], c1, 0, 0, 0);
       }
     }
+    mlp_stamp();
     const int col = 16 * wave + li;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -158,20 +200,23 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
       s_h2[(16 + 4 * lg + i) * G::LDH + col] = h1;
     }
   }
+  mlp_stamp();
   __syncthreads();
+  mlp_stamp();
   if (wave < G::NW3) {                                      // layer 3: one 16-row block x 16 output columns per wave
     const int rb = wave / G::CB3;
     f4 c = {0, 0, 0, 0};
     const float* ap = s_h2 + (16 * rb + li) * G::LDH + lg * KS2;
 #pragma unroll
     for (int m = 0; m < KS2 / 4; ++m) {
-      const f4 a = *(const f4*)(ap + 4 * m);
+      const f4 a = MI_MLP_LD(ap + 4 * m);
 #pragma unroll
       for (int v = 0; v < 4; ++v) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a[v], w3f[4 * m + v], c, 0, 0, 0);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) out4[i] = c[i] + b3v;
   }
+  mlp_stamp();
 }
 
 struct MlpArgs {
@@ -467,6 +512,17 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(Pers
     s_c.idx_y0 = (cur_y == yb) ? 1 : 0; s_c.idx_y1 = (cur_y == yb) ? 0 : 1;
     s_c.idx_k[0] = (cur_f == fa) ? 2 : 2 + S; s_c.idx_k[S] = (cur_f == fa) ? 2 + S : 2;
     persist_write_back(A, s_c);
+#ifdef MI_TRACE
+    for (int w = 0; w < 2; ++w) {                             // 9 stamps per evaluation: [0] entry [1] barrier1 [2] L1 chain [3] act1+write [4] barrier2
+      const long long* q = mi_mlp_tr[w];                      // [5] L2 chain [6] act2+write [7] barrier3 [8] L3 chain... [9] end
+      for (int e = 20; e < 34 && 9 * e + 9 < mi_mlp_tn[w]; ++e) {
+        const long long* p = q + 9 * e;
+        printf("[mlp trace] wave %d eval %2d: bar1 %5lld L1 %5lld act1 %5lld bar2 %5lld L2 %5lld act2 %5lld bar3 %5lld L3 %5lld | to next %5lld\n", 4 * w, e,
+               p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[6] - p[5], p[7] - p[6], p[8] - p[7], p[9] - p[8]);
+      }
+      mi_mlp_tn[w] = 0;
+    }
+#endif
   }
 }
 
