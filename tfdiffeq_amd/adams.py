@@ -101,9 +101,17 @@ class VariableCoefficientAdamsBashforth(AdaptiveStepsizeODESolver):
 
     def _ratios(self, errs, tolerance):
         """misc._compute_error_ratio with an explicit tolerance: mean((err/tol)^2) = sum err^2 / (N tol^2)."""
-        sums = torch.cat([_scaled_sumsq(e, None, e, 0.0, float(tol)) for e, tol in zip(errs, tolerance)]).cpu().numpy()
+        return self._ratios_many([errs], tolerance)[0]
+
+    def _ratios_many(self, groups, tolerance):
+        """The error ratios of several candidate estimates (one tuple of tensors per group) with ONE device-to-host copy."""
+        sums = torch.cat([_scaled_sumsq(e, None, e, 0.0, float(tol)) for errs in groups for e, tol in zip(errs, tolerance)]).cpu().numpy()
+        out, i = [], 0
         with np.errstate(all='ignore'):
-            return tuple(_np_dtype(e.dtype).type(s_ / float(e.numel())) for s_, e in zip(sums, errs))
+            for errs in groups:
+                out.append(tuple(_np_dtype(e.dtype).type(sums[i + j] / float(e.numel())) for j, e in enumerate(errs)))
+                i += len(errs)
+        return out
 
     def _adaptive_adams_step(self, vcabm_state, final_t):
         y0, prev_f, prev_t, next_t, prev_phi, order = vcabm_state
@@ -124,7 +132,19 @@ class VariableCoefficientAdamsBashforth(AdaptiveStepsizeODESolver):
         with np.errstate(all='ignore'):                                                  # one scalar per component (F3)
             tolerance = tuple(dt_(self.atol[i]) + dt_(self.rtol[i]) * dt_(max(recs[i, 0], recs[i, 1]))
                               for i in range(len(local_error)))
-        error_k = self._ratios(local_error, tolerance)
+        # One read-back for every estimate this step may need ("the order / accept record read once per step"):
+        # the order-selection estimates of adams.py:176-199 only depend on implicit_phi_p, so they are formed speculatively next to
+        # error_k - the same kernels and values as before, two host synchronisations per step (tolerance, ratios) instead of up to five.
+        want_lower = not (len(prev_t) <= 4 or order < 3)
+        want_higher = want_lower and order < self.max_order
+        groups = [local_error]
+        if want_lower:
+            groups.append(tuple(_lincomb(None, [g[order - 1] - g[order - 2]], [iphi_], dt_cast) for iphi_ in implicit_phi_p[order - 1]))
+            groups.append(tuple(_lincomb(None, [g[order - 2] - g[order - 3]], [iphi_], dt_cast) for iphi_ in implicit_phi_p[order - 2]))
+        if want_higher:
+            groups.append(tuple(_lincomb(None, [dt_(gamma_star[order])], [iphi_], dt_cast) for iphi_ in implicit_phi_p[order]))
+        ratios = self._ratios_many(groups, tolerance)
+        error_k = ratios[0]
         accept_step = bool(np.all(np.asarray([float(r) for r in error_k]) <= 1))
         self.stats['n_attempts'] += 1
         if not accept_step:
@@ -137,15 +157,11 @@ class VariableCoefficientAdamsBashforth(AdaptiveStepsizeODESolver):
         if len(prev_t) <= 4 or order < 3:
             next_order = min(order + 1, 3, self.max_order)
         else:
-            error_km1 = self._ratios(tuple(_lincomb(None, [g[order - 1] - g[order - 2]], [iphi_], dt_cast)
-                                           for iphi_ in implicit_phi_p[order - 1]), tolerance)
-            error_km2 = self._ratios(tuple(_lincomb(None, [g[order - 2] - g[order - 3]], [iphi_], dt_cast)
-                                           for iphi_ in implicit_phi_p[order - 2]), tolerance)
+            error_km1, error_km2 = ratios[1], ratios[2]
             if min(error_km1 + error_km2) < max(error_k):
                 next_order = order - 1
             elif order < self.max_order:
-                error_kp1 = self._ratios(tuple(_lincomb(None, [dt_(gamma_star[order])], [iphi_], dt_cast)
-                                               for iphi_ in implicit_phi_p[order]), tolerance)
+                error_kp1 = ratios[3]
                 if max(error_kp1) < max(error_k):
                     next_order = order + 1
         dt_next = dt if next_order > order else _optimal_step_size(dt, error_k, self.safety, self.ifactor, self.dfactor,
