@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define MI_ODE_ABI_VERSION 9
+#define MI_ODE_ABI_VERSION 10
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -174,13 +174,17 @@ typedef struct mi_ode_desc {
    * ms_am0[o] = MOULTON[o + 1][0] / DIVISOR[o + 1], o = 0 .. 12 (rows of unused orders: zeros).  rtol / atol: the corrector's
    * convergence test (misc.py:129-134; odeint passes ITS rtol / atol).  stats.n_rejected = steps whose corrector did not converge
    * (the reference prints a warning for each and drops its oldest history entry, fixed_adams.py:197-200). */
-  int32_t multistep;          /* 0: none, 1: Adams-Bashforth ('explicit_adams'), 2: Adams-Bashforth-Moulton ('fixed_adams') */
+  int32_t multistep;          /* 0: none, 1: Adams-Bashforth ('explicit_adams'), 2: Adams-Bashforth-Moulton ('fixed_adams'),
+                               * 3: the variable-step, variable-order Adams solver ('adams', adams.py:66-211; ABI 10): adaptive = 1, the whole
+                               * mi_ode_integrate call is ONE launch for the row-local catalogue systems (csrc/mi_ode_adams_vc.h); uses
+                               * rtol / atol / safety / ifactor / dfactor, ms_max_order (<= 12) and ms_gamma_star; the tableau is ignored */
   int32_t ms_max_order;       /* <= 12 (fixed_adams.py:89) */
   int32_t ms_max_iters;       /* corrector iterations (fixed_adams.py:90: 4) */
   int32_t ms_min_order;       /* below it the start-up RK4 3/8 step runs (fixed_adams.py:88: 4) */
   const double* ms_ab;
   const double* ms_am;
   const double* ms_am0;
+  const double* ms_gamma_star; /* multistep = 3: HOST array of 13 doubles (adams.py:15-18), copied at create */
 } mi_ode_desc;
 #define MI_ODE_SEGMENT_ALIGN 256
 

@@ -235,7 +235,7 @@ int main() {
     if (ast.n_launches != 1 || ast.n_accepted < 1 || at1 != at0) { printf("FAIL adjoint interval\n"); return 1; }
     MI(mi_ode_adjoint_destroy(ah));
   }
-  // ---- 5. fixed-grid Adams-Bashforth in one launch (mi_ode_desc.multistep, ABI 9) vs a host loop ------------------
+  // ---- 5. fixed-grid Adams-Bashforth in one launch (mi_ode_desc.multistep) vs a host loop ------------------
   {
     // tables as the reference forms them in Python floats: (1 / divisor) * c_j, orders 1..4 (fixed_adams.py:9-86)
     static double ab[13 * 12], am[13 * 12], am0[13];

@@ -90,3 +90,57 @@ def test_the_corrector_that_does_not_converge_is_reported_like_the_reference(cap
     assert solver.n_not_converged > 0 and st['n_rejected'] == solver.n_not_converged, (st, solver.n_not_converged)
     assert capfd.readouterr().err.count('Functional iteration did not converge') >= st['n_rejected']
     assert np.abs(sol.cpu().numpy() - ref).max() <= 1e-11 * max(1.0, np.abs(ref).max())
+
+
+# ---------------------------------------------------------------------------------------------
+# 'adams': the variable-step, variable-order solver (adams.py:66-211) in one launch (csrc/mi_ode_adams_vc.h)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('dtype', [np.float64, np.float32])
+@pytest.mark.parametrize('problem,batch', [('lv', 1), ('lv', 5000), ('lorenz', 300), ('lorenz', 70000), ('spiral', 64)])
+def test_variable_order_adams_in_one_launch(problem, batch, dtype):
+    """Against the numpy oracle (same attempt / accept sequence: the orders, the float32 g vector, the predictor-valued state are the
+    reference's) and against the per-step host loop over plane kernels; one and many workgroups; both dtypes; reversed time."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(9)
+    if problem == 'lv':
+        f, fn, y0 = rhs.LotkaVolterra(1.5, 1.0, 3.0, 1.0), _lv_np, 1.0 + 0.5 * rng.uniform(size=(batch, 2))
+        t = np.linspace(0., 2.0, 9)
+    elif problem == 'lorenz':
+        f, fn, y0 = rhs.Lorenz(), _lorenz_np, np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((batch, 3))
+        t = np.linspace(0., 0.5, 6)
+    else:
+        Am = np.array([[-0.1, 2.0], [-2.0, -0.1]])
+        f, fn, y0 = rhs.CubicLinear(torch.tensor(Am)), (lambda t_, y: (y ** 3) @ Am), np.tile(np.array([[2., 0.]]), (batch, 1))
+        t = np.linspace(0., 5.0, 20) if dtype == np.float64 else np.linspace(0., 1.0, 5)   # (float32: before rounding forks the sequence)
+    y0 = y0.astype(dtype)
+    tol = dict(rtol=1e-6, atol=1e-8) if dtype == np.float64 else dict(rtol=1e-4, atol=1e-6)
+    # g is rounded to float32 every step (adams.py:34): a last-bit difference in dt (the error norm's summation order) can flip a bit of
+    # g, i.e. perturb the step by 1e-8 relative - the band is that, not the float64 roundoff
+    band = 1e-6 if dtype == np.float64 else 2e-4
+    for tt in (t, -t) if problem != 'spiral' else (t,):
+        got = odeint(f, torch.tensor(y0, device=dev()), torch.tensor(tt), method='adams', **tol)
+        st = dict(odeint.last_stats)
+        assert st.get('engine', '').startswith('fused variable-order Adams') and st['n_launches'] == 1 and st['status'] == 0, st
+        scale = max(1.0, float(got.abs().max()))
+        if dtype == np.float64:                                            # (the oracle reverses f itself, misc.py:318-321)
+            ref, rst = OA.odeint(fn, y0, tt, method='adams', return_stats=True, **tol)
+            n_acc = int(sum(1 for r in rst.trace if r[3] > 0))
+            if problem == 'spiral':        # ~280 attempts: a sequence that forks on a last-bit difference of one error ratio (64 equal rows
+                # summed in another order) - the slack the reference-fixture test allows the method (test_gpu_parity.py)
+                assert abs(st['n_attempts'] - len(rst.trace)) <= max(2, len(rst.trace) // 20) and abs(st['n_accepted'] - n_acc) <= max(2, n_acc // 20)
+                assert np.abs(got.cpu().numpy() - ref).max() <= 1e-4 * scale
+            else:
+                assert (st['n_attempts'], st['n_accepted']) == (len(rst.trace), n_acc), (st, len(rst.trace), n_acc)
+                assert np.abs(got.cpu().numpy() - ref).max() <= band * scale
+        # float32: the reference's scheme (state advanced with the PREDICTOR, g in float32) amplifies rounding - numpy's float32 mean
+        # and the kernels' float64 accumulation of the error ratio part ways after a dozen steps, by more than the tolerance (the
+        # float64 oracle itself is 2e-2 off the true solution at rtol 1e-4 on this problem).  The product's two engines agree.
+        loop = odeint(f, torch.tensor(y0, device=dev()), torch.tensor(tt), method='adams', options={'force_plane_kernels': True}, **tol)
+        sl = dict(odeint.last_stats)
+        assert sl.get('engine') == 'plane kernels'
+        if problem == 'spiral':
+            assert abs(sl['n_attempts'] - st['n_attempts']) <= max(2, st['n_attempts'] // 20)
+            assert float((got - loop).abs().max()) <= 1e-4 * scale
+        else:
+            assert (sl['n_attempts'], sl['n_accepted']) == (st['n_attempts'], st['n_accepted']), (sl, st)
+            assert float((got - loop).abs().max()) <= band * scale

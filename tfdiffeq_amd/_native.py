@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH, RHS_PLUGIN = 1, 2, 3, 4, 5, 6
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 MAX_SEGMENTS = 8
 SEGMENT_ALIGN = 256
 IPC_HANDLE_BYTES = 64
@@ -67,7 +67,8 @@ class Desc(C.Structure):
                 ('n_segments', C.c_int32), ('seg_tolerances', C.c_int32), ('seg_rows', C.c_int64 * MAX_SEGMENTS),
                 ('seg_rtol', C.c_double * MAX_SEGMENTS), ('seg_atol', C.c_double * MAX_SEGMENTS),
                 ('multistep', C.c_int32), ('ms_max_order', C.c_int32), ('ms_max_iters', C.c_int32), ('ms_min_order', C.c_int32),
-                ('ms_ab', C.POINTER(C.c_double)), ('ms_am', C.POINTER(C.c_double)), ('ms_am0', C.POINTER(C.c_double))]
+                ('ms_ab', C.POINTER(C.c_double)), ('ms_am', C.POINTER(C.c_double)), ('ms_am0', C.POINTER(C.c_double)),
+                ('ms_gamma_star', C.POINTER(C.c_double))]
 
 
 class CtrlParams(C.Structure):

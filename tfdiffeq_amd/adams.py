@@ -61,6 +61,7 @@ class VariableCoefficientAdamsBashforth(AdaptiveStepsizeODESolver):
 
     def __init__(self, func, y0, rtol, atol, implicit=True, first_step=None, max_order=_MAX_ORDER, safety=0.9,
                  ifactor=10.0, dfactor=0.2, **unused_kwargs):
+        self._force_planes = unused_kwargs.pop('force_plane_kernels', False)
         _handle_unused_kwargs(self, unused_kwargs)
         self.func = func
         self.y0 = y0
@@ -77,6 +78,31 @@ class VariableCoefficientAdamsBashforth(AdaptiveStepsizeODESolver):
     def _f(self, t, y):
         like = self.y0[0]
         return self.func(_scalar_tensor(_np_dtype(like.dtype).type(t), like), y)
+
+    def integrate(self, t):
+        """A row-local catalogue system with a single state tensor: the whole call - the deque of backward differences, g / beta,
+        the error ratios, the order selection - is ONE kernel launch (csrc/mi_ode_adams_vc.h).  Everything else: the per-step loop of
+        the base class over plane kernels."""
+        from .solvers import _EULER_SHAPE, _FusedEngine, _cached_engine, _fusable
+        from .misc import _assert_increasing
+        rhs = _fusable(self.func, self.y0) if not self._force_planes else None
+        if rhs is not None and getattr(rhs, 'multistep_fused', False) and len(self.y0) == 1:
+            _assert_increasing(t)
+            y = self.y0[0]
+            key = ('adams_vc', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device), self.max_order,
+                   float(self.rtol[0]), float(self.atol[0]), float(self.safety), float(self.ifactor), float(self.dfactor))
+            try:
+                eng = _cached_engine(key, lambda: _FusedEngine(rhs, y, True, _EULER_SHAPE, rtol=self.rtol[0], atol=self.atol[0],
+                                                               safety=float(self.safety), ifactor=float(self.ifactor),
+                                                               dfactor=float(self.dfactor), multistep=(3, self.max_order, gamma_star)))
+            except N.NativeError:
+                eng = None                            # (a batch whose workgroups cannot be co-resident): the per-step loop
+            if eng is not None:
+                out = eng.integrate(t.to(torch.float64).numpy(), y)
+                self.stats = eng.stats.as_dict()
+                self.stats['engine'] = 'fused variable-order Adams kernel (one launch)'
+                return (out,)
+        return super(VariableCoefficientAdamsBashforth, self).integrate(t)
 
     def before_integrate(self, t):
         for y_ in self.y0:

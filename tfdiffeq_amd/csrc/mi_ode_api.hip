@@ -13,6 +13,7 @@
 #include "mi_ode_step_fused.h"
 #include "mi_ode_persist.h"
 #include "mi_ode_adams.h"
+#include "mi_ode_adams_vc.h"
 #include "mi_ode_mlp.h"
 #include "mi_ode_plugin.h"
 
@@ -400,7 +401,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     // row-local families; schedules 2-4 only
     const bool classic = tb.fsal && (tb.n_stages == 3 || tb.n_stages == 6);
     const bool wide = (tb.fsal && tb.n_stages == 13) || (!tb.fsal && tb.n_stages == 1);
-    if (!classic && !wide) { mi_set_error("fused adaptive engine: no kernels for a %d-row %s tableau", tb.n_stages, tb.fsal ? "FSAL-shaped" : "non-FSAL"); return MI_ODE_E_INVALID; }
+    if (!classic && !wide && desc->multistep != 3) { mi_set_error("fused adaptive engine: no kernels for a %d-row %s tableau", tb.n_stages, tb.fsal ? "FSAL-shaped" : "non-FSAL"); return MI_ODE_E_INVALID; }
     if (desc->interp != MI_ODE_INTERP_QUARTIC_MID && tb.n_stages != 6) { mi_set_error("tsit5 dense output needs 7 stage derivatives"); return MI_ODE_E_INVALID; }
   }
   mi_ode_solver* h = new mi_ode_solver();
@@ -458,6 +459,27 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   }
   rc = h->is_f32 ? mi_stage_geometry_f32(h) : mi_stage_geometry_f64(h);
   if (rc != 0) { delete h; return rc; }
+  if (desc->multistep == 3) {                      // the variable-order Adams solver in one launch (mi_ode_adams_vc.h)
+    const bool rowlocal_cat = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ;
+    if (!desc->adaptive || !rowlocal_cat || desc->ms_gamma_star == nullptr || desc->ms_max_order < 1 || desc->ms_max_order > kVcMaxOrder ||
+        h->d.world_size > 1 || h->nseg > 1 || desc->controller != MI_ODE_CTRL_MISC) {
+      mi_set_error("multistep = 3 ('adams'): adaptive = 1, a row-local catalogue system, one rank, one tensor, the misc controller; 1 <= max_order <= %d, gamma_star", kVcMaxOrder);
+      delete h; return MI_ODE_E_INVALID;
+    }
+    const long long g = (desc->batch + 255) / 256;
+    if (g > 1) {                                   // every attempt's error ratio crosses the workgroups: they must be co-resident
+      const int cap = h->is_f32 ? mi_adams_vc_capacity_f32(h) : mi_adams_vc_capacity_f64(h);
+      if (g > cap || g > kPersistMaxGrid) {
+        mi_set_error("adams in one launch: %lld workgroups cannot be co-resident on this device (%d)", g, cap);
+        delete h; return MI_ODE_E_INVALID;
+      }
+    }
+    memcpy(h->adams_gamma_star, desc->ms_gamma_star, sizeof(h->adams_gamma_star));
+    hipError_t ea = hipHostMalloc((void**)&h->adams_res, 4 * sizeof(long long), hipHostMallocDefault);
+    if (ea != hipSuccess) { mi_set_error("multistep result record: %s", hipGetErrorString(ea)); delete h; return MI_ODE_E_HIP; }
+    for (int i = 0; i < 4; ++i) h->adams_res[i] = 0;
+    h->d.ms_gamma_star = nullptr;                  // (caller-owned host array: not kept)
+  } else
   if (desc->multistep != 0) {                      // fixed-grid Adams family in one launch (mi_ode_adams.h)
     const bool rowlocal_cat = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ;
     if (desc->adaptive || !rowlocal_cat || (desc->multistep != 1 && desc->multistep != 2) || desc->ms_ab == nullptr || desc->ms_am == nullptr ||
@@ -858,6 +880,49 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   return (int)h->ctl_host->status;
 }
 
+// 'adams' (adams.py:66-211) for the row-local catalogue systems: the whole call in one launch (mi_ode_adams_vc.h)
+static int integrate_adams_vc(mi_ode_solver* h, const void* y0_dev, const double* t_host, int32_t T, void* out_dev, mi_ode_stats* stats,
+                              hipStream_t st) {
+  h->n_launches = 0; h->n_polls = 0;
+  int rc = ensure_t_out(h, T);
+  if (rc != 0) return rc;
+  MI_HIP(hipStreamSynchronize(st));              // the pinned staging buffer may still be in flight from a previous call
+  memcpy(h->t_out_host, t_host, (size_t)T * sizeof(double));
+  MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)T * sizeof(double), hipMemcpyHostToDevice, st));
+  h->t_out_busy = 1;
+  AdamsVcArgs A;
+  memset(&A, 0, sizeof(A));
+  A.f.y0 = y0_dev; A.f.out = out_dev; A.f.t = h->t_out_dev; A.f.batch = h->d.batch; A.f.T = T; A.f.dim = (int)h->d.dim; A.f.rhs = h->rhs;
+  A.cp = h->cp;
+  A.cp.init_order = 2;                           // adams.py:115-118: the first step is the order-2 heuristic, whatever the solver's order
+  A.cp.controller = MI_ODE_CTRL_MISC;
+  A.max_order = h->d.ms_max_order;
+  A.max_attempts = h->d.max_num_steps > 0 ? h->d.max_num_steps : (1LL << 31);
+  memcpy(A.gamma_star, h->adams_gamma_star, sizeof(A.gamma_star));
+  A.result = h->adams_res;
+  A.p.s.partials = h->partials; A.p.seq_base = h->seq; A.p.nseg = 1; A.p.world = 1;
+  A.p.spin_limit = h->persist_spin_limit > 0 ? h->persist_spin_limit : (1 << 17);
+  A.p.spin_first = 1 << 12; if (A.p.spin_first > A.p.spin_limit) A.p.spin_first = A.p.spin_limit;
+  A.p.xspin_limit = A.p.spin_limit;
+  A.p.sleep_first = 16; A.p.sleep_poll = 2;
+  const long long g = (h->d.batch + 255) / 256;
+  rc = h->is_f32 ? mi_launch_adams_vc_f32(h, A, (int)g, st) : mi_launch_adams_vc_f64(h, A, (int)g, st);
+  if (rc != 0) return rc;
+  MI_HIP(hipStreamSynchronize(st));              // the kernel's last act: {attempts, accepted, nfe, status} into pinned memory
+  h->seq += (unsigned)(3 * h->adams_res[0] + 16);  // up to three hand-offs per attempt + the two of before_integrate
+  if (h->seq >= 0xE0000000u) h->seq = 0;
+  if (stats) {
+    memset(stats, 0, sizeof(*stats));
+    stats->n_attempts = h->adams_res[0]; stats->n_accepted = h->adams_res[1]; stats->n_rejected = h->adams_res[0] - h->adams_res[1];
+    stats->nfe = h->adams_res[2];
+    stats->status = (uint32_t)h->adams_res[3];
+    stats->t = t_host[T - 1];
+    stats->n_launches = h->n_launches;
+    stats->n_polls = 1;
+  }
+  return (int)h->adams_res[3];
+}
+
 extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const double* t_host, int32_t T, void* out_dev,
                                 mi_ode_stats* stats, void* stream) {
   if (h == nullptr || y0_dev == nullptr || t_host == nullptr || out_dev == nullptr || T < 1) { mi_set_error("bad argument"); return MI_ODE_E_INVALID; }
@@ -867,6 +932,7 @@ extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const doubl
       if (stats) { memset(stats, 0, sizeof(*stats)); stats->status = MI_ODE_ST_BAD_T; }
       return MI_ODE_ST_BAD_T;                  // _assert_increasing (misc.py:158-159)
     }
+  if (h->d.multistep == 3) return integrate_adams_vc(h, y0_dev, t_host, T, out_dev, stats, st);
   const bool multi = h->d.world_size > 1 || h->d.allgather != nullptr || h->nccl_comm != nullptr;
   if (h->persist && T > 1 && h->d.adaptive && (!multi || h->xrank_on)) {
     const int prc = integrate_persist(h, y0_dev, t_host, T, out_dev, stats, st);

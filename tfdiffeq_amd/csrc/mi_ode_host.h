@@ -2,7 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "mi_ode_dev.h"
-namespace mi { struct AdamsArgs; }
+namespace mi { struct AdamsArgs; struct AdamsVcArgs; }
 
 namespace mi {
 struct StepArgs;
@@ -89,7 +89,8 @@ struct mi_ode_solver {
   int nseg;                   // tuple state: components packed into the one buffer (mi_ode_desc.n_segments), 0 / 1: a single tensor
   int seg_blk[MI_ODE_MAX_SEGMENTS + 1];   // first workgroup of every component in the whole-call kernel's grid
   double* adams_tab;          // device: the multistep coefficient tables of the descriptor (mi_ode_adams.h), or null
-  long long* adams_res;       // pinned host: {steps whose corrector did not converge, status}
+  long long* adams_res;       // pinned host: {steps whose corrector did not converge, status}; multistep = 3: {attempts, accepted, nfe, status}
+  double adams_gamma_star[13]; // multistep = 3 (adams.py:15-18)
   int lin_dp;                 // FAM_LINEAR_MFMA: tile width the kernels are instantiated for (16 / 32 / 64 / 128 >= dim, zero padded)
   // bookkeeping
   long long n_launches;
@@ -118,6 +119,10 @@ int mi_launch_fixed_f64(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
 int mi_launch_adams_f64(mi_ode_solver* h, mi::AdamsArgs& A, int grid, hipStream_t st);
 int mi_launch_adams_f32(mi_ode_solver* h, mi::AdamsArgs& A, int grid, hipStream_t st);
 int mi_adams_capacity_f64(mi_ode_solver* h);
+int mi_launch_adams_vc_f64(mi_ode_solver* h, mi::AdamsVcArgs& A, int grid, hipStream_t st);
+int mi_launch_adams_vc_f32(mi_ode_solver* h, mi::AdamsVcArgs& A, int grid, hipStream_t st);
+int mi_adams_vc_capacity_f64(mi_ode_solver* h);
+int mi_adams_vc_capacity_f32(mi_ode_solver* h);
 int mi_adams_capacity_f32(mi_ode_solver* h);
 int mi_launch_fixed_f32(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
 int mi_launch_persist_f64(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);

@@ -122,7 +122,11 @@ class _FusedEngine(object):
         d.chunk_attempts = int(chunk_attempts)
         d.profile = 1 if profile else 0
         d.fusion = {'auto': 0, 'stage': 1, 'step': 2, 'step_split': 3, 'whole': 4}.get(fusion, fusion)
-        if multistep is not None:              # fixed-grid Adams family in one launch (include/mi_ode.h: multistep): the coefficient
+        if multistep is not None and int(multistep[0]) == 3:       # the variable-order 'adams' solver in one launch: (3, max_order, gamma_star)
+            d.multistep, d.ms_max_order = 3, int(multistep[1])
+            self._ms_tabs = ((C.c_double * 13)(*[float(v) for v in multistep[2]][:13]),)
+            d.ms_gamma_star = C.cast(self._ms_tabs[0], C.POINTER(C.c_double))
+        elif multistep is not None:            # fixed-grid Adams family in one launch (include/mi_ode.h: multistep): the coefficient
             kind, max_order, max_iters, min_order, ab, am, am0 = multistep      # tables as host arrays, formed in Python floats
             d.multistep, d.ms_max_order, d.ms_max_iters, d.ms_min_order = int(kind), int(max_order), int(max_iters), int(min_order)
             self._ms_tabs = ((C.c_double * (13 * 12))(*ab), (C.c_double * (13 * 12))(*am), (C.c_double * 13)(*am0))
