@@ -2,7 +2,7 @@
 //   1. fixed grid RK4 (3/8 rule) on a Lorenz batch vs a scalar host loop written here   (bit-exact expected)
 //   2. adaptive Dopri5 on the same batch vs the fine RK4 solution                        (1e-6)
 //   3. the stateless plane kernel mi_ode_lincomb vs a host loop                          (bit-exact expected)
-//   3b. tuple state, 4. fused adjoint interval, 5. fixed-grid Adams-Bashforth in one launch vs a host loop, 6. 300000 trajectories in one launch
+//   3b. tuple state, 4. fused adjoint interval, 5. fixed-grid Adams-Bashforth in one launch vs a host loop, 6. 300000 trajectories in one launch, 7. the variable-order Adams solver in one launch
 // Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -I include tests/c_abi/c_abi_smoke.cpp -L tfdiffeq_amd -lmi_ode
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -317,6 +317,43 @@ int main() {
            big_attempts, (long long)st.n_attempts, md6);
     if (big_launches != 1 || big_attempts != st.n_attempts || !(md6 <= 1e-12)) { printf("FAIL large batch\n"); return 1; }
     MI(mi_ode_destroy(hb)); MI(mi_ode_destroy(hs));
+  }
+  // ---- 7. the variable-order Adams solver in one launch (mi_ode_desc.multistep = 3, ABI 10) vs the fine RK4 solution ----------
+  {
+    const double gamma_star[13] = {1, -0.5, -0.08333333333333333, -0.041666666666666664, -0.02638888888888889, -0.01875, -0.014269179894179895,
+                                   -0.01136739417989418, -0.00935653659611993, -0.00789255, -0.00678585, -0.00592406, -0.00523669};   // adams.py:15-18
+    mi_ode_desc dv = d;                                                  // the dopri5 descriptor of section 2: rtol 1e-9, atol 1e-11, misc controller
+    memset(&dv.tableau, 0, sizeof(dv.tableau));
+    dv.multistep = 3; dv.ms_max_order = 12; dv.ms_gamma_star = gamma_star;
+    mi_ode_handle hv = nullptr;
+    MI(mi_ode_create(&dv, &hv));
+    const double t7[3] = {0.0, 0.25, 0.5};
+    bits = mi_ode_integrate(hv, d_y0, t7, 3, d_out, &st, nullptr);
+    if (bits != 0) { printf("FAIL adams status %d %s\n", bits, mi_ode_last_error()); return 1; }
+    CK(hipMemcpy(out.data(), d_out, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    double md7 = 0;
+    for (int b = 0; b < B; ++b) {
+      double y[3] = {y0[3 * b], y0[3 * b + 1], y0[3 * b + 2]};
+      const int sub = 32;
+      for (int i = 0; i < 40 * sub; ++i) {
+        const double dt = 0.0125 / sub;
+        double k1[3], k2[3], k3[3], k4[3], ys[3];
+        lorenz(y, k1);
+        for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * k1[q] / 3;
+        lorenz(ys, k2);
+        for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * (k1[q] / -3 + k2[q]);
+        lorenz(ys, k3);
+        for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * (k1[q] - k2[q] + k3[q]);
+        lorenz(ys, k4);
+        for (int q = 0; q < 3; ++q) y[q] = y[q] + (k1[q] + 3 * k2[q] + 3 * k3[q] + k4[q]) * (dt / 8);
+        if (i + 1 == 20 * sub) for (int q = 0; q < 3; ++q) md7 = fmax(md7, fabs(out[n + 3 * b + q] - y[q]));
+        if (i + 1 == 40 * sub) for (int q = 0; q < 3; ++q) md7 = fmax(md7, fabs(out[2 * n + 3 * b + q] - y[q]));
+      }
+    }
+    printf("adams (variable order, one launch): attempts %lld accepted %lld nfe %lld launches %lld, max |adams - fine rk4| = %.3e\n",
+           (long long)st.n_attempts, (long long)st.n_accepted, (long long)st.nfe, (long long)st.n_launches, md7);
+    if (st.n_launches != 1 || st.n_accepted < 2 || !(md7 < 1e-4)) { printf("FAIL adams\n"); return 1; }
+    MI(mi_ode_destroy(hv));
   }
   printf("C-ABI OK (abi %d)\n", mi_ode_abi_version());
   return 0;
