@@ -311,15 +311,20 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
     float y0e[4], k[S + 1][4], ys[4], kn[4];
     // (measured in round 3: prefetching the next tile's y0 / f0 into registers, as the linear kernels do, changes nothing here -
     // 0.3385 vs 0.3386 ms per config-5 call - and costs 12 more spilled registers: the loads stay where they are)
+    // (scalar tile base + 32-bit element offsets: no 64-bit vector index arithmetic per access, as in the linear tile kernels)
+    const long long left = A.batch - row0;
+    const int nr = left < G::R ? (int)left : G::R;           // rows of this tile that exist
+    const long long tb = row0 * d;
+    const unsigned e0 = (unsigned)(rbase * d + col);         // element i of this thread: tb + e0 + i * d
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long row = row0 + rbase + i;
-      const bool ok = owner && row < A.batch;
-      y0e[i] = ok ? stream_load<SC0>(P.y0 + row * d + col) : 0.f;
-      k[0][i] = (ok && MODE != MLP_F0) ? stream_load<SC0>(P.f0 + row * d + col) : 0.f;
+      const bool ok = owner && rbase + i < nr;
+      const unsigned eo = e0 + (unsigned)(i * d);
+      y0e[i] = ok ? stream_load<SC0>(P.y0 + tb + eo) : 0.f;
+      k[0][i] = (ok && MODE != MLP_F0) ? stream_load<SC0>(P.f0 + tb + eo) : 0.f;
       if (MODE == MLP_F0 && ok) {
-        if (copy_a != nullptr) ((float*)copy_a)[row * d + col] = y0e[i];
-        if (copy_b != nullptr) ((float*)copy_b)[row * d + col] = y0e[i];
+        if (copy_a != nullptr) ((float*)copy_a + tb)[eo] = y0e[i];
+        if (copy_b != nullptr) ((float*)copy_b + tb)[eo] = y0e[i];
       }
     }
     if (MODE == MLP_F0) {
@@ -327,10 +332,9 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
       cx.eval(kn, sign * P.t0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const long long row = row0 + rbase + i;
-        if (owner && row < A.batch) {
+        if (owner && rbase + i < nr) {
           const float f0 = sign * kn[i];
-          P.f1[row * d + col] = f0;
+          (P.f1 + tb)[e0 + (unsigned)(i * d)] = f0;
           const float sc = (float)A.cp.atol + fabsf(y0e[i]) * (float)A.cp.rtol;      // misc.py:225
           const double q0 = (double)(y0e[i] / sc), q1 = (double)(f0 / sc);
           acc.suma += q0 * q0; acc.sumb += q1 * q1;
@@ -347,8 +351,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
       cx.eval(kn, sign * (P.t0 + hs));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const long long row = row0 + rbase + i;
-        if (owner && row < A.batch) {
+        if (owner && rbase + i < nr) {
           const float sc = (float)A.cp.atol + fabsf(y0e[i]) * (float)A.cp.rtol;
           const double q = (double)((sign * kn[i] - k[0][i]) / sc);            // misc.py:237
           acc.suma += q * q;
@@ -375,16 +378,16 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
     for_stages<1, S>(stage);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const long long row = row0 + rbase + i;
-      if (owner && row < A.batch) {
+      if (owner && rbase + i < nr) {
         float kk[S + 1];
 #pragma unroll
         for (int j = 0; j <= S; ++j) kk[j] = k[j][i];
         float err, ymid;
         step_finish<float, S>(y0e[i], kk, hs, A, err, ymid, !TS && P.j_hi > P.j_lo);
-        const long long idx = row * d + col;
-        P.y1[idx] = ys[i];
-        P.f1[idx] = k[S][i];
+        const unsigned eo = e0 + (unsigned)(i * d);
+        const long long idx = tb + eo;
+        (P.y1 + tb)[eo] = ys[i];
+        (P.f1 + tb)[eo] = k[S][i];
         step_emit<float, S, TS>(A, P, y0e[i], ys[i], kk, ymid, idx, t_out);
         acc.maxa = fmax(acc.maxa, (double)fabsf(y0e[i]));
         acc.maxb = fmax(acc.maxb, (double)fabsf(ys[i]));
