@@ -341,7 +341,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
           if (!finite_(y0e[i])) acc.flag = 1;
         }
       }
-      __syncthreads();
+      
       continue;
     }
     if (MODE == MLP_INITB) {
@@ -357,7 +357,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
           acc.suma += q * q;
         }
       }
-      __syncthreads();
+      
       continue;
     }
     // ---- MLP_STEP: all S stages --------------------------------------------------------------------------
@@ -394,7 +394,8 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
         acc.suma += (double)err * (double)err;
       }
     }
-    __syncthreads();
+    // (no barrier at the end of a tile: the next tile's first LDS write is to s_x, which every wavefront finished reading before it
+    // passed the second barrier of this tile's last evaluation; s_h1 / s_h2 are only written behind the next evaluation's barriers)
   }
 }
 
