@@ -610,6 +610,18 @@ sr = dict(odeint.last_stats)
 mine = ref[:, mcut[rank]:mcut[rank + 1]]
 out['mlp'] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
               'launches': sb['n_launches'], 'status': sb['status']}
+# more trajectories per rank than one per thread keeps co-resident: the plane-streaming whole-call kernel (k_persist_rowlocal_planes)
+# with the same cross-rank hand-off; MI_ODE_PERSIST_PLANES_GRID keeps every process' grid small enough to share the one GPU
+per = 135000
+fullP = np.array([1., 1., 1.]) + 1e-2 * np.random.default_rng(6).standard_normal((per * world, 3))
+yp = torch.tensor(fullP[per * rank:per * (rank + 1)], device='cuda:0')
+tp = torch.tensor([0., 0.1, 0.25])
+b = odeint(rhs.Lorenz(), yp, tp, rtol=1e-6, atol=1e-9, method='dopri5', options={'process_group': dist.group.WORLD})
+sb = dict(odeint.last_stats)
+ref = odeint(rhs.Lorenz(), torch.tensor(fullP, device='cuda:0'), tp, rtol=1e-6, atol=1e-9, method='dopri5')
+sr = dict(odeint.last_stats)
+out['lorenz_planes'] = {'diff': float((b - ref[:, per * rank:per * (rank + 1)]).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
+                        'launches': sb['n_launches'], 'status': sb['status'], 'transport': sb['cross_rank']}
 print('RESULT' + json.dumps({'rank': rank, 'out': out}), flush=True)
 dist.barrier()
 dist.destroy_process_group()
@@ -637,7 +649,7 @@ def test_cross_rank_handoff_two_processes_share_the_gpu(world, mode, needle):
     for rank in range(world):
         env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                    REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY='0',
-                   TFDIFFEQ_AMD_XRANK=mode)
+                   TFDIFFEQ_AMD_XRANK=mode, MI_ODE_PERSIST_PLANES_GRID='16')
         procs.append(subprocess.Popen([sys.executable, '-c', _TWO_RANK_SCRIPT], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
     outs = []
     for p_ in procs:
