@@ -2,14 +2,17 @@
 """The reference's DETEST harness (tests/DETEST/run.py:25-60; problems tests/DETEST/detest.py:9-351) on the ONE-LAUNCH kernels,
 with the CPU restatement of the reference path beside it.
 
-Every problem A1..E5 from t = 0 to 20 with dopri5 at tol = rtol = atol in {1e-3, 1e-6, 1e-9}; per problem
+Every problem A1..E5 from t = 0 to 20 with dopri5 AND adams (the two methods of the reference's harness, run.py:28) at tol = rtol =
+atol in {1e-3, 1e-6, 1e-9}; per problem
 `NFE | wall | RMS error` for
   * GPU: the problem as a device right-hand side - `rhs.CustomRowLocal` source (classes A, B, D, E: dim <= 4) or `rhs.Linear`
     (B2, C1-C4: y' = A y, dim 3 / 10 / 51 on the MFMA tile kernels, zero padded) - i.e. the whole `odeint` call is one launch of
     the whole-integration kernel; C5 (five-body problem, a [2, 3, 5] state) has no row-local kernel and runs as a Python callable
     on the plane-kernel engine (marked *);
   * CPU: oracle/ode_torch_cpu.odeint_dopri5 - the op-for-op torch-CPU eager restatement of the reference's Dopri5 path - on the
-    SAME problem definitions (oracle/detest_problems.py with xp = torch), on this host.
+    SAME problem definitions (oracle/detest_problems.py with xp = torch), on this host; for adams the numpy restatement
+    (oracle/adams_numpy.py, one core).  adams on the GPU: the variable-order kernel (csrc/mi_ode_adams_vc.h, one launch) for the
+    row-local problems; the linear systems and C5 take the per-step loop over plane kernels (marked +).
 The error is against a tol 1e-12 solution of the numpy oracle, as the reference's harness measures against its own tight solve.
 Single trajectories: these runs are latency-bound (one thread of one wavefront per problem) - the table is the reference's own
 timing harness, not a throughput claim.
@@ -64,10 +67,11 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--tols', default='1e-3,1e-6,1e-9')
     ap.add_argument('--no-cpu', action='store_true')
+    ap.add_argument('--methods', default='dopri5,adams')
     ap.add_argument('--build-only', action='store_true', help='compile the plugins (no GPU needed) and exit')
     args = ap.parse_args()
     from tfdiffeq_amd import rhs
-    from oracle import detest_problems as DP, ode_numpy as O, ode_torch_cpu as TC       # problem definitions / checker / CPU baseline
+    from oracle import adams_numpy as OA, detest_problems as DP, ode_numpy as O, ode_torch_cpu as TC   # problem definitions / checker / CPU baseline
     dev_rhs = {}
     for name, (dim, body) in BODIES.items():
         dev_rhs[name] = rhs.CustomRowLocal(dim, body)
@@ -89,45 +93,62 @@ def main():
         f_np, y0_np = DP.problem(name, np)
         ref[name] = O.odeint(f_np, y0_np, tn, rtol=1e-12, atol=1e-12, method='dopri5')[1]
     print('host: %d logical CPUs, torch threads %d; GPU: %s' % (os.cpu_count(), torch.get_num_threads(), torch.cuda.get_device_name(0)))
-    for tol in tols:
-        print('======= dopri5 | tol=%e =======' % tol)
+    for method in args.methods.split(','):
+      for tol in tols:
+        print('======= %s | tol=%e =======' % (method, tol))
         print('%-4s | %22s | %28s | %28s' % ('', 'NFE  gpu / cpu', 'wall ms  gpu / cpu (speed-up)', 'RMS error  gpu / cpu'))
         tot = {'gn': 0, 'cn': 0, 'gt': 0.0, 'ct': 0.0, 'ge': [], 'ce': []}
         for name in DP.NAMES:
             f_t, y0_t = DP.problem(name, torch, like=like)
+            calls = [0]
             if name in dev_rhs:
                 f_gpu, y0_gpu, mark = dev_rhs[name], y0_t.reshape(1, -1).contiguous(), ' '
             else:
-                calls = [0]
-
                 def f_gpu(t_, y_, f_t=f_t, calls=calls):
                     calls[0] += 1
                     return f_t(t_, y_)
                 y0_gpu, mark = y0_t, '*'
             walls = []
-            for rep in range(4):                                  # 1 warm-up (engine creation, module load) + 3 timed
+            reps = 4 if method == 'dopri5' else 2                 # 1 warm-up (engine creation, module load) + timed runs
+            for rep in range(reps):
+                if rep == reps - 1 and mark == ' ':
+                    f_gpu.nfe = 0
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                est = odeint(f_gpu, y0_gpu, tt, rtol=tol, atol=tol, method='dopri5')
+                est = odeint(f_gpu, y0_gpu, tt, rtol=tol, atol=tol, method=method)
                 torch.cuda.synchronize()
                 if rep:
                     walls.append(time.perf_counter() - t0)
             st = dict(odeint.last_stats)
             g_wall = float(np.median(walls))
-            g_nfe = int(st.get('nfe', 0)) if mark == ' ' else calls[0] // 4          # (4 calls of odeint: the count of one)
+            if mark == ' ':
+                g_nfe = int(st['nfe']) if st.get('nfe') else int(f_gpu.nfe)      # (the per-step loop counts calls of the device RHS)
+                if method == 'adams' and not str(st.get('engine', '')).startswith('fused'):
+                    mark = '+'
+            else:
+                g_nfe = calls[0] // reps
             g_err = float(np.sqrt(np.mean((est[1].cpu().numpy().reshape(ref[name].shape) - ref[name]) ** 2)))
             c_wall = c_err = float('nan')
             c_nfe = 0
             if not args.no_cpu:
-                f_c, y0_c = DP.problem(name, torch)
                 walls = []
-                for rep in range(2):
+                if method == 'dopri5':
+                    f_c, y0_c = DP.problem(name, torch)
+                    for rep in range(2):
+                        t0 = time.perf_counter()
+                        sol_c, st_c = TC.odeint_dopri5(f_c, y0_c, [0., DP.T_END], rtol=tol, atol=tol)
+                        if rep:
+                            walls.append(time.perf_counter() - t0)
+                    c_nfe = int(st_c.nfe)
+                    c_err = float(np.sqrt(np.mean((sol_c[1].numpy() - ref[name]) ** 2)))
+                else:
+                    f_np, y0_np = DP.problem(name, np)
                     t0 = time.perf_counter()
-                    sol_c, st_c = TC.odeint_dopri5(f_c, y0_c, [0., DP.T_END], rtol=tol, atol=tol)
-                    if rep:
-                        walls.append(time.perf_counter() - t0)
-                c_wall, c_nfe = float(np.median(walls)), int(st_c.nfe)
-                c_err = float(np.sqrt(np.mean((sol_c[1].numpy() - ref[name]) ** 2)))
+                    sol_c, st_c = OA.odeint(f_np, y0_np, tn, rtol=tol, atol=tol, method='adams', return_stats=True)
+                    walls.append(time.perf_counter() - t0)
+                    c_nfe = int(st_c.nfe)
+                    c_err = float(np.sqrt(np.mean((np.asarray(sol_c)[1] - ref[name]) ** 2)))
+                c_wall = float(np.median(walls))
             print('%-3s%s | %10d / %-9d | %9.3f / %9.3f (%5.1fx) | %12.3e / %-12.3e' % (
                 name, mark, g_nfe, c_nfe, 1e3 * g_wall, 1e3 * c_wall, c_wall / g_wall if g_wall > 0 else float('nan'), g_err, c_err))
             tot['gn'] += g_nfe; tot['cn'] += c_nfe; tot['gt'] += g_wall; tot['ct'] += c_wall
@@ -135,7 +156,7 @@ def main():
         print('Total NFE %d / %d | Total time %.3f ms / %.3f ms | GeomAvg error %.3e / %.3e' % (
             tot['gn'], tot['cn'], 1e3 * tot['gt'], 1e3 * tot['ct'], float(np.exp(np.mean(np.log(tot['ge'])))),
             float(np.exp(np.mean(np.log(tot['ce'])))) if not args.no_cpu else float('nan')))
-    print('(* Python callable on the plane-kernel engine: no row-local kernel for a [2, 3, 5] state)')
+    print('(* Python callable on the plane-kernel engine: no row-local kernel for a [2, 3, 5] state;  + adams: per-step loop over plane kernels)')
 
 
 if __name__ == '__main__':

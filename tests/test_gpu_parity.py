@@ -973,11 +973,20 @@ def test_custom_rhs_plugin_runs_the_catalogue_kernels_bit_for_bit():
     # too many trajectories for the co-resident grid: one launch per attempt, still the plugin's kernels
     big = to_dev(np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((200000, 3)), torch.float64)
     tb = torch.tensor([0., 0.1])
-    pb = odeint(custom, big, tb, method='dopri5')
-    assert odeint.last_stats['n_launches'] > 1
-    bb = odeint(builtin, big, tb, method='dopri5')           # (the catalogue system continues on the plane-streaming whole-call kernel:
-    assert odeint.last_stats['n_launches'] == 1              #  another grid, so the error norm's partial sums fold in another order)
-    assert float((pb - bb).abs().max()) <= 1e-12
+    pb = odeint(custom, big, tb, method='dopri5')            # (plugin ABI 2: the plane-streaming whole-call kernel is instantiated for
+    assert odeint.last_stats['n_launches'] == 1              #  plugins too - same kernel, same grid, same bits as the catalogue system)
+    bb = odeint(builtin, big, tb, method='dopri5')
+    assert odeint.last_stats['n_launches'] == 1
+    assert torch.equal(pb, bb)
+    # the Adams family in one launch for a plugin: the kernels of the catalogue systems, instantiated for the user's functor
+    y0m = to_dev(np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((300, 3)), torch.float64)
+    for method, t_ in (('adams', torch.tensor([0., 0.1, 0.3])), ('fixed_adams', torch.tensor(np.linspace(0., 0.1, 21))),
+                       ('explicit_adams', torch.tensor(np.linspace(0., 0.1, 21)))):
+        pa = odeint(custom, y0m, t_, method=method, rtol=1e-6, atol=1e-8)
+        sp = dict(odeint.last_stats)
+        ba = odeint(builtin, y0m, t_, method=method, rtol=1e-6, atol=1e-8)
+        assert sp['n_launches'] == 1 and odeint.last_stats['n_launches'] == 1 and 'fused' in sp.get('engine', ''), (method, sp)
+        assert torch.equal(pa, ba), method
     with pytest.raises(Exception, match='per-stage'):
         odeint(custom, big[:10], tb, method='dopri5', options={'fusion': 'stage'})
 
@@ -1159,9 +1168,6 @@ def test_whole_integration_kernel_status_paths():
     big = to_dev(np.ones((600000, 3)), torch.float64)        # beyond one trajectory per thread: the plane-streaming whole-call kernel
     odeint(rhs.Lorenz(), big, torch.tensor([0., 0.1], dtype=torch.float64), method='dopri5', options={'fusion': 'whole'})
     assert dict(odeint.last_stats)['n_launches'] == 1
-    from tfdiffeq_amd import plugin_examples                  # RHS plugins only have the one-trajectory-per-thread kernel
-    with pytest.raises(Exception):
-        odeint(plugin_examples.lorenz(), big, tt, method='dopri5', options={'fusion': 'whole'})
 
 
 # ---------------------------------------------------------------------------------------------

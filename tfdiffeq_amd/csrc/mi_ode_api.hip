@@ -460,7 +460,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   rc = h->is_f32 ? mi_stage_geometry_f32(h) : mi_stage_geometry_f64(h);
   if (rc != 0) { delete h; return rc; }
   if (desc->multistep == 3) {                      // the variable-order Adams solver in one launch (mi_ode_adams_vc.h)
-    const bool rowlocal_cat = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ;
+    const bool rowlocal_cat = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
+                              h->family == FAM_PLUGIN;
     if (!desc->adaptive || !rowlocal_cat || desc->ms_gamma_star == nullptr || desc->ms_max_order < 1 || desc->ms_max_order > kVcMaxOrder ||
         h->d.world_size > 1 || h->nseg > 1 || desc->controller != MI_ODE_CTRL_MISC) {
       mi_set_error("multistep = 3 ('adams'): adaptive = 1, a row-local catalogue system, one rank, one tensor, the misc controller; 1 <= max_order <= %d, gamma_star", kVcMaxOrder);
@@ -481,7 +482,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     h->d.ms_gamma_star = nullptr;                  // (caller-owned host array: not kept)
   } else
   if (desc->multistep != 0) {                      // fixed-grid Adams family in one launch (mi_ode_adams.h)
-    const bool rowlocal_cat = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ;
+    const bool rowlocal_cat = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
+                              h->family == FAM_PLUGIN;
     if (desc->adaptive || !rowlocal_cat || (desc->multistep != 1 && desc->multistep != 2) || desc->ms_ab == nullptr || desc->ms_am == nullptr ||
         desc->ms_am0 == nullptr || desc->ms_max_order < 1 || desc->ms_max_order > kAdamsMaxOrder || desc->ms_max_iters < 1 ||
         desc->ms_min_order < 1 || h->d.world_size > 1 || h->nseg > 1) {
@@ -555,7 +557,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       const int cap = mlp ? mi_persist_capacity_mlp_f32(h) : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
       capable = cap > 0 && g <= cap;
     }
-    if (!capable && desc->adaptive && rowlocal && h->family != FAM_PLUGIN && h->nseg <= 1) {
+    if (!capable && desc->adaptive && rowlocal && h->nseg <= 1) {
       // more trajectories than one-per-thread keeps co-resident: the same loop with the state in HBM planes, a co-resident
       // grid walking the batch (k_persist_rowlocal_planes)
       h->persist_planes = 1;

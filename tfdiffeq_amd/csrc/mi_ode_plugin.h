@@ -2,7 +2,8 @@
 // against these headers into its own shared object and handed to libmi_ode through mi_ode_rhs.plugin
 // (kind = MI_ODE_RHS_PLUGIN).  The plugin instantiates the SAME row-local kernels the built-in catalogue uses
 // (k_persist_rowlocal: the whole adaptive integration in one launch; k_step_rowlocal: one launch per attempt;
-// k_stage_rowlocal<F0 / INITB>: before_integrate; k_fixed_rowlocal: Euler / RK4 on a fixed grid) for its functor,
+// k_stage_rowlocal<F0 / INITB>: before_integrate; k_fixed_rowlocal: Euler / RK4 on a fixed grid; k_persist_rowlocal_planes: any
+// batch size; k_fixed_adams_rowlocal / k_adams_vc_rowlocal: the Adams family in one launch) for its functor,
 // so a custom system runs on exactly the code path of rhs.Lorenz & co.  (Per-stage kernels are not instantiated:
 // fusion = 1 is rejected for plugins.)
 //
@@ -21,8 +22,10 @@
 #pragma once
 #include "mi_ode_host.h"
 #include "mi_ode_persist.h"
+#include "mi_ode_adams.h"
+#include "mi_ode_adams_vc.h"
 
-#define MI_ODE_PLUGIN_ABI 1
+#define MI_ODE_PLUGIN_ABI 2
 
 struct mi_ode_rowlocal_plugin {
   int abi;                     // MI_ODE_PLUGIN_ABI
@@ -34,6 +37,9 @@ struct mi_ode_rowlocal_plugin {
   int (*launch_step)(mi_ode_solver* h, mi::StepArgs* A, hipStream_t st);
   int (*launch_fixed)(mi_ode_solver* h, mi::FixedArgs* A, hipStream_t st);
   const void* (*persist_fn)(int S, int ts_dense);              // k_persist_rowlocal instantiation, or null
+  // plugin ABI 2:
+  const void* (*persist_planes_fn)(int S, int ts_dense);       // k_persist_rowlocal_planes (more trajectories than one per thread), or null
+  const void* (*multistep_fn)(int kind);                       // 1 / 2: k_fixed_adams_rowlocal, 3: k_adams_vc_rowlocal (mi_ode_desc.multistep)
 };
 
 namespace mi {
@@ -71,9 +77,21 @@ struct RowLocalPlugin {
     if (S == 1 && !ts_dense) return (const void*)k_persist_rowlocal<T, 1, false, RHS, false>;       // adaptive_heun (not FSAL shaped)
     return nullptr;
   }
+  static const void* persist_planes_fn(int S, int ts_dense) {
+    if (S == 6) return ts_dense ? (const void*)k_persist_rowlocal_planes<T, 6, true, RHS> : (const void*)k_persist_rowlocal_planes<T, 6, false, RHS>;
+    if (S == 3 && !ts_dense) return (const void*)k_persist_rowlocal_planes<T, 3, false, RHS>;
+    if (S == 13 && !ts_dense) return (const void*)k_persist_rowlocal_planes<T, 13, false, RHS, true>;
+    if (S == 1 && !ts_dense) return (const void*)k_persist_rowlocal_planes<T, 1, false, RHS, false>;
+    return nullptr;
+  }
+  static const void* multistep_fn(int kind) {
+    if (kind == 1 || kind == 2) return (const void*)k_fixed_adams_rowlocal<T, RHS>;
+    if (kind == 3) return (const void*)k_adams_vc_rowlocal<T, RHS>;
+    return nullptr;
+  }
   static const mi_ode_rowlocal_plugin* table(int dtype) {
     static const mi_ode_rowlocal_plugin t = {MI_ODE_PLUGIN_ABI, dtype, RHS::D, 0, sizeof(mi_ode_solver),
-                                            &launch_init, &launch_step, &launch_fixed, &persist_fn};
+                                            &launch_init, &launch_step, &launch_fixed, &persist_fn, &persist_planes_fn, &multistep_fn};
     return &t;
   }
 };

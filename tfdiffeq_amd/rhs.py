@@ -72,8 +72,9 @@ class DeviceRHS(object):
 
     @property
     def multistep_fused(self):
-        """True: 'explicit_adams' / 'fixed_adams' run as one launch (csrc/mi_ode_adams.h: the row-local catalogue systems)."""
-        return bool(self.row_local) and self.kind != N.RHS_PLUGIN
+        """True: 'explicit_adams' / 'fixed_adams' / 'adams' run as one launch (csrc/mi_ode_adams.h, mi_ode_adams_vc.h): the row-local
+        catalogue systems and (plugin ABI 2) user-defined row-local systems."""
+        return bool(self.row_local)
 
     def supports(self, y0):
         """True when the fused kernels can take this state tensor."""
