@@ -353,6 +353,23 @@ int mi_ode_error_norms(int32_t dtype, int64_t n, const void* err_dev, const void
 /* result_dev[1] (double) = sum_i ((x[i] - (xsub ? xsub[i] : 0)) / (atol + |y0[i]| * rtol))^2   (misc.py:225-237) */
 int mi_ode_scaled_sumsq(int32_t dtype, int64_t n, const void* x_dev, const void* xsub_dev, const void* y0_dev,
                         double rtol, double atol, double* result_dev, void* workspace_dev, void* stream);
+/* The variable-order Adams solver's host loop (tfdiffeq/adams.py:134-210, any callable f) on four plane kernels instead of one linear
+ * combination at a time.  phi: the implicit-phi planes, newest first (`order` of them); g: the values of the float32 g vector,
+ * g[0..order]; beta[0..order-1] (beta[0] unused); all planes hold n elements of `dtype`.
+ *   predict     p = y + dt * sum_{j < max(1, order-1)} g_j explicit_phi_j,  explicit_phi_0 = phi_0, explicit_phi_j = beta_j phi_j
+ *   correct     ip_0 = f_p, ip_j = ip_{j-1} - explicit_phi_{j-1};  y_next = p + dt g_{order-1} ip_{order-1};  also returns the planes
+ *               ip_order, ip_{order-1}, ip_{order-2} (nullable) and result[4] = {max|y|, max|y_next|, sum local_error^2, nonfinite(y)}
+ *   error_sums  result[2] = sums of ((dt * coef) x / tol)^2 for one or two planes (xb nullable): the error ratios times n
+ *   update_phi  new_0 = f_new, new_j = new_{j-1} - explicit_phi_{j-1}, j <= order  (order + 1 output planes) */
+int mi_ode_adams_predict(int32_t dtype, int64_t n, const void* y_dev, const void* const* phi_dev, int32_t order, const double* g,
+                         const double* beta, double dt, void* p_out_dev, void* stream);
+int mi_ode_adams_correct(int32_t dtype, int64_t n, const void* y_dev, const void* p_dev, const void* f_p_dev, const void* const* phi_dev,
+                         int32_t order, const double* g, const double* beta, double dt, void* y_next_out_dev, void* ip_k_out_dev,
+                         void* ip_k1_out_dev, void* ip_k2_out_dev, double* result_dev, void* workspace_dev, void* stream);
+int mi_ode_adams_error_sums(int32_t dtype, int64_t n, const void* xa_dev, double coef_a, const void* xb_dev, double coef_b, double dt,
+                            double tol, double* result_dev, void* workspace_dev, void* stream);
+int mi_ode_adams_update_phi(int32_t dtype, int64_t n, const void* f_new_dev, const void* const* phi_dev, int32_t order,
+                            const double* beta, void* const* new_phi_out_dev, void* stream);
 /* result_dev[1] (double) = 1.0 if ANY element violates |a - b| < atol + rtol * max(|a|, |b|), else 0.0
  * (misc._has_converged, misc.py:129-134: the corrector iteration test of fixed_adams.py:196) */
 int mi_ode_not_converged(int32_t dtype, int64_t n, const void* a_dev, const void* b_dev, double rtol, double atol,

@@ -144,6 +144,15 @@ _PROTOS = {
                                       C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]),
     'mi_ode_not_converged': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    'mi_ode_adams_predict': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_double),
+                                       C.POINTER(C.c_double), C.c_double, C.c_void_p, C.c_void_p]),
+    'mi_ode_adams_correct': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32,
+                                       C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double, C.c_void_p, C.c_void_p, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mi_ode_adams_error_sums': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.c_double, C.c_void_p, C.c_double, C.c_double, C.c_double,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    'mi_ode_adams_update_phi': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_void_p), C.c_void_p]),
     'mi_ode_interp_eval': (C.c_int, [C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p),
                                      C.c_int32, C.POINTER(C.c_double), C.c_double, C.c_double, C.c_double,
                                      C.c_double, C.c_void_p, C.c_void_p]),

@@ -14,6 +14,7 @@
 #include "mi_ode_persist.h"
 #include "mi_ode_adams.h"
 #include "mi_ode_adams_vc.h"
+#include "mi_ode_adams_planes.h"
 #include "mi_ode_mlp.h"
 #include "mi_ode_plugin.h"
 
@@ -1371,6 +1372,7 @@ __global__ __launch_bounds__(256) void k_finalize_records(const double* part, in
   if (threadIdx.x == 0) {
     if (what == 0) { result[0] = rec[R_MAXA]; result[1] = rec[R_MAXB]; result[2] = rec[R_SUMA]; result[3] = rec[R_FLAG]; }
     else if (what == 2) result[0] = rec[R_FLAG];
+    else if (what == 3) { result[0] = rec[R_SUMA]; result[1] = rec[R_SUMB]; }
     else result[0] = rec[R_SUMA];
   }
 }
@@ -1442,6 +1444,90 @@ extern "C" int mi_ode_scaled_sumsq(int32_t dtype, int64_t n, const void* x_dev, 
   else if (dtype == MI_ODE_F32) hipLaunchKernelGGL(k_scaled_sumsq<float>, dim3(g), dim3(256), 0, st, (const float*)x_dev, (const float*)xsub_dev, (const float*)y0_dev, (long long)n, rtol, atol, part);
   else { mi_set_error("bad dtype"); return MI_ODE_E_INVALID; }
   hipLaunchKernelGGL(k_finalize_records, dim3(1), dim3(256), 0, st, (const double*)part, g, result_dev, 1);
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- the variable-order Adams solver's host loop on four plane kernels (mi_ode_adams_planes.h) -------------------------------
+namespace {
+int adams_planes_common(AdamsPlaneArgs& A, int32_t dtype, int64_t n, const void* const* phi, int32_t order, const double* g, const double* beta,
+                        double dt, const char* who) {
+  memset(&A, 0, sizeof(A));
+  if (n <= 0 || order < 1 || order > kAdamsPlanesMax - 1 || phi == nullptr || (dtype != MI_ODE_F32 && dtype != MI_ODE_F64)) {
+    mi_set_error("%s: bad argument (1 <= order <= %d)", who, kAdamsPlanesMax - 1);
+    return MI_ODE_E_INVALID;
+  }
+  A.n = n; A.order = order; A.dt = dt;
+  for (int j = 0; j < order; ++j) { if (phi[j] == nullptr) { mi_set_error("%s: phi[%d] is null", who, j); return MI_ODE_E_INVALID; } A.phi[j] = phi[j]; }
+  if (g != nullptr) for (int j = 0; j <= order; ++j) A.g[j] = g[j];
+  if (beta != nullptr) for (int j = 0; j < order; ++j) A.beta[j] = beta[j];
+  return 0;
+}
+}  // namespace
+
+extern "C" int mi_ode_adams_predict(int32_t dtype, int64_t n, const void* y_dev, const void* const* phi_dev, int32_t order, const double* g,
+                                    const double* beta, double dt, void* p_out_dev, void* stream) {
+  AdamsPlaneArgs A;
+  int rc = adams_planes_common(A, dtype, n, phi_dev, order, g, beta, dt, "adams_predict");
+  if (rc != 0) return rc;
+  if (!y_dev || !p_out_dev || !g || !beta) { mi_set_error("adams_predict: null argument"); return MI_ODE_E_INVALID; }
+  A.y0 = y_dev; A.out[0] = p_out_dev;
+  const int gr = streaming_grid(n);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_ODE_F64) hipLaunchKernelGGL(k_adams_predict<double>, dim3(gr), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(k_adams_predict<float>, dim3(gr), dim3(256), 0, st, A);
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mi_ode_adams_correct(int32_t dtype, int64_t n, const void* y_dev, const void* p_dev, const void* f_p_dev, const void* const* phi_dev,
+                                    int32_t order, const double* g, const double* beta, double dt, void* y_next_out_dev, void* ip_k_out_dev,
+                                    void* ip_k1_out_dev, void* ip_k2_out_dev, double* result_dev, void* workspace_dev, void* stream) {
+  AdamsPlaneArgs A;
+  int rc = adams_planes_common(A, dtype, n, phi_dev, order, g, beta, dt, "adams_correct");
+  if (rc != 0) return rc;
+  if (!y_dev || !p_dev || !f_p_dev || !g || !beta || !y_next_out_dev || !ip_k_out_dev || !ip_k1_out_dev || !result_dev || !workspace_dev) {
+    mi_set_error("adams_correct: null argument"); return MI_ODE_E_INVALID;
+  }
+  A.y0 = y_dev; A.p = p_dev; A.f = f_p_dev;
+  A.out[0] = y_next_out_dev; A.out[1] = ip_k_out_dev; A.out[2] = ip_k1_out_dev; A.out[3] = ip_k2_out_dev;
+  A.part = (double*)workspace_dev;
+  const int gr = streaming_grid(n);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_ODE_F64) hipLaunchKernelGGL(k_adams_correct<double>, dim3(gr), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(k_adams_correct<float>, dim3(gr), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_finalize_records, dim3(1), dim3(256), 0, st, (const double*)A.part, gr, result_dev, 0);
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mi_ode_adams_error_sums(int32_t dtype, int64_t n, const void* xa_dev, double coef_a, const void* xb_dev, double coef_b, double dt,
+                                       double tol, double* result_dev, void* workspace_dev, void* stream) {
+  if (n <= 0 || !xa_dev || !result_dev || !workspace_dev || (dtype != MI_ODE_F32 && dtype != MI_ODE_F64)) { mi_set_error("adams_error_sums: bad argument"); return MI_ODE_E_INVALID; }
+  AdamsPlaneArgs A;
+  memset(&A, 0, sizeof(A));
+  A.n = n; A.dt = dt; A.tol = tol; A.xa = xa_dev; A.xb = xb_dev; A.ca = coef_a; A.cb = coef_b; A.part = (double*)workspace_dev;
+  const int gr = streaming_grid(n);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_ODE_F64) hipLaunchKernelGGL(k_adams_error_sums<double>, dim3(gr), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(k_adams_error_sums<float>, dim3(gr), dim3(256), 0, st, A);
+  hipLaunchKernelGGL(k_finalize_records, dim3(1), dim3(256), 0, st, (const double*)A.part, gr, result_dev, 3);
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int mi_ode_adams_update_phi(int32_t dtype, int64_t n, const void* f_new_dev, const void* const* phi_dev, int32_t order,
+                                       const double* beta, void* const* new_phi_out_dev, void* stream) {
+  AdamsPlaneArgs A;
+  int rc = adams_planes_common(A, dtype, n, phi_dev, order, nullptr, beta, 0.0, "adams_update_phi");
+  if (rc != 0) return rc;
+  if (!f_new_dev || !beta || !new_phi_out_dev) { mi_set_error("adams_update_phi: null argument"); return MI_ODE_E_INVALID; }
+  A.f = f_new_dev;
+  for (int j = 0; j <= order; ++j) { if (new_phi_out_dev[j] == nullptr) { mi_set_error("adams_update_phi: output %d is null", j); return MI_ODE_E_INVALID; } A.out[j] = new_phi_out_dev[j]; }
+  const int gr = streaming_grid(n);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_ODE_F64) hipLaunchKernelGGL(k_adams_update_phi<double>, dim3(gr), dim3(256), 0, st, A);
+  else hipLaunchKernelGGL(k_adams_update_phi<float>, dim3(gr), dim3(256), 0, st, A);
   MI_HIP(hipGetLastError());
   return 0;
 }
