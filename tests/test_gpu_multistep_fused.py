@@ -144,3 +144,20 @@ def test_variable_order_adams_in_one_launch(problem, batch, dtype):
         else:
             assert (sl['n_attempts'], sl['n_accepted']) == (st['n_attempts'], st['n_accepted']), (sl, st)
             assert float((got - loop).abs().max()) <= band * scale
+
+
+def test_variable_order_adams_output_grids():
+    """One requested time (solution = [y0], the solver still runs before_integrate) and 200 of them (every output is a state that
+    landed exactly on its time: the steps are clipped, adams.py:136-137) - fused kernel against the per-step loop."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(4)
+    y0 = torch.tensor(1.0 + 0.5 * rng.uniform(size=(100, 2)), device=dev())
+    one = odeint(rhs.LotkaVolterra(), y0, torch.tensor([0.5]), method='adams')
+    assert one.shape == (1, 100, 2) and torch.equal(one[0], y0) and dict(odeint.last_stats).get('engine', '').startswith('fused variable-order')
+    tm = torch.tensor(np.linspace(0., 1., 200))
+    a = odeint(rhs.LotkaVolterra(), y0, tm, method='adams', rtol=1e-6, atol=1e-8)
+    sa = dict(odeint.last_stats)
+    b = odeint(rhs.LotkaVolterra(), y0, tm, method='adams', rtol=1e-6, atol=1e-8, options={'force_plane_kernels': True})
+    sb = dict(odeint.last_stats)
+    assert sa['n_launches'] == 1 and sa['n_attempts'] == sb['n_attempts'] >= 199 and sb.get('engine') == 'plane kernels'
+    assert float((a - b).abs().max()) <= 1e-12

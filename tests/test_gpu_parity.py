@@ -843,6 +843,23 @@ def test_whole_integration_kernel_beyond_one_trajectory_per_thread(problem, batc
     assert float((a32 - b32).abs().max()) <= 2e-5 * scale
 
 
+@pytest.mark.parametrize('method', ['dopri5', 'tsit5'])
+@pytest.mark.parametrize('T', [2, 300])
+def test_plane_streaming_kernel_dense_output_grids(T, method):
+    """k_persist_rowlocal_planes emits dense output speculatively inside the attempt pass (output times beyond the few that travel as
+    kernel arguments come from a device array): 2 and 300 requested times, quartic (dopri5) and the tsit5 interpolant."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(0)
+    y0 = to_dev(np.array([1., 1., 1.]) + 1e-2 * rng.standard_normal((140000, 3)), torch.float64)
+    t = torch.tensor(np.linspace(0., 0.3, T))
+    a = odeint(rhs.Lorenz(), y0, t, rtol=1e-6, atol=1e-9, method=method, options={'fusion': 'step'})
+    sa = dict(odeint.last_stats)
+    b = odeint(rhs.Lorenz(), y0, t, rtol=1e-6, atol=1e-9, method=method)
+    sb = dict(odeint.last_stats)
+    assert sb['n_launches'] == 1 and sa['n_launches'] > 1 and sa['n_attempts'] == sb['n_attempts'] and sb['status'] == 0
+    assert float((a - b).abs().max()) <= 1e-11 * max(1.0, float(a.abs().max()))
+
+
 @pytest.mark.parametrize('method', ['dopri5', 'bosh3', 'tsit5'])
 @pytest.mark.parametrize('problem', ['linear16', 'linear32_bias', 'linear128', 'linear64_f32', 'linear128_big'])
 def test_whole_integration_mfma_kernel_equals_launch_per_attempt(problem, method):
