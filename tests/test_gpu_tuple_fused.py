@@ -157,3 +157,32 @@ def test_fixed_grid_tuple_state_on_the_one_launch_kernel(method):
     for got, rf, c in zip(sol, ref, comps):
         assert tuple(got.shape) == (21,) + c.shape
         assert np.abs(got.cpu().numpy() - rf).max() < 1e-12
+
+
+@pytest.mark.parametrize('method', ['dopri5', 'tsit5'])
+def test_large_tuple_state_on_the_plane_streaming_kernel(method):
+    """More rows than one trajectory per thread keeps co-resident (three components, 100 000 / 50 000 / 20 001 trajectories): the
+    workgroups of the plane-streaming whole-call kernel are dealt to the components in proportion to their rows, every component
+    keeps its own error ratio.  One launch; the attempt sequence of the oracle and of the plane-kernel engine."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(17)
+    comps = [np.array([1., 1., 1.]) + s * rng.standard_normal(shape) for s, shape in ((1e-2, (100000, 3)), (1.0, (50000, 3)), (1e-1, (20001, 3)))]
+    t = np.array([0., 0.1, 0.25])
+    tol = dict(rtol=1e-6, atol=1e-9)
+    f = rhs.PerComponent(rhs.Lorenz())
+    y0 = tuple(torch.tensor(c, device=dev()) for c in comps)
+    sol = odeint(f, y0, torch.tensor(t), method=method, **tol)
+    st = dict(odeint.last_stats)
+    assert st.get('components') == 3 and st['n_launches'] == 1 and st['status'] == 0, st
+    planes = odeint(f, y0, torch.tensor(t), method=method, options={'force_plane_kernels': True}, **tol)
+    ps = dict(odeint.last_stats)
+    assert ps.get('engine') == 'plane kernels' and (st['n_attempts'], st['n_accepted']) == (ps['n_attempts'], ps['n_accepted']), (st, ps)
+    if method == 'dopri5':
+        ref, rst = O.odeint(lambda t_, ys: tuple(_lorenz_np(t_, y) for y in ys), tuple(comps), t, method=method, return_stats=True, **tol)
+        assert (st['n_attempts'], st['n_accepted']) == (rst.n_attempts, rst.n_accepted)
+    for k, (got, pl, c) in enumerate(zip(sol, planes, comps)):
+        assert tuple(got.shape) == (3,) + c.shape
+        scale = max(1.0, float(pl.abs().max()))
+        assert float((got - pl).abs().max()) < 1e-9 * scale, k
+        if method == 'dopri5':
+            assert np.abs(got.cpu().numpy() - ref[k]).max() < 1e-9 * scale, k

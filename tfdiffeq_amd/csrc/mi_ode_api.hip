@@ -558,7 +558,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       const int cap = mlp ? mi_persist_capacity_mlp_f32(h) : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
       capable = cap > 0 && g <= cap;
     }
-    if (!capable && desc->adaptive && rowlocal && h->nseg <= 1) {
+    if (!capable && desc->adaptive && rowlocal) {
       // more trajectories than one-per-thread keeps co-resident: the same loop with the state in HBM planes, a co-resident
       // grid walking the batch (k_persist_rowlocal_planes)
       h->persist_planes = 1;
@@ -569,8 +569,29 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       if (gp > h->num_cus) gp = h->num_cus;                  // the hand-off is all-to-all: one (large) workgroup per CU
       if (const char* eg = getenv("MI_ODE_PERSIST_PLANES_GRID")) { const long long v = atoll(eg); if (v >= 1 && v <= gp) gp = v; }
       if (gp > (desc->batch + h->persist_planes_block - 1) / h->persist_planes_block) gp = (desc->batch + h->persist_planes_block - 1) / h->persist_planes_block;
+      if (h->nseg > 1 && gp < h->nseg) gp = 0;               // tuple state: every component needs a workgroup of its own
       if (cap > 0 && gp >= 1) { capable = true; g = gp; }
       else h->persist_planes = 0;
+      if (h->persist_planes && h->nseg > 1) {
+        // tuple state on the plane-streaming kernel: the grid's workgroups are dealt to the components in proportion to their rows
+        // (at least one each); a workgroup walks the rows of ITS component only, so the per-component fold of the hand-off is the
+        // register-resident kernel's (seg_blk = first workgroup of a component)
+        long long total = 0;
+        for (int k = 0; k < h->nseg; ++k) total += desc->seg_rows[k];
+        int used = 0;
+        for (int k = 0; k < h->nseg; ++k) {
+          long long share = (long long)((double)g * (double)desc->seg_rows[k] / (double)total);
+          const long long need = (desc->seg_rows[k] + h->persist_planes_block - 1) / h->persist_planes_block;
+          if (share > need) share = need;
+          if (share < 1) share = 1;
+          const int left_for_rest = h->nseg - 1 - k;
+          if (used + share > g - left_for_rest) share = g - left_for_rest - used;
+          h->seg_blk[k] = used;
+          used += (int)share;
+        }
+        h->seg_blk[h->nseg] = used;
+        g = used;
+      }
     }
     h->persist_capable = capable ? 1 : 0;          // (a peer mailbox connected later can still switch the one-launch schedule on)
     const bool can = capable && (single || h->xrank_dev != nullptr);

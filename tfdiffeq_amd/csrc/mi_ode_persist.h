@@ -606,8 +606,27 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
   double r[5], rec[kRec], n_tot = 0.0;
   if (threadIdx.x == 0) { persist_init_ctl(s_c, A); sh.ok = 1; }
   __syncthreads();
-  const long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x, pitch = (long long)gridDim.x * blockDim.x;
-  const long long batch = A.s.batch;
+  // this thread's rows: first, first + pitch, ... < batch.  Tuple state (nseg > 1): the workgroup belongs to ONE component - rows
+  // seg_off .. seg_off + seg_rows of the packed buffer (components padded to MI_ODE_SEGMENT_ALIGN rows), walked by that
+  // component's workgroups only, so a workgroup's record is a record of its component (grid_reduce folds per seg_blk range)
+  const int nseg = A.nseg;
+  long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x, pitch = (long long)gridDim.x * blockDim.x;
+  long long batch = A.s.batch;
+  if (nseg > 1) {
+    int sg = 0;
+    long long off = 0;
+    for (int k = 1; k < nseg; ++k)
+      if ((int)blockIdx.x >= A.seg_blk[k]) {
+        off += (A.seg_rows[k - 1] + MI_ODE_SEGMENT_ALIGN - 1) / MI_ODE_SEGMENT_ALIGN * MI_ODE_SEGMENT_ALIGN;
+        sg = k;
+      }
+    first = off + (long long)((int)blockIdx.x - A.seg_blk[sg]) * blockDim.x + threadIdx.x;
+    pitch = (long long)(A.seg_blk[sg + 1] - A.seg_blk[sg]) * blockDim.x;
+    batch = off + A.seg_rows[sg];
+  }
+  auto seg_counts = [&]() {                                   // thread 0: element counts into the components' records
+    for (int k = 0; k < nseg; ++k) sh.seg_rec[k][R_N] = (double)(A.seg_rows[k] * (long long)D);
+  };
 
   T* const ya = (T*)(A.s.planes);
   T* const yb = (T*)(A.s.planes + A.s.stride);
@@ -651,7 +670,10 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
       }
     }
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
+    if (threadIdx.x == 0 && ok) {
+      if (nseg > 1) { seg_counts(); controller_apply_seg(&s_c, &sh.seg, sh.seg_rec, nseg, PH_F0, cp); }
+      else { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
+    }
     __syncthreads();
   }
   if (cp.auto_first_step && ok) {                             // second half (misc.py:235-245)
@@ -673,7 +695,10 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
       }
     }
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
-    if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
+    if (threadIdx.x == 0 && ok) {
+      if (nseg > 1) { seg_counts(); controller_apply_seg(&s_c, &sh.seg, sh.seg_rec, nseg, PH_INITB, cp); }
+      else { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
+    }
   }
   auto publish = [&](const AttemptState& st) {                // thread 0: what the next attempt needs
     sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.accepted = st.accepted; sh.pub.done = st.done;
@@ -757,6 +782,7 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
     if (threadIdx.x == 0) {
       AttemptState st = sh.st;
       if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
+      else if (nseg > 1) { seg_counts(); attempt_core_seg(st, sh.seg_rec, nseg, cp, A.seg_tol ? A.seg_rtol : nullptr, A.seg_atol); }
       else { fill_record(rec, r, n_tot); attempt_core(st, rec, cp); }
       publish(st);
       sh.st = st;
@@ -767,8 +793,8 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
 
   // final state for mi_ode_get_state: plane indices as controller_apply's rotation would have left them
   if (cur_y == y_user) {                                      // no accepted step (error exit): seed plane 0 with y0
-    const long long n = batch * D;
-    for (long long i = first; i < n; i += pitch) ya[i] = y_user[i];
+    for (long long row = first; row < batch; row += pitch)
+      *(Row*)(ya + row * D) = *(const Row*)(y_user + row * D);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     sh.st.store(s_c);
