@@ -255,3 +255,23 @@ def test_fused_paths_are_not_chosen_for_host_tensors_or_uncovered_functions():
     import pytest
     with pytest.raises(TypeError):
         rhs.PerComponent(lambda t, y: y)                                                         # not a DeviceRHS
+
+
+def test_adams_scalars_match_the_oracle():
+    """g (float32) and beta of adams.py:29-63 as tfdiffeq_amd/adams.py hands them to the plane kernels (and as csrc/mi_ode_adams_vc.h
+    recomputes them on the device) against the oracle's g_and_explicit_phi, on random histories of every order."""
+    import collections
+    from oracle import adams_numpy as OA
+    from tfdiffeq_amd import adams
+    rng = np.random.default_rng(3)
+    for order in range(1, 13):
+        for _ in range(5):
+            steps = rng.uniform(0.01, 0.2, size=order + 1)
+            prev_t = collections.deque([np.float64(v) for v in (np.cumsum(steps)[:-1][::-1])], maxlen=13)   # newest first
+            next_t = np.float64(np.cumsum(steps)[-1])
+            phi = collections.deque([(np.full((2,), float(j + 1)),) for j in range(order)], maxlen=order)
+            g_ref, ephi_ref = OA.g_and_explicit_phi(prev_t, next_t, phi, order)
+            g, beta = adams.g_and_beta(prev_t, next_t, order)
+            assert g.dtype == np.float32 and np.array_equal(g, g_ref)
+            for j in range(order):                                   # explicit_phi_j = beta_j * phi_j
+                assert np.array_equal(np.float64(beta[j]) * phi[j][0], ephi_ref[j][0]), (order, j)
