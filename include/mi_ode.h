@@ -43,6 +43,8 @@
 extern "C" {
 #endif
 
+/* 9: mi_ode_desc.multistep (fixed-grid Adams family).  10: multistep = 3 + ms_gamma_star (variable-order Adams), the four
+ * mi_ode_adams_* plane entry points. */
 #define MI_ODE_ABI_VERSION 10
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
