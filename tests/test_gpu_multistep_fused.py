@@ -161,3 +161,19 @@ def test_variable_order_adams_output_grids():
     sb = dict(odeint.last_stats)
     assert sa['n_launches'] == 1 and sa['n_attempts'] == sb['n_attempts'] >= 199 and sb.get('engine') == 'plane kernels'
     assert float((a - b).abs().max()) <= 1e-12
+
+
+@pytest.mark.parametrize('max_order', [2, 4, 7])
+def test_variable_order_adams_max_order_option(max_order):
+    """options={'max_order': n} (adams.py:87-90) caps the order selection of the one-launch kernel exactly as it caps the per-step loop's."""
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(2)
+    y0 = torch.tensor(1.0 + 0.5 * rng.uniform(size=(500, 2)), device=dev())
+    t = torch.tensor(np.linspace(0., 2., 7))
+    a = odeint(rhs.LotkaVolterra(), y0, t, method='adams', rtol=1e-6, atol=1e-8, options={'max_order': max_order})
+    sa = dict(odeint.last_stats)
+    b = odeint(rhs.LotkaVolterra(), y0, t, method='adams', rtol=1e-6, atol=1e-8, options={'max_order': max_order, 'force_plane_kernels': True})
+    sb = dict(odeint.last_stats)
+    assert sa.get('engine', '').startswith('fused variable-order') and sb.get('engine') == 'plane kernels'
+    assert (sa['n_attempts'], sa['n_accepted']) == (sb['n_attempts'], sb['n_accepted']), (sa, sb)
+    assert float((a - b).abs().max()) <= 1e-9
