@@ -180,11 +180,19 @@ def _is_finite(tensor):
 
 
 def _decreasing(t):
+    if t.device.type == 'cpu' and t.numel() <= 64:          # the usual handful of output times: python floats, no tensor kernels
+        v = t.tolist()
+        return all(b < a for a, b in zip(v, v[1:]))
     return bool((t[1:] < t[:-1]).all())
 
 
 def _assert_increasing(t):
-    assert bool((t[1:] > t[:-1]).all()), 't must be strictly increasing or decrasing'   # misc.py:159 (sic)
+    if t.device.type == 'cpu' and t.numel() <= 64:
+        v = t.tolist()
+        ok = all(b > a for a, b in zip(v, v[1:]))
+    else:
+        ok = bool((t[1:] > t[:-1]).all())
+    assert ok, 't must be strictly increasing or decrasing'   # misc.py:159 (sic)
 
 
 def _handle_unused_kwargs(solver, unused_kwargs):
@@ -192,9 +200,19 @@ def _handle_unused_kwargs(solver, unused_kwargs):
         warnings.warn('{}: Unexpected arguments {}'.format(solver.__class__.__name__, unused_kwargs))   # misc.py:178-181
 
 
+_F32_DETOUR = {}
+
+
 def _convert_to_tensor(a, dtype=None, device=None):
     """misc.py:137-144 for HOST scalars: a python float becomes float32 FIRST, then is cast - so 0.9 ends up
     as 0.8999999761581421 in float64.  Returns a numpy scalar."""
+    if type(a) is float and dtype is np.float64:             # the controller constants of every call (safety, ifactor, dfactor)
+        hit = _F32_DETOUR.get(a)
+        if hit is None:
+            hit = _F32_DETOUR[a] = np.float64(np.float32(a))
+            if len(_F32_DETOUR) > 256:
+                _F32_DETOUR.clear()
+        return hit
     if isinstance(a, torch.Tensor):
         a = a.item()
     if isinstance(a, (float, np.floating)) and not isinstance(a, (np.float64, np.float32)):

@@ -366,9 +366,20 @@ def _cached_engine(key, factory):
     return eng
 
 
+_TABLEAU_KEYS = {}
+
+
 def _tableau_key(tb, c_mid):
-    return (tuple(tb.alpha), tuple(tuple(r) for r in tb.beta), tuple(tb.c_sol), tuple(tb.c_error),
-            None if c_mid is None else tuple(c_mid))
+    """By-value key of a tableau; the module-level tableau objects are immutable, so the tuples are built once per object."""
+    memo = (id(tb), id(c_mid))
+    hit = _TABLEAU_KEYS.get(memo)
+    if hit is None or hit[0] is not tb or hit[1] is not c_mid:
+        hit = (tb, c_mid, (tuple(tb.alpha), tuple(tuple(r) for r in tb.beta), tuple(tb.c_sol), tuple(tb.c_error),
+                           None if c_mid is None else tuple(c_mid)))
+        if len(_TABLEAU_KEYS) > 64:
+            _TABLEAU_KEYS.clear()
+        _TABLEAU_KEYS[memo] = hit
+    return hit[2]
 
 
 def _fusable_tuple(func, y0):
