@@ -32,6 +32,14 @@
  *        mi_ode_error_norms    <- misc._compute_error_ratio reductions (misc.py:256-263)
  *        mi_ode_scaled_sumsq   <- misc._norm(x / scale)   (misc.py:170-175, 225-237)
  *        mi_ode_interp_eval    <- interp._interp_fit + _interp_evaluate / tsit5._interp_eval_tsit5
+ *
+ *  (C) opaque right-hand side, controller on the device (mi_ode_opq_*) - f is still
+ *      evaluated by the caller between launches, but an attempt contains no host
+ *      decision, so the caller can record it once as a hipGraph and replay it:
+ *        mi_ode_opq_finish     <- rk_common.py:60 (error estimate) + misc._compute_error_ratio +
+ *                                 the accept test + misc._optimal_step_size (dopri5.py:103-121)
+ *        mi_ode_opq_commit     <- the accepted branch of _adaptive_dopri5_step (dopri5.py:113-121)
+ *                                 + Dopri5Solver.advance's _interp_evaluate (dopri5.py:87)
  */
 #ifndef MI_ODE_H
 #define MI_ODE_H
@@ -44,8 +52,9 @@ extern "C" {
 #endif
 
 /* 9: mi_ode_desc.multistep (fixed-grid Adams family).  10: multistep = 3 + ms_gamma_star (variable-order Adams), the four
- * mi_ode_adams_* plane entry points. */
-#define MI_ODE_ABI_VERSION 10
+ * mi_ode_adams_* plane entry points.  11: family (C) mi_ode_opq_* (opaque right-hand side, device-resident controller: what a
+ * captured hipGraph of an attempt needs), mi_ode_stats.clock_mhz. */
+#define MI_ODE_ABI_VERSION 11
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -197,6 +206,8 @@ typedef struct mi_ode_stats {
   uint32_t status;            /* MI_ODE_ST_* bits */
   int32_t n_polls;            /* host synchronisations taken */
   int64_t n_launches;         /* kernels enqueued */
+  double clock_mhz;           /* shader clock the one-launch kernels of the call ran at (their own cycle counter against the
+                                 100 MHz constant clock); 0 where not measured */
 } mi_ode_stats;
 
 typedef struct mi_ode_solver* mi_ode_handle;
@@ -207,7 +218,7 @@ const char* mi_ode_status_string(uint32_t status_bits);   /* reference assertion
 const char* mi_ode_last_error(void);                      /* thread-local text of the last negative return */
 int64_t mi_ode_reduce_workspace_bytes(void);              /* scratch the stateless reductions need */
 int64_t mi_ode_sizeof(int32_t which);                     /* 0: mi_ode_desc, 1: mi_ode_stats, 2: mi_ode_tableau, 3: mi_ode_rhs,
-                                                             5: mi_ode_ctrl_params, 6: mi_ode_adjoint_desc
+                                                             5: mi_ode_ctrl_params, 6: mi_ode_adjoint_desc, 7: mi_ode_opq_desc
                                                              (lets a foreign-language binding verify its struct layout) */
 
 /* ---- (A) fused engine ---------------------------------------------------------------------- */
@@ -340,6 +351,48 @@ int mi_ode_rk_stage_combine(int32_t dtype, int64_t n, const void* y0_dev, const 
 /* {max|y0|, max|y1|, sum err^2, nonfinite} of one attempt (misc.py:256-263): mi_ode_error_norms under its 8(b) name */
 int mi_ode_rk_error_reduce(int32_t dtype, int64_t n, const void* err_dev, const void* y0_dev, const void* y1_dev,
                            double* result_dev, void* workspace_dev, void* stream);
+
+/* ---- (C) opaque right-hand side, device-resident controller ------------------------------------------------ */
+/* The reference's own call shape - odeint(func, y0, t) with a Python callable (tests/odeint_tests.py:30-77,
+ * examples/ode_demo.py:39,169) - costs one host decision per attempt when the controller runs on the host
+ * (dopri5.py:103-121 reads the error ratio back).  Here the scalar state of the solver (rk_state.t0 / t1 / dt, the output
+ * cursor, the counters, the reference's assertions as status bits) lives in a device record; the caller evaluates f between
+ * our launches, the stage combinations are mi_ode_lincomb_dev with scale_dev = mi_ode_opq_dt_dev(h), and f receives its time
+ * argument as a 0-d view of the stage-time array - so one attempt
+ *     for sigma = 1..S:  y_sigma = lincomb_dev(y0, k_1..k_sigma, beta_sigma);  k_{sigma+1} = f(ts[sigma-1], y_sigma)
+ *     [not FSAL shaped: y1 = lincomb_dev(y0, k, c_sol)]                          (rk_common.py:49-56)
+ *     mi_ode_opq_finish(y0, y1, k);  mi_ode_opq_commit(y0, f0, y1, k)
+ * contains no host value and can be captured as a hipGraph and replayed.  A tuple state has n_comp components (all pointer
+ * arrays are [n_comp], k is [n_comp][S + 1] flattened, k[c][0] = f0 of component c); ratios are per component, accepted if all
+ * are <= 1, python max() of them drives the step size (misc.py:250-287); the tsit5 controller pools them (tsit5.py:126-138).
+ * Every kernel is a no-op once the record says `done` (all outputs produced, or a status bit), and mi_ode_opq_commit is a
+ * no-op after a rejected attempt: a host that replays attempts blindly in chunks and polls once per chunk is correct. */
+typedef struct mi_ode_opq_desc {
+  int32_t dtype;              /* enum mi_ode_dtype of every component */
+  int32_t n_comp;             /* 1 .. MI_ODE_MAX_SEGMENTS */
+  int64_t n[MI_ODE_MAX_SEGMENTS];                 /* elements per component */
+  mi_ode_tableau tableau;     /* 1, 3, 6 or 13 rows (dense output is instantiated for S + 1 = 2, 4, 7, 14 stage derivatives) */
+  int32_t controller, interp, order, init_order;  /* as mi_ode_desc */
+  double rtol[MI_ODE_MAX_SEGMENTS], atol[MI_ODE_MAX_SEGMENTS];   /* one pair per component (dopri5.py:60-61); tsit5: pair 0 */
+  double safety, ifactor, dfactor;                /* the float32-rounded values (misc.py:137-144) */
+  int64_t max_num_steps;
+} mi_ode_opq_desc;
+typedef struct mi_ode_opq* mi_ode_opq_handle;
+int mi_ode_opq_create(const mi_ode_opq_desc* desc, mi_ode_opq_handle* out);
+int mi_ode_opq_destroy(mi_ode_opq_handle h);
+/* device address of rk_state.dt (float64): the scale_dev of the attempt's mi_ode_lincomb_dev calls */
+const double* mi_ode_opq_dt_dev(mi_ode_opq_handle h);
+/* Arms an integration: rk_state = (t0, t0, first_dt) (dopri5.py:79), the output cursor over t_out_host[0 .. n_out-1]
+ * (strictly increasing, all > t0; solvers.py:31-35), out_dev[c] = the [n_out, n[c]] solution rows of component c, and the
+ * first attempt's stage times into stage_times_dev ([S] elements of the state dtype; rewritten after every attempt). */
+int mi_ode_opq_begin(mi_ode_opq_handle h, double t0, double first_dt, const double* t_out_host, int32_t n_out,
+                     void* const* out_dev, void* stage_times_dev, void* stream);
+int mi_ode_opq_finish(mi_ode_opq_handle h, const void* const* y0_dev, const void* const* y1_dev, const void* const* k_dev,
+                      void* stream);
+int mi_ode_opq_commit(mi_ode_opq_handle h, void* const* y0_dev, void* const* f0_dev, const void* const* y1_dev,
+                      const void* const* k_dev, void* stream);
+/* Reads the scalar state back (one stream synchronisation): *done, the counters, status bits (also the return value). */
+int mi_ode_opq_poll(mi_ode_opq_handle h, mi_ode_stats* stats, int32_t* done, void* stream);
 
 /* ---- (B) stateless plane kernels (arbitrary Python f, tuple states) ------------------------- */
 /* out[i] = (base ? base[i] : 0) + sum_j (scale * coef[j]) * xs[j][i]       (misc.py:118-121; zeros not skipped) */

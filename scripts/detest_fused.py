@@ -69,11 +69,14 @@ def main():
     ap.add_argument('--no-cpu', action='store_true')
     ap.add_argument('--methods', default='dopri5,adams')
     ap.add_argument('--build-only', action='store_true', help='compile the plugins (no GPU needed) and exit')
+    ap.add_argument('--callable', action='store_true', help='every problem as a PYTHON callable (the reference\'s call shape): the GPU column '
+                    'is then the device-controlled callable path (graph_step.DeviceControlledRK), not the one-launch kernels')
+    ap.add_argument('--graph-mode', default='auto', help="--callable: options={'graph': auto|host|True|False}")
     args = ap.parse_args()
     from tfdiffeq_amd import rhs
     from oracle import adams_numpy as OA, detest_problems as DP, ode_numpy as O, ode_torch_cpu as TC   # problem definitions / checker / CPU baseline
     dev_rhs = {}
-    for name, (dim, body) in BODIES.items():
+    for name, (dim, body) in ({} if args.callable else BODIES).items():
         dev_rhs[name] = rhs.CustomRowLocal(dim, body)
     if args.build_only:
         for name, f in dev_rhs.items():
@@ -82,8 +85,9 @@ def main():
         return
     from tfdiffeq_amd import odeint
     dev = torch.device('cuda:0')
-    for name in LINEAR:
+    for name in (() if args.callable else LINEAR):
         dev_rhs[name] = rhs.Linear.from_matrix(torch.tensor(linear_matrix(name)))
+    gmode = {'True': True, 'False': False}.get(args.graph_mode, args.graph_mode)
     like = torch.zeros(1, device=dev, dtype=torch.float64)
     tt = torch.tensor([0., DP.T_END], dtype=torch.float64)
     tn = np.array([0., DP.T_END])
@@ -115,7 +119,8 @@ def main():
                     f_gpu.nfe = 0
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
-                est = odeint(f_gpu, y0_gpu, tt, rtol=tol, atol=tol, method=method)
+                opts = {'graph': gmode} if (args.callable and method == 'dopri5') else None
+                est = odeint(f_gpu, y0_gpu, tt, rtol=tol, atol=tol, method=method, options=opts)
                 torch.cuda.synchronize()
                 if rep:
                     walls.append(time.perf_counter() - t0)
@@ -127,6 +132,8 @@ def main():
                     mark = '+'
             else:
                 g_nfe = calls[0] // reps
+                if 'device-controlled' in str(st.get('engine')):  # replayed evaluations do not run Python: the kernel-side count + the
+                    g_nfe = 2 + int(st.get('nfe', 0))             # two evaluations of before_integrate
             g_err = float(np.sqrt(np.mean((est[1].cpu().numpy().reshape(ref[name].shape) - ref[name]) ** 2)))
             c_wall = c_err = float('nan')
             c_nfe = 0

@@ -4,8 +4,22 @@ kernels deliver).
 A band B for a comparison `key` means   |got - ref| <= B * (1 + |ref|)   for every element.  The bands live in
 tests/golden/fp32_bands.json: B = 10 x the largest value of  max |got - ref| / (1 + |ref|)  OBSERVED on the MI355X (two
 runs; scripts/measure_fp32_bands.sh regenerates them), never below 2e-6 (a few float32 ulps of an O(1) state).
-The observed values are kept next to the bands.  Recording mode (TFDIFFEQ_AMD_RECORD_BANDS=<file>): nothing is
-asserted, every comparison appends {key: observed} to <file>.
+The observed values are kept next to the bands.
+
+A recorded band is a regression guard, not a correctness argument (it was derived from this implementation's own output), so
+every comparison is ALSO held to an a-priori ceiling that does not depend on what was observed:
+    state comparisons   1e-3  = 8 x [eps32 (6e-8) x 7 stage evaluations x 300 attempts], the roundoff a float32 Dopri5 run of the
+                                longest fixture can accumulate if every rounding error lined up - and the local tolerances of the
+                                float32 cases (rtol 1e-4 .. 1e-3) allow no less;
+    scalar deviations   the caller's `ceiling` (gradient comparisons state theirs next to the call), default 1e-3.
+The assertion is  observed <= min(recorded band, ceiling).  Two groups need a ceiling above 1e-3 and say so at the call:
+relu-network gradients (kinks: a sample that crosses one between the float32 and the float64 solve changes a whole column of
+the weight gradient; observed 2.5e-3 .. 4.7e-3, ceiling 1e-2) and dopri8 in float32 (13-stage combination with coefficients up to
+~2e2 in magnitude: cancellation noise 3e-4 observed, ceiling 3e-3).
+
+Recording mode (TFDIFFEQ_AMD_RECORD_BANDS=<file>): every comparison appends {key: observed} to <file> and asserts only the
+a-priori ceiling; the session then ENDS WITH A NON-ZERO EXIT STATUS and a banner (tests/conftest.py) - a run in recording mode can
+never be mistaken for a green parity run, whatever inherited the variable.
 """
 import json
 import os
@@ -30,11 +44,21 @@ def observed(got, ref):
     return float((np.abs(got - ref) / (1.0 + np.abs(ref))).max())
 
 
-def assert_f32(got, ref, key):
+CEILING = 1e-3          # a-priori bound of every float32 comparison (module docstring); callers with a reason pass their own
+recorded = []           # keys recorded in this session (recording mode): tests/conftest.py turns a non-empty list into a failed session
+
+
+def _record(key, obs):
+    recorded.append(key)
+    with open(_REC, 'a') as f:
+        f.write(json.dumps({'key': key, 'observed': obs}) + '\n')
+
+
+def assert_f32(got, ref, key, ceiling=CEILING):
     obs = observed(got, ref)
+    assert obs <= ceiling, '%s: max |got - ref| / (1 + |ref|) = %.3e above the a-priori ceiling %.1e' % (key, obs, ceiling)
     if _REC:
-        with open(_REC, 'a') as f:
-            f.write(json.dumps({'key': key, 'observed': obs}) + '\n')
+        _record(key, obs)
         return
     b = _bands().get(key)
     assert b is not None, 'no float32 band for %r in tests/golden/fp32_bands.json (scripts/measure_fp32_bands.sh records them)' % key
@@ -42,12 +66,12 @@ def assert_f32(got, ref, key):
         key, obs, b['band'], b['observed'])
 
 
-def assert_scalar(value, key):
-    """A scalar deviation (e.g. a relative gradient error) against its recorded band (10 x observed, same file)."""
+def assert_scalar(value, key, ceiling=CEILING):
+    """A scalar deviation (e.g. a relative gradient error) against min(its recorded band (10 x observed, same file), ceiling)."""
     value = float(value)
+    assert value <= ceiling, '%s: %.3e above the a-priori ceiling %.1e' % (key, value, ceiling)
     if _REC:
-        with open(_REC, 'a') as f:
-            f.write(json.dumps({'key': key, 'observed': value}) + '\n')
+        _record(key, value)
         return
     b = _bands().get(key)
     assert b is not None, 'no band for %r in tests/golden/fp32_bands.json (scripts/measure_fp32_bands.sh records them)' % key

@@ -27,3 +27,13 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """A session that RECORDED float32 bands asserted none of them (tests/bands.py): it must not look like a green parity run."""
+    if os.environ.get('TFDIFFEQ_AMD_RECORD_BANDS'):
+        from tests import bands
+        if bands.recorded:
+            sys.stderr.write('\n*** TFDIFFEQ_AMD_RECORD_BANDS is set: %d float32 comparisons were RECORDED, not asserted against their bands - '
+                             'this session does not count as a parity run (exit status 3) ***\n' % len(bands.recorded))
+            session.exitstatus = 3

@@ -344,4 +344,7 @@ def test_default_odenet_trains_on_the_fused_kernels(act):
     ref64[1].pow(2).sum().backward()
     # (relu: the kinks cap what an adaptive solve of tolerance 1e-5 delivers, on either path - its recorded bands are wider)
     for i, (pg, pc) in enumerate(zip(block.odefunc.parameters(), cpu64.parameters())):
-        assert_scalar(_rel(pg.grad.cpu().double(), pc.grad), 'default_odenet_grads/%s/param%d' % (act, i))
+        # a-priori ceilings (tests/bands.py): relu - a sample crossing a kink between the float32 and the float64 solve changes a whole
+        # column of the weight gradient (1e-2); softplus - smooth, the default tol 1e-3 of ODEBlock bounds the two solves' distance (3e-3)
+        assert_scalar(_rel(pg.grad.cpu().double(), pc.grad), 'default_odenet_grads/%s/param%d' % (act, i),
+                      ceiling=1e-2 if act == 'relu' else 3e-3)

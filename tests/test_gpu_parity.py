@@ -1130,7 +1130,8 @@ def test_wide_and_non_fsal_tableaus_on_the_row_local_kernels(problem, method):
                 assert abs(sc['n_attempts'] - sa['n_attempts']) <= 1, (sa, sc)
                 assert (a - c).abs().max().item() <= 1e-9 * scale
             else:
-                assert_f32(a.cpu(), c.cpu(), 'wide_tableau/%s/%s/%s/fused_vs_planes' % (problem, method, 'fwd' if float(tt[-1]) > 0 else 'rev'))
+                assert_f32(a.cpu(), c.cpu(), 'wide_tableau/%s/%s/%s/fused_vs_planes' % (problem, method, 'fwd' if float(tt[-1]) > 0 else 'rev'),
+                           ceiling=3e-3 if method == 'dopri8' else 1e-3)      # dopri8 in float32: cancellation in the 13-stage combination
 
 
 _TIMEOUT_SCRIPT = r"""

@@ -377,15 +377,20 @@ def test_detest_problem_on_the_plane_kernel_engine(name):
     d, meta = load('fn_detest')
     y_like = torch.zeros(1, device=dev(), dtype=torch.float64)
     f, y0 = DP.problem(name, torch, like=y_like)
-    nfe = [0]
+    class Counted(object):                     # the reference's own harness counts like this (tests/DETEST/run.py:14-22); evaluations
+        def __init__(self):                    # that a recorded hipGraph replays do not run Python and are credited to `nfe` afterwards
+            self.nfe = 0
 
-    def counted(t, y):
-        nfe[0] += 1
-        return f(t, y)
+        def __call__(self, t, y):
+            self.nfe += 1
+            return f(t, y)
+    counted = Counted()
+    nfe = [0]
     for tol, ref_nfe, att, acc in d[name + '_runs']:
-        nfe[0] = 0
+        counted.nfe = 0
         sol = odeint(counted, y0, torch.tensor([0., DP.T_END], dtype=torch.float64), rtol=float(tol), atol=float(tol), method='dopri5')
         st = dict(odeint.last_stats)
+        nfe[0] = counted.nfe
         ref = d['%s_y20_tol%g' % (name, tol)]
         got = sol[1].cpu().numpy()
         assert np.abs(got - ref).max() <= ATOL + RTOL * np.abs(ref).max() + 50 * tol * max(1.0, np.abs(ref).max()) * (st['n_attempts'] != att), \
@@ -599,7 +604,7 @@ def test_dopri8_on_the_linear_tile_kernels(dim, batch):
     assert np.abs(outs['auto'].cpu().numpy() - ref).max() < 1e-6
     assert float((outs['auto'] - planes).abs().max()) < 1e-6
     odeint(f, to_dev(y0), torch.tensor(t), method='dopri8', options={'fusion': 'stage'}, **tol)     # no per-stage kernels for 13 rows:
-    assert odeint.last_stats.get('engine') == 'plane kernels'                                      # the generic engine takes it
+    assert str(odeint.last_stats.get('engine')).startswith(('plane kernels', 'device-controlled'))                                      # the generic engine takes it
 
 
 @pytest.mark.gpu

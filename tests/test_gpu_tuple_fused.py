@@ -135,10 +135,10 @@ def test_what_the_segmented_engine_does_not_take_stays_generic():
     f = rhs.PerComponent(rhs.Lorenz())
     t = torch.tensor([0., 0.05])
     odeint(f, y + tuple(torch.randn(4, 3, dtype=torch.float64, device=dev()) for _ in range(7)), t, method='dopri5')   # 9 components
-    assert odeint.last_stats.get('engine') == 'plane kernels'
+    assert str(odeint.last_stats.get('engine')).startswith(('plane kernels', 'device-controlled'))
     odeint(rhs.PerComponent(rhs.Linear(torch.eye(16, dtype=torch.float64, device=dev()))),
            tuple(torch.randn(10, 16, dtype=torch.float64, device=dev()) for _ in range(2)), t, method='dopri5')       # not a row-local system
-    assert odeint.last_stats.get('engine') == 'plane kernels'
+    assert str(odeint.last_stats.get('engine')).startswith(('plane kernels', 'device-controlled'))
     with pytest.raises(TypeError):
         rhs.PerComponent(lambda t_, y_: y_)
 

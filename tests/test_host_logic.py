@@ -32,11 +32,11 @@ def _tab_arrays(tb):
 def test_library_exports_every_declared_symbol_and_layout_matches():
     lib = N.load()                               # raises if a prototype is missing or a struct size differs
     header = open(os.path.join(ROOT, 'include', 'mi_ode.h')).read()
-    declared = sorted(set(re.findall(r'^(?:int|int64_t|const char\*)\s+(mi_ode_[a-z_0-9]+)\(', header, flags=re.M)))
+    declared = sorted(set(re.findall(r'^(?:int|int64_t|const char\*|const double\*)\s+(mi_ode_[a-z_0-9]+)\(', header, flags=re.M)))
     assert declared == list(N.EXPORTED_SYMBOLS), (declared, N.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mi_ode_abi_version() == N.ABI_VERSION == 10
+    assert lib.mi_ode_abi_version() == N.ABI_VERSION == 11
     assert lib.mi_ode_sizeof(0) == C.sizeof(N.Desc) and lib.mi_ode_sizeof(1) == C.sizeof(N.Stats)
     assert lib.mi_ode_status_string(N.ST_MAX_STEPS).decode().startswith('max_num_steps exceeded')
     assert lib.mi_ode_status_string(N.ST_DT_UNDERFLOW).decode().startswith('underflow in dt')

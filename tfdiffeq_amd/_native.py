@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH, RHS_PLUGIN = 1, 2, 3, 4, 5, 6
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 MAX_SEGMENTS = 8
 SEGMENT_ALIGN = 256
 IPC_HANDLE_BYTES = 64
@@ -82,10 +82,18 @@ class AdjointDesc(C.Structure):
                 ('order', C.c_int32), ('init_order', C.c_int32), ('max_num_steps', C.c_int64)]
 
 
+class OpqDesc(C.Structure):
+    """mi_ode_opq_desc: adaptive RK over an opaque (Python) right-hand side with the controller on the device."""
+    _fields_ = [('dtype', C.c_int32), ('n_comp', C.c_int32), ('n', C.c_int64 * MAX_SEGMENTS), ('tableau', Tableau),
+                ('controller', C.c_int32), ('interp', C.c_int32), ('order', C.c_int32), ('init_order', C.c_int32),
+                ('rtol', C.c_double * MAX_SEGMENTS), ('atol', C.c_double * MAX_SEGMENTS),
+                ('safety', C.c_double), ('ifactor', C.c_double), ('dfactor', C.c_double), ('max_num_steps', C.c_int64)]
+
+
 class Stats(C.Structure):
     _fields_ = [('n_attempts', C.c_int64), ('n_accepted', C.c_int64), ('n_rejected', C.c_int64), ('nfe', C.c_int64),
                 ('t', C.c_double), ('dt', C.c_double), ('last_ratio', C.c_double),
-                ('status', C.c_uint32), ('n_polls', C.c_int32), ('n_launches', C.c_int64)]
+                ('status', C.c_uint32), ('n_polls', C.c_int32), ('n_launches', C.c_int64), ('clock_mhz', C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -128,6 +136,15 @@ _PROTOS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     'mi_ode_adjoint_dynamics': (C.c_int, [C.c_void_p, C.POINTER(Rhs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    'mi_ode_opq_create': (C.c_int, [C.POINTER(OpqDesc), C.POINTER(C.c_void_p)]),
+    'mi_ode_opq_destroy': (C.c_int, [C.c_void_p]),
+    'mi_ode_opq_dt_dev': (C.c_void_p, [C.c_void_p]),
+    'mi_ode_opq_begin': (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.POINTER(C.c_double), C.c_int32, C.POINTER(C.c_void_p),
+                                   C.c_void_p, C.c_void_p]),
+    'mi_ode_opq_finish': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_void_p]),
+    'mi_ode_opq_commit': (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                    C.POINTER(C.c_void_p), C.c_void_p]),
+    'mi_ode_opq_poll': (C.c_int, [C.c_void_p, C.POINTER(Stats), C.POINTER(C.c_int32), C.c_void_p]),
     'mi_ode_controller_update': (C.c_int, [C.POINTER(CtrlParams), C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                            C.POINTER(C.c_double), C.c_void_p]),
     'mi_ode_rk_stage_combine': (C.c_int, [C.c_int32, C.c_int64, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_double),
@@ -194,7 +211,7 @@ def load():
         fn.argtypes = args
     if lib.mi_ode_abi_version() != ABI_VERSION:
         raise NativeError('libmi_ode.so ABI version mismatch')
-    for which, st in ((0, Desc), (1, Stats), (2, Tableau), (3, Rhs), (5, CtrlParams), (6, AdjointDesc)):
+    for which, st in ((0, Desc), (1, Stats), (2, Tableau), (3, Rhs), (5, CtrlParams), (6, AdjointDesc), (7, OpqDesc)):
         if lib.mi_ode_sizeof(which) != C.sizeof(st):
             raise NativeError('struct layout mismatch for %s: C %d vs ctypes %d'
                               % (st.__name__, lib.mi_ode_sizeof(which), C.sizeof(st)))

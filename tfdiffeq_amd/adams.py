@@ -75,7 +75,7 @@ class VariableCoefficientAdamsBashforth(AdaptiveStepsizeODESolver):
         """A row-local catalogue system with a single state tensor: the whole call - the deque of backward differences, g / beta,
         the error ratios, the order selection - is ONE kernel launch (csrc/mi_ode_adams_vc.h).  Everything else: the per-step loop of
         the base class over plane kernels."""
-        from .solvers import _EULER_SHAPE, _FusedEngine, _cached_engine, _fusable
+        from .solvers import _EULER_SHAPE, _FusedEngine, _cached_engine_or_none, _fusable, SyncTimeout
         from .misc import _assert_increasing
         rhs = _fusable(self.func, self.y0) if not self._force_planes else None
         if rhs is not None and getattr(rhs, 'multistep_fused', False) and len(self.y0) == 1:
@@ -83,14 +83,17 @@ class VariableCoefficientAdamsBashforth(AdaptiveStepsizeODESolver):
             y = self.y0[0]
             key = ('adams_vc', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device), self.max_order,
                    float(self.rtol[0]), float(self.atol[0]), float(self.safety), float(self.ifactor), float(self.dfactor))
-            try:
-                eng = _cached_engine(key, lambda: _FusedEngine(rhs, y, True, _EULER_SHAPE, rtol=self.rtol[0], atol=self.atol[0],
-                                                               safety=float(self.safety), ifactor=float(self.ifactor),
-                                                               dfactor=float(self.dfactor), multistep=(3, self.max_order, gamma_star)))
-            except N.NativeError:
-                eng = None                            # (a batch whose workgroups cannot be co-resident): the per-step loop
+            # (None: a batch whose workgroups cannot be co-resident - remembered under the key - the per-step loop)
+            eng = _cached_engine_or_none(key, lambda: _FusedEngine(rhs, y, True, _EULER_SHAPE, rtol=self.rtol[0], atol=self.atol[0],
+                                                                   safety=float(self.safety), ifactor=float(self.ifactor),
+                                                                   dfactor=float(self.dfactor), multistep=(3, self.max_order, gamma_star)))
+            out = None
             if eng is not None:
-                out = eng.integrate(t.to(torch.float64).numpy(), y)
+                try:
+                    out = eng.integrate(t.to(torch.float64).numpy(), y)
+                except SyncTimeout:                   # hand-off timed out (shared GPU): nothing was committed, take the per-step loop
+                    out = None
+            if out is not None:
                 self.stats = eng.stats.as_dict()
                 self.stats['engine'] = 'fused variable-order Adams kernel (one launch)'
                 return (out,)

@@ -177,6 +177,19 @@ def _fused_plan(func, n_tensors, cfg, like, f_params):
     return eng, mlp, base
 
 
+def _trainable(func):
+    """The tensors the backward solve differentiates with respect to: the module's grad-requiring parameters, then the bare
+    grad-requiring tensors a wrapped plain callable closes over (odeint._callable_module), in a fixed order."""
+    ps = [p for p in func.parameters() if p.requires_grad]
+    base = getattr(func, 'base_func', func)
+    have = {id(p) for p in ps}
+    for e in getattr(base, '_mi_extra_params', ()):
+        if e.requires_grad and id(e) not in have:
+            ps.append(e)
+            have.add(id(e))
+    return ps
+
+
 class _TupleModule(torch.nn.Module):
     """adjoint.py:203-211."""
 
@@ -224,7 +237,7 @@ class _OdeintAdjointMethod(torch.autograd.Function):
     def backward(ctx, *grad_output):
         func, cfg, n_tensors = ctx.func, ctx.cfg, ctx.n_tensors
         t, flat_params, *ans = ctx.saved_tensors
-        f_params = tuple(p for p in func.parameters() if p.requires_grad)
+        f_params = tuple(_trainable(func))
         like = ans[0]
         grad_output = tuple(g if g is not None else torch.zeros_like(a) for g, a in zip(grad_output, ans))
         plan = _fused_plan(func, n_tensors, cfg, like, f_params)
@@ -349,7 +362,7 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
         tensor_input = True
         y0 = (y0,)
         func = _TupleModule(func)
-    params = [p for p in func.parameters() if p.requires_grad]
+    params = _trainable(func)
     flat_params = _flatten(params) if params else torch.zeros(0, device=y0[0].device, dtype=y0[0].dtype)
     cfg = dict(rtol=rtol, atol=atol, method=method, options=options, adjoint_method=adjoint_method,
                adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol, adjoint_options=adjoint_options)

@@ -40,9 +40,9 @@ __global__ __launch_bounds__(256) void k_fixed_adams_rowlocal(AdamsArgs A) {
   __shared__ PersistShared sh;
   const RHS rhs(A.f.rhs);
   const T sign = (T)A.f.rhs.sign;
-  const long long n = A.f.batch * D;
-  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool active = row < A.f.batch;
+  long long n, off;                                          // elements per solution row; this thread's first element
+  bool active;
+  rowmap<RHS>(A.f.batch, A.f.dim, off, active, n);
   const T* y0p = (const T*)A.f.y0;
   T* out = (T*)A.f.out;
   const double* AB = A.tab;
@@ -55,8 +55,8 @@ __global__ __launch_bounds__(256) void k_fixed_adams_rowlocal(AdamsArgs A) {
 #pragma unroll
   for (int d = 0; d < D; ++d) y.v[d] = (T)0;
   if (active) {
-    y = *(const Row*)(y0p + row * D);
-    *(Row*)(out + row * D) = y;                              // solution = [y0]
+    y = *(const Row*)(y0p + off);
+    *(Row*)(out + off) = y;                                  // solution = [y0]
   }
   T hist[kAdamsHist][D];                                     // hist[0] = newest
 #pragma unroll
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_fixed_adams_rowlocal(AdamsArgs A) {
 #pragma unroll
         for (int d = 0; d < D; ++d)
           o.v[d] = (tj == t0) ? y.v[d] : ((tj == t1) ? yn.v[d] : y.v[d] + ((yn.v[d] - y.v[d]) / (t1 - t0)) * (tj - t0));
-        *(Row*)(out + (long long)j_out * n + row * D) = o;
+        *(Row*)(out + (long long)j_out * n + off) = o;
       }
       ++j_out;
     }

@@ -61,9 +61,9 @@ __global__ __launch_bounds__(256, 2) void k_adams_vc_rowlocal(AdamsVcArgs A) {  
   __shared__ VcShared vs;
   const RHS rhs(A.f.rhs);
   const T sign = (T)A.f.rhs.sign;
-  const long long n = A.f.batch * D;
-  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const bool live = row < A.f.batch;
+  long long n, off;                                          // elements per solution row; this thread's first element
+  bool live;
+  rowmap<RHS>(A.f.batch, A.f.dim, off, live, n);
   const CtrlParams cp = A.cp;
   const double n_tot = (double)cp.n_local;
   Ctl& c = sh.c;
@@ -78,8 +78,8 @@ __global__ __launch_bounds__(256, 2) void k_adams_vc_rowlocal(AdamsVcArgs A) {  
 #pragma unroll
   for (int d = 0; d < D; ++d) y.v[d] = (T)0;
   if (live) {
-    y = *(const Row*)((const T*)A.f.y0 + row * D);
-    *(Row*)(out + row * D) = y;                              // solution[0] = y0 (solvers.py:30)
+    y = *(const Row*)((const T*)A.f.y0 + off);
+    *(Row*)(out + off) = y;                                  // solution[0] = y0 (solvers.py:30)
   }
   T phi[kVcPhi][D];
 #pragma unroll
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_adams_vc_rowlocal(AdamsVcArgs A) {  
       }
     }
     if (uniform_i(vs.done)) break;
-    if (live) *(Row*)(out + (long long)i_out * n + row * D) = y;
+    if (live) *(Row*)(out + (long long)i_out * n + off) = y;
   }
   __syncthreads();
   if (blockIdx.x == 0 && threadIdx.x == 0 && A.result != nullptr) {

@@ -54,6 +54,7 @@ extern "C" int64_t mi_ode_sizeof(int32_t which) {
     case 4: return (int64_t)sizeof(mi_ode_solver);          /* what a RHS plugin must have been compiled against */
     case 5: return (int64_t)sizeof(mi_ode_ctrl_params);
     case 6: return (int64_t)sizeof(mi_ode_adjoint_desc);
+    case 7: return (int64_t)sizeof(mi_ode_opq_desc);
     default: return -1;
   }
 }
@@ -271,6 +272,7 @@ static void fill_stats(mi_ode_solver* h, mi_ode_stats* s) {
   s->status = c->status;
   s->n_polls = h->n_polls;
   s->n_launches = h->n_launches;
+  s->clock_mhz = c->clk_ticks > 0 ? 100.0 * (double)c->clk_cycles / (double)c->clk_ticks : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -318,7 +320,10 @@ static int pick_family(mi_ode_solver* h) {
     case MI_ODE_RHS_MLP_TANH: {
       const int hd = r.hidden;
       if (!h->is_f32) { mi_set_error("fused MLP kernel is fp32 only"); return MI_ODE_E_INVALID; }
-      if (!h->d.adaptive) { mi_set_error("fused MLP kernel: adaptive solvers only"); return MI_ODE_E_INVALID; }
+      if (!h->d.adaptive && (h->d.multistep != 0 || (h->d.tableau.n_stages != 0 && h->d.tableau.n_stages != 3))) {
+        mi_set_error("fused MLP kernels on a fixed grid: euler or rk4 (3/8 rule) in one launch (k_fixed_mlp); no multistep kernel");
+        return MI_ODE_E_INVALID;
+      }
       if (D < 1 || D > 64 || hd < 1 || hd > 128 || !r.w[0] || !r.w[1] || !r.w[2]) {
         mi_set_error("fused MLP kernel supports dim <= 64, hidden <= 128 (got %d, %d)", D, hd);
         return MI_ODE_E_INVALID;
@@ -331,6 +336,25 @@ static int pick_family(mi_ode_solver* h) {
       mi_set_error("RHS kind %d has no fused kernel yet", r.kind);
       return MI_ODE_E_INVALID;
   }
+}
+
+// The one-launch multistep kernels (mi_ode_adams.h, mi_ode_adams_vc.h): a thread per trajectory for the row-local families, a
+// thread per state element - floor(256 / dim) trajectories per workgroup - for the matrix families (RhsLinearCoop).
+static bool multistep_family(const mi_ode_solver* h) {
+  const bool rowlocal = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
+                        h->family == FAM_PLUGIN;
+  const bool coop = (h->family == FAM_LINEAR_MFMA || h->family == FAM_LINEAR_VALU) && h->d.dim >= 1 && h->d.dim <= 256;
+  return rowlocal || coop;
+}
+static long long multistep_grid(const mi_ode_solver* h) {
+  if (h->family == FAM_LINEAR_MFMA || h->family == FAM_LINEAR_VALU) {
+    const long long tpw = 256 / h->d.dim;
+    return (h->d.batch + tpw - 1) / tpw;
+  }
+  return (h->d.batch + 255) / 256;
+}
+static void multistep_rhs(const mi_ode_solver* h, RhsParams& r) {
+  if (h->family == FAM_LINEAR_MFMA || h->family == FAM_LINEAR_VALU) r.hidden = (int)h->d.dim;   // (RhsLinearCoop reads the row length here)
 }
 
 static void fill_step_args(mi_ode_solver* h, StepArgs& A) {
@@ -418,7 +442,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   hipDeviceProp_t prop;
   if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) {
     mi_set_error("cannot query device");
-    delete h;
+    mi_ode_destroy(h);
     return MI_ODE_E_HIP;
   }
   h->num_cus = prop.multiProcessorCount;
@@ -428,14 +452,14 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   h->rhs.sign = desc->rhs.sign == 0.0 ? 1.0 : desc->rhs.sign;
   h->rhs.hidden = desc->rhs.hidden;
   int rc = pick_family(h);
-  if (rc != 0) { delete h; return rc; }
-  if (desc->adaptive && tb.n_stages != 3 && tb.n_stages != 6) {
+  if (rc != 0) { mi_ode_destroy(h); return rc; }
+  if (desc->adaptive && desc->multistep != 3 && tb.n_stages != 3 && tb.n_stages != 6) {   // (multistep = 3: no tableau at all)
     const bool rowlocal_fam = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
                               h->family == FAM_PLUGIN;
     const bool mfma13 = (h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP) && tb.fsal && tb.n_stages == 13;   // dopri8 on the tile kernels
     if (!(rowlocal_fam || mfma13) || desc->fusion == 1) {
       mi_set_error("%d-row tableaus run on the whole-attempt / whole-call kernels of the row-local families and (13 rows) of the MFMA-linear and MLP families only (no per-stage kernels)", tb.n_stages);
-      delete h; return MI_ODE_E_INVALID;
+      mi_ode_destroy(h); return MI_ODE_E_INVALID;
     }
   }
   h->nseg = desc->n_segments > 1 ? desc->n_segments : 0;
@@ -455,48 +479,46 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     if (!ok || rows != desc->batch) {
       mi_set_error("tuple states: 2..%d components of >= 1 row each, every component padded to %d rows (batch = the padded total), a row-local RHS, an "
                    "adaptive tableau, one rank, fusion 0 or 4", MI_ODE_MAX_SEGMENTS, MI_ODE_SEGMENT_ALIGN);
-      delete h; return MI_ODE_E_INVALID;
+      mi_ode_destroy(h); return MI_ODE_E_INVALID;
     }
   }
   rc = h->is_f32 ? mi_stage_geometry_f32(h) : mi_stage_geometry_f64(h);
-  if (rc != 0) { delete h; return rc; }
+  if (rc != 0) { mi_ode_destroy(h); return rc; }
   if (desc->multistep == 3) {                      // the variable-order Adams solver in one launch (mi_ode_adams_vc.h)
-    const bool rowlocal_cat = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
-                              h->family == FAM_PLUGIN;
+    const bool rowlocal_cat = multistep_family(h);
     if (!desc->adaptive || !rowlocal_cat || desc->ms_gamma_star == nullptr || desc->ms_max_order < 1 || desc->ms_max_order > kVcMaxOrder ||
         h->d.world_size > 1 || h->nseg > 1 || desc->controller != MI_ODE_CTRL_MISC) {
-      mi_set_error("multistep = 3 ('adams'): adaptive = 1, a row-local catalogue system, one rank, one tensor, the misc controller; 1 <= max_order <= %d, gamma_star", kVcMaxOrder);
-      delete h; return MI_ODE_E_INVALID;
+      mi_set_error("multistep = 3 ('adams'): adaptive = 1, a row-local catalogue system or a matrix RHS of dim <= 256, one rank, one tensor, the misc controller; 1 <= max_order <= %d, gamma_star", kVcMaxOrder);
+      mi_ode_destroy(h); return MI_ODE_E_INVALID;
     }
-    const long long g = (desc->batch + 255) / 256;
+    const long long g = multistep_grid(h);
     if (g > 1) {                                   // every attempt's error ratio crosses the workgroups: they must be co-resident
       const int cap = h->is_f32 ? mi_adams_vc_capacity_f32(h) : mi_adams_vc_capacity_f64(h);
       if (g > cap || g > kPersistMaxGrid) {
         mi_set_error("adams in one launch: %lld workgroups cannot be co-resident on this device (%d)", g, cap);
-        delete h; return MI_ODE_E_INVALID;
+        mi_ode_destroy(h); return MI_ODE_E_INVALID;
       }
     }
     memcpy(h->adams_gamma_star, desc->ms_gamma_star, sizeof(h->adams_gamma_star));
     hipError_t ea = hipHostMalloc((void**)&h->adams_res, 4 * sizeof(long long), hipHostMallocDefault);
-    if (ea != hipSuccess) { mi_set_error("multistep result record: %s", hipGetErrorString(ea)); delete h; return MI_ODE_E_HIP; }
+    if (ea != hipSuccess) { mi_set_error("multistep result record: %s", hipGetErrorString(ea)); mi_ode_destroy(h); return MI_ODE_E_HIP; }
     for (int i = 0; i < 4; ++i) h->adams_res[i] = 0;
     h->d.ms_gamma_star = nullptr;                  // (caller-owned host array: not kept)
   } else
   if (desc->multistep != 0) {                      // fixed-grid Adams family in one launch (mi_ode_adams.h)
-    const bool rowlocal_cat = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
-                              h->family == FAM_PLUGIN;
+    const bool rowlocal_cat = multistep_family(h);
     if (desc->adaptive || !rowlocal_cat || (desc->multistep != 1 && desc->multistep != 2) || desc->ms_ab == nullptr || desc->ms_am == nullptr ||
         desc->ms_am0 == nullptr || desc->ms_max_order < 1 || desc->ms_max_order > kAdamsMaxOrder || desc->ms_max_iters < 1 ||
         desc->ms_min_order < 1 || h->d.world_size > 1 || h->nseg > 1) {
-      mi_set_error("multistep: fixed grid, a row-local catalogue system, one rank, one tensor; 1 <= max_order <= %d, max_iters >= 1, coefficient tables", kAdamsMaxOrder);
-      delete h; return MI_ODE_E_INVALID;
+      mi_set_error("multistep: fixed grid, a row-local catalogue system or a matrix RHS of dim <= 256, one rank, one tensor; 1 <= max_order <= %d, max_iters >= 1, coefficient tables", kAdamsMaxOrder);
+      mi_ode_destroy(h); return MI_ODE_E_INVALID;
     }
-    const long long g = (desc->batch + 255) / 256;
+    const long long g = multistep_grid(h);
     if (desc->multistep == 2 && g > 1) {           // the corrector's convergence test couples the workgroups: they must be co-resident
       const int cap = h->is_f32 ? mi_adams_capacity_f32(h) : mi_adams_capacity_f64(h);
       if (g > cap || g > kPersistMaxGrid) {
         mi_set_error("fixed_adams in one launch: %lld workgroups cannot be co-resident on this device (%d)", g, cap);
-        delete h; return MI_ODE_E_INVALID;
+        mi_ode_destroy(h); return MI_ODE_E_INVALID;
       }
     }
     double tab[2 * 13 * 12 + 13];
@@ -506,7 +528,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     hipError_t ea = hipMalloc((void**)&h->adams_tab, sizeof(tab));
     if (ea == hipSuccess) ea = hipMemcpy(h->adams_tab, tab, sizeof(tab), hipMemcpyHostToDevice);
     if (ea == hipSuccess) ea = hipHostMalloc((void**)&h->adams_res, 2 * sizeof(long long), hipHostMallocDefault);
-    if (ea != hipSuccess) { mi_set_error("multistep tables: %s", hipGetErrorString(ea)); delete h; return MI_ODE_E_HIP; }
+    if (ea != hipSuccess) { mi_set_error("multistep tables: %s", hipGetErrorString(ea)); mi_ode_destroy(h); return MI_ODE_E_HIP; }
     h->adams_res[0] = h->adams_res[1] = 0;
     h->d.ms_ab = h->d.ms_am = h->d.ms_am0 = nullptr;   // (caller-owned host arrays: not kept)
   }
@@ -514,12 +536,12 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     const bool can = desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
                                         h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP ||
                                         h->family == FAM_PLUGIN);
-    if (h->family == FAM_PLUGIN && desc->fusion == 1) { mi_set_error("RHS plugins have no per-stage kernels (fusion = 1)"); delete h; return MI_ODE_E_INVALID; }
-    if (h->family == FAM_MLP && desc->fusion == 1) { mi_set_error("the MLP family only has a whole-attempt kernel"); delete h; return MI_ODE_E_INVALID; }
+    if (h->family == FAM_PLUGIN && desc->fusion == 1) { mi_set_error("RHS plugins have no per-stage kernels (fusion = 1)"); mi_ode_destroy(h); return MI_ODE_E_INVALID; }
+    if (h->family == FAM_MLP && desc->fusion == 1) { mi_set_error("the MLP family only has a whole-attempt kernel"); mi_ode_destroy(h); return MI_ODE_E_INVALID; }
     const bool can_fixed = !desc->adaptive && (h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV ||
-                                               h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA ||
+                                               h->family == FAM_LORENZ || h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP ||
                                                h->family == FAM_PLUGIN);
-    if (desc->fusion == 2 && !can && !can_fixed) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); delete h; return MI_ODE_E_INVALID; }
+    if (desc->fusion == 2 && !can && !can_fixed) { mi_set_error("fusion=2: no whole-attempt kernel for this problem"); mi_ode_destroy(h); return MI_ODE_E_INVALID; }
     h->step_fused = (can && desc->fusion != 1) ? 1 : 0;
     h->ts_dense = (desc->interp != MI_ODE_INTERP_QUARTIC_MID) ? 1 : 0;
     // In-kernel controller (last workgroup): measured equal or better than a separate k_controller launch for the
@@ -541,7 +563,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     if (desc->xrank_host != nullptr) {           // cross-rank hand-off segment: make it visible to this GPU
       if (h->d.world_size > kXMaxWorld || desc->xrank_bytes < mi_ode_xrank_bytes(h->d.world_size)) {
         mi_set_error("xrank_host: world_size <= %d and at least %lld bytes are needed", kXMaxWorld, (long long)mi_ode_xrank_bytes(h->d.world_size));
-        delete h; return MI_ODE_E_INVALID;
+        mi_ode_destroy(h); return MI_ODE_E_INVALID;
       }
       void* dptr = nullptr;
       hipError_t re = hipHostRegister(desc->xrank_host, (size_t)desc->xrank_bytes, hipHostRegisterMapped | hipHostRegisterPortable);
@@ -595,11 +617,11 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     }
     h->persist_capable = capable ? 1 : 0;          // (a peer mailbox connected later can still switch the one-launch schedule on)
     const bool can = capable && (single || h->xrank_dev != nullptr);
-    if (desc->fusion == 4 && !can && single) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local or MFMA-linear RHS, single rank, every workgroup co-resident)"); delete h; return MI_ODE_E_INVALID; }
+    if (desc->fusion == 4 && !can && single) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local or MFMA-linear RHS, single rank, every workgroup co-resident)"); mi_ode_destroy(h); return MI_ODE_E_INVALID; }
     h->persist = (can && (desc->fusion == 4 || desc->fusion == 0)) ? 1 : 0;
     if (h->nseg > 1 && !h->persist) {
       mi_set_error("tuple states run on the whole-call kernel only, and its grid (%lld workgroups) is not co-resident on this device", g);
-      delete h; return MI_ODE_E_INVALID;
+      mi_ode_destroy(h); return MI_ODE_E_INVALID;
     }
     h->persist_grid = (int)g;
     h->persist_sleep_first = g <= 32 ? 16 : 32;
@@ -700,6 +722,7 @@ extern "C" int mi_ode_begin(mi_ode_handle h, const void* y0_dev, double t0, void
 static int begin_impl(mi_ode_handle h, const void* y0_dev, double t0, void* first_out_dev, void* stream) {
   if (h == nullptr || y0_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
   if (!h->d.adaptive) { mi_set_error("mi_ode_begin on a fixed-grid handle"); return MI_ODE_E_INVALID; }
+  if (h->d.multistep != 0) { mi_set_error("multistep handles run through mi_ode_integrate / mi_ode_fixed_grid_integrate only"); return MI_ODE_E_INVALID; }
   if (h->nseg > 1) { mi_set_error("tuple states: mi_ode_integrate with at least two times only (whole-call kernel)"); return MI_ODE_E_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   MI_HIP(hipStreamSynchronize(st));            // the pinned staging record may still be in flight from a previous call
@@ -775,6 +798,7 @@ static int begin_impl(mi_ode_handle h, const void* y0_dev, double t0, void* firs
 
 extern "C" int mi_ode_advance(mi_ode_handle h, const double* t_out_host, int32_t n_out, void* out_dev, void* stream) {
   if (h == nullptr || (n_out > 0 && (t_out_host == nullptr || out_dev == nullptr))) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (h->d.multistep != 0) { mi_set_error("multistep handles run through mi_ode_integrate / mi_ode_fixed_grid_integrate only"); return MI_ODE_E_INVALID; }
   if (!h->begun) { mi_set_error("mi_ode_advance before mi_ode_begin"); return MI_ODE_E_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   if (n_out <= 0) return 0;
@@ -889,6 +913,22 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   {
     const Ctl* cc = h->ctl_host;
     const double na = cc->n_attempt > 0 ? (double)cc->n_attempt : 1.0;
+    if (h->family == FAM_LINEAR_MFMA) {
+      // per hand-off: spread of the workgroups' arrival times (skew) and how long after the LAST arrival the last workgroup left (latency)
+      static long long stamps[8 * kMaxBlocks * 2];
+      const int G = h->persist_grid;
+      if (G <= kMaxBlocks && hipMemcpy(stamps, h->partials + 8192, sizeof(long long) * 8 * G * 2, hipMemcpyDeviceToHost) == hipSuccess) {
+        for (int g = 0; g < 8 && g < (int)cc->n_attempt + 2; ++g) {
+          long long a_min = (1LL << 62), a_max = 0, l_min = (1LL << 62), l_max = 0; double a_sum = 0;
+          for (int b = 0; b < G; ++b) {
+            const long long a = stamps[(g * G + b) * 2], l = stamps[(g * G + b) * 2 + 1];
+            if (a < a_min) a_min = a; if (a > a_max) a_max = a; if (l < l_min) l_min = l; if (l > l_max) l_max = l; a_sum += (double)a;
+          }
+          fprintf(stderr, "[persist skew] hand-off %d: arrivals spread %.2f us (mean arrives %.2f us before the last), first leaves %.2f us / last leaves %.2f us after the last arrival\n",
+                  g, 0.01 * (a_max - a_min), 0.01 * ((double)a_max - a_sum / G), 0.01 * (l_min - a_max), 0.01 * (l_max - a_max));
+        }
+      }
+    }
     if (h->family == FAM_LINEAR_MFMA)
       fprintf(stderr, "[persist prof] attempts %lld  us: f0 pass %.1f  initial-step pass %.1f  attempt passes %.1f (%.1f each)  hand-offs %.1f\n",
               cc->n_attempt, 0.01 * cc->prof[0], 0.01 * cc->prof[1], 0.01 * cc->prof[2], 0.01 * cc->prof[2] / na, 0.01 * cc->prof[3]);
@@ -929,7 +969,8 @@ static int integrate_adams_vc(mi_ode_solver* h, const void* y0_dev, const double
   A.p.spin_first = 1 << 12; if (A.p.spin_first > A.p.spin_limit) A.p.spin_first = A.p.spin_limit;
   A.p.xspin_limit = A.p.spin_limit;
   A.p.sleep_first = 16; A.p.sleep_poll = 2;
-  const long long g = (h->d.batch + 255) / 256;
+  multistep_rhs(h, A.f.rhs);
+  const long long g = multistep_grid(h);
   rc = h->is_f32 ? mi_launch_adams_vc_f32(h, A, (int)g, st) : mi_launch_adams_vc_f64(h, A, (int)g, st);
   if (rc != 0) return rc;
   MI_HIP(hipStreamSynchronize(st));              // the kernel's last act: {attempts, accepted, nfe, status} into pinned memory
@@ -1111,6 +1152,7 @@ extern "C" int mi_ode_get_profile(mi_ode_handle h, double* out4) {
 
 extern "C" int mi_ode_get_state(mi_ode_handle h, void* y_dev, void* f_dev, void* stream) {
   if (h == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  if (h->d.multistep != 0) { mi_set_error("get_state: the one-launch multistep kernels keep their state in registers (the solution rows are the output)"); return MI_ODE_E_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   int rc = poll_ctl(h, st);
   if (rc != 0) return rc;
@@ -1162,7 +1204,7 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
   h->n_launches = 0; h->n_polls = 0;
   const size_t pbytes = (size_t)h->n * h->elt;
   if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
-       h->family == FAM_LINEAR_MFMA || h->family == FAM_PLUGIN) && h->d.fusion != 1) {
+       h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP || h->family == FAM_PLUGIN) && h->d.fusion != 1) {
     // trajectories never interact on a fixed grid: the whole integration is ONE launch
     // (k_fixed_rowlocal for the tiny row-local systems, k_fixed_linear_mfma for the linear RHS)
     int rcf = ensure_t_out(h, T + (own_grid ? G : 0));
@@ -1187,7 +1229,8 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
       AA.p.spin_first = 1 << 12; if (AA.p.spin_first > AA.p.spin_limit) AA.p.spin_first = AA.p.spin_limit;
       AA.p.xspin_limit = AA.p.spin_limit;
       AA.p.sleep_first = 16; AA.p.sleep_poll = 2;
-      const long long g = (h->d.batch + 255) / 256;
+      multistep_rhs(h, AA.f.rhs);
+      const long long g = multistep_grid(h);
       rcf = h->is_f32 ? mi_launch_adams_f32(h, AA, (int)g, st) : mi_launch_adams_f64(h, AA, (int)g, st);
       if (rcf != 0) return rcf;
       MI_HIP(hipStreamSynchronize(st));            // the kernel's last act: {steps without convergence, status} into pinned memory
@@ -1209,6 +1252,8 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
       rcf = h->plugin->launch_fixed(h, &F, st);
       if (rcf != 0) { mi_set_error("plugin fixed-grid kernel launch failed"); return rcf; }
       h->n_launches += 1;
+    } else if (h->family == FAM_MLP) {
+      rcf = mi_launch_fixed_mlp_f32(h, F, st);
     } else {
       rcf = h->is_f32 ? mi_launch_fixed_f32(h, F, st) : mi_launch_fixed_f64(h, F, st);
     }
@@ -1287,6 +1332,7 @@ extern "C" int mi_ode_rk_step_fused(mi_ode_handle h, const void* y0_dev, const v
                                     void* y1_dev, void* f1_dev, double* err_norms_host, void* k_out_dev, void* stream) {
   if (h == nullptr || y0_dev == nullptr || f0_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
   if (!h->d.adaptive) { mi_set_error("rk_step_fused needs an adaptive handle"); return MI_ODE_E_INVALID; }
+  if (h->d.multistep != 0) { mi_set_error("rk_step_fused: a multistep handle has no Runge-Kutta tableau"); return MI_ODE_E_INVALID; }
   if (h->family == FAM_MLP) { mi_set_error("rk_step_fused: not available for the MLP family"); return MI_ODE_E_INVALID; }
   hipStream_t st = (hipStream_t)stream;
   const mi_ode_tableau& tb = h->d.tableau;

@@ -11,7 +11,32 @@
 #include <stdint.h>
 #include "../../include/mi_ode.h"
 
+// The MFMA-linear family (rhs.Linear on the tile kernels: config 4) forms its stage / error / mid-point combinations with fused
+// multiply-adds - acc = fma(dt * c_j, k_j, acc), one rounding per term where the reference's add_n((scale * c_j) * k_j) has two.
+// On this part every fp64 vector instruction takes its issue time from the fp64 matrix pipe, and these
+// combinations are most of the vector work of an attempt: 0 restores the reference's two roundings (measured: config 4 is 2.2 %
+// slower per call, 3.2 % per attempt pass).  All schedules of the family (per-stage, whole-attempt, whole-call) follow the same
+// setting and stay bit-identical to each other; the family never was bit-identical to the oracle (the matrix product's summation
+// order differs), its parity bar is the north star's rtol 1e-5 / atol 1e-6 and, in the tests, 1e-12 per attempt.  Every other
+// family (row-local systems, MLP, VALU fallback, plane kernels) keeps the reference's operation order to the bit.
+#ifndef MI_LIN_FMA
+#define MI_LIN_FMA 1
+#endif
+
 namespace mi {
+
+// acc + c * k with two roundings, or with one (FMA)
+template <bool FMA, typename T>
+__device__ __forceinline__ T madd(T c, T k, T acc) {
+  if constexpr (FMA) {
+    if constexpr (sizeof(T) == 8) return __builtin_fma(c, k, acc);
+    else return __builtin_fmaf(c, k, acc);
+  } else {
+    return acc + c * k;
+  }
+}
+template <typename T>
+__device__ __forceinline__ T lin_madd(T c, T k, T acc) { return madd<(MI_LIN_FMA != 0), T>(c, k, acc); }
 
 constexpr int kMaxK = MI_ODE_MAX_K;       // stage derivative planes (S + 1)
 constexpr int kNumPlanes = 2 + kMaxK;     // y_a, y_b, k_0..k_S
@@ -38,6 +63,7 @@ struct Ctl {
   int y0_nonfinite;
   int accepted;             // result of the last attempt
   long long prof[4];        // -DMI_PERSIST_PROF: wall_clock64 ticks (10 ns) in stages / reduce+hand-off / controller / emit
+  long long clk_cycles, clk_ticks;   // whole-call kernels: shader cycles and 10 ns ticks between entry and the final write-back
 };
 
 // Stage kernel flavours.  STAGE / LAST_FSAL follow rk_common.py:49-60 literally (operation
@@ -129,7 +155,7 @@ __device__ __forceinline__ bool resolve(const StageArgs& A, Resolved<T>& R) {
 // per-element stage math (shared by every kernel shape)
 // ------------------------------------------------------------------------------------------
 // ys and the auxiliary partial sum, from y0 and the NK loaded stage derivatives.
-template <typename T, int NK, int MODE>
+template <typename T, int NK, int MODE, bool FMA = false>
 __device__ __forceinline__ T combine_elem(T y0, const T* k, T hs, const StageArgs& A, T& aux) {
   aux = (T)0;
   if constexpr (MODE == M_FX_RK4_2) {
@@ -146,11 +172,11 @@ __device__ __forceinline__ T combine_elem(T y0, const T* k, T hs, const StageArg
   } else {
     T acc = (hs * (T)A.a[0]) * k[0];                    // misc.py:121: (scale * x) * y, summed in order
 #pragma unroll
-    for (int j = 1; j < NK; ++j) acc = acc + (hs * (T)A.a[j]) * k[j];
+    for (int j = 1; j < NK; ++j) acc = madd<FMA, T>(hs * (T)A.a[j], k[j], acc);
     if constexpr (MODE == M_LAST_FSAL) {
       T er = (hs * (T)A.e[0]) * k[0];
 #pragma unroll
-      for (int j = 1; j < NK; ++j) er = er + (hs * (T)A.e[j]) * k[j];
+      for (int j = 1; j < NK; ++j) er = madd<FMA, T>(hs * (T)A.e[j], k[j], er);
       aux = er;
     }
     return y0 + acc;                                    // rk_common.py:51
@@ -183,10 +209,10 @@ __device__ __forceinline__ void reduce_flat(T y0, T ys, const StageArgs& A, Acc&
 
 // epilogue once kn = f(ts, ys) is known; y0 / k0 are only read for the modes that need them.
 // Returns the y1 value to store (LAST_FSAL: ys itself is stored by the flat phase).
-template <typename T, int NK, int MODE>
+template <typename T, int NK, int MODE, bool FMA = false>
 __device__ __forceinline__ T epilogue_elem(T y0, T k0, T kn, T aux, T hs, const StageArgs& A, Acc& acc) {
   if constexpr (MODE == M_LAST_FSAL) {
-    const T err = aux + (hs * (T)A.e[NK]) * kn;         // rk_common.py:60, last term of the add_n
+    const T err = madd<FMA, T>(hs * (T)A.e[NK], kn, aux);   // rk_common.py:60, last term of the add_n
     acc.suma += (double)err * (double)err;
     return (T)0;
   } else if constexpr (MODE == M_F0) {

@@ -134,6 +134,7 @@ int mi_persist_capacity_f32(mi_ode_solver* h);
 int mi_launch_persist_mlp_f32(mi_ode_solver* h, mi::PersistArgs& A, int grid, hipStream_t st);
 int mi_persist_capacity_mlp_f32(mi_ode_solver* h);
 int mi_launch_mlp_f32(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st);
+int mi_launch_fixed_mlp_f32(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
 int mi_stage_geometry_f64(mi_ode_solver* h);
 int mi_stage_geometry_f32(mi_ode_solver* h);
 

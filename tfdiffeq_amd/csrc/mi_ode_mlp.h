@@ -399,6 +399,82 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
   }
 }
 
+// Fixed grid (solvers.py:82-104) for the ODEFunc MLP: trajectories never interact on a fixed grid, so a 32-row tile runs through
+// EVERY grid interval with y and k_1..k_4 in registers (Euler: fixed_grid.py:6-7; RK4 3/8 rule: rk_common.py:73-81 - the
+// arithmetic of k_fixed_rowlocal / k_fixed_linear_mfma, true divisions included), the weight slices stay resident, solution[i+1]
+// is streamed; one launch per call.  Traffic = y0 in + T solution rows out; bound: fp32 matrix pipe.  The time the network
+// sees (time-dependent first layer, dense_odenet.py:79-84) is the step function's t + eps and the 3/8 rule's stage times.
+template <int DP, int HP, int ACT>
+__global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_fixed_mlp(FixedArgs A) {
+  using G = MlpGeom<DP, HP>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  MlpCtx<DP, HP, ACT> cx;
+  cx.init(A.rhs, A.dim, smem_raw);
+  const int d = cx.d;
+  const float sign = cx.sign;
+  const long long ntiles = (A.batch + G::R - 1) / G::R;
+  const long long n = A.batch * d;
+  const float* y0p = (const float*)A.y0;
+  float* out = (float*)A.out;
+  const float eps = (float)A.eps;
+  for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+    float y[4];
+    long long idx[4];
+    bool ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const long long row = tile_i * G::R + cx.rbase + i;
+      ok[i] = cx.owner && row < A.batch;
+      idx[i] = row * d + cx.col;
+      y[i] = ok[i] ? y0p[idx[i]] : 0.f;
+      if (ok[i]) out[idx[i]] = y[i];                          // solution = [y0]
+    }
+    int j = 1;
+    for (int s = 0; s < A.M; ++s) {
+      const float t0 = (float)A.grid[s];                      // solvers.py:84: the grid is cast to the STATE dtype
+      const float t1 = (float)A.grid[s + 1];
+      const float dt = t1 - t0;
+      const float te = t0 + eps;                              // fixed_grid.py:7 / :42
+      float k1[4], k2[4], k3[4], k4[4], ys[4], yn[4], kn[4];
+      cx.put_x(y);
+      cx.eval(kn, sign * te);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) k1[i] = sign * kn[i];
+      if (!A.rk4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yn[i] = y[i] + dt * k1[i];                          // fixed_grid.py:7
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ys[i] = y[i] + dt * k1[i] / 3.0f;                   // rk_common.py:77
+        cx.put_x(ys);
+        cx.eval(kn, sign * (te + dt / 3.0f));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { k2[i] = sign * kn[i]; ys[i] = y[i] + dt * (k1[i] / -3.0f + k2[i]); }    // :78
+        cx.put_x(ys);
+        cx.eval(kn, sign * (te + dt * 2.0f / 3.0f));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { k3[i] = sign * kn[i]; ys[i] = y[i] + dt * (k1[i] - k2[i] + k3[i]); }    // :79
+        cx.put_x(ys);
+        cx.eval(kn, sign * (te + dt));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          k4[i] = sign * kn[i];
+          yn[i] = y[i] + (k1[i] + 3.0f * k2[i] + 3.0f * k3[i] + k4[i]) * (dt / 8.0f);                       // :81
+        }
+      }
+      while (j < A.T && t1 >= (float)A.t[j]) {               // solvers.py:97-100, _linear_interp :106-115
+        const float tj = (float)A.t[j];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (ok[i]) out[(long long)j * n + idx[i]] = (tj == t0) ? y[i] : ((tj == t1) ? yn[i] : y[i] + ((yn[i] - y[i]) / (t1 - t0)) * (tj - t0));
+        ++j;
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) y[i] = yn[i];
+    }
+  }
+}
+
 template <int DP, int HP, int ACT, int MODE, int S, bool TS>
 __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
   using G = MlpGeom<DP, HP>;

@@ -26,9 +26,12 @@ namespace mi {
 #ifdef MI_PERSIST_PROF
 #define MI_TICK(var) const long long var = (long long)wall_clock64()
 #define MI_TOCK(slot, a, b) do { if (threadIdx.x == 0 && blockIdx.x == 0) s_c.prof[slot] += (b) - (a); } while (0)   /* s_c: LDS */
+// every workgroup: when it reached hand-off `g` and when it left it (skew between workgroups vs latency of the exchange)
+#define MI_SKEW(g, which) do { if (threadIdx.x == 0 && (g) < 8u) ((long long*)(A.s.partials + 8192))[((g) * gridDim.x + blockIdx.x) * 2 + (which)] = (long long)wall_clock64(); } while (0)
 #else
 #define MI_TICK(var)
 #define MI_TOCK(slot, a, b)
+#define MI_SKEW(g, which)
 #endif
 
 constexpr int kPersistTSmall = 8;      // output times that travel as kernel arguments
@@ -71,6 +74,8 @@ __device__ __forceinline__ void persist_init_ctl(Ctl& c, const PersistArgs& A) {
   c.dt = A.s.cp.auto_first_step ? 0.0 : A.first_dt;
   c.idx_y0 = 0; c.idx_y1 = 1;
   for (int j = 0; j < kMaxK; ++j) c.idx_k[j] = 2 + j;
+  c.clk_cycles = -(long long)__builtin_readcyclecounter();    // closed by persist_write_back: the shader clock this launch ran at
+  c.clk_ticks = -(long long)wall_clock64();
 }
 
 // every thread: output times into LDS when they fit (kernel arguments for tiny T, else the uploaded array)
@@ -88,7 +93,9 @@ __device__ __forceinline__ const double* persist_stage_tout(const PersistArgs& A
 
 static_assert(sizeof(Ctl) % sizeof(long long) == 0, "Ctl is copied to the host in 8-byte words");
 
-__device__ __forceinline__ void persist_write_back(const PersistArgs& A, const Ctl& c) {
+__device__ __forceinline__ void persist_write_back(const PersistArgs& A, Ctl& c) {
+  c.clk_cycles += (long long)__builtin_readcyclecounter();     // shader cycles / 10 ns ticks of this launch (mi_ode_stats.clock_mhz)
+  c.clk_ticks += (long long)wall_clock64();
   *A.s.ctl = c;                                               // device copy (mi_ode_get_state / get_stats)
   if (A.ctl_host != nullptr) {
     const long long* src = (const long long*)&c;
@@ -840,7 +847,9 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     lin_f0_pass<T, D, true>(A.s, y_user, fa, (T*)nullptr, (T*)A.out0, cx, acc);
     MI_TICK(tf1);
     MI_TOCK(0, tf0, tf1);
+    MI_SKEW(gen, 0);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    MI_SKEW(gen - 1u, 1);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
     __syncthreads();
   }
@@ -850,7 +859,9 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     lin_initb_pass<T, D, true>(A.s, y_user, fa, (T)uniform_d(s_c.h0), cx, acc);
     MI_TICK(ti1);
     MI_TOCK(1, ti0, ti1);
+    MI_SKEW(gen, 0);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    MI_SKEW(gen - 1u, 1);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
   }
   // The scalar state of the loop rests in LDS between attempts (thread 0 pulls it into registers only around
@@ -899,7 +910,9 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     }
 #endif
     MI_TICK(ta1);
+    MI_SKEW(gen, 0);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);                   // (its barriers also fence the reads of sh.pub above)
+    MI_SKEW(gen - 1u, 1);
     MI_TICK(ta2);
     MI_TOCK(2, ta0, ta1); MI_TOCK(3, ta1, ta2);
     if (threadIdx.x == 0) {

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(D * 4) void k_stage_linear_mfma(StageArgs A) {
 #pragma unroll
         for (int j = 0; j < NK; ++j) kk[j] = pl[j + 1][c].v[v];
         T aux;
-        const T ys = combine_elem<T, NK, MODE>(pl[0][c].v[v], kk, hs, A, aux);
+        const T ys = combine_elem<T, NK, MODE, (MI_LIN_FMA != 0)>(pl[0][c].v[v], kk, hs, A, aux);
         if (ok) reduce_flat<T, MODE>(pl[0][c].v[v], ys, A, acc);
         ysc.v[v] = ys;
         auxc.v[v] = aux;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(D * 4) void k_stage_linear_mfma(StageArgs A) {
           if constexpr (mode_needs_y0_epi(MODE)) y0v = R.y0[idx];
           if constexpr (MODE == M_INITB) k0v = R.k[0][idx];
           if constexpr (NEED_AUX) auxv = s_aux[rr * LD + col];
-          const T v = epilogue_elem<T, NK, MODE>(y0v, k0v, kn, auxv, hs, A, acc);
+          const T v = epilogue_elem<T, NK, MODE, (MI_LIN_FMA != 0)>(y0v, k0v, kn, auxv, hs, A, acc);
           if constexpr (MODE == M_FX_EULER || MODE == M_FX_RK4_4) R.y1[idx] = v;
         }
       }

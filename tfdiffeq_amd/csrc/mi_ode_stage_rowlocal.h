@@ -5,6 +5,7 @@
 // => (NK + 2) planes of traffic per stage, +1 for the last: the 34-units-per-attempt
 // structure of SURVEY.md 8(d).  Bound: HBM (a handful of flops per element).
 #pragma once
+#include <type_traits>
 #include "mi_ode_dev.h"
 
 namespace mi {
@@ -36,6 +37,58 @@ struct RhsLinear2 {
     f[1] = y[0] * w01 + y[1] * w11;
   }
 };
+
+// y @ W (+ b) / (y ** 3) @ W of ANY dim <= 256 for the one-launch MULTISTEP kernels (mi_ode_adams.h, mi_ode_adams_vc.h): those keep a
+// trajectory's state and its history of derivatives in registers, which a dim-51 system (DETEST C4) does not fit into one
+// thread's - so here a thread owns ONE state element (D = 1: its history is 13 registers again) and the threads of a trajectory
+// evaluate f together: the state goes through LDS, every thread forms its column's dot product (the order of the VALU linear
+// kernels: fma over k = 0 .. dim-1).  A 256-thread workgroup holds floor(256 / dim) trajectories; `rowmap` gives a thread its
+// element.  The kernels call rhs() from uniform control flow (it contains barriers).
+template <typename T>
+struct RhsLinearCoop {
+  static constexpr int D = 1;
+  static constexpr bool kCoop = true;
+  const T* W;
+  const T* bias;
+  int dim, cube;
+  __device__ explicit RhsLinearCoop(const RhsParams& p) : W((const T*)p.w[0]), bias((const T*)p.b[0]), dim(p.hidden), cube(p.cube) {}
+  __device__ __forceinline__ void operator()(T, const T* y, T* f) const {
+    __shared__ T s_y[256];
+    const int slot = (int)threadIdx.x / dim, col = (int)threadIdx.x - slot * dim;
+    __syncthreads();                                         // the previous evaluation's readers are done
+    s_y[threadIdx.x] = cube ? y[0] * y[0] * y[0] : y[0];
+    __syncthreads();
+    T acc = (T)0;
+    if ((slot + 1) * dim <= (int)blockDim.x) {
+      const T* yr = s_y + slot * dim;
+      for (int k = 0; k < dim; ++k) acc = fma(yr[k], W[(long long)k * dim + col], acc);
+      if (bias != nullptr) acc = acc + bias[col];
+    }
+    f[0] = acc;
+  }
+};
+template <class R, class = void>
+struct rhs_is_coop : std::false_type {};
+template <class R>
+struct rhs_is_coop<R, std::void_t<decltype(R::kCoop)>> : std::true_type {};
+
+// which element(s) of the state this thread owns: offset of its first element, whether it exists, elements per plane
+template <class RHS>
+__device__ __forceinline__ void rowmap(long long batch, int dim, long long& off, bool& live, long long& n_plane) {
+  if constexpr (rhs_is_coop<RHS>::value) {
+    const int tpw = (int)blockDim.x / dim;                   // trajectories per workgroup
+    const int slot = (int)threadIdx.x / dim, col = (int)threadIdx.x - slot * dim;
+    const long long traj = (long long)blockIdx.x * tpw + slot;
+    live = slot < tpw && traj < batch;
+    off = traj * dim + col;
+    n_plane = batch * dim;
+  } else {
+    const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    live = row < batch;
+    off = row * RHS::D;
+    n_plane = batch * RHS::D;
+  }
+}
 
 // Lotka-Volterra, examples/ode_usage.ipynb cells 39-42 / README.md:67-82
 template <typename T>

@@ -460,6 +460,8 @@ __device__ __forceinline__ T stream_load(const T* p) {
   else return *p;
 }
 
+// (Round 4, measured and removed: loading a workgroup's first tile of the NEXT pass before it enters the grid hand-off.  The
+// hand-off's barriers carry a vmcnt(0) - the loads were simply waited for there: hand-offs 40 -> 57 us per call, passes unchanged.)
 // One adaptive attempt over this workgroup's tiles (tile = blockIdx.x, + gridDim.x, ...).
 template <typename T, int D, int S, bool TS, bool SC0>
 __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPlanes<T, S>& P, LinCtx<T, D>& cx, Acc& acc,
@@ -501,7 +503,7 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
       for (int i = 0; i < 4; ++i) {
         T a_ = cb[0] * k[0][i];                              // misc._scaled_dot_product order (rk_common.py:51)
 #pragma unroll
-        for (int j = 1; j < SG; ++j) a_ = a_ + cb[j] * k[j][i];
+        for (int j = 1; j < SG; ++j) a_ = lin_madd(cb[j], k[j][i], a_);
         ys[i] = y0e[i] + a_;
       }
       cx.rhs_eval(ys, k[SG], [&] {                           // next: row SG + 1 of beta, after the last stage c_error
@@ -516,14 +518,14 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
     for (int j = 0; j <= S; ++j) {
       const T ce = cnx[j];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) err4[i] = (j == 0) ? ce * k[0][i] : err4[i] + ce * k[j][i];
+      for (int i = 0; i < 4; ++i) err4[i] = (j == 0) ? ce * k[0][i] : lin_madd(ce, k[j][i], err4[i]);
     }
     if (need_mid) {
 #pragma unroll
       for (int j = 0; j <= S; ++j) {
         const T cm = coef[CF::kMid + j];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) ym4[i] = (j == 0) ? cm * k[0][i] : ym4[i] + cm * k[j][i];
+        for (int i = 0; i < 4; ++i) ym4[i] = (j == 0) ? cm * k[0][i] : ym4[i] + cm * k[j][i];   // (two roundings: k_emit's y_mid)
       }
     }
     const int nr = cx.rows_here(tile_i, A.batch);

@@ -114,3 +114,261 @@ class GraphedFixedStep(object):
             self.graph.replay()
             for out, y_ in zip(outs, self.y):
                 out[i + 1].copy_(y_)
+
+
+# ---------------------------------------------------------------------------------------------
+# adaptive RK for a Python callable with the controller on the device (libmi_ode family C, include/mi_ode.h)
+# ---------------------------------------------------------------------------------------------
+class _AutogradSeen(object):
+    """Context that notices autograd recording inside f (a saved-tensor hook fires): such a right-hand side (the adjoint's
+    augmented dynamics, Hamiltonian networks) must never be stream-captured - torch.autograd.grad under capture aborts."""
+
+    def __init__(self):
+        self.seen = False
+        self._ctx = None
+
+    def __enter__(self):
+        def pack(x):
+            self.seen = True
+            return x
+        self._ctx = torch.autograd.graph.saved_tensors_hooks(pack, lambda x: x)
+        self._ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        return self._ctx.__exit__(*exc)
+
+
+def _credit_nfe(func, missing):
+    """Adds `missing` evaluations to an integer `nfe` attribute of the user's callable (unwrapping misc._TupleFunc /
+    _ReverseFunc and the adjoint's tuple module), if it keeps one."""
+    if missing <= 0:
+        return
+    base = func
+    for _ in range(8):
+        nxt = getattr(base, 'base', None)
+        if nxt is None:
+            nxt = getattr(base, 'base_func', None)
+        if nxt is None:
+            break
+        base = nxt
+    cur = getattr(base, 'nfe', None)
+    if isinstance(cur, int) and not isinstance(cur, bool):
+        try:
+            base.nfe = cur + int(missing)
+        except Exception:
+            pass
+
+
+_OPQ_FREE = {}                 # descriptor bytes -> idle native handles (a handle is in use by at most one integrate() at a time)
+_OPQ_MAX_IDLE = 8
+
+
+def _opq_handle(lib, key, desc, device):
+    import ctypes as C
+    from . import _native as N
+    free = _OPQ_FREE.get(key)
+    if free:
+        return free.pop()
+    idle = sum(len(v) for v in _OPQ_FREE.values())
+    while idle >= _OPQ_MAX_IDLE:                                 # bounded: drop idle handles of other problems
+        for k_ in list(_OPQ_FREE):
+            if _OPQ_FREE[k_]:
+                lib.mi_ode_opq_destroy(_OPQ_FREE[k_].pop())
+                idle -= 1
+                break
+        else:
+            break
+    h = C.c_void_p()
+    with torch.cuda.device(device):
+        N.check(lib.mi_ode_opq_create(C.byref(desc), C.byref(h)), 'mi_ode_opq_create')
+    return h
+
+
+def clear_opq_handles():
+    from . import _native as N
+    lib = N.load()
+    for k_ in list(_OPQ_FREE):
+        for h in _OPQ_FREE.pop(k_):
+            lib.mi_ode_opq_destroy(h)
+
+
+class DeviceControlledRK(object):
+    """One `integrate()` of an adaptive Runge-Kutta solver (dopri5.py:70-121 and its siblings) for an arbitrary Python
+    right-hand side, with the scalar state of the solver on the device.
+
+    An attempt is: S x (stage combination `mi_ode_lincomb_dev`, f), `mi_ode_opq_finish` (error estimate, norms, controller:
+    accept test, next step size, output cursor), `mi_ode_opq_commit` (dense output of the requested times inside an accepted
+    step, state <- y1 / f1).  It contains no host value, so it runs
+      * eagerly - Python calls f every stage, the host reads the `done` flag back once per attempt - or
+      * as a hipGraph recorded once (after the eager attempts that served as warm-up) and replayed in chunks, the host
+        reading the scalar state back once per chunk.
+    `graph`: False never captures, True captures after the first eager attempt, 'auto' (default of the solvers) captures when
+    enough attempts remain to pay for the recording and f was not seen to use autograd."""
+
+    EAGER_FIRST = 2            # 'auto': eager attempts before a capture is considered (they are the warm-up of the capture)
+    MIN_REMAINING = 12         # 'auto': capture only if about this many attempts are still to come
+    MAX_CHUNK = 64
+
+    def __init__(self, solver, graph='auto'):
+        import ctypes as C
+        import numpy as np
+        from . import _native as N
+        from .misc import _DevScalar
+        from .rk_common import _is_fsal_shaped
+        from .solvers import _fill_tableau
+        self.N, self.C = N, C
+        self.lib = N.load()
+        self.solver = solver
+        self.func = solver.func
+        self.tableau = solver.tableau
+        self.fsal = _is_fsal_shaped(self.tableau)
+        self.graph_mode = graph
+        y0 = solver.y0
+        self.device = y0[0].device
+        self.dtype = y0[0].dtype
+        self.ncomp = len(y0)
+        d = N.OpqDesc()
+        d.dtype = N.dtype_code(self.dtype)
+        d.n_comp = self.ncomp
+        for c, y in enumerate(y0):
+            d.n[c] = int(y.numel())
+        _fill_tableau(d.tableau, self.tableau, solver.c_mid)
+        d.controller, d.interp, d.order, d.init_order = solver.controller, solver.interp, solver.order, solver.init_order
+        if solver.pooled_ratio:
+            rt, at = [float(solver.rtol)] * self.ncomp, [float(solver.atol)] * self.ncomp
+        else:
+            rt, at = [float(r) for r in solver.rtol], [float(a) for a in solver.atol]
+        for c in range(self.ncomp):
+            d.rtol[c], d.atol[c] = rt[c], at[c]
+        d.safety, d.ifactor, d.dfactor = float(solver.safety), float(solver.ifactor), float(solver.dfactor)
+        d.max_num_steps = int(solver.max_num_steps)
+        self.S = len(self.tableau.alpha)
+        self._key = (bytes(d), str(self.device))
+        self.h = _opq_handle(self.lib, self._key, d, self.device)
+        h = self.h
+        self.dt_dev = _DevScalar(self.lib.mi_ode_opq_dt_dev(h))
+        self.ts = torch.zeros(self.S, dtype=self.dtype, device=self.device)
+        self.ts_views = [self.ts[s] for s in range(self.S)]      # what f receives as t: 0-d views, rewritten by the controller
+        self.stats = N.Stats()
+        self.graph = None
+        self.py_calls = 0
+        self.captured = False
+        self._np = np
+
+    def close(self):
+        """Drops the recorded graph and hands the native handle back to the cache (handles are reused across odeint calls: no
+        hipMalloc / hipFree per call)."""
+        self.graph = None
+        self._keep = None
+        if getattr(self, 'h', None):
+            _OPQ_FREE.setdefault(self._key, []).append(self.h)
+            self.h = None
+
+    # -- one attempt (eager, or under capture) ------------------------------------------------------
+    def _ptr_array(self, tensors):
+        return (self.C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+    def _attempt(self):
+        from .misc import _contig, _lincomb
+        tb = self.tableau
+        k = [[f0_] for f0_ in self.F0]
+        yi = None
+        for s, beta_i in enumerate(tb.beta):
+            yi = tuple(_lincomb(y0_, beta_i, k_, self.dt_dev) for y0_, k_ in zip(self.Y0, k))      # rk_common.py:51
+            self.py_calls += 1
+            for k_, f_ in zip(k, self.func(self.ts_views[s], yi)):                                   # rk_common.py:52
+                k_.append(_contig(f_))
+        if not self.fsal:                                                                            # rk_common.py:54-56
+            yi = tuple(_lincomb(y0_, tb.c_sol, k_, self.dt_dev) for y0_, k_ in zip(self.Y0, k))
+        st = self.N.stream_ptr(self.device)
+        y0p, f0p, y1p = self._ptr_array(self.Y0), self._ptr_array(self.F0), self._ptr_array(yi)
+        kp = self._ptr_array([x for k_ in k for x in k_])
+        self.N.check(self.lib.mi_ode_opq_finish(self.h, y0p, y1p, kp, st), 'mi_ode_opq_finish')
+        self.N.check(self.lib.mi_ode_opq_commit(self.h, y0p, f0p, y1p, kp, st), 'mi_ode_opq_commit')
+        return yi, k          # (kept alive by the caller until the stream has consumed them)
+
+    def _poll(self):
+        done = self.C.c_int32(0)
+        rc = self.N.check(self.lib.mi_ode_opq_poll(self.h, self.C.byref(self.stats), self.C.byref(done), self.N.stream_ptr(self.device)),
+                          'mi_ode_opq_poll')
+        return bool(done.value), rc
+
+    def _try_capture(self):
+        """Record one attempt.  True on success; False (and eager from then on) when f is not capture-safe."""
+        try:
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._keep = self._attempt()
+            self.graph = g
+            self.captured = True
+            return True
+        except Exception as e:                                   # host synchronisation / data-dependent control flow inside f, ...
+            import warnings
+            self.graph = None
+            try:
+                torch.cuda.synchronize(self.device)
+            except Exception:
+                pass
+            warnings.warn('tfdiffeq_amd: the right-hand side cannot be recorded as a hipGraph (%s: %s); continuing with one '
+                          'Python evaluation per stage' % (type(e).__name__, str(e).split('\n')[0][:200]))
+            return False
+
+    def _remaining(self, t_end):
+        dt = self.stats.dt
+        if not (dt > 0):
+            return 1
+        return max(1, int(min(1e6, self._np.ceil((t_end - self.stats.t) / dt))))
+
+    # -- the whole integrate() ------------------------------------------------------------------------
+    def integrate(self, t64, y0, f0, first_dt):
+        """t64: increasing float64 numpy array of T >= 1 times; y0 / f0: tuples of device tensors.  Returns the tuple of
+        [T, *shape] solutions and fills `self.stats` / `self.info`."""
+        N, C = self.N, self.C
+        T = int(t64.shape[0])
+        outs = tuple(torch.empty((T,) + tuple(y.shape), dtype=y.dtype, device=y.device) for y in y0)
+        for o, y in zip(outs, y0):
+            o[0].copy_(y)
+        self.info = {'engine': 'device-controlled attempts (one Python evaluation per stage)', 'replays': 0, 'polls': 0}
+        if T == 1:
+            return outs
+        # static state buffers: commit() moves y1 / f1 into them on accept, the stage combinations always read them
+        self.Y0 = tuple(torch.empty_like(y, memory_format=torch.contiguous_format).copy_(y) for y in y0)
+        self.F0 = tuple(torch.empty_like(f, memory_format=torch.contiguous_format).copy_(f) for f in f0)
+        n_out = T - 1
+        tt = self._np.ascontiguousarray(t64[1:], dtype=self._np.float64)
+        rows = (C.c_void_p * self.ncomp)(*[o[1].data_ptr() for o in outs])
+        with torch.cuda.device(self.device):
+            rc = N.check(self.lib.mi_ode_opq_begin(self.h, float(t64[0]), float(first_dt), tt.ctypes.data_as(C.POINTER(C.c_double)), n_out,
+                                                   rows, C.c_void_p(self.ts.data_ptr()), N.stream_ptr(self.device)), 'mi_ode_opq_begin')
+            assert rc == 0, N.status_message(rc)
+            t_end = float(t64[-1])
+            mode = self.graph_mode
+            eager = 0
+            done = False
+            autograd = _AutogradSeen()
+            while not done:
+                with autograd:
+                    keep = self._attempt()
+                eager += 1
+                done, rc = self._poll()
+                del keep
+                self.info['polls'] += 1
+                if done or mode is False or autograd.seen:
+                    continue
+                if mode is True or (eager >= self.EAGER_FIRST and self._remaining(t_end) >= self.MIN_REMAINING):
+                    if not self._try_capture():
+                        mode = False
+                        continue
+                    self.info['engine'] = 'device-controlled attempts (hipGraph replay, %d eager attempts first)' % eager
+                    while not done:
+                        chunk = min(self.MAX_CHUNK, max(2, self._remaining(t_end)))
+                        for _ in range(chunk):
+                            self.graph.replay()
+                        self.info['replays'] += chunk
+                        done, rc = self._poll()
+                        self.info['polls'] += 1
+        self.info['eager_attempts'] = eager
+        self.info['autograd_in_f'] = autograd.seen
+        return outs

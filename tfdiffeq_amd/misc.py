@@ -78,9 +78,17 @@ def _possibly_nonzero(x):
 # ---------------------------------------------------------------------------------------------
 # plane kernels
 # ---------------------------------------------------------------------------------------------
+class _DevScalar(object):
+    """A float64 scalar in device memory that is not a torch tensor (the step size inside libmi_ode's controller record)."""
+    __slots__ = ('ptr',)
+
+    def __init__(self, ptr):
+        self.ptr = int(ptr)
+
+
 def _lincomb(base, coefs, xs, scale):
     """out = base + add_n([(scale * c_j) * x_j])  on device (mi_ode_lincomb).  `scale` is a host scalar, or a 0-d float64
-    device tensor that the kernel reads when it runs (mi_ode_lincomb_dev: graph replays with a new dt)."""
+    device tensor / a `_DevScalar` that the kernel reads when it runs (mi_ode_lincomb_dev: graph replays with a new dt)."""
     xs = [_contig(x) for x in xs]
     x0 = xs[0]
     N.require_gpu_tensor(x0, 'state')
@@ -95,9 +103,13 @@ def _lincomb(base, coefs, xs, scale):
     cf = (C.c_double * nx)(*[float(c) for c in coefs])
     base_c = _contig(base) if base is not None else None
     lib = N.load()
-    if isinstance(scale, torch.Tensor):
-        assert scale.dtype == torch.float64 and scale.numel() == 1 and scale.device == x0.device
-        N.check(lib.mi_ode_lincomb_dev(N.dtype_code(x0.dtype), n, _ptr(base_c), ptrs, cf, nx, C.c_void_p(scale.data_ptr()),
+    if isinstance(scale, (torch.Tensor, _DevScalar)):
+        if isinstance(scale, torch.Tensor):
+            assert scale.dtype == torch.float64 and scale.numel() == 1 and scale.device == x0.device
+            sp = scale.data_ptr()
+        else:
+            sp = scale.ptr
+        N.check(lib.mi_ode_lincomb_dev(N.dtype_code(x0.dtype), n, _ptr(base_c), ptrs, cf, nx, C.c_void_p(sp),
                                        _ptr(out), N.stream_ptr(x0.device)), 'mi_ode_lincomb_dev')
         return out
     N.check(lib.mi_ode_lincomb(N.dtype_code(x0.dtype), n, _ptr(base_c), ptrs, cf, nx, float(scale), _ptr(out),

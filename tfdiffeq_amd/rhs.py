@@ -99,6 +99,12 @@ class _MatRHS(DeviceRHS):
         self.row_local = self.dim == 2 and self.b is None       # 2x2 systems travel by value to the row-local kernels
         self.tile_dopri8 = isinstance(self, Linear) and 3 <= self.dim <= 128    # the MFMA tile kernels also exist for the 13-row tableau
 
+    @property
+    def multistep_fused(self):
+        """The Adams family in one launch: 2 x 2 systems on the thread-per-trajectory kernels, any other dim <= 256 with a thread per
+        state element (csrc/mi_ode_stage_rowlocal.h: RhsLinearCoop; round 4) - as long as the batch's workgroups are co-resident."""
+        return self.row_local or 1 <= self.dim <= 256
+
     def fill(self, rhs, dtype, device):
         keep = super(_MatRHS, self).fill(rhs, dtype, device)
         Wd = self._dev(self.W, dtype, device)
@@ -219,7 +225,7 @@ class MLP(DeviceRHS):
                 h = act(h)
         return h
 
-    fixed_grid_fused = False     # the fused MLP kernel is the whole-attempt (adaptive) kernel only
+    fixed_grid_fused = True      # euler / rk4 (3/8 rule): the whole fixed-grid integration in one launch (k_fixed_mlp, round 4)
 
     def supports(self, y0):
         return (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype == torch.float32

@@ -184,6 +184,13 @@ class _FusedEngine(object):
         self.stats = N.Stats()
         self.xrank = False
         self.transport = 'single rank' if process_group is None else 'allgather hook (torch.distributed)'
+        # what was tried to carry the per-attempt record across ranks, in order, and how it ended on THIS rank - a first run on a
+        # multi-GPU node says by itself why it ended up on the transport it used (bench.py prints every rank's list)
+        self.transport_log = []
+        self._selftest_ok = False
+
+        def tried(name, ok, why=''):
+            self.transport_log.append({'transport': name, 'ok': bool(ok), 'why': why})
         if process_group is not None:
             import torch.distributed as dist
 
@@ -200,12 +207,17 @@ class _FusedEngine(object):
                 if have:
                     with torch.cuda.device(self.device):
                         ok = self.lib.mi_ode_xrank_selftest(self.h, self._stream()) == 0
+                self._selftest_ok = ok
                 if all_agree(ok):
                     N.check(self.lib.mi_ode_xrank_enable(self.h, 1), 'mi_ode_xrank_enable')
                     return True
                 return False
 
             world, rank = d.world_size, d.rank
+            if 'rccl' not in allow:
+                tried('rccl', False, 'not allowed by TFDIFFEQ_AMD_XRANK=%s' % want)
+            elif dist.get_backend(process_group) != 'nccl':
+                tried('rccl', False, 'the process group is %s, not nccl (RCCL)' % dist.get_backend(process_group))
             if 'rccl' in allow and dist.get_backend(process_group) == 'nccl':
                 # the launch-per-attempt schedule then needs no callback into Python (rank 0 draws the id, everybody joins)
                 ids = [None]
@@ -213,32 +225,59 @@ class _FusedEngine(object):
                     buf = (C.c_char * N.RCCL_ID_BYTES)()
                     ids[0] = bytes(buf) if self.lib.mi_ode_rccl_unique_id(buf) == 0 else None
                 dist.broadcast_object_list(ids, src=dist.get_global_rank(process_group, 0), group=process_group)
-                ok = False
+                ok, why = False, 'rank 0 could not draw an ncclUniqueId: ' + N.last_error() if ids[0] is None else ''
                 if ids[0] is not None:
                     with torch.cuda.device(self.device):
                         ok = self.lib.mi_ode_rccl_connect(self.h, ids[0], world, rank) == 0
+                    if not ok:
+                        why = 'mi_ode_rccl_connect: ' + N.last_error()
                 if all_agree(ok):
                     self.transport = 'ncclAllGather enqueued by libmi_ode (launch per attempt)'
-                elif ok:                       # some rank could not join: everybody drops back to the hook together
-                    self.lib.mi_ode_rccl_connect(self.h, None, 0, 0)
+                    tried('rccl', True, 'communicator of %d ranks inside libmi_ode' % world)
+                else:
+                    tried('rccl', False, why or 'another rank could not join the communicator')
+                    if ok:                     # some rank could not join: everybody drops back to the hook together
+                        self.lib.mi_ode_rccl_connect(self.h, None, 0, 0)
+            if not adaptive:
+                tried('peer', False, 'fixed grid: no exchange needed')
+            elif 'peer' not in allow:
+                tried('peer', False, 'not allowed by TFDIFFEQ_AMD_XRANK=%s' % want)
             if adaptive and 'peer' in allow:
                 buf = (C.c_char * N.IPC_HANDLE_BYTES)()
                 with torch.cuda.device(self.device):
                     ok = self.lib.mi_ode_xpeer_prepare(self.h, buf) == 0
+                why = '' if ok else 'mi_ode_xpeer_prepare (mailbox allocation / hipIpcGetMemHandle): ' + N.last_error()
                 handles = [None] * world
                 dist.all_gather_object(handles, bytes(buf) if ok else None, group=process_group)
-                ok = ok and all(hd is not None for hd in handles)
+                if ok and not all(hd is not None for hd in handles):
+                    ok, why = False, 'rank(s) %s could not export a mailbox' % [q for q, hd in enumerate(handles) if hd is None]
                 if ok:
                     blob = b''.join(handles)
                     with torch.cuda.device(self.device):
                         ok = self.lib.mi_ode_xpeer_connect(self.h, blob, world) == 0
-                if all_agree(ok) and selftest_and_enable():
+                    if not ok:
+                        why = 'mi_ode_xpeer_connect (hipIpcOpenMemHandle of a peer mailbox): ' + N.last_error()
+                if not all_agree(ok):
+                    tried('peer', False, why or 'another rank could not map the mailboxes')
+                elif selftest_and_enable():
                     self.xrank = True
                     self.transport = 'in-kernel hand-off through peer device memory (xGMI mailboxes), one launch per call'
+                    tried('peer', True, 'mailboxes mapped, self-test passed on every rank')
+                else:
+                    tried('peer', False, 'the bounded in-kernel self-test did not see every peer\'s records on some rank (this rank: %s)'
+                          % ('passed' if self._selftest_ok else 'FAILED'))
+            if adaptive and not self.xrank and 'host' not in allow:
+                tried('host', False, 'not allowed by TFDIFFEQ_AMD_XRANK=%s' % want)
             if adaptive and not self.xrank and 'host' in allow:   # (group-uniform condition: self._xr may be None on ONE rank only)
                 if selftest_and_enable(self._xr is not None):
                     self.xrank = True
                     self.transport = 'in-kernel hand-off through a shared host segment, one launch per call'
+                    tried('host', True, '/dev/shm segment registered with HIP, self-test passed on every rank')
+                else:
+                    tried('host', False, 'no /dev/shm segment on this rank (another node?)' if self._xr is None else
+                          'the bounded in-kernel self-test failed on some rank (this rank: %s)' % ('passed' if self._selftest_ok else 'FAILED'))
+            if not self.xrank and self.transport.startswith('allgather hook'):
+                tried('hook', True, 'torch.distributed all-gather through the ctypes callback (last resort)')
 
     def close(self):
         if getattr(self, 'h', None) is not None and self.h:
@@ -264,7 +303,7 @@ class _FusedEngine(object):
             return
         msg = N.status_message(bits)
         if bits & N.ST_SYNC_TIMEOUT:       # engine fault, not one of the reference's assertions
-            raise RuntimeError(msg + " - retry with options={'fusion': 'step'}")
+            raise SyncTimeout(msg + " - retry with options={'fusion': 'step'}")
         if bits & N.ST_MAX_STEPS:
             msg = 'max_num_steps exceeded ({}>={})'.format(self.desc.max_num_steps, self.desc.max_num_steps)
         if bits & N.ST_DT_UNDERFLOW:
@@ -348,9 +387,33 @@ _ENGINE_CACHE_MAX = 8
 
 
 def clear_engine_cache():
+    _NO_ENGINE.clear()
     while _ENGINE_CACHE:
         _, eng = _ENGINE_CACHE.popitem()
         eng.close()
+
+
+class SyncTimeout(RuntimeError):
+    """The in-kernel grid hand-off of a one-launch kernel timed out (the GPU is shared with another persistent kernel).  Nothing
+    was committed: callers with a per-step loop (the multistep solvers) take it instead."""
+
+
+_NO_ENGINE = set()            # keys whose one-launch engine could not be created (e.g. the batch's workgroups are not co-resident):
+                              # remembered, so that every later odeint() call of that shape does not repeat mi_ode_create's
+                              # hipMalloc / hipFree (which synchronises the device) before taking its per-step loop
+
+
+def _cached_engine_or_none(key, factory):
+    """_cached_engine, but a NativeError at creation is remembered under `key` and answered with None from then on."""
+    if key in _NO_ENGINE:
+        return None
+    try:
+        return _cached_engine(key, factory)
+    except N.NativeError:
+        if len(_NO_ENGINE) > 256:
+            _NO_ENGINE.clear()
+        _NO_ENGINE.add(key)
+        return None
 
 
 def _cached_engine(key, factory):
@@ -537,17 +600,20 @@ class FixedGridODESolver(object):
             # their batch-wide convergence test - in ONE launch (csrc/mi_ode_adams.h)
             y = self.y0[0]
             key = ('multistep', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device), ms[:4], float(self.rtol), float(self.atol))
-            try:
-                eng = _cached_engine(key, lambda: _FusedEngine(rhs, y, False, _EULER_SHAPE, rtol=self.rtol, atol=self.atol, multistep=ms))
-            except N.NativeError:
-                eng = None                            # (e.g. a batch whose workgroups cannot be co-resident): the per-step loop below
+            # (None: e.g. a batch whose workgroups cannot be co-resident - remembered - the per-step loop below)
+            eng = _cached_engine_or_none(key, lambda: _FusedEngine(rhs, y, False, _EULER_SHAPE, rtol=self.rtol, atol=self.atol, multistep=ms))
+            out = None
             if eng is not None:
-                if default_grid and self.eps == 0.0:
-                    out = eng.integrate(t.to(torch.float64).numpy(), y)
-                else:
-                    time_grid = self.grid_constructor(self.func, self.y0, t)
-                    assert bool(time_grid[0] == t[0]) and bool(time_grid[-1] == t[-1])        # solvers.py:87
-                    out = eng.integrate(t.to(torch.float64).numpy(), y, grid=time_grid.to(torch.float64).numpy(), eps=float(self.eps))
+                try:
+                    if default_grid and self.eps == 0.0:
+                        out = eng.integrate(t.to(torch.float64).numpy(), y)
+                    else:
+                        time_grid = self.grid_constructor(self.func, self.y0, t)
+                        assert bool(time_grid[0] == t[0]) and bool(time_grid[-1] == t[-1])        # solvers.py:87
+                        out = eng.integrate(t.to(torch.float64).numpy(), y, grid=time_grid.to(torch.float64).numpy(), eps=float(self.eps))
+                except SyncTimeout:                   # the grid hand-off timed out (shared GPU): nothing was committed, the per-step
+                    out = None                        # loop below does the same arithmetic
+            if out is not None:
                 self.stats = eng.stats.as_dict()
                 self.stats['engine'] = 'fused multistep kernel (one launch)'
                 for _ in range(int(self.stats.get('n_rejected', 0))):                         # fixed_adams.py:197-199
@@ -639,7 +705,13 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         self._chunk_attempts = unused_kwargs.pop('chunk_attempts', 0)
         self._force_planes = unused_kwargs.pop('force_plane_kernels', False)
         self._profile = unused_kwargs.pop('profile', False)
-        self._graph = bool(unused_kwargs.pop('graph', False))      # plane path: replay one hipGraph per attempt (graph_step.py)
+        # Python-callable path (graph_step.DeviceControlledRK): 'auto' (default) - the controller runs on the device, attempts are
+        # evaluated eagerly first and replayed as one hipGraph once enough of them remain to pay for the recording; True - record
+        # after the first attempt; False - never record; 'host' - the round-1 loop with the controller on the host (one
+        # synchronisation per attempt), which is also what a process group or force_plane_kernels selects
+        self._graph = unused_kwargs.pop('graph', 'auto')
+        if self._graph not in ('auto', 'host', True, False):
+            raise ValueError("options['graph'] must be True, False, 'auto' or 'host'")
         self._graph_attempt = None
         self._fusion = unused_kwargs.pop('fusion', 0)
         _handle_unused_kwargs(self, unused_kwargs)
@@ -709,6 +781,9 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         _assert_increasing(t)
         eng = self._make_engine()
         if eng is None:
+            out = self._integrate_device_controlled(t)
+            if out is not None:
+                return out
             out = super(_AdaptiveRKSolver, self).integrate(t)
             self.stats = {'engine': 'plane kernels', 'n_attempts': getattr(self, '_n_attempts', 0),
                           'n_accepted': getattr(self, '_n_accepted', 0), 'status': 0}
@@ -719,6 +794,8 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         finally:
             self.stats = eng.stats.as_dict()
             self.stats['cross_rank'] = eng.transport
+            if eng.transport_log:
+                self.stats['cross_rank_log'] = list(eng.transport_log)
             if self._profile:
                 self.stats['profile'] = [a - b for a, b in zip(eng.profile(), prof0)]
         if self._packed is not None:                             # [T, padded rows, dim] -> one [T, *shape] tensor per component
@@ -726,6 +803,49 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             self.stats['components'] = len(rows)
             return tuple(out[:, o:o + r].reshape((out.shape[0],) + tuple(c.shape)) for c, r, o in zip(self.y0, rows, offs))
         return (out,)
+
+    # -- Python callable, controller on the device (graph_step.DeviceControlledRK) -----------------
+    def _integrate_device_controlled(self, t):
+        """AdaptiveStepsizeODESolver.integrate (solvers.py:27-35) with the attempt loop's scalars on the device; None when this
+        problem has to take the host-controlled loop below (process group, mixed dtypes, an empty component, the 'host' option)."""
+        if self._graph == 'host' or self._force_planes or self._exchange is not None:
+            return None
+        y0 = self.y0
+        if not (1 <= len(y0) <= N.MAX_SEGMENTS) or len(self.tableau.alpha) + 1 not in (2, 4, 7, 14):
+            return None
+        like = y0[0]
+        if like.dtype not in (torch.float32, torch.float64):
+            return None
+        if any(y.dtype != like.dtype or y.device != like.device or y.numel() == 0 or not y.is_cuda for y in y0):
+            return None
+        if self.interp != N.INTERP_QUARTIC_MID and len(self.tableau.alpha) != 6:
+            return None
+        from .graph_step import DeviceControlledRK, _credit_nfe
+        t64 = t.to(torch.float64)                     # solvers.py:30
+        self.before_integrate(t64)                    # f0 and the first step size, as the reference forms them (dopri5.py:70-79)
+        eng = DeviceControlledRK(self, graph=self._graph)
+        try:
+            outs = eng.integrate(t64.numpy(), y0, self.rk_state.f1, float(self.rk_state.dt))
+            st = eng.stats.as_dict()
+            info = dict(eng.info)
+            py_calls = eng.py_calls
+        finally:
+            eng.close()
+        self.stats = st
+        self.stats.update(info)
+        self.stats['n_polls'] = info.get('polls', 0)
+        # Python side effects of f (an evaluation counter, tests/DETEST/run.py:18-21) happen once per RECORDED evaluation: credit
+        # the evaluations the replays performed to an integer `nfe` attribute of the callable, if it keeps one
+        _credit_nfe(self.func, int(st['nfe']) - py_calls)
+        bits = int(st['status'])
+        if bits:
+            msg = N.status_message(bits)
+            if bits & N.ST_MAX_STEPS:
+                msg = 'max_num_steps exceeded ({}>={})'.format(self.max_num_steps, self.max_num_steps)
+            if bits & N.ST_DT_UNDERFLOW:
+                msg = 'underflow in dt {}'.format(st['dt'])
+            raise AssertionError(msg)                 # dopri5.py:85-100
+        return outs
 
     # -- plane-kernel path (any callable, tuple states) -------------------------------------------
     def before_integrate(self, t):
@@ -778,7 +898,7 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         dt = np.float64(dt)
         assert t0 + dt > t0, 'underflow in dt {}'.format(dt)
         recs = None
-        if self._graph and self._exchange is None:
+        if self._graph is True and self._exchange is None:
             # the whole attempt (S evaluations of f, stage arithmetic, error norms) is one hipGraph replay (graph_step.py)
             g = self._graph_attempt
             if g is None or not g.matches(y0):
