@@ -26,7 +26,7 @@ roofline:     the dominant kernel of the measured schedule; durations from HIP e
               the timed process), null if none is committed for the kernel.
 cpu_baseline: SURVEY.md 8(d): the op-for-op torch-CPU eager restatement of the reference path (oracle/ode_torch_cpu.py,
               kind "port") on this host at the METRIC's configuration - the full 65536 x 128 shard - in worker processes whose
-              threads are pinned (sched_setaffinity to the first n allowed CPUs + OMP_PROC_BIND=close; 8 = one CCD of this EPYC):
+              threads are pinned (the parent restricts each worker to n CPUs on n distinct cores before exec, OMP_PROC_BIND=close; 8 = one CCD of this EPYC):
               8 threads 1 warm-up + up to 3 runs, 32 threads 1 + 2, 1 thread 1 + 1 (a 10 s budget per leg: one call takes 5 - 10 s
               at this size - the eager ops stream 64 MB planes through freshly mapped memory), min / median / max reported; the numpy oracle's
               full-shard run is kept as `numpy_oracle` and supplies `parity_max_abs_diff` (GPU result vs oracle on the SAME
@@ -104,12 +104,11 @@ def cpu_model():
 
 
 def cpu_worker(threads, runs):
-    """Child process of cpu_baseline(): the torch-CPU restatement on the full config-4 shard with `threads` pinned threads.
-    Affinity and the OpenMP binding are fixed BEFORE torch creates its thread pool.  Prints one JSON line."""
-    allowed = sorted(os.sched_getaffinity(0))
-    cpus = allowed[:threads]
-    os.sched_setaffinity(0, set(cpus))           # (the parent put OMP_NUM_THREADS / OMP_PROC_BIND=close / OMP_PLACES=cores into the
-    torch.set_num_threads(threads)               #  environment; the pool's threads are created after this call and inherit the mask)
+    """Child process of cpu_baseline(): the torch-CPU restatement on the full config-4 shard with `threads` threads.  The PARENT
+    restricted this process to `threads` CPUs - one per physical core - before exec (the OpenMP runtime reads its binding variables
+    and the affinity mask when `import torch` loads it, i.e. before any line of this function runs).  Prints one JSON line."""
+    cpus = [int(c) for c in os.environ.get('BENCH_WORKER_CPUS', '').split(',') if c] or sorted(os.sched_getaffinity(0))   # (the main
+    torch.set_num_threads(threads)             # thread's own mask is one place by now: the parent says what the process was given)
     from oracle import ode_torch_cpu as TC
     A, y0 = config4(BATCH, DIM, 3)
     W = A.t().contiguous()
@@ -124,6 +123,24 @@ def cpu_worker(threads, runs):
         if times and time.perf_counter() - t_begin > CPU_LEG_BUDGET_S:     # a slow host: fewer runs, never fewer than one
             break
     print(json.dumps({'threads': threads, 'cpus': cpus, 'runs': len(times), 'warmup_runs': 1, 'times_s': times, 'attempts': int(st.n_attempts)}))
+
+
+def _one_cpu_per_core(allowed, n):
+    """The first n CPUs of `allowed` that sit on n different physical cores (SMT siblings skipped), in CPU order: on the EPYC hosts
+    of the GPU boxes CPUs 0-7 are the eight cores of one CCD, their siblings are 128-135."""
+    seen, out = set(), []
+    for c in sorted(allowed):
+        try:
+            sib = open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c).read().strip()
+        except OSError:
+            sib = str(c)
+        if sib in seen:
+            continue
+        seen.add(sib)
+        out.append(c)
+        if len(out) == n:
+            break
+    return out
 
 
 def _ranges(cpus):
@@ -144,17 +161,20 @@ def cpu_baseline(gpu_result):
     import subprocess
     from oracle import ode_numpy as O
     n_all = os.cpu_count() or 1
-    n_allowed = len(os.sched_getaffinity(0))
+    allowed = os.sched_getaffinity(0)
     res = {}
     attempts = None
     for nt, runs in CPU_PLAN:
-        if nt > n_allowed:
+        cpus = _one_cpu_per_core(allowed, nt)
+        if len(cpus) < nt:
             continue
         env = dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES='', OMP_NUM_THREADS=str(nt), MKL_NUM_THREADS=str(nt),
-                   OMP_PROC_BIND='close', OMP_PLACES='cores')      # (read by the OpenMP runtime when the worker loads it)
+                   OMP_PROC_BIND='close', OMP_PLACES='cores',      # (read by the OpenMP runtime when the worker loads it)
+                   BENCH_WORKER_CPUS=','.join(str(c) for c in cpus))
         try:
             out = subprocess.run([sys.executable, os.path.abspath(__file__), '--cpu-worker', str(nt), '--cpu-runs', str(runs)],
-                                 capture_output=True, text=True, timeout=600, env=env)
+                                 capture_output=True, text=True, timeout=600, env=env,
+                                 preexec_fn=lambda c=cpus: os.sched_setaffinity(0, set(c)))     # before exec: the mask the runtime sees
             rec = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:                              # pragma: no cover - the line then carries what went wrong
             res['%d_threads' % nt] = {'threads': nt, 'error': '%s: %s' % (type(e).__name__, str(e)[:200])}
@@ -302,14 +322,21 @@ def main():
         sys.exit(2)
     if args.config != 4 and world > 1:
         raise SystemExit('configs 1, 2, 3, 5 are single-GPU workloads (BASELINE.json)')
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    # BENCH_SHARE_GPU=1 (test hook for one-GPU boxes): every rank computes on cuda:0 and the group is gloo - the whole N > 1 code
+    # path of this file (sharding, per-rank logs, the transport survey) runs, the kernels of the ranks share the device
+    share = os.environ.get('BENCH_SHARE_GPU') == '1'
+    torch.cuda.set_device(0 if share else local_rank)
+    dev = torch.device('cuda', 0 if share else local_rank)
+    cdev = torch.device('cpu') if share else dev                           # where collective scalars live (gloo: host tensors)
     group = None
     use_dist = world > 1 or os.environ.get('BENCH_FORCE_DIST') == '1'     # the latter: exercise the N>1 plumbing on one GPU
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
         group = dist.group.WORLD
     n_gpus = world
 
@@ -360,7 +387,7 @@ def main():
     elapsed = time.perf_counter() - t_start
     per_rank = None
     if use_dist:
-        el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         elapsed = float(el.item())
         per_rank = [None] * world
@@ -393,7 +420,7 @@ def main():
                 for _ in range(3):
                     _, st_s = step()
                 torch.cuda.synchronize()
-                el_s = torch.tensor([time.perf_counter() - t_s], dtype=torch.float64, device=dev)
+                el_s = torch.tensor([time.perf_counter() - t_s], dtype=torch.float64, device=cdev)
                 dist.all_reduce(el_s, op=dist.ReduceOp.MAX)
                 ran = str(st_s.get('cross_rank', '?'))
                 entry.update({'ran': ran, 'pinned_transport_ran': {'peer': 'peer device memory', 'host': 'host segment', 'rccl': 'ncclAllGather',

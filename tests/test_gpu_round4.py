@@ -178,7 +178,9 @@ def test_cubic_matrix_system_and_bias_on_the_cooperative_multistep_kernels():
     y0 = torch.tensor(0.5 * rng.standard_normal((40, 6)), device=dev())
     for f in (rhs.CubicLinear(W), rhs.Linear(W, torch.tensor(0.1 * rng.standard_normal(6)))):
         for method in ('adams', 'fixed_adams'):
-            t = torch.tensor(np.linspace(0., 1., 6 if method == 'adams' else 41))     # (a fixed grid the corrector converges on)
+            # (fixed grid: steps inside the stability region of the order-12 Adams pair - at dt = 0.025 the reference's explicit solver
+            # blows up on this oscillatory system and the implicit one does not converge, on any engine)
+            t = torch.tensor(np.linspace(0., 1., 6) if method == 'adams' else np.linspace(0., 0.2, 41))
             a = odeint(f, y0, t, method=method, rtol=1e-6, atol=1e-8)
             assert dict(odeint.last_stats).get('engine', '').startswith('fused'), odeint.last_stats
             b = odeint(lambda t_, y: f.forward(t_, y), y0, t, method=method, rtol=1e-6, atol=1e-8)
