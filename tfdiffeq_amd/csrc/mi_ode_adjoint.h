@@ -558,6 +558,9 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
   };
   // (keeping the list in scalar registers and stepping (tile, entry, half) cursors instead of dividing was tried: the SGPRs
   // spill to VGPR lanes and the pass loses 15 %)
+  // (round 4: walking the tiles NEWEST FIRST, so that the part of the ~490 MB scratch still in the 256 MB memory-side cache is read
+  // before it is evicted, changes nothing - 549 vs 551 us for the two passes of a segment, profiles/r04_adjoint_reverse_order.txt:
+  // the pass is not waiting for the stream)
   // Software pipeline, prefetch distance TWO half items (one was measured latency bound: a step took ~6 us whatever its
   // MFMA count): two register sets each for the staged chunks and for this wave's own operands (its g1, g2, h2 columns),
   // the loop body is two steps so that no set is ever copied while its loads fly.

@@ -1203,8 +1203,13 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
   }
   h->n_launches = 0; h->n_polls = 0;
   const size_t pbytes = (size_t)h->n * h->elt;
+  if (h->d.multistep != 0 && (h->d.fusion == 1 || !multistep_family(h))) {     // (never fall through to the Runge-Kutta loop below)
+    mi_set_error("multistep handles run on the one-launch kernels only");
+    return MI_ODE_E_INVALID;
+  }
   if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
-       h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP || h->family == FAM_PLUGIN) && h->d.fusion != 1) {
+       h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP || h->family == FAM_PLUGIN ||
+       (h->family == FAM_LINEAR_VALU && h->d.multistep != 0)) && h->d.fusion != 1) {
     // trajectories never interact on a fixed grid: the whole integration is ONE launch
     // (k_fixed_rowlocal for the tiny row-local systems, k_fixed_linear_mfma for the linear RHS)
     int rcf = ensure_t_out(h, T + (own_grid ? G : 0));
