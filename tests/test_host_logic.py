@@ -178,10 +178,10 @@ def test_rhs_plugin_builds_and_exports_its_table():
     class Table(C.Structure):
         _fields_ = [('abi', C.c_int), ('dtype', C.c_int), ('dim', C.c_int), ('reserved', C.c_int), ('solver_size', C.c_size_t),
                     ('launch_init', C.c_void_p), ('launch_step', C.c_void_p), ('launch_fixed', C.c_void_p), ('persist_fn', C.c_void_p),
-                    ('persist_planes_fn', C.c_void_p), ('multistep_fn', C.c_void_p)]        # (plugin ABI 2)
+                    ('persist_planes_fn', C.c_void_p), ('multistep_fn', C.c_void_p)]        # (plugin ABI 2; ABI 3: the clock probe pointer in FixedArgs)
     tb = Table.from_address(table)
     core = N.load()
-    assert tb.abi == 2 and tb.dtype == N.dtype_code(torch.float64) and tb.dim == 2
+    assert tb.abi == 3 and tb.dtype == N.dtype_code(torch.float64) and tb.dim == 2
     assert tb.solver_size == core.mi_ode_sizeof(4)
     assert tb.launch_init and tb.launch_step and tb.launch_fixed and tb.persist_fn and tb.persist_planes_fn and tb.multistep_fn
     assert not lib.mi_ode_plugin_get(N.dtype_code(torch.float32))                      # built for one dtype only

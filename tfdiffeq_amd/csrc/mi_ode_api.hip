@@ -1223,6 +1223,10 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
     memset(&F, 0, sizeof(F));
     F.grid = own_grid ? h->t_out_dev + T : h->t_out_dev; F.M = (own_grid ? G : T) - 1; F.eps = eps;
     F.y0 = y0_dev; F.out = out_dev; F.t = h->t_out_dev; F.batch = h->d.batch; F.T = T; F.rk4 = euler ? 0 : 1; F.dim = (int)h->d.dim; F.rhs = h->rhs;
+    // the stream was synchronised above: the PREVIOUS fixed-grid launch of this handle has stored its clock probe (this call's own
+    // launch is not waited for - solvers.py:82-104 has no reason to block)
+    const double prev_mhz = h->ctl_host->clk_ticks > 0 ? 100.0 * (double)h->ctl_host->clk_cycles / (double)h->ctl_host->clk_ticks : 0.0;
+    F.clk = &h->ctl_host->clk_cycles;
     if (h->d.multistep != 0) {                     // Adams-Bashforth(-Moulton): one launch, the history in registers (mi_ode_adams.h)
       AdamsArgs AA;
       memset(&AA, 0, sizeof(AA));
@@ -1269,6 +1273,7 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
       stats->n_attempts = stats->n_accepted = (own_grid ? G : T) - 1;
       stats->t = t_host[T - 1];
       stats->n_launches = h->n_launches;
+      stats->clock_mhz = prev_mhz;               // (of the previous call on this handle; 0 on the first)
     }
     return 0;
   }

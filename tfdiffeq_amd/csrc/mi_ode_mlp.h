@@ -16,6 +16,29 @@ namespace mi {
 
 enum MlpMode { MLP_F0 = 0, MLP_INITB = 1, MLP_STEP = 2 };
 
+// As in the MFMA-linear family (MI_LIN_FMA, mi_ode_dev.h): the stage / error combinations of the MLP tile kernels are chains of
+// fused multiply-adds - one rounding per term where the reference's add_n((scale * c_j) * k_j) has two.  The fp32 vector ALU shares
+// its issue slots with the fp32 matrix pipe (scripts/micro/mfma_fill.hip), and this family never was bit-comparable with the
+// reference (tanh / softplus from the transcendental unit, the matrix products' summation order): its parity bar are the float32
+// bands of tests/bands.py.  0 restores the two roundings.
+#ifndef MI_MLP_FMA
+#define MI_MLP_FMA 1
+#endif
+template <int SG>
+__device__ __forceinline__ float mlp_combine(float y0, const float* k, float hs, const StepArgs& A) {
+  float acc = (hs * (float)A.beta[SG - 1][0]) * k[0];
+#pragma unroll
+  for (int j = 1; j < SG; ++j) acc = madd<(MI_MLP_FMA != 0), float>(hs * (float)A.beta[SG - 1][j], k[j], acc);
+  return y0 + acc;
+}
+template <int S>
+__device__ __forceinline__ float mlp_error(const float* k, float hs, const StepArgs& A) {
+  float er = (hs * (float)A.e[0]) * k[0];
+#pragma unroll
+  for (int j = 1; j <= S; ++j) er = madd<(MI_MLP_FMA != 0), float>(hs * (float)A.e[j], k[j], er);
+  return er;
+}
+
 template <int DP, int HP>
 struct MlpGeom {
   static constexpr int CB3 = DP / 16;                       // column blocks of the output layer
@@ -368,7 +391,7 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
         float kk[SG];
 #pragma unroll
         for (int j = 0; j < SG; ++j) kk[j] = k[j][i];
-        ys[i] = step_combine<float, SG>(y0e[i], kk, hs, A);
+        ys[i] = mlp_combine<SG>(y0e[i], kk, hs, A);
       }
       cx.put_x(ys);
       cx.eval(kn, sign * (P.t0 + (float)A.alpha[SG - 1] * hs));                 // rk_common.py:50, in the state dtype
@@ -383,7 +406,9 @@ __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<flo
 #pragma unroll
         for (int j = 0; j <= S; ++j) kk[j] = k[j][i];
         float err, ymid;
-        step_finish<float, S>(y0e[i], kk, hs, A, err, ymid, !TS && P.j_hi > P.j_lo);
+        if (!TS && P.j_hi > P.j_lo) step_finish<float, S>(y0e[i], kk, hs, A, err, ymid, true);     // (y_mid: the plain form, rare)
+        else ymid = y0e[i];
+        err = mlp_error<S>(kk, hs, A);
         const unsigned eo = e0 + (unsigned)(i * d);
         const long long idx = tb + eo;
         (P.y1 + tb)[eo] = ys[i];
@@ -417,6 +442,8 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_fixed_mlp(FixedA
   const float* y0p = (const float*)A.y0;
   float* out = (float*)A.out;
   const float eps = (float)A.eps;
+  FixedClk clk;
+  clk.begin();
   for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
     float y[4];
     long long idx[4];
@@ -473,6 +500,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_fixed_mlp(FixedA
       for (int i = 0; i < 4; ++i) y[i] = yn[i];
     }
   }
+  clk.end(A.clk);
 }
 
 template <int DP, int HP, int ACT, int MODE, int S, bool TS>

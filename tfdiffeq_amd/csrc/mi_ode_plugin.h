@@ -25,7 +25,7 @@
 #include "mi_ode_adams.h"
 #include "mi_ode_adams_vc.h"
 
-#define MI_ODE_PLUGIN_ABI 2
+#define MI_ODE_PLUGIN_ABI 3
 
 struct mi_ode_rowlocal_plugin {
   int abi;                     // MI_ODE_PLUGIN_ABI

@@ -248,6 +248,21 @@ struct FixedArgs {
   int rk4;                     // 0: Euler, 1: RK4 (3/8 rule)
   int dim;                     // row length (tile kernels: may be smaller than their instantiated width)
   RhsParams rhs;
+  long long* clk;              // pinned host {shader cycles, 10 ns ticks} of workgroup 0's run (mi_ode_stats.clock_mhz), or null
+};
+
+// shader clock of a fixed-grid launch: thread 0 of workgroup 0 brackets its whole loop (a one-trajectory call IS that thread)
+struct FixedClk {
+  long long c0 = 0, w0 = 0;
+  __device__ __forceinline__ void begin() {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c0 = (long long)__builtin_readcyclecounter(); w0 = (long long)wall_clock64(); }
+  }
+  __device__ __forceinline__ void end(long long* clk) const {
+    if (blockIdx.x == 0 && threadIdx.x == 0 && clk != nullptr) {
+      __hip_atomic_store(clk + 0, (long long)__builtin_readcyclecounter() - c0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(clk + 1, (long long)wall_clock64() - w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 };
 
 template <typename T, class RHS>
@@ -259,6 +274,8 @@ __global__ __launch_bounds__(256) void k_fixed_rowlocal(FixedArgs A) {
   const long long n = A.batch * D;
   const T* y0p = (const T*)A.y0;
   T* out = (T*)A.out;
+  FixedClk clk;
+  clk.begin();
   for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < A.batch;
        row += (long long)gridDim.x * blockDim.x) {
     Row y = *(const Row*)(y0p + row * D);
@@ -307,6 +324,7 @@ __global__ __launch_bounds__(256) void k_fixed_rowlocal(FixedArgs A) {
       y = yn;
     }
   }
+  clk.end(A.clk);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -684,6 +702,8 @@ __global__ __launch_bounds__(D * 4) void k_fixed_linear_mfma(FixedArgs A) {
   const long long n = A.batch * A.dim;
   const T* y0p = (const T*)A.y0;
   T* out = (T*)A.out;
+  FixedClk clk;
+  clk.begin();
   for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
     T y[4];
     long long idx[4];
@@ -730,6 +750,7 @@ __global__ __launch_bounds__(D * 4) void k_fixed_linear_mfma(FixedArgs A) {
       for (int i = 0; i < 4; ++i) y[i] = yn[i];
     }
   }
+  clk.end(A.clk);
 }
 
 template <typename T, int D>
