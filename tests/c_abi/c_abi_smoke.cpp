@@ -3,6 +3,8 @@
 //   2. adaptive Dopri5 on the same batch vs the fine RK4 solution                        (1e-6)
 //   3. the stateless plane kernel mi_ode_lincomb vs a host loop                          (bit-exact expected)
 //   3b. tuple state, 4. fused adjoint interval, 5. fixed-grid Adams-Bashforth in one launch vs a host loop, 6. 300000 trajectories in one launch, 7. the variable-order Adams solver in one launch
+//   8. family C (ABI 11): f evaluated by a kernel of THIS program between the library's launches, the controller on the device, one
+//      attempt captured as a hipGraph and replayed in blind chunks
 // Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -I include tests/c_abi/c_abi_smoke.cpp -L tfdiffeq_amd -lmi_ode
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -14,6 +16,16 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); return 2; } } while (0)
 #define MI(x) do { int r_ = (x); if (r_ < 0) { printf("mi_ode error %d: %s (%s)\n", r_, mi_ode_last_error(), #x); return 3; } } while (0)
+
+// the CALLER's right-hand side for section 8 (family C: opaque RHS): a kernel of this program, not of the library
+__global__ void k_user_lorenz(const double* y, double* f, long long rows) {
+  const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const double a = y[3 * r], b = y[3 * r + 1], c = y[3 * r + 2];
+  f[3 * r] = 10.0 * (b - a);
+  f[3 * r + 1] = a * (28.0 - c) - b;
+  f[3 * r + 2] = a * b - (8.0 / 3.0) * c;
+}
 
 static void lorenz(const double* y, double* f) {
   f[0] = 10.0 * (y[1] - y[0]);
@@ -354,6 +366,87 @@ int main() {
            (long long)st.n_attempts, (long long)st.n_accepted, (long long)st.nfe, (long long)st.n_launches, md7);
     if (st.n_launches != 1 || st.n_accepted < 2 || !(md7 < 1e-4)) { printf("FAIL adams\n"); return 1; }
     MI(mi_ode_destroy(hv));
+  }
+  // ---- 8. family C (ABI 11): opaque right-hand side, controller on the device, one attempt recorded as a hipGraph and replayed ----
+  {
+    mi_ode_opq_desc od;
+    memset(&od, 0, sizeof(od));
+    od.dtype = MI_ODE_F64; od.n_comp = 1; od.n[0] = n;
+    od.tableau = d.tableau;                                              // the dopri5 tableau of section 2
+    od.controller = MI_ODE_CTRL_MISC; od.interp = MI_ODE_INTERP_QUARTIC_MID; od.order = 5; od.init_order = 4;
+    od.rtol[0] = 1e-9; od.atol[0] = 1e-11; od.safety = (double)0.9f; od.ifactor = 10.0; od.dfactor = (double)0.2f; od.max_num_steps = 100000;
+    mi_ode_opq_handle ho = nullptr;
+    MI(mi_ode_opq_create(&od, &ho));
+    hipStream_t s8;
+    CK(hipStreamCreate(&s8));
+    double *Y0, *F0, *YS[6], *K[7], *ts;
+    CK(hipMalloc(&Y0, n * sizeof(double))); CK(hipMalloc(&F0, n * sizeof(double))); CK(hipMalloc(&ts, 6 * sizeof(double)));
+    for (int i = 0; i < 6; ++i) { CK(hipMalloc(&YS[i], n * sizeof(double))); CK(hipMalloc(&K[i + 1], n * sizeof(double))); }
+    K[0] = F0;
+    CK(hipMemcpy(Y0, d_y0, n * sizeof(double), hipMemcpyDeviceToDevice));
+    const dim3 ug((unsigned)((B + 255) / 256)), ub(256);
+    hipLaunchKernelGGL(k_user_lorenz, ug, ub, 0, s8, (const double*)Y0, F0, (long long)B);           // f0 (dopri5.py:71)
+    const double t8[2] = {0.25, 0.5};
+    void* rows8[1] = {d_out + n};                                        // solution rows 1, 2 (row 0 = y0 is the caller's)
+    MI(mi_ode_opq_begin(ho, 0.0, 1e-3, t8, 2, rows8, ts, s8));
+    const double* dt_dev = mi_ode_opq_dt_dev(ho);
+    auto attempt = [&]() -> int {                                        // rk_common.py:49-60 + dopri5.py:103-121: no host value inside
+      for (int sg = 0; sg < 6; ++sg) {
+        const void* ks[7];
+        for (int j = 0; j <= sg; ++j) ks[j] = K[j];
+        MI(mi_ode_lincomb_dev(MI_ODE_F64, n, Y0, ks, beta[sg], sg + 1, dt_dev, YS[sg], s8));
+        hipLaunchKernelGGL(k_user_lorenz, ug, ub, 0, s8, (const double*)YS[sg], K[sg + 1], (long long)B);    // (Lorenz ignores ts[sg])
+      }
+      const void* y0p[1] = {Y0}; const void* y1p[1] = {YS[5]}; const void* kp[7];
+      void* y0w[1] = {Y0}; void* f0w[1] = {F0};
+      for (int j = 0; j < 7; ++j) kp[j] = K[j];
+      MI(mi_ode_opq_finish(ho, y0p, y1p, kp, s8));
+      MI(mi_ode_opq_commit(ho, y0w, f0w, y1p, kp, s8));
+      return 0;
+    };
+    mi_ode_stats st8;
+    int32_t done8 = 0;
+    if (attempt() != 0) return 3;                                        // one eager attempt (warm-up), then record the next one
+    MI(mi_ode_opq_poll(ho, &st8, &done8, s8));
+    hipGraph_t graph; hipGraphExec_t gexec;
+    CK(hipStreamBeginCapture(s8, hipStreamCaptureModeThreadLocal));
+    if (attempt() != 0) return 3;
+    CK(hipStreamEndCapture(s8, &graph));
+    CK(hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0));
+    int replays = 0, polls = 1;
+    while (!done8 && replays < 100000) {
+      for (int c = 0; c < 16; ++c) CK(hipGraphLaunch(gexec, s8));        // blind chunk: attempts after `done` are no-ops
+      replays += 16;
+      int rc8 = mi_ode_opq_poll(ho, &st8, &done8, s8);
+      if (rc8 != 0) { printf("FAIL family C status %d %s\n", rc8, mi_ode_last_error()); return 1; }
+      ++polls;
+    }
+    CK(hipMemcpy(out.data(), d_out, (size_t)3 * n * sizeof(double), hipMemcpyDeviceToHost));
+    double md8 = 0;
+    for (int b = 0; b < B; ++b) {
+      double y[3] = {y0[3 * b], y0[3 * b + 1], y0[3 * b + 2]};
+      const int sub = 32;
+      for (int i = 0; i < 40 * sub; ++i) {
+        const double dt = 0.0125 / sub;
+        double k1[3], k2[3], k3[3], k4[3], ys[3];
+        lorenz(y, k1);
+        for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * k1[q] / 3;
+        lorenz(ys, k2);
+        for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * (k1[q] / -3 + k2[q]);
+        lorenz(ys, k3);
+        for (int q = 0; q < 3; ++q) ys[q] = y[q] + dt * (k1[q] - k2[q] + k3[q]);
+        lorenz(ys, k4);
+        for (int q = 0; q < 3; ++q) y[q] = y[q] + (k1[q] + 3 * k2[q] + 3 * k3[q] + k4[q]) * (dt / 8);
+        if (i + 1 == 20 * sub) for (int q = 0; q < 3; ++q) md8 = fmax(md8, fabs(out[n + 3 * b + q] - y[q]));
+        if (i + 1 == 40 * sub) for (int q = 0; q < 3; ++q) md8 = fmax(md8, fabs(out[2 * n + 3 * b + q] - y[q]));
+      }
+    }
+    printf("family C (opaque RHS, device controller, hipGraph replay): attempts %lld accepted %lld, %d replays, %d read-backs, max |dopri5 - fine rk4| = %.3e\n",
+           (long long)st8.n_attempts, (long long)st8.n_accepted, replays, polls, md8);
+    if (!done8 || st8.n_accepted < 2 || polls * 4 > (int)st8.n_attempts + 8 || !(md8 < 1e-6)) { printf("FAIL family C\n"); return 1; }
+    CK(hipGraphExecDestroy(gexec)); CK(hipGraphDestroy(graph));
+    MI(mi_ode_opq_destroy(ho));
+    CK(hipStreamDestroy(s8));
   }
   printf("C-ABI OK (abi %d)\n", mi_ode_abi_version());
   return 0;
