@@ -143,6 +143,10 @@ __device__ __forceinline__ void mlp_stamp() {
 #else
 __device__ __forceinline__ void mlp_stamp() {}
 #endif
+// (Round 4: a 16-row tile on FOUR wavefronts - each owning 32 hidden columns, so that an activation element is read from LDS by 4
+// wavefronts instead of 8 - with two such workgroups per CU to fill each other's barrier bubbles was built for the 64 x 128 geometry:
+// it needs 354 registers per wavefront (128 of them weight slices); at two wavefronts per SIMD it spills 87 and takes 0.455 ms per
+// config-5 call against 0.333, with the whole register file (one wavefront per SIMD, nothing spilled) 0.370 ms.  Removed.)
 // (Round 3: issuing the LDS reads of the NEXT group of MFMAs before the current group - explicit operand pipelining with
 // sched_group_barrier - changed nothing, 0.351 vs 0.343 ms at config 5: the two wavefronts of a SIMD interleave their fp32 chains and
 // cover each other's LDS round trips.  What the reads cost is the start of every chain after its barrier (profiles/r03_mlp_timeline.txt).
