@@ -19,7 +19,8 @@
 //     1/G slice of theta in a fixed order and contributes that slice's norms to the second hand-off of the attempt;
 //   * FSAL for theta: the activations of stage 6 of an accepted step are stage 0 of the next one (ping-pong slot);
 //   * dense output at t_{i-1} (interp.py:6-67): y and a from registers in the attempt that covers it (speculative, as
-//     in the forward kernels); theta in an epilogue after the accepted last step (two more GEMM passes: y_mid, f_1, f_0).
+//     in the forward kernels); theta in an epilogue after the accepted last step: ONE more weight-gradient pass (the fit folded
+//     into per-stage weights).
 // Controller: every workgroup applies it redundantly to the same combined records (mi_ode_persist.h).
 // Bound: fp32 matrix pipe - per row and stage 65536 MAC (forward + backward data) + 65536 MAC (weight gradients, two
 // combinations) at 64-128-128-64, against 2.5 KB of scratch traffic.
@@ -1038,45 +1039,45 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
   }
 
   const long long tk_epi = (long long)wall_clock64();
-  // ---- theta at t_end: interp.py:6-67 over the accepted last step (y_mid, f_1 and f_0 are three more combinations) ----
+  // ---- theta at t_end: interp.py:6-67 over the accepted last step -------------------------------------------------------------
+  // The fit is linear in (y0, y1, y_mid, f0, f1) and each of them is theta_0 plus a combination of the stage derivatives, so
+  // the interpolated value is ONE combination with weights that depend on x = (t_end - t0) / dt only (the theta_0 terms of the
+  // x^4, x^3, x^2 coefficients cancel: -8 - 8 + 16 = 18 + 14 - 32 = -11 - 5 + 16 = 0):
+  //   theta(x) = theta_0 + dt sum_j [ b_j (-8x^4 + 14x^3 - 5x^2) + c_mid_j (16x^4 - 32x^3 + 16x^2)
+  //                                   + [j = 0] (-2x^4 + 5x^3 - 4x^2 + x) + [j = S] (2x^4 - 3x^3 + x^2) ] k_j
+  // - one weight-gradient pass.  (Rounds 2-3 ran three: y_mid, f_1, f_0, 282 us per segment at config 5's shape against 200.
+  // As a third combination of the last attempt's own pass it needs 192 accumulator registers of the 256 a wavefront has at two
+  // per SIMD: built, spills in the loop, 1040 us per pass.  As a second pass of every attempt that covers t_end - speculative,
+  // like the dense output of y and a, and without the hand-off below - it costs 167 us per such attempt, rejected ones included:
+  // 1442 us per segment of two attempts against 1531, but a training step with a rejected attempt was no faster than before.)
   const bool finished = uniform_i((int)sh.st.status) == 0 && uniform_i(sh.st.accepted) != 0;
   if (finished) {
     const double dt_l = uniform_d(sh.st.emit_dt), ts_l = uniform_d(sh.st.emit_t0), tn_l = uniform_d(sh.st.emit_t1);
     const int s0c = uniform_i(ash.s0_cur), thc = uniform_i(ash.th_cur);      // after the swap: s0c holds stage S, 1 - s0c stage 0
     const float hs = (float)dt_l;
-    // y_mid needs every stage, f_1 and f_0 one slot each: three single-combination passes
+    const float x = interp_x<float>(ts_l, tn_l, A.t_end);
     if (threadIdx.x == 0) {
+      const float x2 = x * x, x3 = x2 * x, x4 = x2 * x2;
+      const float px1 = -8.f * x4 + 14.f * x3 - 5.f * x2, pxm = 16.f * x4 - 32.f * x3 + 16.f * x2;
+      const float px0 = -2.f * x4 + 5.f * x3 - 4.f * x2 + x, pxS = 2.f * x4 - 3.f * x3 + x2;
       AdjWList& L = ash.wl[0];
       L.n = 0;
       for (int j = 0; j <= S; ++j) {
-        const float cm = (hs * A.cm[j]) * msign;
-        if (cm == 0.f) continue;
+        const float wx = (j < S ? A.cb[S - 1][j] : 0.f) * px1 + A.cm[j] * pxm + (j == 0 ? px0 : 0.f) + (j == S ? pxS : 0.f);
+        if (wx == 0.f) continue;
         L.slot[L.n] = j == 0 ? 1 - s0c : (j == S ? s0c : j);
-        L.c[0][L.n] = cm; L.c[1][L.n] = 0.f;
+        L.c[0][L.n] = (hs * wx) * msign; L.c[1][L.n] = 0.f;
         ++L.n;
       }
-      AdjWList& L1 = ash.wl[1];
-      L1.n = 1; L1.slot[0] = s0c; L1.c[0][0] = msign; L1.c[1][0] = 0.f;
     }
     __syncthreads();
     adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 0, 0);
-    adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 1, 1);
-    if (threadIdx.x == 0) { AdjWList& L0 = ash.wl[1]; L0.n = 1; L0.slot[0] = 1 - s0c; L0.c[0][0] = msign; L0.c[1][0] = 0.f; }
-    __syncthreads();
-    adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 1, 2);
     Acc h1;
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
     if (ok) {
-      const float x = interp_x<float>(ts_l, tn_l, A.t_end);
       const float* th0p = thp[1 - thc];
-      const float* th1p = thp[thc];
-      adj_slice<3>(A, slice_scratch, [&](int p, const float* s) {
-        const float th0 = th0p[p], th1 = th1p[p];
-        float co[5];
-        quartic_from_mid<float>(th0, th1, th0 + s[0], s[2], s[1], hs, co);
-        A.th_out[p] = quartic_eval<float>(co, x);
-      });
-      if (blockIdx.x == 0 && threadIdx.x == 0) {
+      adj_slice<1>(A, slice_scratch, [&](int p, const float* s) { A.th_out[p] = th0p[p] + s[0]; });
+      if (blockIdx.x == 0 && threadIdx.x == 0) {            // adj_t: the fit of a constant, evaluated as the reference does
         const float at = ash.adjt;
         float co[5];
         quartic_from_mid<float>(at, at, at, 0.f, 0.f, hs, co);
