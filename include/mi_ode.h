@@ -54,7 +54,7 @@ extern "C" {
 /* 9: mi_ode_desc.multistep (fixed-grid Adams family).  10: multistep = 3 + ms_gamma_star (variable-order Adams), the four
  * mi_ode_adams_* plane entry points.  11: family (C) mi_ode_opq_* (opaque right-hand side, device-resident controller: what a
  * captured hipGraph of an attempt needs), mi_ode_stats.clock_mhz. */
-#define MI_ODE_ABI_VERSION 11
+#define MI_ODE_ABI_VERSION 12
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -309,6 +309,11 @@ typedef struct mi_ode_adjoint_desc {
   double safety, ifactor, dfactor;
   int32_t order, init_order;
   int64_t max_num_steps;
+  int32_t time_dependent;     /* 1: the network of dense_odenet.py:79-84 with time_dependent=True - fc1 sees concat([t, x]): mi_ode_rhs.w[0]
+                               * is [dim + 1, hidden] (row 0 = w_t multiplies t, mi_ode_rhs.scalars[1] != 0), adj_t has the derivative
+                               * -adj_y^T df/dt, and adj_params starts with the `hidden` entries of w_t (canonical order
+                               * w_t, W1 [dim,hidden], b1, W2, b2, W3, b3) */
+  int32_t reserved;
 } mi_ode_adjoint_desc;
 typedef struct mi_ode_adjoint* mi_ode_adjoint_handle;
 int mi_ode_adjoint_create(const mi_ode_adjoint_desc* desc, mi_ode_adjoint_handle* out);
@@ -324,6 +329,10 @@ int mi_ode_adjoint_segment(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, const
  * f_out = f(y), vjp_y_out = -adj_y^T df/dy, vjp_params_out = -adj_y^T df/dparams (canonical order). */
 int mi_ode_adjoint_dynamics(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, const void* y_dev, const void* adj_y_dev,
                             void* f_out_dev, void* vjp_y_out_dev, void* vjp_params_out_dev, void* stream);
+/* ... at time t (the time-dependent network; mi_ode_adjoint_dynamics evaluates at t = 0).  -adj_y^T df/dt is not a separate output:
+ * it is dot(w_t, b1 slice of vjp_params_out) (the identity the segment kernel integrates adj_t with). */
+int mi_ode_adjoint_dynamics_at(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, double t, const void* y_dev, const void* adj_y_dev,
+                               void* f_out_dev, void* vjp_y_out_dev, void* vjp_params_out_dev, void* stream);
 
 /* ---- function-level parity surface of the step controller ----------------------------------- */
 /* The scalar tail of one step attempt exactly as the kernels run it (csrc/mi_ode_ctrl_dev.h, ONE device thread per case):

@@ -30,16 +30,16 @@ def _canon(func, tensors):
     return torch.cat([w1.t().reshape(-1), b1, w2.t().reshape(-1), b2, w3.t().reshape(-1), b3])
 
 
-def _func(dim, hidden, seed, non_linearity='tanh'):
+def _func(dim, hidden, seed, non_linearity='tanh', time_dependent=False):
     from tfdiffeq_amd.models import ODEFunc
     torch.manual_seed(seed)
-    return ODEFunc(dim, hidden, non_linearity=non_linearity).to(dev())
+    return ODEFunc(dim, hidden, non_linearity=non_linearity, time_dependent=time_dependent).to(dev())
 
 
-def _engine(batch, dim, hidden, tol=1e-3, max_num_steps=1000):
+def _engine(batch, dim, hidden, tol=1e-3, max_num_steps=1000, time_dependent=False):
     from tfdiffeq_amd import adjoint as ADJ
     f32 = lambda v: float(np.float32(v))     # noqa: E731
-    return ADJ._FusedAdjointEngine(batch, dim, hidden, tol, tol, f32(0.9), f32(10.0), f32(0.2), max_num_steps, dev())
+    return ADJ._FusedAdjointEngine(batch, dim, hidden, tol, tol, f32(0.9), f32(10.0), f32(0.2), max_num_steps, dev(), time_dependent)
 
 
 def _rel(a, b):
@@ -73,10 +73,12 @@ def _plane_segment(func, y, a, adj_t, theta, t0, t1, tol, max_num_steps=1000):
 
     def aug(tt, ya):
         with torch.enable_grad():
+            t_ = tt.detach().requires_grad_(True)
             y_ = ya[0].detach().requires_grad_(True)
-            fe = func(tt, y_)
-            vj = torch.autograd.grad(fe, (y_,) + fp, -ya[1])
-        return (fe.detach(), vj[0], torch.zeros_like(ya[2]), _canon(func, vj[1:]))
+            fe = func(t_, y_)
+            vj = torch.autograd.grad(fe, (t_, y_) + fp, -ya[1], allow_unused=True)
+        vt = torch.zeros_like(ya[2]) if vj[0] is None else vj[0].to(ya[2].dtype).reshape(ya[2].shape)     # (None: time-independent network)
+        return (fe.detach(), vj[1], vt, _canon(func, vj[2:]))
     with torch.no_grad():
         out = T.odeint(aug, (y, a, adj_t, theta), torch.tensor([t0, t1], dtype=torch.float64), rtol=tol, atol=tol, method='dopri5',
                        options={'max_num_steps': max_num_steps})
@@ -245,9 +247,8 @@ def test_cases_the_fused_kernel_does_not_cover_stay_on_the_plane_engine():
     blk.odefunc.fc2.bias.requires_grad_(False)
     blk(x.clone().requires_grad_(True)).sum().backward()
     assert odeint_adjoint.last_backward_stats['engine'] == 'plane kernels'
-    # a non-linearity the kernels do not know, time dependent network, float64 state
-    for kw, dt in ((dict(non_linearity='ELU'), torch.float32), (dict(non_linearity='tanh', time_dependent=True), torch.float32),
-                   (dict(non_linearity='tanh'), torch.float64)):
+    # a non-linearity the kernels do not know, float64 state
+    for kw, dt in ((dict(non_linearity='ELU'), torch.float32), (dict(non_linearity='tanh'), torch.float64)):
         blk = models.ODEBlock(models.ODEFunc(8, 16, **kw), adjoint=True).to(dev()).to(dt)
         blk(x.to(dt).clone().requires_grad_(True)).sum().backward()
         assert odeint_adjoint.last_backward_stats['engine'] == 'plane kernels', kw
@@ -348,3 +349,139 @@ def test_default_odenet_trains_on_the_fused_kernels(act):
         # column of the weight gradient (1e-2); softplus - smooth, the default tol 1e-3 of ODEBlock bounds the two solves' distance (3e-3)
         assert_scalar(_rel(pg.grad.cpu().double(), pc.grad), 'default_odenet_grads/%s/param%d' % (act, i),
                       ceiling=1e-2 if act == 'relu' else 3e-3)
+
+
+# ---------------------------------------------------------------------------------------------
+# the time-dependent network (dense_odenet.py:79-84: fc1 sees concat([t, x])) - round 4.  adj_t has a real derivative
+# (-a^T df/dt = dot(w_t, -a^T df/db1)), theta starts with w_t, the stage time shifts the first layer's bias.
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('batch,dim,hidden,t', [(8, 4, 16, 0.0), (100, 10, 100, 0.7), (300, 64, 128, -1.3), (5000, 48, 96, 2.5)])
+def test_time_dependent_dynamics_match_autograd(batch, dim, hidden, t):
+    func = _func(dim, hidden, 41, time_dependent=True)
+    g = torch.Generator(device='cpu').manual_seed(42)
+    y = torch.randn(batch, dim, generator=g).to(dev())
+    a = torch.randn(batch, dim, generator=g).to(dev())
+    eng = _engine(batch, dim, hidden, time_dependent=True)
+    try:
+        assert eng.n_params == sum(p.numel() for p in func.parameters())
+        f, vy, vp = eng.dynamics(func.device_rhs(), y, a, t)
+    finally:
+        eng.close()
+    yr = y.clone().requires_grad_(True)
+    tr = torch.tensor(t, device=dev(), requires_grad=True)
+    fr = func(tr, yr)
+    grads = torch.autograd.grad(fr, (tr, yr) + tuple(func.parameters()), -a)
+    assert _rel(f, fr.detach()) < 3e-6
+    assert _rel(vy, grads[1]) < 3e-6
+    assert _rel(vp, _canon(func, grads[2:])) < 1e-5          # the canonical W1 block is [1 + dim, hidden]: its first row is the gradient of w_t
+    # the identity the segment kernel integrates adj_t with: -a^T df/dt = dot(w_t, b1 slice of -a^T df/dtheta)
+    w_t = func.fc1.weight.detach()[:, 0]
+    o = (1 + dim) * hidden
+    assert abs(float(torch.dot(w_t, vp[o:o + hidden])) - float(grads[0])) <= 2e-5 * max(abs(float(grads[0])), float(vp[o:o + hidden].abs().max()))
+
+
+@pytest.mark.parametrize('batch,dim,hidden,tol,t0,t1', [
+    (8, 4, 16, 1e-3, 1.0, 0.0), (100, 10, 16, 1e-4, 1.0, 0.0), (300, 64, 128, 1e-3, 1.0, 0.0), (64, 8, 32, 1e-6, 1.0, 0.25),
+    (64, 8, 32, 1e-4, 0.5, 2.0), (2000, 33, 70, 1e-5, 0.7, -0.4)])
+def test_time_dependent_segment_matches_the_plane_kernel_engine(batch, dim, hidden, tol, t0, t1):
+    """One backward interval of the time-dependent network: same attempts and accepted steps as the generic tuple path; a, theta
+    and the now evolving adj_t within fp32 roundoff per step of it."""
+    func = _func(dim, hidden, 43, time_dependent=True)
+    g = torch.Generator(device='cpu').manual_seed(44)
+    y = torch.randn(batch, dim, generator=g).to(dev())
+    a = (torch.randn(batch, dim, generator=g) / batch).to(dev())
+    eng = _engine(batch, dim, hidden, tol, time_dependent=True)
+    theta = (0.01 * torch.randn(eng.n_params, generator=g)).to(dev())
+    adj_t = torch.tensor(0.3, device=dev())
+    try:
+        a1, t_1, p1 = eng.segment(func.device_rhs(), y, a, adj_t, theta, t0, t1)
+        st = eng.stats.as_dict()
+    finally:
+        eng.close()
+    ref, rs = _plane_segment(func, y, a, adj_t, theta, t0, t1, tol)
+    assert st['status'] == 0 and st['n_launches'] == 1
+    assert (st['n_attempts'], st['n_accepted']) == (rs['n_attempts'], rs['n_accepted'])
+    nsteps = max(st['n_accepted'], 1)
+    assert _rel(a1, ref[1][1]) < 4e-6 * nsteps
+    assert _rel(p1, ref[3][1]) < 4e-6 * nsteps
+    # adj_t: the generic path sums the batch's -a df/dt per stage in fp32 (one rocBLAS reduction of batch x hidden products), the
+    # kernel takes dot(w_t, .) of fp32 column sums: both carry ~sqrt(batch) ulp of the LARGEST product, not of the (cancelling) sum
+    scale = max(abs(float(ref[2][1])), abs(float(adj_t)), float(ref[3][1].abs().max()))
+    assert abs(float(t_1) - float(ref[2][1])) <= 2e-5 * nsteps * scale, (float(t_1), float(ref[2][1]))
+    assert float(t_1) != float(adj_t)                      # it did evolve
+
+
+@pytest.mark.parametrize('batch,dim,hidden,tol,act', [(64, 8, 32, 1e-3, 'tanh'), (1000, 16, 64, 1e-4, 'softplus'), (4096, 64, 128, 1e-3, 'relu')])
+def test_time_dependent_odeblock_trains_on_the_fused_adjoint(batch, dim, hidden, tol, act):
+    from tfdiffeq_amd import models
+    torch.manual_seed(45)
+    block = models.ODEBlock(models.ODEFunc(dim, hidden, time_dependent=True, non_linearity=act), tol=tol, adjoint=True).to(dev())
+    x = torch.randn(batch, dim, generator=torch.Generator().manual_seed(46)).to(dev())
+    out_f, gx_f, gp_f, st_f = _grads(block, x, True)
+    out_p, gx_p, gp_p, st_p = _grads(block, x, False)
+    assert st_f['engine'].startswith('fused adjoint kernel') and st_p['engine'] == 'plane kernels'
+    assert all(s['n_launches'] == 1 and s['status'] == 0 for s in st_f['segments'])
+    assert torch.equal(out_f, out_p)
+    # Band: the solver tolerance (see test_odeblock_gradients_fused_against_plane_kernel_adjoint) - two solves whose controllers
+    # may pick different valid step sequences differ by a small multiple of it (observed: 1.3 x tol for softplus at 1e-4);
+    # relu: kinks, see test_default_odenet_trains_on_the_fused_kernels
+    band = 3 * max(2e-5, tol) * (10 if act == 'relu' else 1)
+    assert _rel(gx_f, gx_p) < band
+    for a_, b_ in zip(gp_f, gp_p):
+        assert _rel(a_, b_) < band
+
+
+@pytest.mark.parametrize('rtol,atol,band', [(1e-5, 1e-7, 1e-4), (1e-7, 1e-9, 1e-5)])
+def test_time_dependent_time_gradients_over_several_intervals(rtol, atol, band):
+    """dL/dt_i of the time-dependent network (adjoint.py:134-140, 162-166): adj_t now integrates -a^T df/dt between the output times.
+    Band: ten solver tolerances at 1e-5 (adj_t's error estimate is a dot product of cancelling terms - the two engines' controllers
+    pick different, equally valid step sequences; observed 4e-5), and the agreement tightens with the tolerance (observed 2e-6 at 1e-7)."""
+    from tfdiffeq_amd import odeint_adjoint
+    from tfdiffeq_amd import adjoint as ADJ
+    func = _func(5, 24, 47, time_dependent=True)
+    y0 = torch.randn(70, 5, generator=torch.Generator().manual_seed(48)).to(dev())
+    w = torch.randn(4, 70, 5, generator=torch.Generator().manual_seed(49)).to(dev())
+    res = {}
+    for fused in (True, False):
+        ADJ.FUSED, ADJ.FUSED_FORWARD = fused, False
+        try:
+            for p in func.parameters():
+                p.grad = None
+            yi = y0.clone().requires_grad_(True)
+            t = torch.tensor([0.0, 0.3, 0.8, 1.5], requires_grad=True)
+            sol = odeint_adjoint(func, yi, t, rtol=rtol, atol=atol, method='dopri5')
+            (sol * w).sum().backward()
+            res[fused] = (sol.detach(), yi.grad.clone(), t.grad.clone(), [p.grad.clone() for p in func.parameters()],
+                          dict(odeint_adjoint.last_backward_stats))
+        finally:
+            ADJ.FUSED, ADJ.FUSED_FORWARD = True, True
+    assert res[True][4]['engine'].startswith('fused') and len(res[True][4]['segments']) == 3
+    assert torch.equal(res[True][0], res[False][0])
+    assert _rel(res[True][1], res[False][1]) < band
+    assert _rel(res[True][2], res[False][2]) < band
+    assert float(res[True][2].abs().min()) > 0               # every dL/dt_i is live
+    for a_, b_ in zip(res[True][3], res[False][3]):
+        assert _rel(a_, b_) < band
+
+
+def test_time_dependent_gradients_against_autograd_through_the_restatement():
+    """The independent checker for the time-dependent network: float64 autograd through oracle/ode_torch_cpu.odeint_dopri5 (rtol
+    1e-9) = the exact gradient of the exact flow; the fused fp32 adjoint at rtol = atol = 1e-6 agrees to the adjoint's own accuracy.
+    A-priori band 2e-4: what the time-independent twin of this test observes (2e-5, tests/golden/fp32_bands.json) x 10."""
+    from tfdiffeq_amd import odeint_adjoint
+    from oracle import ode_torch_cpu as TC
+    func = _func(6, 24, 50, time_dependent=True)
+    cpu64 = copy.deepcopy(func).cpu().double()
+    y0 = torch.randn(40, 6, generator=torch.Generator().manual_seed(51))
+    w = torch.randn(40, 6, generator=torch.Generator().manual_seed(52))
+    y64 = y0.double().requires_grad_(True)
+    sol64, _ = TC.odeint_dopri5(lambda t_, y_: cpu64(t_, y_), y64, [0.25, 1.5], rtol=1e-9, atol=1e-11)
+    (sol64[1] * w.double()).sum().backward()
+    yi = y0.to(dev()).requires_grad_(True)
+    sol = odeint_adjoint(func, yi, torch.tensor([0.25, 1.5]), rtol=1e-6, atol=1e-6, method='dopri5')
+    (sol[1] * w.to(dev())).sum().backward()
+    assert odeint_adjoint.last_backward_stats['engine'].startswith('fused')
+    assert _rel(yi.grad.cpu().double(), y64.grad) < 2e-4
+    for pg, pc in zip(func.parameters(), cpu64.parameters()):
+        assert _rel(pg.grad.cpu().double(), pc.grad) < 2e-4
+    assert float(func.fc1.weight.grad[:, 0].abs().max()) > 0        # the column of fc1 that multiplies t is trained too

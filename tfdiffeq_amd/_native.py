@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH, RHS_PLUGIN = 1, 2, 3, 4, 5, 6
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
-ABI_VERSION = 11
+ABI_VERSION = 12
 MAX_SEGMENTS = 8
 SEGMENT_ALIGN = 256
 IPC_HANDLE_BYTES = 64
@@ -79,7 +79,8 @@ class CtrlParams(C.Structure):
 class AdjointDesc(C.Structure):
     _fields_ = [('batch', C.c_int64), ('dim', C.c_int32), ('hidden', C.c_int32), ('tableau', Tableau),
                 ('rtol', C.c_double), ('atol', C.c_double), ('safety', C.c_double), ('ifactor', C.c_double), ('dfactor', C.c_double),
-                ('order', C.c_int32), ('init_order', C.c_int32), ('max_num_steps', C.c_int64)]
+                ('order', C.c_int32), ('init_order', C.c_int32), ('max_num_steps', C.c_int64),
+                ('time_dependent', C.c_int32), ('reserved', C.c_int32)]
 
 
 class OpqDesc(C.Structure):
@@ -136,6 +137,8 @@ _PROTOS = {
                                          C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
     'mi_ode_adjoint_dynamics': (C.c_int, [C.c_void_p, C.POINTER(Rhs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                           C.c_void_p]),
+    'mi_ode_adjoint_dynamics_at': (C.c_int, [C.c_void_p, C.POINTER(Rhs), C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p, C.c_void_p]),
     'mi_ode_opq_create': (C.c_int, [C.POINTER(OpqDesc), C.POINTER(C.c_void_p)]),
     'mi_ode_opq_destroy': (C.c_int, [C.c_void_p]),
     'mi_ode_opq_dt_dev': (C.c_void_p, [C.c_void_p]),

@@ -37,9 +37,10 @@ def _flatten(seq):
 
 class _FusedAdjointEngine(object):
     """Owns one mi_ode_adjoint handle: the augmented system (y, adj_y, adj_t, adj_params) of adjoint.py:57-178 for a
-    [batch, dim] float32 state and the dim -> hidden -> hidden -> dim MLP (rhs.MLP: relu, softplus or tanh)."""
+    [batch, dim] float32 state and the dim -> hidden -> hidden -> dim MLP (rhs.MLP: relu, softplus or tanh; time_dependent:
+    the first layer sees concat([t, x]), dense_odenet.py:79-84 - adj_params then starts with w_t, the row of W1 that multiplies t)."""
 
-    def __init__(self, batch, dim, hidden, rtol, atol, safety, ifactor, dfactor, max_num_steps, device):
+    def __init__(self, batch, dim, hidden, rtol, atol, safety, ifactor, dfactor, max_num_steps, device, time_dependent=False):
         from .dopri5 import _DORMAND_PRINCE_SHAMPINE_TABLEAU, DPS_C_MID
         from .solvers import _fill_tableau
         self.lib = N.load()
@@ -51,6 +52,7 @@ class _FusedAdjointEngine(object):
         d.safety, d.ifactor, d.dfactor = float(safety), float(ifactor), float(dfactor)
         d.order, d.init_order = 5, 4                     # dopri5.py:68, 74
         d.max_num_steps = int(max_num_steps)
+        d.time_dependent = 1 if time_dependent else 0
         self.desc = d
         h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -101,15 +103,15 @@ class _FusedAdjointEngine(object):
             raise AssertionError(msg)                      # what the reference's solver raises (dopri5.py:85-100)
         return a_out, t_out, p_out
 
-    def dynamics(self, mlp, y, adj_y):
-        """One evaluation of the augmented dynamics (adjoint.py:69-105): (f, -adj_y^T df/dy, -adj_y^T df/dparams)."""
+    def dynamics(self, mlp, y, adj_y, t=0.0):
+        """One evaluation of the augmented dynamics at time t (adjoint.py:69-105): (f, -adj_y^T df/dy, -adj_y^T df/dparams)."""
         r, keep = self._rhs(mlp)
         y, adj_y = y.contiguous(), adj_y.contiguous()
         f, vy = torch.empty_like(y), torch.empty_like(y)
         vp = torch.empty(self.n_params, dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            N.check(self.lib.mi_ode_adjoint_dynamics(self.h, C.byref(r), y.data_ptr(), adj_y.data_ptr(), f.data_ptr(), vy.data_ptr(),
-                                                     vp.data_ptr(), N.stream_ptr(self.device)), 'mi_ode_adjoint_dynamics')
+            N.check(self.lib.mi_ode_adjoint_dynamics_at(self.h, C.byref(r), float(t), y.data_ptr(), adj_y.data_ptr(), f.data_ptr(), vy.data_ptr(),
+                                                        vp.data_ptr(), N.stream_ptr(self.device)), 'mi_ode_adjoint_dynamics_at')
         del keep
         return f, vy, vp
 
@@ -129,12 +131,13 @@ def clear_adjoint_engines():
 
 
 def canonical_to_module_order(base, theta):
-    """adj_params in the kernel's canonical order (W1 [in,out], b1, W2, b2, W3, b3) -> the flat order of base.parameters()
-    (torch.nn.Linear keeps [out, in] weights)."""
-    d, hd = base.fc1.in_features, base.fc1.out_features
-    sizes = [d * hd, hd, hd * hd, hd, hd * d, d]
+    """adj_params in the kernel's canonical order (W1 [in,out], b1, W2, b2, W3, b3; the time-dependent W1 is [1 + dim, hidden]
+    with the row of t first, as fc1 sees concat([t, x])) -> the flat order of base.parameters() (torch.nn.Linear keeps
+    [out, in] weights)."""
+    din, hd, d = base.fc1.in_features, base.fc1.out_features, base.fc3.out_features
+    sizes = [din * hd, hd, hd * hd, hd, hd * d, d]
     w1, b1, w2, b2, w3, b3 = torch.split(theta, sizes)
-    return torch.cat([w1.reshape(d, hd).t().reshape(-1), b1, w2.reshape(hd, hd).t().reshape(-1), b2,
+    return torch.cat([w1.reshape(din, hd).t().reshape(-1), b1, w2.reshape(hd, hd).t().reshape(-1), b2,
                       w3.reshape(hd, d).t().reshape(-1), b3])
 
 
@@ -161,15 +164,15 @@ def _fused_plan(func, n_tensors, cfg, like, f_params):
         return None                                      # first_step / safety / ... : not wired into the fused controller
     mlp = get()
     y1 = like[0]
-    if mlp is None or mlp.time_dependent or not mlp.supports(y1):
-        return None                                      # time dependence: adj_t has a real derivative, generic path
+    if mlp is None or not mlp.supports(y1):
+        return None
     batch = y1.numel() // y1.shape[-1]
     if batch < 1:
         return None
     f32 = lambda v: float(np.float32(v))                 # noqa: E731  (misc.py:137-144: python float -> float32 -> float64)
     try:
         eng = _cached_adjoint_engine(batch, int(y1.shape[-1]), int(mlp.hidden), float(cfg['adjoint_rtol']), float(cfg['adjoint_atol']),
-                                     f32(0.9), f32(10.0), f32(0.2), int(max_num_steps), str(like.device))
+                                     f32(0.9), f32(10.0), f32(0.2), int(max_num_steps), str(like.device), bool(mlp.time_dependent))
     except N.NativeError as e:                           # e.g. no memory for the activation scratch (15 KB per row): the generic path
         import warnings                                  # needs none
         warnings.warn('fused adjoint engine unavailable (%s): using the plane-kernel path' % e)

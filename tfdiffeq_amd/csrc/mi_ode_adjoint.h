@@ -8,7 +8,13 @@
 //     kernel: a workgroup owns its tiles for the whole segment; per stage one forward pass (three MFMA layers) and one
 //     backward-data pass (the three transposed layers) give k_y = s f and k_a = -s a^T df/dy; the stage derivatives
 //     of both components stay in registers, as in mi_ode_mlp.h;
-//   * component adj_t is a scalar with zero derivative (f does not depend on t): thread 0 carries it;
+//   * component adj_t is a scalar.  Time-independent network: zero derivative, thread 0 carries it.  Time-dependent network
+//     (dense_odenet.py:79-84: fc1 sees concat([t, x]), W1 = [dim + 1, hidden] with row 0 = w_t multiplying t): the stage time
+//     shifts the first layer's bias (b1 + t_s w_t, as in the forward kernels), and -a^T df/dt = sum_c w_t[c] (-a^T df/db1[c]):
+//     adj_t's derivative is dot(w_t, .) of the b1 slice of theta's derivative, so its step, its error estimate, its initial-
+//     step norms and its dense output are dot(w_t, .) of the b1 slices of the theta COMBINATIONS the kernel forms anyway (one
+//     more hand-off per attempt carries the two dot products); the gradient of w_t itself is the b1 column sum weighted with
+//     the stage time (one more bias-like sum in the weight-gradient pass);
 //   * component theta = adj_params (P = all weights and biases, canonical order W1 b1 W2 b2 W3 b3, weights [in, out])
 //     has k_theta = -s sum_rows X^T Delta (X: layer inputs, Delta: back-propagated signals).  theta never feeds back
 //     into f, so only LINEAR COMBINATIONS over the stages are needed: theta_1 = theta_0 + sum_j (dt c_sol_j) k_j,
@@ -83,6 +89,8 @@ struct AdjArgs {
   AdjResult* res;
   double t_end;
   float cb[6][8], ce[8], cm[8];   // the tableau in the state dtype (beta rows, c_error, c_mid): scalar operands, no conversions in the kernel
+  float ca[8];                 // alpha (stage times, rk_common.py:50) in the state dtype: stage j + 1 is evaluated at t + ca[j] dt
+  int td;                      // 1: time-dependent first layer (rhs.s[1] != 0): theta starts with the hidden entries of w_t
   int mode;                    // 0: segment, 1: one evaluation of the augmented dynamics; 2 / 3: time `bench_iters` tile passes /
                                // weight-gradient passes of one attempt (no hand-offs; tuning aid, MI_ODE_ADJOINT_BENCH)
   int bench_iters;
@@ -108,6 +116,7 @@ struct AdjCtx {
   lds_float *s_w1, *s_w3, *s_x, *s_a, *s_hA, *s_hB;
   float w2f[G::KS2], w2t[G::KS2];                           // W2[k][col] and W2[col][k] of this wave's 16 hidden columns
   float b1v, b2v, b3v, sign;
+  float wtv;                                                // w_t[col12] (time-dependent network), else 0
   int lane, wave, li, lg, d, hd, col, col12, rbase;
   bool owner;
 
@@ -129,6 +138,7 @@ struct AdjCtx {
     col12 = 16 * wave + li;
     b1v = (B1 != nullptr && wave < G::NW12 && col12 < hd) ? B1[col12] : 0.f;
     b2v = (B2 != nullptr && wave < G::NW12 && col12 < hd) ? B2[col12] : 0.f;
+    wtv = (rhs.s[1] != 0.0 && wave < G::NW12 && col12 < hd) ? ((const g_float*)rhs.w[0])[col12] : 0.f;
     col = 16 * (wave % G::CB) + li;
     b3v = (B3 != nullptr && wave < G::NW3 && col < d) ? B3[col] : 0.f;
     owner = wave < G::NW3 && col < d;
@@ -137,7 +147,7 @@ struct AdjCtx {
   // W1 and W3 into LDS, zero padded (once per launch)
   template <class RHS>
   __device__ __forceinline__ void stage_weights(const RHS& rhs) {
-    const g_float* W1 = (const g_float*)rhs.w[0];
+    const g_float* W1 = (const g_float*)rhs.w[0] + (rhs.s[1] != 0.0 ? hd : 0);      // the rows that multiply x (row 0 of the time-dependent W1 is w_t)
     const g_float* W3 = (const g_float*)rhs.w[2];
     for (int i = threadIdx.x; i < DP * HP; i += blockDim.x) {
       const int k = i / HP, n = i % HP;
@@ -166,8 +176,10 @@ struct AdjCtx {
 
   // One evaluation for the tile whose stage inputs are xs (y component) and as (a component), 4 elements per owner
   // thread.  f4 = f(xs), v4 = as^T df/dy (both unsigned).  act != nullptr: the six activation planes go to that slot.
+  // ts: the time the network sees (direction sign applied) - it shifts the first layer's bias by ts w_t.
   // Every thread of the workgroup must call it.
-  __device__ __forceinline__ void eval(const float* xs, const float* as, float* f4, float* v4, g_float* act) {
+  __device__ __forceinline__ void eval(const float* xs, const float* as, float* f4, float* v4, g_float* act, float ts) {
+    const float b1e = b1v + ts * wtv;
     constexpr int KS1 = G::KS1, KS2 = G::KS2;
     if (wave < G::NW3) {
 #pragma unroll
@@ -197,8 +209,8 @@ struct AdjCtx {
       }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        h1k[i] = mlp_act<ACT>(c0[i] + b1v);
-        h1k[4 + i] = mlp_act<ACT>(c1[i] + b1v);
+        h1k[i] = mlp_act<ACT>(c0[i] + b1e);
+        h1k[4 + i] = mlp_act<ACT>(c1[i] + b1e);
         s_hA[(4 * lg + i) * G::LDH + col12] = h1k[i];
         s_hA[(16 + 4 * lg + i) * G::LDH + col12] = h1k[4 + i];
       }
@@ -340,6 +352,7 @@ struct AdjWList {              // one weight-gradient pass: activation slots and
   int n;
   int slot[8];
   float c[2][8];
+  float ts[8];                 // the time the network saw at that slot's stage (time-dependent network: the gradient of w_t)
 };
 
 struct AdjShared {
@@ -350,7 +363,9 @@ struct AdjShared {
   float d0[4], d1[4], d2[4];   // misc._select_initial_step intermediates per component (y, a, adj_t, theta)
   float h0;
   double ymax, amax, thmax;    // max |.| of the current state (the accepted y1 of the previous step)
-  float adjt;
+  float adjt;                  // adj_t of the current state ...
+  float adjt_prev;             // ... and at the start of the last accepted step (dense output)
+  float f0t;                   // time-dependent network: f0 of the adj_t component (misc._select_initial_step)
   int s0_cur, th_cur, skip_initb;
 };
 typedef MI_LDS AdjShared lds_AdjShared;
@@ -413,7 +428,7 @@ __device__ __attribute__((noinline)) void adj_tile_pass(const AdjArgs* A_, unsig
       ka[0][i] = (ok && MODE != ADJ_F0) ? (P.fa0 + ebase)[eo[i]] : 0.f;
     }
     if (MODE == ADJ_F0) {
-      cx.eval(y0e, a0e, fn, vn, act_tile + (long long)P.s0_cur * G::SLOT);
+      cx.eval(y0e, a0e, fn, vn, act_tile + (long long)P.s0_cur * G::SLOT, sign * (float)P.t_start);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const long long row = row0 + rbase + i;
@@ -434,7 +449,7 @@ __device__ __attribute__((noinline)) void adj_tile_pass(const AdjArgs* A_, unsig
     if (MODE == ADJ_INITB) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) { ys[i] = y0e[i] + hs * ky[0][i]; as[i] = a0e[i] + hs * ka[0][i]; }          // misc.py:235
-      cx.eval(ys, as, fn, vn, act_tile + 2LL * G::SLOT);
+      cx.eval(ys, as, fn, vn, act_tile + 2LL * G::SLOT, sign * ((float)P.t_start + hs));
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const long long row = row0 + rbase + i;
@@ -461,7 +476,7 @@ __device__ __attribute__((noinline)) void adj_tile_pass(const AdjArgs* A_, unsig
         // stage 1 (c_sol = c_err = c_mid = 0 there for the FSAL pairs in use) leaves no activations; stage S is stage 0 of
         // the next step if this one is accepted
         g_float* act = (SG == 1 || (A.bench_flags & 32)) ? nullptr : act_tile + (long long)(SG == S ? 1 - P.s0_cur : SG) * G::SLOT;
-        cx.eval(ys, as, fn, vn, act);
+        cx.eval(ys, as, fn, vn, act, sign * ((float)P.t_start + A.ca[SG - 1] * hs));     // rk_common.py:50, in the state dtype
 #pragma unroll
         for (int i = 0; i < 4; ++i) { ky[SG][i] = sign * fn[i]; ka[SG][i] = -(sign * vn[i]); }
       };
@@ -538,9 +553,10 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
   const bool mm = w < G::NW12;                              // waves that own output columns
   adj_f4 g1[NC][CB], g2[NC][HB], g3[NC][CB];
   float s1[NC], s2[NC], s3[NC][CB];
+  float st[NC];                                             // sum of t_s (c g1): the gradient of w_t (time-dependent network)
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
-    s1[c] = s2[c] = 0.f;
+    s1[c] = s2[c] = 0.f; st[c] = 0.f;
 #pragma unroll
     for (int b = 0; b < CB; ++b) { g1[c][b] = adj_f4{0, 0, 0, 0}; g3[c][b] = adj_f4{0, 0, 0, 0}; s3[c][b] = 0.f; }
 #pragma unroll
@@ -599,6 +615,7 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
     float cf[NC];
 #pragma unroll
     for (int c = 0; c < NC; ++c) cf[c] = uniform_f(L.c[c][q]);
+    const float tq = uniform_f(L.ts[q]);
     const lds_float* src = stg + (step & 1) * (SHC * LDC) + 4 * lg;
     {                                                       // layer 2: W2 += h1^T (c g2)
       adj_f4 ah1[HB];
@@ -627,6 +644,7 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
         for (int c = 0; c < NC; ++c) {
           const float sb1 = cf[c] * bg1[j];
           s1[c] += sb1;
+          st[c] += tq * sb1;
 #pragma unroll
           for (int b = 0; b < CB; ++b) g1[c][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(ax[b][j], sb1, g1[c][b], 0, 0, 0);
 #pragma unroll
@@ -661,8 +679,9 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
     }
   }
   if (mm && !(abl & 8)) {
-    // canonical order: W1 [d][hd], b1 [hd], W2 [hd][hd], b2 [hd], W3 [hd][d], b3 [d]
-    const int oW1 = 0, oB1 = d * hd, oW2 = oB1 + hd, oB2 = oW2 + hd * hd, oW3 = oB2 + hd, oB3 = oW3 + hd * d;
+    // canonical order: (w_t [hd] when time-dependent,) W1 [d][hd], b1 [hd], W2 [hd][hd], b2 [hd], W3 [hd][d], b3 [d]
+    const int td = A.td;
+    const int oW1 = td * hd, oB1 = oW1 + d * hd, oW2 = oB1 + hd, oB2 = oW2 + hd * hd, oW3 = oB2 + hd, oB3 = oW3 + hd * d;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       g_float* out = (g_float*)A.wpart + ((long long)blockIdx.x * 3 + c_base + c) * A.Ppad;
@@ -689,10 +708,12 @@ __device__ __attribute__((noinline)) void adj_wgrad_pass(const AdjArgs* A_, unsi
           if (m < hd && n < d) adj_store_agent(out + (unsigned)(oW3 + m * d + n), g3[c][b][i]);
         }
       // bias gradients: a lane summed rows 8 lg .. 8 lg + 7 of every tile; fold the four lane groups
-      float t1 = s1[c], t2 = s2[c];
+      float t1 = s1[c], t2 = s2[c], tt = st[c];
       t1 += __shfl_xor(t1, 16, 64); t1 += __shfl_xor(t1, 32, 64);
       t2 += __shfl_xor(t2, 16, 64); t2 += __shfl_xor(t2, 32, 64);
+      tt += __shfl_xor(tt, 16, 64); tt += __shfl_xor(tt, 32, 64);
       if (lg == 0 && colw < hd) { adj_store_agent(out + (unsigned)(oB1 + colw), t1); adj_store_agent(out + (unsigned)(oB2 + colw), t2); }
+      if (td && lg == 0 && colw < hd) adj_store_agent(out + (unsigned)colw, tt);
 #pragma unroll
       for (int b = 0; b < CB; ++b) {
         float t3 = s3[c][b];
@@ -784,7 +805,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
   }
   lds_float* const slice_scratch = (lds_float*)(size_t)smem + (DP * AdjGeom<DP, HP>::LW1 + HP * AdjGeom<DP, HP>::LW3);   // the activation tiles' LDS
   CtrlParams cp = SA.cp;
-  if (threadIdx.x == 0) { sh.tout[0] = A.t_end; persist_init_ctl(s_c, A.p); sh.ok = 1; ash.s0_cur = 0; ash.th_cur = 0; ash.skip_initb = 0; ash.adjt = *A.adjt_in; }
+  if (threadIdx.x == 0) { sh.tout[0] = A.t_end; persist_init_ctl(s_c, A.p); sh.ok = 1; ash.s0_cur = 0; ash.th_cur = 0; ash.skip_initb = 0; ash.adjt = *A.adjt_in; ash.adjt_prev = ash.adjt; ash.f0t = 0.f; }
   cp.t_out = sh.tout;
   __syncthreads();
   const long long npl = SA.batch * (long long)SA.dim;
@@ -795,6 +816,13 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
   float* const thp[2] = {A.theta, A.theta + A.Ppad};
   float* const f0th = A.theta + 2 * (long long)A.Ppad;
   const float msign = -(float)SA.rhs.sign;                  // k_theta = -s X^T Delta
+  const float sgn = (float)SA.rhs.sign;
+  // time-dependent network: theta = (w_t, W1, b1, ...); adj_t's derivative is dot(w_t, b1 slice of theta's derivative)
+  const int td = A.td;
+  const int oB1 = (td + SA.dim) * SA.rhs.hidden, hd_ = SA.rhs.hidden;
+  const g_float* const wt_row = (const g_float*)SA.rhs.w[0];
+  auto wt_of = [&](int p) -> float { return (td && p >= oB1 && p < oB1 + hd_) ? wt_row[p - oB1] : 0.f; };
+  double r4[5];
   const float rtol = (float)cp.rtol, atol = (float)cp.atol;
   const double n_state = (double)cp.n_local, n_theta = (double)A.P;
   unsigned gen = 0;
@@ -810,22 +838,23 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
       P.y0 = A.y_in; P.a0 = A.a_in; P.fy0 = nullptr; P.fa0 = nullptr; P.y1 = nullptr; P.a1 = nullptr;
       P.fy1 = (A.mode == 1 && A.y_out != nullptr) ? A.y_out : fypl[0];
       P.fa1 = (A.mode == 1) ? A.a_out : fapl[0];
-      P.hs = 0.f; P.emit = 0; P.s0_cur = 0; P.t_start = P.t_new = P.dt64 = 0.0;
+      P.hs = 0.f; P.emit = 0; P.s0_cur = 0; P.t_start = A.p.t0; P.t_new = P.dt64 = 0.0;
       AdjWList& L = ash.wl[0];
-      L.n = 1; L.slot[0] = 0; L.c[0][0] = msign; L.c[1][0] = 0.f;
+      L.n = 1; L.slot[0] = 0; L.c[0][0] = msign; L.c[1][0] = 0.f; L.ts[0] = sgn * (float)A.p.t0;
     }
     __syncthreads();
     adj_tile_pass<DP, HP, ACT, ADJ_F0, S>(Ap, smem, ash_off);
     adj_wgrad_pass<DP, HP, 1>(Ap, smem, ash_off, 0, 0);
     const Acc h1 = adj_record(ash.blk[0][0], ash.blk[1][0], ash.blk[0][2], ash.blk[0][3], (int)ash.blk[0][4]);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
-    Acc accT;
+    Acc accT, accD;
     if (ok) {
       adj_slice<1>(A, slice_scratch, [&](int p, const float* s) {
         const float th0 = A.th_in[p];
         if (A.mode == 1) { A.th_out[p] = s[0]; return; }
         thp[0][p] = th0;
         f0th[p] = s[0];
+        accD.suma += (double)(wt_of(p) * s[0]);
         const float sc = atol + fabsf(th0) * rtol;
         const double q0 = (double)(th0 / sc), q1 = (double)(s[0] / sc);
         accT.suma += q0 * q0; accT.sumb += q1 * q1;
@@ -846,7 +875,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
         P.hs = 0.05f; P.t_start = 0.0; P.dt64 = 0.05; P.t_new = 0.05; P.emit = 0; P.s0_cur = 0;
         AdjWList& L = ash.wl[0];
         L.n = 6;
-        for (int q = 0; q < 6; ++q) { L.slot[q] = q == 0 ? 0 : (q == 5 ? 1 : q + 1); L.c[0][q] = 0.01f * (q + 1); L.c[1][q] = -0.02f * (q + 1); }
+        for (int q = 0; q < 6; ++q) { L.slot[q] = q == 0 ? 0 : (q == 5 ? 1 : q + 1); L.c[0][q] = 0.01f * (q + 1); L.c[1][q] = -0.02f * (q + 1); L.ts[q] = 0.f; }
       }
       __syncthreads();
       const long long tb0 = (long long)wall_clock64();
@@ -868,7 +897,13 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     Acc h3;
     h3.suma = accT.suma; h3.sumb = accT.sumb;
     ok = ok && grid_reduce(A.p, h3, sh, gen++, r3, n_tot);
+    if (td) {                                               // f0 of adj_t = dot(w_t, b1 slice of f0_theta)
+      Acc h4;
+      h4.suma = accD.suma;
+      ok = ok && grid_reduce(A.p, h4, sh, gen++, r4, n_tot);
+    }
     if (threadIdx.x == 0 && ok) {
+      if (td) ash.f0t = (float)r4[2];
       s_c.nfe += 1;
       s_c.y0_nonfinite = r1[4] != 0.0;
       ash.ymax = r1[0]; ash.amax = r1[1]; ash.thmax = r2[0];
@@ -876,7 +911,8 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
       const double qt = (double)(at / sct);
       ash.d0[0] = adj_rms(r1[2], n_state); ash.d1[0] = adj_rms(r1[3], n_state);
       ash.d0[1] = adj_rms(r2[2], n_state); ash.d1[1] = adj_rms(r2[3], n_state);
-      ash.d0[2] = adj_rms(qt * qt, 1.0);   ash.d1[2] = adj_rms(0.0, 1.0);
+      const double qf = (double)(ash.f0t / sct);
+      ash.d0[2] = adj_rms(qt * qt, 1.0);   ash.d1[2] = adj_rms(qf * qf, 1.0);
       ash.d0[3] = adj_rms(r3[2], n_theta); ash.d1[3] = adj_rms(r3[3], n_theta);
       float h0;
       if (adj_pymax(ash.d0, 4) < 1e-5f || adj_pymax(ash.d1, 4) < 1e-5f) h0 = 1e-6f;                    // misc.py:230-231
@@ -906,9 +942,9 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     if (threadIdx.x == 0) {
       AdjPlanes& P = ash.P;
       P.y0 = A.y_in; P.a0 = A.a_in; P.fy0 = fypl[0]; P.fa0 = fapl[0]; P.y1 = nullptr; P.a1 = nullptr; P.fy1 = nullptr; P.fa1 = nullptr;
-      P.hs = ash.h0; P.emit = 0; P.s0_cur = 0; P.t_start = P.t_new = P.dt64 = 0.0;
+      P.hs = ash.h0; P.emit = 0; P.s0_cur = 0; P.t_start = A.p.t0; P.t_new = P.dt64 = 0.0;
       AdjWList& L = ash.wl[0];
-      L.n = 1; L.slot[0] = 2; L.c[0][0] = msign; L.c[1][0] = 0.f;
+      L.n = 1; L.slot[0] = 2; L.c[0][0] = msign; L.c[1][0] = 0.f; L.ts[0] = sgn * ((float)A.p.t0 + ash.h0);
     }
     __syncthreads();
     adj_tile_pass<DP, HP, ACT, ADJ_INITB, S>(Ap, smem, ash_off);
@@ -921,17 +957,20 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
         const float sc = atol + fabsf(thp[0][p]) * rtol;
         const double q = (double)((s[0] - f0th[p]) / sc);
         accT.suma += q * q;
+        accT.sumb += (double)(wt_of(p) * s[0]);           // f1 of adj_t rides in the free sum of this record
       });
     }
     Acc h2;
-    h2.suma = accT.suma;
+    h2.suma = accT.suma; h2.sumb = accT.sumb;
     ok = ok && grid_reduce(A.p, h2, sh, gen++, r2, n_tot);
     if (threadIdx.x == 0 && ok) {
       s_c.nfe += 1;
       const float h0 = ash.h0;
       ash.d2[0] = adj_rms(r1[2], n_state) / h0;
       ash.d2[1] = adj_rms(r1[3], n_state) / h0;
-      ash.d2[2] = adj_rms(0.0, 1.0) / h0;
+      const float sct = atol + fabsf(ash.adjt) * rtol;
+      const double qd = td ? (double)(((float)r2[3] - ash.f0t) / sct) : 0.0;
+      ash.d2[2] = adj_rms(qd * qd, 1.0) / h0;
       ash.d2[3] = adj_rms(r2[2], n_theta) / h0;
       float h1v;
       if (adj_pymax(ash.d1, 4) <= 1e-15f && adj_pymax(ash.d2, 4) <= 1e-15f) h1v = nan_maxf(1e-6f, h0 * 1e-3f);    // misc.py:239-241
@@ -980,6 +1019,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
         if (cs == 0.f && ce == 0.f) continue;
         L.slot[L.n] = j == 0 ? s0c : (j == S ? 1 - s0c : j);
         L.c[0][L.n] = cs; L.c[1][L.n] = ce;
+        L.ts[L.n] = sgn * ((float)t1_u + (j == 0 ? 0.f : A.ca[j - 1]) * hs);
         ++L.n;
       }
     }
@@ -992,7 +1032,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     const Acc h1 = adj_record(ash.blk[0][1], ash.blk[1][1], ash.blk[0][2], ash.blk[1][2], 0);
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
     const long long tk3 = (long long)wall_clock64();
-    Acc accT;
+    Acc accT, accD;
     if (ok) {
       const float* th0p = thp[thc];
       float* th1p = thp[1 - thc];
@@ -1001,12 +1041,19 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
         th1p[p] = th1;
         accT.maxb = fmax(accT.maxb, (double)fabsf(th1));
         accT.suma += (double)s[1] * (double)s[1];
+        const float w = wt_of(p);
+        accD.suma += (double)(w * s[0]); accD.sumb += (double)(w * s[1]);
       });
     }
     const long long tk4 = (long long)wall_clock64();
     Acc h2;
     h2.maxa = accT.maxb; h2.suma = accT.suma;
     ok = ok && grid_reduce(A.p, h2, sh, gen++, r2, n_tot);
+    if (td) {                                               // adj_t's step and error estimate: dot(w_t, b1 slice) of theta's two combinations
+      Acc h3;
+      h3.suma = accD.suma; h3.sumb = accD.sumb;
+      ok = ok && grid_reduce(A.p, h3, sh, gen++, r4, n_tot);
+    }
     if (threadIdx.x == 0) {
       prof[0] += tk1 - tk0; prof[1] += tk2 - tk1; prof[2] += tk3 - tk2; prof[3] += tk4 - tk3; prof[4] += (long long)wall_clock64() - tk4;
       AttemptState st = sh.st;
@@ -1016,7 +1063,13 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
         rec[R_SUMB] = 0; rec[R_FLAG] = 0; rec[6] = rec[7] = 0;
         rec[R_MAXA] = ash.ymax; rec[R_MAXB] = r1[0]; rec[R_SUMA] = r1[2]; rec[R_N] = n_state; ratios[0] = error_ratio(rec, cp);
         rec[R_MAXA] = ash.amax; rec[R_MAXB] = r1[1]; rec[R_SUMA] = r1[3]; rec[R_N] = n_state; ratios[1] = error_ratio(rec, cp);
-        {                                                   // adj_t: zero derivative, zero error estimate (misc.py:256-263 all the same)
+        float adjt1 = ash.adjt;
+        if (td) {
+          adjt1 = ash.adjt + (float)r4[2];
+          const float errt = (float)r4[3];
+          rec[R_MAXA] = (double)fabsf(ash.adjt); rec[R_MAXB] = (double)fabsf(adjt1); rec[R_SUMA] = (double)errt * (double)errt; rec[R_N] = 1.0;
+          ratios[2] = error_ratio(rec, cp);
+        } else {                                            // adj_t: zero derivative, zero error estimate (misc.py:256-263 all the same)
           const float tolt = atol + rtol * fabsf(ash.adjt);
           const float q = 0.0f / tolt;
           ratios[2] = (double)(q * q);
@@ -1029,7 +1082,10 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
           accept = accept && (ratios[i] <= 1.0);            // dopri5.py:108
         }
         attempt_tail(st, rmax, accept, cp);
-        if (st.accepted) { ash.ymax = r1[0]; ash.amax = r1[1]; ash.thmax = r2[0]; ash.s0_cur = 1 - s0c; ash.th_cur = 1 - thc; }
+        if (st.accepted) {
+          ash.ymax = r1[0]; ash.amax = r1[1]; ash.thmax = r2[0]; ash.s0_cur = 1 - s0c; ash.th_cur = 1 - thc;
+          ash.adjt_prev = ash.adjt; ash.adjt = adjt1;
+        }
       }
       publish(st);
       sh.st = st;
@@ -1067,6 +1123,7 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
         if (wx == 0.f) continue;
         L.slot[L.n] = j == 0 ? 1 - s0c : (j == S ? s0c : j);
         L.c[0][L.n] = (hs * wx) * msign; L.c[1][L.n] = 0.f;
+        L.ts[L.n] = sgn * ((float)ts_l + (j == 0 ? 0.f : A.ca[j - 1]) * hs);
         ++L.n;
       }
     }
@@ -1076,8 +1133,15 @@ __global__ __launch_bounds__((64 * AdjGeom<DP, HP>::NW)) void k_adjoint_mlp(cons
     ok = grid_reduce(A.p, h1, sh, gen++, r1, n_tot);
     if (ok) {
       const float* th0p = thp[1 - thc];
-      adj_slice<1>(A, slice_scratch, [&](int p, const float* s) { A.th_out[p] = th0p[p] + s[0]; });
-      if (blockIdx.x == 0 && threadIdx.x == 0) {            // adj_t: the fit of a constant, evaluated as the reference does
+      Acc accD;
+      adj_slice<1>(A, slice_scratch, [&](int p, const float* s) {
+        A.th_out[p] = th0p[p] + s[0];
+        accD.suma += (double)(wt_of(p) * s[0]);
+      });
+      if (td) {                                             // adj_t(t_end) = adj_t at the start of the last step + dot(w_t, b1 slice of the same combination)
+        ok = grid_reduce(A.p, accD, sh, gen++, r4, n_tot);
+        if (ok && blockIdx.x == 0 && threadIdx.x == 0) *A.adjt_out = ash.adjt_prev + (float)r4[2];
+      } else if (blockIdx.x == 0 && threadIdx.x == 0) {     // adj_t: the fit of a constant, evaluated as the reference does
         const float at = ash.adjt;
         float co[5];
         quartic_from_mid<float>(at, at, at, 0.f, 0.f, hs, co);

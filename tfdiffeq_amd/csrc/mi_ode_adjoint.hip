@@ -86,7 +86,7 @@ extern "C" int mi_ode_adjoint_create(const mi_ode_adjoint_desc* desc, mi_ode_adj
   h->hp = pad16(desc->hidden, 16, 128);
   for (int act = 0; act < 3; ++act) h->fn[act] = adj_fn_dims(h->dp, h->hp, act, &h->lds, &h->block);
   const int d = desc->dim, hd = desc->hidden;
-  h->P = d * hd + hd + hd * hd + hd + hd * d + d;
+  h->P = (desc->time_dependent ? hd : 0) + d * hd + hd + hd * hd + hd + hd * d + d;
   h->Ppad = (h->P + 63) / 64 * 64;
   h->ntiles = (desc->batch + 31) / 32;
   int dev = 0, cus = 0, per_cu = 0;
@@ -143,9 +143,9 @@ static int adj_launch(mi_ode_adjoint* h, const mi_ode_rhs* rhs, int mode, const 
       rhs->w[2] == nullptr) {
     mi_set_error("fused adjoint: rhs must be the MLP-tanh descriptor the handle was created for"); return MI_ODE_E_INVALID;
   }
-  if (rhs->scalars[1] != 0.0) {                  // (mi_ode_rhs carries no dim: this is the one shape mismatch the descriptor can show)
-    mi_set_error("fused adjoint: the kernel covers the time-independent network only (rhs.scalars[1] != 0: w[0] is [dim + 1, hidden] - "
-                 "adj_t has a real derivative there); use the generic adjoint");
+  if ((rhs->scalars[1] != 0.0) != (h->d.time_dependent != 0)) {   // (mi_ode_rhs carries no dim: this is the one shape mismatch the descriptor can show)
+    mi_set_error("fused adjoint: the handle was created with time_dependent = %d but rhs.scalars[1] says %s (w[0] is [dim + 1, hidden] for the "
+                 "time-dependent network)", (int)h->d.time_dependent, rhs->scalars[1] != 0.0 ? "time-dependent" : "time-independent");
     return MI_ODE_E_INVALID;
   }
   MI_HIP(hipStreamSynchronize(st));              // the pinned argument block may still be in flight from a previous call
@@ -163,6 +163,8 @@ static int adj_launch(mi_ode_adjoint* h, const mi_ode_rhs* rhs, int mode, const 
   for (int i = 0; i < 6; ++i)
     for (int j = 0; j <= i; ++j) A.cb[i][j] = (float)tb.beta[i][j];
   for (int j = 0; j <= 6; ++j) { A.ce[j] = (float)tb.c_error[j]; A.cm[j] = (float)tb.c_mid[j]; }
+  for (int j = 0; j < 6; ++j) A.ca[j] = (float)tb.alpha[j];
+  A.td = h->d.time_dependent ? 1 : 0;
   S.partials = h->partials;
   const bool reversed = mode == 0 && t_end < t_start;       // misc.py:311-321: t <- -t, f <- -f(-t, y)
   for (int i = 0; i < 8; ++i) S.rhs.s[i] = rhs->scalars[i];
@@ -242,5 +244,13 @@ extern "C" int mi_ode_adjoint_dynamics(mi_ode_adjoint_handle h, const mi_ode_rhs
       vjp_params_out_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
   // (theta / adj_t inputs are not read by the dynamics; the kernel wants valid pointers)
   return adj_launch(h, rhs, 1, y_dev, adj_y_dev, h->theta, vjp_params_out_dev, 0.0, 1.0, f_out_dev, vjp_y_out_dev, h->theta, vjp_params_out_dev,
+                    nullptr, (hipStream_t)stream);
+}
+
+extern "C" int mi_ode_adjoint_dynamics_at(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, double t, const void* y_dev, const void* adj_y_dev,
+                                          void* f_out_dev, void* vjp_y_out_dev, void* vjp_params_out_dev, void* stream) {
+  if (h == nullptr || y_dev == nullptr || adj_y_dev == nullptr || f_out_dev == nullptr || vjp_y_out_dev == nullptr ||
+      vjp_params_out_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
+  return adj_launch(h, rhs, 1, y_dev, adj_y_dev, h->theta, vjp_params_out_dev, t, t + 1.0, f_out_dev, vjp_y_out_dev, h->theta, vjp_params_out_dev,
                     nullptr, (hipStream_t)stream);
 }

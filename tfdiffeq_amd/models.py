@@ -3,8 +3,8 @@
 `ODEBlock` is config 5's real caller: t = [0, 1], rtol = atol = tol (1e-3), `max_num_steps = 1000`, optional zero
 augmentation, returns the state at t = 1 (dense_odenet.py:131-191).  When the ODEFunc has a relu (the reference's default),
 softplus or tanh non-linearity, inference runs on the fused MFMA kernel (`rhs.MLP`, csrc/mi_ode_mlp.h; `time_dependent=True`
-included: the stage time only shifts the first layer's bias) and training of the time-independent network on it plus the
-fused adjoint kernel (csrc/mi_ode_adjoint.h); otherwise the plane-kernel engine (and the generic `odeint_adjoint`) take over.
+included: the stage time only shifts the first layer's bias) and training on it plus the fused adjoint kernel
+(csrc/mi_ode_adjoint.h; time-dependent networks too); otherwise the plane-kernel engine (and the generic `odeint_adjoint`) take over.
 """
 import torch
 from torch import nn
