@@ -43,6 +43,7 @@ yo = torch.rand(4096, 2, dtype=torch.float64, device=dev) + 0.5
 to = torch.tensor([0., 50.0], dtype=torch.float64)
 for label, opts in (("default ('auto': device controller, eager first, then one hipGraph replay per attempt)", None),
                     ("graph=True (record after the first attempt)", {'graph': True}),
+                    ("graph='reuse' (the attempt recorded by the first call is replayed by the later ones)", {'graph': 'reuse'}),
                     ("graph=False (device controller, one Python evaluation per stage)", {'graph': False}),
                     ("graph='host' (rounds 1-3: controller on the host, one synchronisation per attempt)", {'graph': 'host'})):
     run('3-op callable b4096 dopri5 t=[0,50], ' + label, osc3, yo, to, reps=3, method='dopri5', rtol=1e-6, atol=1e-9, options=opts)
@@ -64,6 +65,8 @@ for m in ('dopri5', 'tsit5', 'rk4'):
     if m != 'rk4':
         run('python callable lorenz b4096 %s, graph=True' % m, lorenz, y0, tt, method=m, rtol=1e-6, atol=1e-9,
             options={'graph': True})
+        run("python callable lorenz b4096 %s, graph='reuse'" % m, lorenz, y0, tt, method=m, rtol=1e-6, atol=1e-9,
+            options={'graph': 'reuse'})
         run('python callable lorenz b4096 %s, host controller' % m, lorenz, y0, tt, method=m, rtol=1e-6, atol=1e-9,
             options={'graph': 'host'})
         t10 = torch.tensor([0., 10.0], dtype=torch.float64)

@@ -238,3 +238,61 @@ def test_reference_unit_test_shapes_through_the_default_path():
         assert rel < {'bosh3': 5e-3, 'adaptive_heun': 5e-3}.get(method, 1e-4), (method, rel)
         host = odeint(sine, y0, t, method=method, options={'graph': 'host'}).cpu().numpy()[:, 0]
         assert np.abs(got - host).max() <= 1e-9 * np.abs(host).max(), method
+
+
+def test_recorded_attempt_reused_across_calls():
+    """options={'graph': 'reuse'}: the first call records the attempt, later calls with the same callable / shapes / tolerances only
+    reset the controller and replay - identical bits to the default schedule for new initial values, other time grids (more output
+    times, reversed), and after an in-place parameter update; a different callable, shape or tolerance records its own."""
+    from tfdiffeq_amd import graph_step, odeint
+    graph_step.clear_recorded_attempts()
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            torch.manual_seed(3)
+            self.lin = torch.nn.Linear(3, 3).double()
+            self.nfe = 0
+
+        def forward(self, t, y):
+            self.nfe += 1
+            return torch.tanh(self.lin(y)) - 0.1 * y * torch.cos(t)
+    net = Net().to(dev())
+    opts = {'graph': 'reuse'}
+    with torch.no_grad():
+        cases = [(y0_lorenz(64, 5), torch.tensor([0., 2.0, 4.0], dtype=torch.float64)),
+                 (y0_lorenz(64, 6), torch.tensor([0., 1.0, 1.5, 5.0, 5.1], dtype=torch.float64)),
+                 (y0_lorenz(64, 7), torch.tensor([3.0, 1.0, 0.0], dtype=torch.float64))]
+        for i, (y0, t) in enumerate(cases):
+            net.nfe = 0
+            got = odeint(net, y0.to(dev()), t, rtol=1e-7, atol=1e-9, method='dopri5', options=dict(opts))
+            st = dict(odeint.last_stats)
+            nfe_reuse = net.nfe
+            if i == 0 or i == 2:                                   # (reversed time wraps f differently: a recording of its own)
+                assert 'eager attempts first' in st['engine'], st
+            else:
+                assert 'recorded by an earlier call' in st['engine'] and st['replays'] >= st['n_attempts'], st
+            net.nfe = 0
+            ref = odeint(net, y0.to(dev()), t, rtol=1e-7, atol=1e-9, method='dopri5')
+            rs = dict(odeint.last_stats)
+            assert torch.equal(got, ref)
+            assert (st['n_attempts'], st['n_accepted'], st['nfe']) == (rs['n_attempts'], rs['n_accepted'], rs['nfe'])
+            assert nfe_reuse == net.nfe == 2 + 6 * st['n_attempts']   # replayed evaluations are credited to the module's counter (dopri5.py:71-75 + six per attempt)
+        assert len(graph_step._RECORDED) == 2
+        # an optimizer-style in-place update is seen by the replays (the graph reads the parameter's memory)
+        y0, t = cases[0]
+        net.lin.weight.mul_(0.5)
+        got = odeint(net, y0.to(dev()), t, rtol=1e-7, atol=1e-9, method='dopri5', options=dict(opts))
+        assert 'recorded by an earlier call' in odeint.last_stats['engine']
+        ref = odeint(net, y0.to(dev()), t, rtol=1e-7, atol=1e-9, method='dopri5')
+        assert torch.equal(got, ref)
+        # other tolerances / shapes / callables do not hit the recording
+        odeint(net, y0.to(dev()), t, rtol=1e-6, atol=1e-9, method='dopri5', options=dict(opts))
+        assert 'eager attempts first' in odeint.last_stats['engine']
+        odeint(net, y0_lorenz(32, 5).to(dev()), t, rtol=1e-7, atol=1e-9, method='dopri5', options=dict(opts))
+        assert 'eager attempts first' in odeint.last_stats['engine']
+        odeint(lorenz, y0.to(dev()), torch.tensor([0., 0.5], dtype=torch.float64), rtol=1e-7, atol=1e-9, method='dopri5', options=dict(opts))
+        assert 'eager attempts first' in odeint.last_stats['engine']
+        assert len(graph_step._RECORDED) <= graph_step._RECORDED_MAX
+    graph_step.clear_recorded_attempts()
+    assert len(graph_step._RECORDED) == 0

@@ -8,6 +8,8 @@ estimate and its norms - and replayed per attempt with new (t0, dt); the host on
 and runs the controller.  Opt-in (`options={'graph': True}`): f must be capture-safe (static shapes, no host
 synchronisation, no data-dependent Python control flow), which holds for the usual tensor-expression right-hand sides.
 """
+import collections
+
 import torch
 
 from .misc import _error_norms
@@ -188,9 +190,83 @@ def _opq_handle(lib, key, desc, device):
 def clear_opq_handles():
     from . import _native as N
     lib = N.load()
+    clear_recorded_attempts()
     for k_ in list(_OPQ_FREE):
         for h in _OPQ_FREE.pop(k_):
             lib.mi_ode_opq_destroy(h)
+
+
+# ---- options={'graph': 'reuse'}: the recorded attempt outlives the call ----------------------------------------------------
+# Recording an attempt costs two eager attempts, the capture and the instantiation of the graph - 2.5 ms for a 3-op callable, 5 ms
+# for a ten-op one, which is most of a call of 40 attempts.  A training loop or a parameter sweep calls odeint with the SAME callable,
+# shapes and tolerances again and again: with graph='reuse' the engine (native handle, static state buffers, the graph) is kept and
+# later calls only copy y0 / f0 in, reset the controller record and replay.  This is a promise BY THE CALLER that f computes the same
+# function of (t, y) every time, up to in-place updates of tensors it reads (optimizer steps): whatever else f depends on - a Python
+# float it closes over, a rebound parameter tensor, module.training - is frozen at its value when the attempt was recorded.  Hence
+# opt-in.  Keyed on the identity of the user's callable (checked through a weak reference), the wrappers around it, the state's
+# shapes / dtype / device and everything the native handle was created with.
+_RECORDED = collections.OrderedDict()
+_RECORDED_MAX = 4
+
+
+def _user_callable(func):
+    chain = []
+    base = func
+    for _ in range(8):
+        chain.append(type(base).__name__)
+        nxt = getattr(base, 'base', None)
+        if nxt is None:
+            nxt = getattr(base, 'base_func', None)
+        if nxt is None:
+            break
+        base = nxt
+    return base, tuple(chain)
+
+
+def _recorded_key(solver):
+    base, chain = _user_callable(solver.func)
+    tol = (tuple(float(r) for r in solver.rtol), tuple(float(a) for a in solver.atol)) if not solver.pooled_ratio else \
+        (float(solver.rtol), float(solver.atol))
+    return (id(base), chain, type(solver).__name__, tuple((tuple(y.shape), y.dtype, str(y.device)) for y in solver.y0), tol,
+            float(solver.safety), float(solver.ifactor), float(solver.dfactor), int(solver.max_num_steps)), base
+
+
+def recorded_engine(solver):
+    """The engine an earlier graph='reuse' call with the same callable / shapes / tolerances left behind, or None."""
+    key, base = _recorded_key(solver)
+    hit = _RECORDED.get(key)
+    if hit is None:
+        return None
+    eng, ref = hit
+    if (ref() if ref is not None else None) is not base or eng.graph is None:          # the id was recycled by another object
+        _RECORDED.pop(key)
+        eng.close()
+        return None
+    _RECORDED.move_to_end(key)
+    return eng
+
+
+def keep_recorded(solver, eng):
+    import weakref
+    key, base = _recorded_key(solver)
+    try:
+        ref = weakref.ref(base)
+    except TypeError:                                            # not weak-referenceable (a builtin, a __slots__ object): nothing to pin the id to
+        eng.close()
+        return
+    old = _RECORDED.pop(key, None)
+    if old is not None and old[0] is not eng:
+        old[0].close()
+    _RECORDED[key] = (eng, ref)
+    while len(_RECORDED) > _RECORDED_MAX:
+        _, (e_, _r) = _RECORDED.popitem(last=False)
+        e_.close()
+
+
+def clear_recorded_attempts():
+    while _RECORDED:
+        _, (e_, _r) = _RECORDED.popitem()
+        e_.close()
 
 
 class DeviceControlledRK(object):
@@ -331,11 +407,19 @@ class DeviceControlledRK(object):
         for o, y in zip(outs, y0):
             o[0].copy_(y)
         self.info = {'engine': 'device-controlled attempts (one Python evaluation per stage)', 'replays': 0, 'polls': 0}
+        self.py_calls = 0
         if T == 1:
             return outs
-        # static state buffers: commit() moves y1 / f1 into them on accept, the stage combinations always read them
-        self.Y0 = tuple(torch.empty_like(y, memory_format=torch.contiguous_format).copy_(y) for y in y0)
-        self.F0 = tuple(torch.empty_like(f, memory_format=torch.contiguous_format).copy_(f) for f in f0)
+        replay_only = self.captured and self.graph is not None    # graph='reuse': an earlier call recorded the attempt
+        if replay_only:
+            for dst, src in zip(self.Y0, y0):
+                dst.copy_(src)
+            for dst, src in zip(self.F0, f0):
+                dst.copy_(src)
+        else:
+            # static state buffers: commit() moves y1 / f1 into them on accept, the stage combinations always read them
+            self.Y0 = tuple(torch.empty_like(y, memory_format=torch.contiguous_format).copy_(y) for y in y0)
+            self.F0 = tuple(torch.empty_like(f, memory_format=torch.contiguous_format).copy_(f) for f in f0)
         n_out = T - 1
         tt = self._np.ascontiguousarray(t64[1:], dtype=self._np.float64)
         rows = (C.c_void_p * self.ncomp)(*[o[1].data_ptr() for o in outs])
@@ -348,6 +432,16 @@ class DeviceControlledRK(object):
             eager = 0
             done = False
             autograd = _AutogradSeen()
+            if replay_only:
+                self.info['engine'] = 'device-controlled attempts (hipGraph recorded by an earlier call, replayed)'
+                chunk = 8                                          # (nothing is known about this call's step sizes yet; replays after `done` are no-ops)
+                while not done:
+                    for _ in range(chunk):
+                        self.graph.replay()
+                    self.info['replays'] += chunk
+                    done, rc = self._poll()
+                    self.info['polls'] += 1
+                    chunk = min(self.MAX_CHUNK, max(2, self._remaining(t_end)))
             while not done:
                 with autograd:
                     keep = self._attempt()

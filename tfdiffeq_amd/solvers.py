@@ -710,8 +710,10 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         # after the first attempt; False - never record; 'host' - the round-1 loop with the controller on the host (one
         # synchronisation per attempt), which is also what a process group or force_plane_kernels selects
         self._graph = unused_kwargs.pop('graph', 'auto')
-        if self._graph not in ('auto', 'host', True, False):
-            raise ValueError("options['graph'] must be True, False, 'auto' or 'host'")
+        # 'reuse' - like True, and the recorded attempt is kept for later calls with the same callable, shapes and tolerances
+        # (graph_step: the caller promises f stays the same function up to in-place updates of the tensors it reads)
+        if self._graph not in ('auto', 'host', 'reuse', True, False):
+            raise ValueError("options['graph'] must be True, False, 'auto', 'host' or 'reuse'")
         self._graph_attempt = None
         self._fusion = unused_kwargs.pop('fusion', 0)
         _handle_unused_kwargs(self, unused_kwargs)
@@ -820,16 +822,24 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             return None
         if self.interp != N.INTERP_QUARTIC_MID and len(self.tableau.alpha) != 6:
             return None
-        from .graph_step import DeviceControlledRK, _credit_nfe
+        from .graph_step import DeviceControlledRK, _credit_nfe, keep_recorded, recorded_engine
         t64 = t.to(torch.float64)                     # solvers.py:30
         self.before_integrate(t64)                    # f0 and the first step size, as the reference forms them (dopri5.py:70-79)
-        eng = DeviceControlledRK(self, graph=self._graph)
+        reuse = self._graph == 'reuse'
+        eng = recorded_engine(self) if reuse else None
+        if eng is None:
+            eng = DeviceControlledRK(self, graph=True if reuse else self._graph)
         try:
             outs = eng.integrate(t64.numpy(), y0, self.rk_state.f1, float(self.rk_state.dt))
             st = eng.stats.as_dict()
             info = dict(eng.info)
             py_calls = eng.py_calls
-        finally:
+        except BaseException:
+            eng.close()
+            raise
+        if reuse and eng.captured and eng.graph is not None:
+            keep_recorded(self, eng)
+        else:
             eng.close()
         self.stats = st
         self.stats.update(info)
