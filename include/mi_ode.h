@@ -393,7 +393,10 @@ int mi_ode_opq_destroy(mi_ode_opq_handle h);
 const double* mi_ode_opq_dt_dev(mi_ode_opq_handle h);
 /* Arms an integration: rk_state = (t0, t0, first_dt) (dopri5.py:79), the output cursor over t_out_host[0 .. n_out-1]
  * (strictly increasing, all > t0; solvers.py:31-35), out_dev[c] = the [n_out, n[c]] solution rows of component c, and the
- * first attempt's stage times into stage_times_dev ([S] elements of the state dtype; rewritten after every attempt). */
+ * first attempt's stage times into stage_times_dev ([S] elements of the state dtype; rewritten after every attempt).
+ * A recorded attempt (finish + commit captured in a hipGraph) stays valid across opq_begin calls: the kernels read the solution
+ * rows' addresses and the output times from tables inside the handle when they run - as long as n_out never exceeds what the
+ * handle has held before (1024 at creation; a larger n_out moves the output-time table, and the attempt must be recorded again). */
 int mi_ode_opq_begin(mi_ode_opq_handle h, double t0, double first_dt, const double* t_out_host, int32_t n_out,
                      void* const* out_dev, void* stage_times_dev, void* stream);
 int mi_ode_opq_finish(mi_ode_opq_handle h, const void* const* y0_dev, const void* const* y1_dev, const void* const* k_dev,

@@ -294,5 +294,12 @@ def test_recorded_attempt_reused_across_calls():
         odeint(lorenz, y0.to(dev()), torch.tensor([0., 0.5], dtype=torch.float64), rtol=1e-7, atol=1e-9, method='dopri5', options=dict(opts))
         assert 'eager attempts first' in odeint.last_stats['engine']
         assert len(graph_step._RECORDED) <= graph_step._RECORDED_MAX
+        # more output times than the native handle has held so far (1024): its output-time table moves, the attempt is recorded again -
+        # and that recording serves the next call
+        for n_t, label in ((1100, 'eager attempts first'), (1100, 'recorded by an earlier call'), (3, 'recorded by an earlier call')):
+            tl = torch.linspace(0., 2., n_t, dtype=torch.float64)
+            got = odeint(net, y0.to(dev()), tl, rtol=1e-7, atol=1e-9, method='dopri5', options=dict(opts))
+            assert label in odeint.last_stats['engine'], (n_t, odeint.last_stats)
+            assert torch.equal(got, odeint(net, y0.to(dev()), tl, rtol=1e-7, atol=1e-9, method='dopri5'))
     graph_step.clear_recorded_attempts()
     assert len(graph_step._RECORDED) == 0

@@ -705,13 +705,14 @@ def test_time_dependent_odefunc_on_the_fused_kernel(act, method):
         # a shifted time grid gives another answer
         shifted = odeint(d, y0, t + 1.0, **kw)
         assert (shifted[-1] - a[-1]).abs().max().item() > 1e-3
-    # ODEBlock: inference on the fused kernel, training through the generic adjoint (adj_t has a real derivative there)
+    # ODEBlock: inference on the fused kernel; training on the fused adjoint kernel too since round 4 (adj_t's derivative is
+    # dot(w_t, .) of theta's b1 slice, tests/test_gpu_adjoint_fused.py)
     block = models.ODEBlock(func, tol=1e-4, adjoint=True, solver='dopri5')
     with torch.no_grad():
         out = block(y0)
     assert odeint.last_stats.get('n_launches') == 1
     x = y0.clone().requires_grad_(True)
     block(x).pow(2).sum().backward()
-    assert not odeint_adjoint.last_backward_stats['engine'].startswith('fused')
+    assert odeint_adjoint.last_backward_stats['engine'].startswith('fused')
     assert x.grad is not None and all(p.grad is not None and torch.isfinite(p.grad).all() for p in func.parameters())
     assert float(func.fc1.weight.grad[:, 0].abs().max()) > 0.0

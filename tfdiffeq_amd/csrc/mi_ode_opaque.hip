@@ -100,7 +100,8 @@ struct OpqCommit {
   void* f0;
   const void* y1;
   const void* k[MI_ODE_MAX_K];   // k[0] is f0's buffer
-  void* out;                     // [n_out, n] solution rows of this component
+  void* const* out_tab;          // device table of the components' solution rows [n_out, n], rewritten by every opq_begin: read when the
+  int comp;                      // kernel runs, so that a recorded attempt replayed by a LATER call writes that call's rows
 };
 
 template <typename T, int NK>
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_opq_commit(const Ctl* c, OpqCommit P, l
   T* y0p = (T*)P.y0;
   T* f0p = (T*)P.f0;
   const T* y1p = (const T*)P.y1;
-  T* out = (T*)P.out;
+  T* out = hi > lo ? (T*)P.out_tab[P.comp] : nullptr;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
     const T y1 = y1p[i];
     const T f1 = ((const T*)P.k[NK - 1])[i];
@@ -146,6 +147,8 @@ struct mi_ode_opq {
   double* t_out_host;          // pinned
   int t_out_cap;
   void* out[MI_ODE_MAX_SEGMENTS];
+  void** out_tab_dev;          // device copy of out[] (what the commit kernels read)
+  void** out_tab_host;         // pinned staging
   int grid[MI_ODE_MAX_SEGMENTS];
   CtrlParams cp;
   InterpParams ip;
@@ -161,6 +164,8 @@ extern "C" int mi_ode_opq_destroy(mi_ode_opq_handle h) {
   if (h->t_out_dev) (void)hipFree(h->t_out_dev);
   if (h->ctl_host) (void)hipHostFree(h->ctl_host);
   if (h->t_out_host) (void)hipHostFree(h->t_out_host);
+  if (h->out_tab_dev) (void)hipFree(h->out_tab_dev);
+  if (h->out_tab_host) (void)hipHostFree(h->out_tab_host);
   delete h;
   return 0;
 }
@@ -188,6 +193,8 @@ extern "C" int mi_ode_opq_create(const mi_ode_opq_desc* d, mi_ode_opq_handle* ou
   h->t_out_cap = 1024;                           // (allocated up front: a captured graph holds the device address)
   if (e == hipSuccess) e = hipMalloc((void**)&h->t_out_dev, (size_t)h->t_out_cap * sizeof(double));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->t_out_host, (size_t)h->t_out_cap * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->out_tab_dev, MI_ODE_MAX_SEGMENTS * sizeof(void*));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&h->out_tab_host, MI_ODE_MAX_SEGMENTS * sizeof(void*));
   if (e != hipSuccess) {
     mi_set_error("opq_create: allocation failed: %s", hipGetErrorString(e));
     mi_ode_opq_destroy(h);
@@ -247,7 +254,8 @@ extern "C" int mi_ode_opq_begin(mi_ode_opq_handle h, double t0, double first_dt,
     MI_HIP(hipMemcpyAsync(h->t_out_dev, h->t_out_host, (size_t)n_out * sizeof(double), hipMemcpyHostToDevice, st));
   }
   h->cp.t_out = h->t_out_dev;
-  for (int k = 0; k < h->d.n_comp; ++k) h->out[k] = n_out > 0 ? out_dev[k] : nullptr;
+  for (int k = 0; k < MI_ODE_MAX_SEGMENTS; ++k) h->out_tab_host[k] = h->out[k] = (k < h->d.n_comp && n_out > 0) ? out_dev[k] : nullptr;
+  MI_HIP(hipMemcpyAsync(h->out_tab_dev, h->out_tab_host, MI_ODE_MAX_SEGMENTS * sizeof(void*), hipMemcpyHostToDevice, st));
   Ctl* c = h->ctl_host;
   memset(c, 0, sizeof(Ctl));
   c->t0 = c->t1 = t0;
@@ -310,7 +318,7 @@ extern "C" int mi_ode_opq_commit(mi_ode_opq_handle h, void* const* y0_dev, void*
   for (int c = 0; c < h->d.n_comp; ++c) {
     OpqCommit P;
     memset(&P, 0, sizeof(P));
-    P.y0 = y0_dev[c]; P.f0 = f0_dev[c]; P.y1 = y1_dev[c]; P.out = h->out[c];
+    P.y0 = y0_dev[c]; P.f0 = f0_dev[c]; P.y1 = y1_dev[c]; P.out_tab = h->out_tab_dev; P.comp = c;
     if (!P.y0 || !P.f0 || !P.y1) { mi_set_error("opq_commit: null state"); return MI_ODE_E_INVALID; }
     for (int j = 0; j < h->nk; ++j) P.k[j] = k_dev[c * h->nk + j];
     const int rc = h->is_f32 ? opq_commit_t<float>(h, P, c, st) : opq_commit_t<double>(h, P, c, st);

@@ -330,6 +330,7 @@ class DeviceControlledRK(object):
         self.graph = None
         self.py_calls = 0
         self.captured = False
+        self._t_cap = 1024                                        # output times the native handle holds without reallocating
         self._np = np
 
     def close(self):
@@ -410,6 +411,10 @@ class DeviceControlledRK(object):
         self.py_calls = 0
         if T == 1:
             return outs
+        n_out = T - 1
+        if self.captured and n_out > self._t_cap:                 # opq_begin is about to move the output-time buffer the recorded kernels
+            self.graph, self._keep, self.captured = None, None, False      # point to (include/mi_ode.h): record again
+        self._t_cap = max(self._t_cap, n_out)
         replay_only = self.captured and self.graph is not None    # graph='reuse': an earlier call recorded the attempt
         if replay_only:
             for dst, src in zip(self.Y0, y0):
@@ -420,7 +425,6 @@ class DeviceControlledRK(object):
             # static state buffers: commit() moves y1 / f1 into them on accept, the stage combinations always read them
             self.Y0 = tuple(torch.empty_like(y, memory_format=torch.contiguous_format).copy_(y) for y in y0)
             self.F0 = tuple(torch.empty_like(f, memory_format=torch.contiguous_format).copy_(f) for f in f0)
-        n_out = T - 1
         tt = self._np.ascontiguousarray(t64[1:], dtype=self._np.float64)
         rows = (C.c_void_p * self.ncomp)(*[o[1].data_ptr() for o in outs])
         with torch.cuda.device(self.device):
