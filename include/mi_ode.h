@@ -334,6 +334,19 @@ int mi_ode_adjoint_dynamics(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, cons
 int mi_ode_adjoint_dynamics_at(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, double t, const void* y_dev, const void* adj_y_dev,
                                void* f_out_dev, void* vjp_y_out_dev, void* vjp_params_out_dev, void* stream);
 
+/* ---- (A'') the linear right-hand side under odeint_adjoint -------------------------------------------------------- */
+/* tfdiffeq/adjoint.py:69-105 for f(t, y) = y W + b: the augmented dynamics are (y W + b, -adj_y W^T, 0, -(y^T adj_y), -sum_rows adj_y).
+ * The first two are the linear right-hand side itself (mi_ode_eval_rhs of a handle created with W, and of one created with -W^T);
+ * the parameter part is a GEMM with M = N = dim and K = batch - the shape vendor BLAS serves worst (0.9 TFLOP/s fp64 in rocBLAS at
+ * 65536 x 128) - and this entry point:
+ *     out_w[dim, dim] = scale * (y^T a)   (weights [in, out], the layout of mi_ode_rhs.w)      out_b[dim] = scale * column sums of a
+ * over two [batch, dim] device planes, dim <= 128, fp32 or fp64 (MFMA); out_b nullable.  Deterministic (slab partials folded in
+ * slab order).  workspace_dev: mi_ode_outer_workspace_bytes(dtype, batch, dim) bytes of device scratch.  Enqueues two kernels on
+ * `stream` and returns: no synchronisation, capturable in a hipGraph. */
+int64_t mi_ode_outer_workspace_bytes(int32_t dtype, int64_t batch, int32_t dim);
+int mi_ode_outer_reduce(int32_t dtype, int64_t batch, int32_t dim, const void* y_dev, const void* a_dev, double scale,
+                        void* out_w_dev, void* out_b_dev, void* workspace_dev, void* stream);
+
 /* ---- function-level parity surface of the step controller ----------------------------------- */
 /* The scalar tail of one step attempt exactly as the kernels run it (csrc/mi_ode_ctrl_dev.h, ONE device thread per case):
  *   phase 2 (attempt): misc._compute_error_ratio's scalar part + accept test + misc._optimal_step_size / tsit5._optimal_step_size

@@ -1,7 +1,8 @@
 """One training step of ODEBlock(adjoint=True) at BASELINE config 5's shape (batch 32768, 64-128-128-64 tanh, fp32, tol 1e-3):
 forward + loss + backward, fused kernels vs the generic plane-kernel path.  Prints one JSON line per mode.
-usage: python scripts/adjoint_train_step.py [fused|planes|both] [steps]"""
+usage: python scripts/adjoint_train_step.py [fused|planes|both] [steps]      (ADJ_TD=1: the time-dependent network)"""
 import json
+import os
 import sys
 import time
 
@@ -14,7 +15,8 @@ mode = sys.argv[1] if len(sys.argv) > 1 else 'both'
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 dev = 'cuda'
 torch.manual_seed(0)
-block = models.ODEBlock(models.ODEFunc(64, 128, non_linearity='tanh'), tol=1e-3, adjoint=True).to(dev)
+block = models.ODEBlock(models.ODEFunc(64, 128, non_linearity='tanh', time_dependent=os.environ.get('ADJ_TD', '0') == '1'), tol=1e-3,
+                        adjoint=True).to(dev)
 x = torch.randn(32768, 64, device=dev)
 w = torch.randn(32768, 64, device=dev)
 

@@ -139,6 +139,9 @@ _PROTOS = {
                                           C.c_void_p]),
     'mi_ode_adjoint_dynamics_at': (C.c_int, [C.c_void_p, C.POINTER(Rhs), C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                              C.c_void_p, C.c_void_p]),
+    'mi_ode_outer_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int64, C.c_int32]),
+    'mi_ode_outer_reduce': (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p]),
     'mi_ode_opq_create': (C.c_int, [C.POINTER(OpqDesc), C.POINTER(C.c_void_p)]),
     'mi_ode_opq_destroy': (C.c_int, [C.c_void_p]),
     'mi_ode_opq_dt_dev': (C.c_void_p, [C.c_void_p]),

@@ -180,6 +180,69 @@ def _fused_plan(func, n_tensors, cfg, like, f_params):
     return eng, mlp, base
 
 
+def _linear_plan(func, n_tensors, cfg, like, f_params):
+    """The `models.LinearODEFunc` whose backward solve can use the MFMA kernels for its augmented dynamics, else None."""
+    if not FUSED or n_tensors != 1 or not isinstance(func, _TupleModule):
+        return None
+    from .models import LinearODEFunc
+    base = func.base_func
+    if not isinstance(base, LinearODEFunc) or not (1 <= base.dim <= 128):
+        return None
+    y1 = like[0]
+    if not (like.is_cuda and like.dtype in (torch.float32, torch.float64) and y1.dim() >= 1 and y1.shape[-1] == base.dim):
+        return None
+    want = [base.weight] + ([base.bias] if base.bias is not None else [])
+    if len(f_params) != len(want) or any(a is not b for a, b in zip(f_params, want)):
+        return None                                      # a frozen parameter: the generic path
+    if any(p.dtype != like.dtype or p.device != like.device or not p.is_contiguous() for p in want):
+        return None
+    return base
+
+
+def _linear_dynamics(base, like):
+    """adjoint.py:69-105 for f = y W + b without a tape: (f, -a W^T, 0, (-(y^T a), -sum_rows a)).  The two state-sized products are
+    the linear right-hand side itself (mi_ode_eval_rhs on the MFMA stage kernel: W, and -W^T kept in a buffer of its own that is
+    refreshed per backward pass), the parameter part is mi_ode_outer_reduce.  Nothing in it synchronises or records autograd, so the
+    device-controlled engine replays an attempt of the augmented system as one hipGraph."""
+    from . import rhs as R
+    from .fixed_grid import Euler
+    from .solvers import _FusedEngine, _cached_engine, _tableau_key
+    lib = N.load()
+    y1 = like[0]
+    dim = base.dim
+    batch = y1.numel() // dim
+    W = base.weight.detach()
+    st = getattr(base, '_adjoint_state', None)
+    if st is None or st['wt'].dtype != W.dtype or st['wt'].device != W.device:
+        wt = torch.empty_like(W)
+        st = {'wt': wt, 'rhs_a': R.Linear(wt)}
+        object.__setattr__(base, '_adjoint_state', st)
+    st['wt'].copy_(-W.t())
+    proto = y1.reshape(batch, dim)
+
+    def engine(r):
+        key = ('rhs evaluation', r.cache_key(proto.dtype, proto.device), (batch, dim), proto.dtype, str(proto.device),
+               _tableau_key(Euler._fused_tableau, None))
+        return _cached_engine(key, lambda: _FusedEngine(r, proto, False, Euler._fused_tableau))
+    eng_y, eng_a = engine(base.device_rhs()), engine(st['rhs_a'])
+    code = N.dtype_code(like.dtype)
+    ws = torch.empty(int(lib.mi_ode_outer_workspace_bytes(code, batch, dim)), dtype=torch.uint8, device=like.device)
+    has_b = base.bias is not None
+    n_w, elt = dim * dim, like.element_size()
+
+    def augmented_dynamics(tt, y_aug):
+        y, a = y_aug[0].contiguous(), y_aug[1].contiguous()
+        fy = eng_y.eval_rhs(y.reshape(batch, dim)).reshape(y.shape)
+        va = eng_a.eval_rhs(a.reshape(batch, dim)).reshape(a.shape)
+        vth = torch.empty(n_w + (dim if has_b else 0), dtype=like.dtype, device=like.device)
+        with torch.cuda.device(like.device):
+            N.check(lib.mi_ode_outer_reduce(code, batch, dim, y.data_ptr(), a.data_ptr(), -1.0, vth.data_ptr(),
+                                            vth.data_ptr() + n_w * elt if has_b else None, ws.data_ptr(), N.stream_ptr(like.device)),
+                    'mi_ode_outer_reduce')
+        return (fy, va, torch.zeros_like(y_aug[2]), vth)
+    return augmented_dynamics
+
+
 def _trainable(func):
     """The tensors the backward solve differentiates with respect to: the module's grad-requiring parameters, then the bare
     grad-requiring tensors a wrapped plain callable closes over (odeint._callable_module), in a fixed order."""
@@ -251,6 +314,14 @@ class _OdeintAdjointMethod(torch.autograd.Function):
                 import warnings                          # persistent kernel): nothing was committed, take the generic path.
                                                          # (Only that: any other native / HIP failure propagates.)
                 warnings.warn('fused adjoint kernel unavailable (%s): falling back to the plane-kernel path' % e)
+        lin = _linear_plan(func, n_tensors, cfg, like, f_params)
+        if lin is not None:
+            res = _OdeintAdjointMethod._generic_backward(func, cfg, n_tensors, t, flat_params, ans, grad_output, f_params, like,
+                                                         augmented_dynamics=_linear_dynamics(lin, like))
+            odeint_adjoint.last_backward_stats = {'engine': 'linear right-hand side: augmented dynamics on the MFMA kernels (' +
+                                                  str(odeint.last_stats.get('engine', 'plane kernels')) + ')',
+                                                  'last_segment': dict(odeint.last_stats)}
+            return res
         odeint_adjoint.last_backward_stats = {'engine': 'plane kernels'}
         return _OdeintAdjointMethod._generic_backward(func, cfg, n_tensors, t, flat_params, ans, grad_output, f_params, like)
 
@@ -309,9 +380,10 @@ class _OdeintAdjointMethod(torch.autograd.Function):
         return (None, None, None, time_vjps, grad_params, adj_y)
 
     @staticmethod
-    def _generic_backward(func, cfg, n_tensors, t, flat_params, ans, grad_output, f_params, like):
+    def _generic_backward(func, cfg, n_tensors, t, flat_params, ans, grad_output, f_params, like, augmented_dynamics=None):
         T = ans[0].shape[0]
-        augmented_dynamics = _OdeintAdjointMethod._augmented_dynamics(func, n_tensors, f_params, like)
+        if augmented_dynamics is None:
+            augmented_dynamics = _OdeintAdjointMethod._augmented_dynamics(func, n_tensors, f_params, like)
         with torch.no_grad():
             adj_y = tuple(g[-1] for g in grad_output)
             adj_params = torch.zeros_like(flat_params, dtype=like.dtype) if flat_params.numel() > 0 else \

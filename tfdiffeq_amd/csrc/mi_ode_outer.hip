@@ -1,0 +1,125 @@
+// Parameter vector-Jacobian products of the LINEAR right-hand side f(t, y) = y W + b over a batch (include/mi_ode.h section A''):
+//     -a^T df/dW = -(y^T a)   [dim, dim] (weights [in, out], the layout of mi_ode_rhs.w)        -a^T df/db = -(column sums of a)
+// i.e. what the reference's augmented dynamics (tfdiffeq/adjoint.py:69-105) obtains from the GradientTape for a dense layer without
+// activation.  It is a GEMM with M = N = dim <= 128 and K = batch (65536 in BASELINE config 4's shape): the shape vendor BLAS
+// libraries serve worst (three GEMMs of that evaluation took 7.1 ms in rocBLAS fp64 - 0.9 TFLOP/s - against 0.16 ms here).
+//
+// k_outer_partial: a workgroup of dim/16 wavefronts takes a contiguous slab of rows; wavefront w owns the 16 output columns
+// 16 w .. 16 w + 15 and keeps the dim x 16 block of y^T a in MFMA accumulators (dim/16 x 4 registers); per 4 rows one operand of
+// `a` and dim/16 operands of `y` per lane (the y operands are shared by the workgroup's wavefronts through the L1), dim/16 MFMAs.
+// The slabs' partial blocks go to a workspace; k_outer_fold sums them in slab order - a fixed summation order, no atomics.
+// Bound: HBM - both planes are read once (2 x batch x dim elements); fp64 MFMA time is 2 batch dim^2 flop (27 us at config 4's shape
+// against 27 us for the 128 MB at 5 TB/s).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "mi_ode_host.h"
+#include "mi_ode_stage_linear.h"
+
+using namespace mi;
+
+namespace {
+
+constexpr int kOuterMaxSlabs = 256;
+
+template <typename T, int D>
+__global__ __launch_bounds__(D * 4) void k_outer_partial(const T* __restrict__ y, const T* __restrict__ a, long long batch, int dim,
+                                                         long long rows_per_slab, T* __restrict__ part) {
+  using TR = MfmaTraits<T>;
+  using acc_t = typename TR::acc_t;
+  constexpr int MB = D / 16;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  acc_t acc[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) acc[m] = acc_t{0, 0, 0, 0};
+  T colsum = (T)0;
+  const long long r0 = (long long)blockIdx.x * rows_per_slab;
+  long long r1 = r0 + rows_per_slab;
+  if (r1 > batch) r1 = batch;
+  const int ncol = 16 * w + li;                                // this lane's column of a (B operand: B[k = lg][n = li])
+  const bool nok = ncol < dim;
+  for (long long k0 = r0; k0 < r1; k0 += 4) {
+    const long long row = k0 + lg;
+    const bool rok = row < r1;
+    const T bv = (rok && nok) ? a[row * dim + ncol] : (T)0;
+    colsum += bv;
+    T av[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) av[m] = (rok && 16 * m + li < dim) ? y[row * dim + 16 * m + li] : (T)0;   // A operand: A[i = li][k = lg] = y[row][16 m + li]
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(av[m], bv, acc[m]);
+  }
+  // this slab's block: [D x D] (padded) then [D] column sums
+  T* out = part + (long long)blockIdx.x * (D * D + D);
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[(16 * m + TR::acc_row(lane, i)) * D + ncol] = acc[m][i];
+  colsum += __shfl_xor(colsum, 16, 64);
+  colsum += __shfl_xor(colsum, 32, 64);
+  if (lg == 0) out[D * D + ncol] = colsum;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_outer_fold(const T* __restrict__ part, int slabs, int dim, T scale, T* __restrict__ out_w,
+                                                    T* __restrict__ out_b) {
+  const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (e >= D * D + D) return;
+  T s = (T)0;
+  for (int g = 0; g < slabs; ++g) s += part[(long long)g * (D * D + D) + e];
+  if (e < D * D) {
+    const int m = e / D, n = e % D;
+    if (m < dim && n < dim) out_w[m * dim + n] = scale * s;
+  } else if (out_b != nullptr && e - D * D < dim) {
+    out_b[e - D * D] = scale * s;
+  }
+}
+
+int pad_dim(int dim) { return dim <= 16 ? 16 : (dim <= 32 ? 32 : (dim <= 64 ? 64 : 128)); }
+
+int slabs_for(long long batch) {
+  long long g = (batch + 255) / 256;                           // at least 256 rows per slab
+  if (g > kOuterMaxSlabs) g = kOuterMaxSlabs;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+template <typename T, int D>
+int outer_launch(long long batch, int dim, const void* y, const void* a, double scale, void* out_w, void* out_b, void* ws, hipStream_t st) {
+  const int slabs = slabs_for(batch);
+  long long rps = (batch + slabs - 1) / slabs;
+  rps = (rps + 3) / 4 * 4;
+  hipLaunchKernelGGL((k_outer_partial<T, D>), dim3(slabs), dim3(D * 4), 0, st, (const T*)y, (const T*)a, batch, dim, rps, (T*)ws);
+  hipLaunchKernelGGL((k_outer_fold<T, D>), dim3((D * D + D + 255) / 256), dim3(256), 0, st, (const T*)ws, slabs, dim, (T)scale, (T*)out_w, (T*)out_b);
+  MI_HIP(hipGetLastError());
+  return 0;
+}
+
+template <typename T>
+int outer_dims(int dp, long long batch, int dim, const void* y, const void* a, double scale, void* out_w, void* out_b, void* ws, hipStream_t st) {
+  switch (dp) {
+    case 16: return outer_launch<T, 16>(batch, dim, y, a, scale, out_w, out_b, ws, st);
+    case 32: return outer_launch<T, 32>(batch, dim, y, a, scale, out_w, out_b, ws, st);
+    case 64: return outer_launch<T, 64>(batch, dim, y, a, scale, out_w, out_b, ws, st);
+    default: return outer_launch<T, 128>(batch, dim, y, a, scale, out_w, out_b, ws, st);
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t mi_ode_outer_workspace_bytes(int32_t dtype, int64_t batch, int32_t dim) {
+  if (batch < 1 || dim < 1 || dim > 128 || (dtype != MI_ODE_F32 && dtype != MI_ODE_F64)) return -1;
+  const int dp = pad_dim(dim);
+  return (int64_t)slabs_for(batch) * (dp * dp + dp) * (dtype == MI_ODE_F64 ? 8 : 4);
+}
+
+extern "C" int mi_ode_outer_reduce(int32_t dtype, int64_t batch, int32_t dim, const void* y_dev, const void* a_dev, double scale,
+                                   void* out_w_dev, void* out_b_dev, void* workspace_dev, void* stream) {
+  if (y_dev == nullptr || a_dev == nullptr || out_w_dev == nullptr || workspace_dev == nullptr) { mi_set_error("outer_reduce: null argument"); return MI_ODE_E_INVALID; }
+  if (batch < 1 || dim < 1 || dim > 128) { mi_set_error("outer_reduce: batch >= 1, 1 <= dim <= 128"); return MI_ODE_E_INVALID; }
+  const int dp = pad_dim(dim);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == MI_ODE_F64) return outer_dims<double>(dp, batch, dim, y_dev, a_dev, scale, out_w_dev, out_b_dev, workspace_dev, st);
+  if (dtype == MI_ODE_F32) return outer_dims<float>(dp, batch, dim, y_dev, a_dev, scale, out_w_dev, out_b_dev, workspace_dev, st);
+  mi_set_error("outer_reduce: dtype must be MI_ODE_F32 or MI_ODE_F64");
+  return MI_ODE_E_INVALID;
+}

@@ -71,6 +71,36 @@ class ODEFunc(nn.Module):
         return desc
 
 
+class LinearODEFunc(nn.Module):
+    """f(t, y) = y W (+ b): the linear system of BASELINE config 4 as a trainable module (not a class of the reference - its
+    models are the MLP above and a convolutional zoo; this is the headline workload's training analogue).
+    `weight` is [dim, dim] in [in, out] layout, so that `forward` is one matmul and the fused kernels read it as it is.
+    Forward: the whole-call MFMA kernel (`rhs.Linear`); backward under `odeint_adjoint`: the reference's augmented system
+    (adjoint.py:69-105) with its three big products on MFMA kernels instead of autograd over rocBLAS (adjoint._linear_dynamics)."""
+
+    def __init__(self, dim, bias=True, dtype=torch.float64):
+        super(LinearODEFunc, self).__init__()
+        self.dim = int(dim)
+        self.nfe = 0
+        w = -0.5 * torch.eye(dim, dtype=dtype) + 0.5 * torch.randn(dim, dim, dtype=dtype) / dim ** 0.5
+        self.weight = nn.Parameter(w)
+        self.bias = nn.Parameter(torch.zeros(dim, dtype=dtype)) if bias else None
+
+    def forward(self, t, y):
+        self.nfe += 1
+        out = torch.matmul(y, self.weight)
+        return out if self.bias is None else out + self.bias
+
+    def device_rhs(self):
+        """`rhs.Linear` over the parameters themselves (no copies: in-place optimizer steps stay visible to the cached engine)."""
+        cached = getattr(self, '_fused_rhs', None)
+        b = None if self.bias is None else self.bias.detach()
+        if cached is None or cached.W.data_ptr() != self.weight.data_ptr() or (b is not None and cached.b.data_ptr() != b.data_ptr()):
+            cached = _rhs.Linear(self.weight.detach(), b)
+            object.__setattr__(self, '_fused_rhs', cached)
+        return cached
+
+
 class ODEBlock(nn.Module):
     """Solves the ODE defined by odefunc (dense_odenet.py:95-191)."""
 
