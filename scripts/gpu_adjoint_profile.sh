@@ -4,8 +4,8 @@
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export PYTHONPATH=$PWD TMPDIR=/tmp; P=$PWD/gpurun_out/profiles_r04; mkdir -p $P
 for td in 0 1; do
   D=$PWD/gpurun_out/prof_adj$td; rm -rf $D
-  (cd /tmp && ADJ_TD=$td rocprofv3 --kernel-trace --stats -d $D -o r -- python $OLDPWD/scripts/adjoint_train_step.py fused 10 > $P/r04_adjoint_td${td}_train_step.txt 2>&1)
-  f=$(find $D -name "r_kernel_stats.csv" | head -1)
+  (cd /tmp && ADJ_TD=$td rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python $OLDPWD/scripts/adjoint_train_step.py fused 10 > $P/r04_adjoint_td${td}_train_step.txt 2>&1)
+  f=$(find $D -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && head -12 "$f" > $P/r04_adjoint_td${td}_kernel_stats.csv
   grep ms_per $P/r04_adjoint_td${td}_train_step.txt | cut -c1-250
   find $D -name "*.csv" -size +2M -delete

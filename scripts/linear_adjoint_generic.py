@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The linear right-hand side under odeint_adjoint at config 4's size (65536 x 128, float64, Dopri5): one training
+"""The linear right-hand side under odeint_adjoint at config 4's size (65536 x 128, float64, Dopri5; docs/KERNELS.md section 4e): one training
 step with the augmented dynamics on the MFMA kernels (models.LinearODEFunc) against the generic path (autograd over rocBLAS: any
 nn.Module), and what the three GEMMs of one augmented evaluation - f = yW, -a W^T, -y^T a, 2 B D^2 flop each - cost in rocBLAS."""
 import time
