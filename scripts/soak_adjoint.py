@@ -32,7 +32,8 @@ for it in range(n):
     if np.min(np.abs(np.diff(ts))) < 1e-3:
         continue
     torch.manual_seed(int(rng.integers(1 << 30)))
-    func = models.ODEFunc(dim, hidden, non_linearity=act).to(dev)
+    td = bool(rng.random() < 0.6)                               # round 4: the time-dependent network (adj_t evolves, theta starts with w_t)
+    func = models.ODEFunc(dim, hidden, non_linearity=act, time_dependent=td).to(dev)
     y0 = torch.randn(batch, dim, device=dev)
     w = torch.randn(T, batch, dim, device=dev)
     res = {}
@@ -44,9 +45,10 @@ for it in range(n):
         for p in f.parameters():
             p.grad = None
         yi = y0.to(dt).clone().requires_grad_(True)
-        sol = odeint_adjoint(f, yi, torch.tensor(ts), rtol=tl, atol=tl, method='dopri5', options={'max_num_steps': 100000})
+        tt = torch.tensor(ts, requires_grad=True)               # dL/dt_i too (adj_t between the output times)
+        sol = odeint_adjoint(f, yi, tt, rtol=tl, atol=tl, method='dopri5', options={'max_num_steps': 100000})
         (sol * w.to(dt)).sum().backward()
-        res[key] = ([yi.grad.double()] + [p.grad.double() for p in f.parameters()], dict(odeint_adjoint.last_backward_stats))
+        res[key] = ([yi.grad.double(), tt.grad.double()] + [p.grad.double() for p in f.parameters()], dict(odeint_adjoint.last_backward_stats))
     ADJ.FUSED, ADJ.FUSED_FORWARD = True, True
     assert res['fused'][1]['engine'].startswith('fused'), res['fused'][1]
 
@@ -59,6 +61,6 @@ for it in range(n):
         print('it %d: fused %.2e generic %.2e  (%.0f s)' % (it, ef, eg, time.time() - t_start), flush=True)
     if not (ef < band) or not np.isfinite(ef):
         fails += 1
-        print('MISMATCH it %d: dim %d hidden %d batch %d act %s tol %.1e T %d ts %s: fused %.2e generic %.2e' % (it, dim, hidden, batch, act, tol, T, ts, ef, eg))
+        print('MISMATCH it %d: dim %d hidden %d batch %d act %s td %s tol %.1e T %d ts %s: fused %.2e generic %.2e' % (it, dim, hidden, batch, act, td, tol, T, ts, ef, eg))
 print('soak: %d problems, %d outside the band, worst error / band %.2f, %.0f s' % (n, fails, worst, time.time() - t_start))
 sys.exit(1 if fails else 0)
