@@ -10,4 +10,3 @@ for td in 0 1; do
   grep ms_per $P/r04_adjoint_td${td}_train_step.txt | cut -c1-250
   find $D -name "*.csv" -size +2M -delete
 done
-python scripts/linear_adjoint_generic.py 2>&1 | grep -v amdgpu.ids | tee $P/r04_linear_adjoint_generic.txt
