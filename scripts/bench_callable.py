@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Cost of the generic path (arbitrary Python callable f(t, y) over torch ops + plane kernels) per RK attempt."""
+import gc
 import json
 import os
 import sys
@@ -21,12 +22,15 @@ def lorenz(t, y):
 def run(name, f, y0, t, reps=5, **kw):
     for _ in range(2):
         odeint(f, y0, t, **kw)
+    gc.collect()                                            # (a full collection inside a three-call timed region reads as +10 ms per call)
+    gc.disable()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
         odeint(f, y0, t, **kw)
     torch.cuda.synchronize()
     ms = 1e3 * (time.perf_counter() - t0) / reps
+    gc.enable()
     st = dict(odeint.last_stats)
     print(json.dumps({'case': name, 'ms_per_call': round(ms, 3), 'attempts': st.get('n_attempts'),
                       'us_per_attempt': round(1e3 * ms / max(st.get('n_attempts') or 1, 1), 1), 'engine': st.get('engine'),
