@@ -2,6 +2,7 @@
 """The linear right-hand side under odeint_adjoint at config 4's size (65536 x 128, float64, Dopri5; docs/KERNELS.md section 4e): one training
 step with the augmented dynamics on the MFMA kernels (models.LinearODEFunc) against the generic path (autograd over rocBLAS: any
 nn.Module), and what the three GEMMs of one augmented evaluation - f = yW, -a W^T, -y^T a, 2 B D^2 flop each - cost in rocBLAS."""
+import os
 import time
 
 import torch
@@ -23,7 +24,8 @@ with torch.no_grad():
 y0 = torch.randn(B, D, dtype=torch.float64, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
 t = torch.tensor([0., 1.], dtype=torch.float64)
 grads = {}
-for fused in (True, False):
+ONLY = os.environ.get('LIN_ONLY') == '1'                    # (profiling runs: the MFMA path alone)
+for fused in ((True,) if ONLY else (True, False)):
     ADJ.FUSED = ADJ.FUSED_FORWARD = fused
     for it in range(3):
         func.weight.grad = None
@@ -41,6 +43,8 @@ for fused in (True, False):
             seg.get('n_attempts'), str(seg.get('engine'))[:70]), flush=True)
     grads[fused] = (func.weight.grad.clone(), yi.grad.clone())
 ADJ.FUSED = ADJ.FUSED_FORWARD = True
+if ONLY:
+    raise SystemExit(0)
 print('gradients, MFMA dynamics vs generic path: dL/dW rel %.2e, dL/dy0 rel %.2e' % tuple(
     float((a_ - b_).abs().max() / b_.abs().max()) for a_, b_ in zip(grads[True], grads[False])))
 a = torch.randn(B, D, dtype=torch.float64, device=dev)

@@ -224,23 +224,36 @@ def _linear_dynamics(base, like):
         key = ('rhs evaluation', r.cache_key(proto.dtype, proto.device), (batch, dim), proto.dtype, str(proto.device),
                _tableau_key(Euler._fused_tableau, None))
         return _cached_engine(key, lambda: _FusedEngine(r, proto, False, Euler._fused_tableau))
-    eng_y, eng_a = engine(base.device_rhs()), engine(st['rhs_a'])
+    rhs_y, rhs_a = base.device_rhs(), st['rhs_a']
     code = N.dtype_code(like.dtype)
     ws = torch.empty(int(lib.mi_ode_outer_workspace_bytes(code, batch, dim)), dtype=torch.uint8, device=like.device)
     has_b = base.bias is not None
     n_w, elt = dim * dim, like.element_size()
 
-    def augmented_dynamics(tt, y_aug):
-        y, a = y_aug[0].contiguous(), y_aug[1].contiguous()
-        fy = eng_y.eval_rhs(y.reshape(batch, dim)).reshape(y.shape)
-        va = eng_a.eval_rhs(a.reshape(batch, dim)).reshape(a.shape)
-        vth = torch.empty(n_w + (dim if has_b else 0), dtype=like.dtype, device=like.device)
-        with torch.cuda.device(like.device):
-            N.check(lib.mi_ode_outer_reduce(code, batch, dim, y.data_ptr(), a.data_ptr(), -1.0, vth.data_ptr(),
-                                            vth.data_ptr() + n_w * elt if has_b else None, ws.data_ptr(), N.stream_ptr(like.device)),
-                    'mi_ode_outer_reduce')
-        return (fy, va, torch.zeros_like(y_aug[2]), vth)
-    return augmented_dynamics
+    class _Dynamics(object):
+        """sign = +1: the augmented dynamics; sign = -1: -dynamics(-t, .) (misc.py:318-321) - the system is autonomous, so the time
+        reversal of `odeint` is the sign alone: the stage kernel multiplies by it (`DeviceRHS.reversed()`), the outer product takes it
+        as its scale factor, and the wrapper's negation pass over the two state-sized components is not needed."""
+
+        def __init__(self, sign):
+            self.sign = sign
+            self.eng_y = engine(rhs_y if sign > 0 else rhs_y.reversed())
+            self.eng_a = engine(rhs_a if sign > 0 else rhs_a.reversed())
+
+        def time_reversed(self):
+            return _Dynamics(-self.sign)
+
+        def __call__(self, tt, y_aug):
+            y, a = y_aug[0].contiguous(), y_aug[1].contiguous()
+            fy = self.eng_y.eval_rhs(y.reshape(batch, dim)).reshape(y.shape)
+            va = self.eng_a.eval_rhs(a.reshape(batch, dim)).reshape(a.shape)
+            vth = torch.empty(n_w + (dim if has_b else 0), dtype=like.dtype, device=like.device)
+            with torch.cuda.device(like.device):
+                N.check(lib.mi_ode_outer_reduce(code, batch, dim, y.data_ptr(), a.data_ptr(), -float(self.sign), vth.data_ptr(),
+                                                vth.data_ptr() + n_w * elt if has_b else None, ws.data_ptr(), N.stream_ptr(like.device)),
+                        'mi_ode_outer_reduce')
+            return (fy, va, torch.zeros_like(y_aug[2]), vth)
+    return _Dynamics(1.0)
 
 
 def _trainable(func):

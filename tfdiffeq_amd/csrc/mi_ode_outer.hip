@@ -2,14 +2,14 @@
 //     -a^T df/dW = -(y^T a)   [dim, dim] (weights [in, out], the layout of mi_ode_rhs.w)        -a^T df/db = -(column sums of a)
 // i.e. what the reference's augmented dynamics (tfdiffeq/adjoint.py:69-105) obtains from the GradientTape for a dense layer without
 // activation.  It is a GEMM with M = N = dim <= 128 and K = batch (65536 in BASELINE config 4's shape): the shape vendor BLAS
-// libraries serve worst (three GEMMs of that evaluation took 7.1 ms in rocBLAS fp64 - 0.9 TFLOP/s - against 0.16 ms here).
+// libraries serve worst (`y.t() @ a` takes 7.0 ms in rocBLAS fp64 - 0.3 TFLOP/s - against 68 us here).
 //
-// k_outer_partial: a workgroup of dim/16 wavefronts takes a contiguous slab of rows; wavefront w owns the 16 output columns
-// 16 w .. 16 w + 15 and keeps the dim x 16 block of y^T a in MFMA accumulators (dim/16 x 4 registers); per 4 rows one operand of
-// `a` and dim/16 operands of `y` per lane (the y operands are shared by the workgroup's wavefronts through the L1), dim/16 MFMAs.
-// The slabs' partial blocks go to a workspace; k_outer_fold sums them in slab order - a fixed summation order, no atomics.
+// k_outer_partial: a workgroup of dim/16 wavefronts takes a contiguous slab of rows, 16 at a time through LDS; wavefront w owns the 16
+// output columns 16 w .. 16 w + 15 and keeps the dim x 16 block of y^T a in MFMA accumulators (dim/16 x 4 registers); per 4 rows one
+// operand of `a`, dim/16 operands of `y` and dim/16 MFMAs.  The slabs' partial blocks go to a workspace; k_outer_fold sums them in a
+// fixed order (eight interleaved chains) - no atomics, the same bits every time.
 // Bound: HBM - both planes are read once (2 x batch x dim elements); fp64 MFMA time is 2 batch dim^2 flop (27 us at config 4's shape
-// against 27 us for the 128 MB at 5 TB/s).
+// against 27 us for the 128 MB at 5 TB/s; measured 52 + 15 us).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mi_ode_host.h"
@@ -26,8 +26,9 @@ __global__ __launch_bounds__(D * 4) void k_outer_partial(const T* __restrict__ y
                                                          long long rows_per_slab, T* __restrict__ part) {
   using TR = MfmaTraits<T>;
   using acc_t = typename TR::acc_t;
-  constexpr int MB = D / 16;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, li = lane & 15, lg = lane >> 4;
+  constexpr int MB = D / 16, NT = D * 4, R = 16, EPT = R * D / NT;   // 16-row tiles (32 KB of LDS at D = 128, fp64; 32 rows: the same 52 us), EPT = 4 elements per thread and plane
+  __shared__ T sy[R * D], sa[R * D];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
   acc_t acc[MB];
 #pragma unroll
   for (int m = 0; m < MB; ++m) acc[m] = acc_t{0, 0, 0, 0};
@@ -36,17 +37,35 @@ __global__ __launch_bounds__(D * 4) void k_outer_partial(const T* __restrict__ y
   long long r1 = r0 + rows_per_slab;
   if (r1 > batch) r1 = batch;
   const int ncol = 16 * w + li;                                // this lane's column of a (B operand: B[k = lg][n = li])
-  const bool nok = ncol < dim;
-  for (long long k0 = r0; k0 < r1; k0 += 4) {
-    const long long row = k0 + lg;
-    const bool rok = row < r1;
-    const T bv = (rok && nok) ? a[row * dim + ncol] : (T)0;
-    colsum += bv;
-    T av[MB];
+  // A tile of both planes goes through LDS once per workgroup (coalesced element loads, zero padded to D columns / R rows); the
+  // wavefronts take their MFMA operands from there.  (Operands straight from global memory - every wavefront reads all of y, eight
+  // times the traffic through L1 / L2 - measured 66-73 us per call at 65536 x 128 whatever the prefetch depth; matrix-pipe time
+  // 27 us, the two planes at 5 TB/s 27 us.)
+  T py[EPT], pa[EPT];
+  auto fetch = [&](long long t0) {
 #pragma unroll
-    for (int m = 0; m < MB; ++m) av[m] = (rok && 16 * m + li < dim) ? y[row * dim + 16 * m + li] : (T)0;   // A operand: A[i = li][k = lg] = y[row][16 m + li]
+    for (int e = 0; e < EPT; ++e) {
+      const int idx = e * NT + tid, row = idx / D, col = idx % D;
+      const bool ok = t0 + row < r1 && col < dim;
+      py[e] = ok ? y[(t0 + row) * dim + col] : (T)0;
+      pa[e] = ok ? a[(t0 + row) * dim + col] : (T)0;
+    }
+  };
+  if (r0 < r1) fetch(r0);
+  for (long long t0 = r0; t0 < r1; t0 += R) {
+    __syncthreads();                                           // (the previous tile's operands have been read)
 #pragma unroll
-    for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(av[m], bv, acc[m]);
+    for (int e = 0; e < EPT; ++e) { sy[e * NT + tid] = py[e]; sa[e * NT + tid] = pa[e]; }
+    __syncthreads();
+    if (t0 + R < r1) fetch(t0 + R);                            // in flight under this tile's MFMAs
+#pragma unroll
+    for (int u = 0; u < R / 4; ++u) {
+      const int row = 4 * u + lg;
+      const T bv = sa[row * D + ncol];
+      colsum += bv;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(sy[row * D + 16 * m + li], bv, acc[m]);   // A operand: A[i = li][k = lg] = y[row][16 m + li]
+    }
   }
   // this slab's block: [D x D] (padded) then [D] column sums
   T* out = part + (long long)blockIdx.x * (D * D + D);
@@ -64,8 +83,17 @@ __global__ __launch_bounds__(256) void k_outer_fold(const T* __restrict__ part, 
                                                     T* __restrict__ out_b) {
   const int e = (int)(blockIdx.x * blockDim.x + threadIdx.x);
   if (e >= D * D + D) return;
-  T s = (T)0;
-  for (int g = 0; g < slabs; ++g) s += part[(long long)g * (D * D + D) + e];
+  // eight independent partial sums (a fixed order all the same): one dependent chain over 256 slabs is 256 memory round trips -
+  // 64 us per call, as long as the partial kernel itself
+  constexpr long long STR = D * D + D;
+  T q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int g = 0;
+  for (; g + 8 <= slabs; g += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) q[u] += part[(long long)(g + u) * STR + e];
+  }
+  for (; g < slabs; ++g) q[0] += part[(long long)g * STR + e];
+  const T s = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
   if (e < D * D) {
     const int m = e / D, n = e % D;
     if (m < dim && n < dim) out_w[m * dim + n] = scale * s;

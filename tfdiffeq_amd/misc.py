@@ -384,7 +384,10 @@ def _check_inputs(func, y0, t):
     t = _as_time_tensor(t)
     if _decreasing(t):
         t = -t
-        func = _ReverseFunc(func)
+        # misc.py:318-321: func <- -func(-t, y).  A callable that can form that itself (`time_reversed()`: e.g. the linear system's
+        # augmented dynamics, whose kernels take the sign as a scale factor) spares the wrapper's negation pass over every component
+        native = getattr(func, 'time_reversed', None)
+        func = native() if callable(native) else _ReverseFunc(func)
     for y0_ in y0:
         if not torch.is_floating_point(y0_):
             raise TypeError('`y0` must be a floating point Tensor but is a {}'.format(y0_.dtype))
