@@ -32,24 +32,57 @@ struct OpqComp {               // one state component of one attempt
 struct OpqErrCoef { double e[MI_ODE_MAX_K]; };
 
 // block records {max|y0|, max|y1|, sum err^2, -, nonfinite(y0)} with err = add_n((dt * c_error_j) * k_j) formed in registers
-template <typename T>
-__global__ __launch_bounds__(256) void k_opq_norms(const Ctl* c, OpqComp P, int nk, OpqErrCoef E, long long n, double* part) {
+// (NK known at compile time and two grid-stride elements per trip: all 2 (NK + 2) loads of a trip are in flight together - with a
+// run-time stage count and one element per trip a 64 MB component took 165 us, 3.5 TB/s)
+template <typename T, int NK>
+__global__ __launch_bounds__(256) void k_opq_norms(const Ctl* c, OpqComp P, OpqErrCoef E, long long n, double* part) {
   if (c->done) return;
   const T hs = (T)c->dt;                                       // rk_common.py:46
   const T* y0 = (const T*)P.y0;
   const T* y1 = (const T*)P.y1;
+  T ce[NK];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) ce[j] = hs * (T)E.e[j];
   Acc acc;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    T er = (hs * (T)E.e[0]) * ((const T*)P.k[0])[i];           // misc._scaled_dot_product order (misc.py:121)
-    for (int j = 1; j < nk; ++j) er = er + (hs * (T)E.e[j]) * ((const T*)P.k[j])[i];
-    const T a = y0[i], b = y1[i];
+  auto fold = [&](T a, T b, const T (&kv)[NK]) {
+    T er = ce[0] * kv[0];                                      // misc._scaled_dot_product order (misc.py:121)
+#pragma unroll
+    for (int j = 1; j < NK; ++j) er = er + ce[j] * kv[j];
     acc.maxa = fmax(acc.maxa, (double)fabs(a));
     acc.maxb = fmax(acc.maxb, (double)fabs(b));
     acc.suma += (double)er * (double)er;
     if (!finite_(a)) acc.flag = 1;
+  };
+  const long long pitch = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  for (; i + pitch < n; i += 2 * pitch) {
+    T k0[NK], k1[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) { k0[j] = ((const T*)P.k[j])[i]; k1[j] = ((const T*)P.k[j])[i + pitch]; }
+    const T a0 = y0[i], b0 = y1[i], a1 = y0[i + pitch], b1 = y1[i + pitch];
+    fold(a0, b0, k0);
+    fold(a1, b1, k1);
+  }
+  if (i < n) {
+    T k0[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) k0[j] = ((const T*)P.k[j])[i];
+    fold(y0[i], y1[i], k0);
   }
   __shared__ double red[80];
   block_reduce_store(acc, red, part + (long long)blockIdx.x * kRec);
+}
+
+template <typename T>
+static int opq_norms_t(int nk, dim3 g, hipStream_t st, const Ctl* ctl, const OpqComp& P, const OpqErrCoef& E, long long n, double* part) {
+  switch (nk) {
+    case 2: hipLaunchKernelGGL((k_opq_norms<T, 2>), g, dim3(256), 0, st, ctl, P, E, n, part); break;
+    case 4: hipLaunchKernelGGL((k_opq_norms<T, 4>), g, dim3(256), 0, st, ctl, P, E, n, part); break;
+    case 7: hipLaunchKernelGGL((k_opq_norms<T, 7>), g, dim3(256), 0, st, ctl, P, E, n, part); break;
+    case 14: hipLaunchKernelGGL((k_opq_norms<T, 14>), g, dim3(256), 0, st, ctl, P, E, n, part); break;
+    default: mi_set_error("opq_finish: unsupported stage count"); return MI_ODE_E_INVALID;
+  }
+  return 0;
 }
 
 struct OpqCtlArgs {
@@ -114,7 +147,18 @@ __global__ __launch_bounds__(256) void k_opq_commit(const Ctl* c, OpqCommit P, l
   T* f0p = (T*)P.f0;
   const T* y1p = (const T*)P.y1;
   T* out = hi > lo ? (T*)P.out_tab[P.comp] : nullptr;
-  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+  const long long pitch = (long long)gridDim.x * blockDim.x;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (hi <= lo) {                                              // no output time inside the step: a copy, four loads in flight per trip
+    const T* f1p = (const T*)P.k[NK - 1];                      // (state buffers may alias nothing the loop still reads: plain copies)
+    for (; i + pitch < n; i += 2 * pitch) {
+      const T ya = y1p[i], fa = f1p[i], yb = y1p[i + pitch], fb = f1p[i + pitch];
+      y0p[i] = ya; f0p[i] = fa; y0p[i + pitch] = yb; f0p[i + pitch] = fb;
+    }
+    if (i < n) { const T ya = y1p[i], fa = f1p[i]; y0p[i] = ya; f0p[i] = fa; }
+    return;
+  }
+  for (; i < n; i += pitch) {
     const T y1 = y1p[i];
     const T f1 = ((const T*)P.k[NK - 1])[i];
     if (hi > lo) {                                             // dopri5.py:87 / interp.py:6-67 / tsit5.py:33-50
@@ -286,8 +330,9 @@ extern "C" int mi_ode_opq_finish(mi_ode_opq_handle h, const void* const* y0_dev,
     }
     if (!P.y0 || !P.y1) { mi_set_error("opq_finish: null state"); return MI_ODE_E_INVALID; }
     double* part = h->partials + (long long)c * kMaxBlocks * kRec;
-    if (h->is_f32) hipLaunchKernelGGL(k_opq_norms<float>, dim3(h->grid[c]), dim3(256), 0, st, (const Ctl*)h->ctl, P, h->nk, h->ec, (long long)h->d.n[c], part);
-    else hipLaunchKernelGGL(k_opq_norms<double>, dim3(h->grid[c]), dim3(256), 0, st, (const Ctl*)h->ctl, P, h->nk, h->ec, (long long)h->d.n[c], part);
+    const int rcn = h->is_f32 ? opq_norms_t<float>(h->nk, dim3(h->grid[c]), st, h->ctl, P, h->ec, (long long)h->d.n[c], part)
+                              : opq_norms_t<double>(h->nk, dim3(h->grid[c]), st, h->ctl, P, h->ec, (long long)h->d.n[c], part);
+    if (rcn != 0) return rcn;
   }
   hipLaunchKernelGGL(k_opq_controller, dim3(1), dim3(64), 0, st, h->ctl, (const double*)h->partials, h->ca, h->cp);
   MI_HIP(hipGetLastError());
