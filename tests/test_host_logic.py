@@ -275,3 +275,65 @@ def test_adams_scalars_match_the_oracle():
             assert g.dtype == np.float32 and np.array_equal(g, g_ref)
             for j in range(order):                                   # explicit_phi_j = beta_j * phi_j
                 assert np.array_equal(np.float64(beta[j]) * phi[j][0], ephi_ref[j][0]), (order, j)
+
+
+def test_time_reversal_uses_the_callables_own_reversal_when_it_has_one():
+    """misc.py:311-321: decreasing t -> t <- -t, func <- -func(-t, y).  A callable with `time_reversed()` (the linear system's augmented
+    dynamics: the sign is a scale factor of its kernels) is asked for that function instead of being wrapped in a negation."""
+    class Dyn(object):
+        def __init__(self, sign=1.0):
+            self.sign = sign
+
+        def time_reversed(self):
+            return Dyn(-self.sign)
+
+        def __call__(self, t, y):
+            return tuple(self.sign * (v + t) for v in y)
+    y0 = (torch.ones(3), torch.zeros(2))
+    plain = lambda t, y: tuple(v + t for v in y)  # noqa: E731
+    for t in ([0.0, 1.0, 2.0], [2.0, 1.0, 0.5]):
+        _, f_nat, _, t_nat = misc._check_inputs(Dyn(), y0, torch.tensor(t))
+        _, f_wrp, _, t_wrp = misc._check_inputs(plain, y0, torch.tensor(t))
+        assert torch.equal(t_nat, t_wrp) and bool((t_nat[1:] > t_nat[:-1]).all())
+        decreasing = t[0] > t[-1]
+        assert isinstance(f_nat, Dyn) and f_nat.sign == (-1.0 if decreasing else 1.0)
+        assert isinstance(f_wrp, misc._ReverseFunc) == decreasing
+        tau = torch.tensor(-1.25 if decreasing else 0.75)
+        # the two formulations are the same function of (tau, y) when the dynamics do not depend on t - which is what a callable
+        # promises by offering time_reversed() with a sign alone
+        a = f_nat(torch.tensor(0.0), y0)
+        b = tuple(-(v) for v in y0) if decreasing else y0
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+        assert all(torch.equal(u, v) for u, v in zip(f_wrp(tau, y0), (tuple(-(v - tau) for v in y0) if decreasing else tuple(v + tau for v in y0))))
+
+
+def test_recorded_attempt_key_follows_the_users_callable_through_the_wrappers():
+    from tfdiffeq_amd import graph_step
+
+    class F(object):
+        def __call__(self, t, y):
+            return y
+    f = F()
+    base, chain = graph_step._user_callable(misc._ReverseFunc(misc._TupleFunc(f)))
+    assert base is f and chain == ('_ReverseFunc', '_TupleFunc', 'F')
+    base2, chain2 = graph_step._user_callable(misc._TupleFunc(f))
+    assert base2 is f and chain2 == ('_TupleFunc', 'F') and chain2 != chain          # reversed time records an attempt of its own
+    m = torch.nn.Linear(2, 2)
+    assert graph_step._user_callable(m)[0] is m                                      # (nn.Module: no `base` attribute to follow)
+
+
+def test_linear_odefunc_descriptor_reads_the_parameters_own_storage():
+    from tfdiffeq_amd import models
+    f = models.LinearODEFunc(5, bias=True)
+    d1 = f.device_rhs()
+    assert d1 is f.device_rhs() and d1.dim == 5 and d1.kind == N.RHS_LINEAR
+    assert d1.W.data_ptr() == f.weight.data_ptr() and d1.b.data_ptr() == f.bias.data_ptr()   # in-place optimizer steps stay visible
+    with torch.no_grad():
+        f.weight.mul_(0.5)
+    assert f.device_rhs() is d1
+    f.weight = torch.nn.Parameter(f.weight.detach().clone())                                # a rebound parameter: a new descriptor
+    assert f.device_rhs() is not d1
+    y = torch.randn(4, 5, dtype=torch.float64)
+    assert torch.allclose(f(torch.tensor(0.0), y), y @ f.weight + f.bias)
+    assert models.LinearODEFunc(3, bias=False).bias is None
