@@ -27,7 +27,7 @@ grads = {}
 ONLY = os.environ.get('LIN_ONLY') == '1'                    # (profiling runs: the MFMA path alone)
 for fused in ((True,) if ONLY else (True, False)):
     ADJ.FUSED = ADJ.FUSED_FORWARD = fused
-    for it in range(3):
+    for it in range(6 if fused else 3):
         func.weight.grad = None
         yi = y0.clone().requires_grad_(True)
         torch.cuda.synchronize(); t0 = time.perf_counter()

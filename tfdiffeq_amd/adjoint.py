@@ -237,13 +237,15 @@ def _linear_dynamics(base, like):
 
         def __init__(self, sign):
             self.sign = sign
-            self.eng_y = engine(rhs_y if sign > 0 else rhs_y.reversed())
-            self.eng_a = engine(rhs_a if sign > 0 else rhs_a.reversed())
+            self.eng_y = self.eng_a = None                   # created on first use: a backward pass only ever runs one direction
 
         def time_reversed(self):
             return _Dynamics(-self.sign)
 
         def __call__(self, tt, y_aug):
+            if self.eng_y is None:
+                self.eng_y = engine(rhs_y if self.sign > 0 else rhs_y.reversed())
+                self.eng_a = engine(rhs_a if self.sign > 0 else rhs_a.reversed())
             y, a = y_aug[0].contiguous(), y_aug[1].contiguous()
             fy = self.eng_y.eval_rhs(y.reshape(batch, dim)).reshape(y.shape)
             va = self.eng_a.eval_rhs(a.reshape(batch, dim)).reshape(a.shape)
