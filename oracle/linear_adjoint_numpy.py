@@ -1,0 +1,67 @@
+"""ORACLE - test infrastructure, not product code.
+
+The augmented dynamics of odeint_adjoint (/root/reference/tfdiffeq/adjoint.py:69-105) for the LINEAR right-hand side f = y W + b, and the
+identity the planned one-launch kernel rests on: the parameter component's Runge-Kutta stage derivatives
+need no per-stage GEMM over the batch.
+
+Direct form (what the reference computes through its tape, stage by stage, rk_common.py:22-61):
+    k_W,sigma = -s Y_sigma^T A_sigma        k_b,sigma = -s sum_rows A_sigma
+with Y_sigma, A_sigma the stage inputs of the y and a = adj_y components ([batch, dim] each), s = +1 / -1 for increasing / decreasing time
+(misc.py:311-321).
+
+Factored form: y' = s (y W + b) and a' = -s a W^T are autonomous and (affine-)linear, so every stage input is the initial value times a
+matrix that depends on (h, W) only, plus - for y - an affine row that depends on (h, W, b) only:
+    Y_sigma = y0 Pi_sigma + 1 r_sigma          A_sigma = a0 Phi_sigma
+    Y_sigma^T A_sigma = Pi_sigma^T (y0^T a0) Phi_sigma + r_sigma^T ((1^T a0) Phi_sigma)
+i.e. with G0 = y0^T a0 ([dim, dim]: ONE product over the batch per step) and g0 = sum_rows a0:
+    U_sigma = G0 Phi_sigma   and   v_sigma = g0 Phi_sigma     are the a-type stage inputs started from the rows of G0 and from g0,
+    Pi_sigma^T U_sigma = (U_sigma^T Pi_sigma)^T               are the HOMOGENEOUS y-type stage-sigma inputs started from the rows of U_sigma^T,
+    r_sigma                                                   is the y-type stage-sigma input started from the zero row.
+Everything after G0 / g0 is Runge-Kutta stages on dim (+1) rows: the work of a few 16-row tiles of the existing tile pass.
+
+`stage_inputs` restates rk_common.py:44-52 (the stage loop) and returns the stage INPUTS; `theta_stage_derivatives_direct` /
+`_factored` are the two forms; tests/test_linear_adjoint_algebra.py holds them together to 1e-13 and checks the direct form against
+torch.autograd (the reference's own route) - CPU only.
+"""
+import numpy as np
+
+
+def stage_inputs(f, y0, h, tableau):
+    """rk_common.py:44-52 for an autonomous f: the inputs y_sigma of every evaluation k_sigma = f(y_sigma), sigma = 0 .. S (sigma = 0: y0
+    itself, the FSAL evaluation; sigma = S: the solution of an FSAL-shaped tableau), and the k's."""
+    k = [f(y0)]
+    ys = [y0]
+    for beta_i in tableau.beta:
+        yi = y0 + sum((h * b) * k_ for b, k_ in zip(beta_i, k))      # rk_common.py:51 (order of the sum: as misc._scaled_dot_product)
+        ys.append(yi)
+        k.append(f(yi))
+    return ys, k
+
+
+def theta_stage_derivatives_direct(W, b, y0, a0, h, s, tableau):
+    """(k_W,sigma, k_b,sigma) for sigma = 0 .. S from the stage inputs of the full batch."""
+    fy = (lambda y: s * (y @ W + b)) if b is not None else (lambda y: s * (y @ W))
+    fa = lambda a: -s * (a @ W.T)  # noqa: E731
+    Ys, _ = stage_inputs(fy, y0, h, tableau)
+    As, _ = stage_inputs(fa, a0, h, tableau)
+    return [(-s * (Y.T @ A), -s * A.sum(0)) for Y, A in zip(Ys, As)]
+
+
+def theta_stage_derivatives_factored(W, b, y0, a0, h, s, tableau):
+    """The same from G0 = y0^T a0 and g0 = sum_rows a0 alone (module docstring)."""
+    D = W.shape[0]
+    fa = lambda a: -s * (a @ W.T)  # noqa: E731
+    fy_hom = lambda y: s * (y @ W)  # noqa: E731
+    G0, g0 = y0.T @ a0, a0.sum(0)
+    UV, _ = stage_inputs(fa, np.vstack([G0, g0[None, :]]), h, tableau)          # rows of G0 and the row g0 through the a-system
+    if b is not None:
+        R, _ = stage_inputs(lambda y: s * (y @ W + b), np.zeros((1, D)), h, tableau)   # the affine response r_sigma
+    out = []
+    for sigma, uv in enumerate(UV):
+        U, v = uv[:D], uv[D]
+        Ysig, _ = stage_inputs(fy_hom, U.T.copy(), h, tableau)                   # only stage sigma of this run is used: U^T Pi_sigma
+        kW = Ysig[sigma].T
+        if b is not None:
+            kW = kW + np.outer(R[sigma][0], v)
+        out.append((-s * kW, -s * v))
+    return out

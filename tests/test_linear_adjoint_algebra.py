@@ -1,0 +1,54 @@
+"""CPU tests of oracle/linear_adjoint_numpy.py: the stage derivatives of the parameter component of odeint_adjoint's augmented system
+(/root/reference/tfdiffeq/adjoint.py:69-105) for f = y W + b - the direct form against torch.autograd (the reference's route: a tape over
+f), and the factored form the planned one-launch kernel uses (one outer product over the batch per step) against the
+direct one."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import linear_adjoint_numpy as LA
+from oracle import ode_numpy as O
+
+
+def _problem(D, B, bias, seed):
+    rng = np.random.default_rng(seed)
+    S_ = rng.standard_normal((D, D))
+    W = -0.4 * np.eye(D) + 0.6 * (S_ - S_.T) / np.sqrt(D) + 0.1 * rng.standard_normal((D, D)) / np.sqrt(D)
+    b = 0.3 * rng.standard_normal(D) if bias else None
+    return W, b, rng.standard_normal((B, D)), rng.standard_normal((B, D)) / B
+
+
+@pytest.mark.parametrize('D,B,bias,s,h', [(3, 7, True, 1.0, 0.2), (6, 50, False, -1.0, 0.35), (16, 300, True, -1.0, 0.1), (5, 1, True, 1.0, 0.8)])
+def test_direct_stage_derivatives_are_the_vjps_autograd_gives(D, B, bias, s, h):
+    W, b, y0, a0 = _problem(D, B, bias, D + B)
+    direct = LA.theta_stage_derivatives_direct(W, b, y0, a0, h, s, O.DOPRI5)
+    fy = (lambda y: s * (y @ W + b)) if bias else (lambda y: s * (y @ W))
+    Ys, _ = LA.stage_inputs(fy, y0, h, O.DOPRI5)
+    As, _ = LA.stage_inputs(lambda a: -s * (a @ W.T), a0, h, O.DOPRI5)
+    for (kW, kb), Y, A in zip(direct, Ys, As):
+        Wt = torch.tensor(W, requires_grad=True)
+        bt = torch.tensor(b, requires_grad=True) if bias else None
+        f = torch.tensor(Y) @ Wt + (bt if bias else 0.0)
+        g = torch.autograd.grad(f, (Wt,) + ((bt,) if bias else ()), torch.tensor(-A))       # adjoint.py:83-95: vjp with -adj_y
+        assert np.abs(s * g[0].numpy() - kW).max() <= 1e-13 * max(1.0, np.abs(kW).max())     # (time reversal: the sign, misc.py:318-321)
+        if bias:
+            assert np.abs(s * g[1].numpy() - kb).max() <= 1e-13 * max(1.0, np.abs(kb).max())
+
+
+@pytest.mark.parametrize('tableau', ['DOPRI5', 'BOSH3'])
+@pytest.mark.parametrize('D,B,bias,s,h', [(3, 7, True, 1.0, 0.2), (6, 50, False, -1.0, 0.35), (16, 300, True, -1.0, 0.1), (32, 1000, True, 1.0, 0.05),
+                                          (5, 1, True, -1.0, 0.8)])
+def test_factored_stage_derivatives_equal_the_direct_ones(tableau, D, B, bias, s, h):
+    tb = getattr(O, tableau)
+    W, b, y0, a0 = _problem(D, B, bias, 3 * D + B)
+    direct = LA.theta_stage_derivatives_direct(W, b, y0, a0, h, s, tb)
+    factored = LA.theta_stage_derivatives_factored(W, b, y0, a0, h, s, tb)
+    assert len(direct) == len(factored) == len(tb.beta) + 1
+    for (kW, kb), (qW, qb) in zip(direct, factored):
+        assert np.abs(kW - qW).max() <= 1e-12 * max(1.0, np.abs(kW).max())
+        assert np.abs(kb - qb).max() <= 1e-12 * max(1.0, np.abs(kb).max())
+    # and with them any combination over the stages - the step, the error estimate (rk_common.py:54-60), the dense-output fold
+    for c in (tb.c_sol, tb.c_error):
+        dW = sum((h * cj) * kW for cj, (kW, _) in zip(c, direct))
+        fW = sum((h * cj) * qW for cj, (qW, _) in zip(c, factored))
+        assert np.abs(dW - fW).max() <= 1e-12 * max(1.0, np.abs(dW).max())
