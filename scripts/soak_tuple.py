@@ -58,11 +58,13 @@ for it in range(n):
     f = rhs.PerComponent(make())
     y0 = tuple(torch.tensor(c, device=dev) for c in comps)
     raised = []
-    for opts in (None, {'force_plane_kernels': True}):
+    # (max_num_steps: a float32 spiral integrated backwards towards its blow-up can take millions of ever smaller accepted steps -
+    # seed 11, problem 54: minutes on the host-controlled loop; both engines must then raise the reference's assertion alike)
+    for opts in ({'max_num_steps': 20000}, {'force_plane_kernels': True, 'max_num_steps': 20000}):
         try:
             res = odeint(f, y0, torch.tensor(ts), method=method, options=opts, **kw)
             raised.append(None)
-            if opts is None:
+            if 'force_plane_kernels' not in opts:
                 a, sa = res, dict(odeint.last_stats)
             else:
                 b, sb = res, dict(odeint.last_stats)
