@@ -6,6 +6,8 @@
 #   bench     bench.py for configs 4 (headline, with the CPU leg) and 1, 2, 3, 5
 #   profiles  rocprofv3 kernel trace + FETCH/WRITE PMC passes of every BASELINE config -> gpurun_out/profiles_r04/
 #   callable  scripts/bench_callable.py + DETEST on the callable path
+#   adjoint   rocprofv3 of training steps on the fused adjoint, models.LinearODEFunc vs the autograd path, mi_ode_outer_reduce alone
+#   soaks     randomised parity soaks (whole vs step, multistep, tuple states)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; mkdir -p gpurun_out; export PYTHONPATH=$PWD TMPDIR=/tmp; R=$PWD
 V=$PWD/tfdiffeq_amd/_variants
@@ -43,5 +45,14 @@ profiles)
   ls -la $P ;;
 callable)
   timeout 900 python scripts/bench_callable.py 2>&1 | grep -v amdgpu.ids | tee gpurun_out/r04_callable.txt ;;
+adjoint)
+  # fused adjoint (rocprofv3 of training steps, both networks), the linear system under odeint_adjoint, the outer-product kernel alone
+  bash scripts/gpu_adjoint_profile.sh 2>&1 | tail -6
+  mkdir -p gpurun_out/profiles_r04
+  (python scripts/linear_adjoint_generic.py; python scripts/bench_outer.py) 2>&1 | grep -v amdgpu.ids | tee gpurun_out/profiles_r04/r04_linear_adjoint.txt ;;
+soaks)
+  (echo "== soak_whole_vs_step.py 11 100"; timeout 100 python scripts/soak_whole_vs_step.py 11 100 2>&1 | tail -1
+   echo "== soak_multistep.py 11 40"; timeout 200 python scripts/soak_multistep.py 11 40 2>&1 | tail -1
+   echo "== soak_tuple.py 100 11"; timeout 300 python scripts/soak_tuple.py 100 11 2>&1 | tail -1) | grep -v amdgpu.ids | tee gpurun_out/r04_soaks_final.txt ;;
 *) echo "unknown stage $1"; exit 2 ;;
 esac
