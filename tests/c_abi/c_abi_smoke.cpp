@@ -5,6 +5,7 @@
 //   3b. tuple state, 4. fused adjoint interval, 5. fixed-grid Adams-Bashforth in one launch vs a host loop, 6. 300000 trajectories in one launch, 7. the variable-order Adams solver in one launch
 //   8. family C (ABI 11): f evaluated by a kernel of THIS program between the library's launches, the controller on the device, one
 //      attempt captured as a hipGraph and replayed in blind chunks
+//   9. (ABI 12) mi_ode_outer_reduce vs a host loop
 // Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -I include tests/c_abi/c_abi_smoke.cpp -L tfdiffeq_amd -lmi_ode
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -447,6 +448,35 @@ int main() {
     CK(hipGraphExecDestroy(gexec)); CK(hipGraphDestroy(graph));
     MI(mi_ode_opq_destroy(ho));
     CK(hipStreamDestroy(s8));
+  }
+  // ---- 9. (ABI 12) mi_ode_outer_reduce: -(y^T a) and -sum_rows a of two [batch, dim] planes vs a host loop (ragged slab, padded width) ----
+  {
+    const int OB = 1003, OD = 20;
+    std::vector<double> hy((size_t)OB * OD), ha((size_t)OB * OD), hw((size_t)OD * OD), hb(OD), rw((size_t)OD * OD, 0.0), rb(OD, 0.0);
+    for (int r = 0; r < OB; ++r)
+      for (int c = 0; c < OD; ++c) { hy[(size_t)r * OD + c] = sin(0.37 * r + c); ha[(size_t)r * OD + c] = cos(0.11 * r - 0.5 * c) / OB; }
+    for (int r = 0; r < OB; ++r)
+      for (int m = 0; m < OD; ++m) {
+        for (int q = 0; q < OD; ++q) rw[(size_t)m * OD + q] -= hy[(size_t)r * OD + m] * ha[(size_t)r * OD + q];
+        rb[m] -= ha[(size_t)r * OD + m];
+      }
+    double *dy9 = nullptr, *da9 = nullptr, *dw9 = nullptr, *db9 = nullptr;
+    void* ws9 = nullptr;
+    const int64_t wsb = mi_ode_outer_workspace_bytes(MI_ODE_F64, OB, OD);
+    if (wsb <= 0) { printf("FAIL outer workspace size\n"); return 1; }
+    CK(hipMalloc((void**)&dy9, hy.size() * 8)); CK(hipMalloc((void**)&da9, ha.size() * 8));
+    CK(hipMalloc((void**)&dw9, hw.size() * 8)); CK(hipMalloc((void**)&db9, hb.size() * 8)); CK(hipMalloc(&ws9, (size_t)wsb));
+    CK(hipMemcpy(dy9, hy.data(), hy.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(da9, ha.data(), ha.size() * 8, hipMemcpyHostToDevice));
+    MI(mi_ode_outer_reduce(MI_ODE_F64, OB, OD, dy9, da9, -1.0, dw9, db9, ws9, nullptr));
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(hw.data(), dw9, hw.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(hb.data(), db9, hb.size() * 8, hipMemcpyDeviceToHost));
+    double md9 = 0.0;
+    for (size_t i = 0; i < hw.size(); ++i) md9 = fmax(md9, fabs(hw[i] - rw[i]));
+    for (int i = 0; i < OD; ++i) md9 = fmax(md9, fabs(hb[i] - rb[i]));
+    printf("outer_reduce (1003 x 20, fp64): max |device - host loop| = %.3e\n", md9);
+    if (!(md9 < 1e-13)) { printf("FAIL outer_reduce\n"); return 1; }
+    if (mi_ode_outer_reduce(MI_ODE_F64, OB, 200, dy9, da9, -1.0, dw9, db9, ws9, nullptr) >= 0) { printf("FAIL outer_reduce accepted dim 200\n"); return 1; }
+    CK(hipFree(dy9)); CK(hipFree(da9)); CK(hipFree(dw9)); CK(hipFree(db9)); CK(hipFree(ws9));
   }
   printf("C-ABI OK (abi %d)\n", mi_ode_abi_version());
   return 0;
