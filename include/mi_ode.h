@@ -338,7 +338,7 @@ int mi_ode_adjoint_dynamics_at(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, d
 /* tfdiffeq/adjoint.py:69-105 for f(t, y) = y W + b: the augmented dynamics are (y W + b, -adj_y W^T, 0, -(y^T adj_y), -sum_rows adj_y).
  * The first two are the linear right-hand side itself (mi_ode_eval_rhs of a handle created with W, and of one created with -W^T);
  * the parameter part is a GEMM with M = N = dim and K = batch - the shape vendor BLAS serves worst (0.3 TFLOP/s fp64 in rocBLAS at
- * 65536 x 128, 7.0 ms against 68 us here) - and this entry point:
+ * 65536 x 128, 7.0 ms against 63 us here) - and this entry point:
  *     out_w[dim, dim] = scale * (y^T a)   (weights [in, out], the layout of mi_ode_rhs.w)      out_b[dim] = scale * column sums of a
  * over two [batch, dim] device planes, dim <= 128, fp32 or fp64 (MFMA); out_b nullable.  Deterministic (slab partials folded in
  * slab order).  workspace_dev: mi_ode_outer_workspace_bytes(dtype, batch, dim) bytes of device scratch.  Enqueues two kernels on

@@ -2,14 +2,14 @@
 //     -a^T df/dW = -(y^T a)   [dim, dim] (weights [in, out], the layout of mi_ode_rhs.w)        -a^T df/db = -(column sums of a)
 // i.e. what the reference's augmented dynamics (tfdiffeq/adjoint.py:69-105) obtains from the GradientTape for a dense layer without
 // activation.  It is a GEMM with M = N = dim <= 128 and K = batch (65536 in BASELINE config 4's shape): the shape vendor BLAS
-// libraries serve worst (`y.t() @ a` takes 7.0 ms in rocBLAS fp64 - 0.3 TFLOP/s - against 68 us here).
+// libraries serve worst (`y.t() @ a` takes 7.0 ms in rocBLAS fp64 - 0.3 TFLOP/s - against 63 us here).
 //
 // k_outer_partial: a workgroup of dim/16 wavefronts takes a contiguous slab of rows, 16 at a time through LDS; wavefront w owns the 16
 // output columns 16 w .. 16 w + 15 and keeps the dim x 16 block of y^T a in MFMA accumulators (dim/16 x 4 registers); per 4 rows one
 // operand of `a`, dim/16 operands of `y` and dim/16 MFMAs.  The slabs' partial blocks go to a workspace; k_outer_fold sums them in a
 // fixed order (eight interleaved chains) - no atomics, the same bits every time.
 // Bound: HBM - both planes are read once (2 x batch x dim elements); fp64 MFMA time is 2 batch dim^2 flop (27 us at config 4's shape
-// against 27 us for the 128 MB at 5 TB/s; measured 52 + 15 us).
+// against 27 us for the 128 MB at 5 TB/s; measured 48 + 15 us).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "mi_ode_host.h"
@@ -21,13 +21,14 @@ namespace {
 
 constexpr int kOuterMaxSlabs = 256;
 
-template <typename T, int D>
+// VL: the planes are staged with 16-byte loads (dim a multiple of 16 bytes' worth of elements, 16-byte aligned planes); else element loads
+template <typename T, int D, bool VL>
 __global__ __launch_bounds__(D * 4) void k_outer_partial(const T* __restrict__ y, const T* __restrict__ a, long long batch, int dim,
                                                          long long rows_per_slab, T* __restrict__ part) {
   using TR = MfmaTraits<T>;
   using acc_t = typename TR::acc_t;
   constexpr int MB = D / 16, NT = D * 4, R = 16, EPT = R * D / NT;   // 16-row tiles (32 KB of LDS at D = 128, fp64; 32 rows: the same 52 us), EPT = 4 elements per thread and plane
-  __shared__ T sy[R * D], sa[R * D];
+  __shared__ __attribute__((aligned(16))) T sy[R * D], sa[R * D];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
   acc_t acc[MB];
 #pragma unroll
@@ -41,21 +42,49 @@ __global__ __launch_bounds__(D * 4) void k_outer_partial(const T* __restrict__ y
   // wavefronts take their MFMA operands from there.  (Operands straight from global memory - every wavefront reads all of y, eight
   // times the traffic through L1 / L2 - measured 66-73 us per call at 65536 x 128 whatever the prefetch depth; matrix-pipe time
   // 27 us, the two planes at 5 TB/s 27 us.)
+  constexpr int VEC = TR::VEC, CPT = EPT / VEC;                 // 16-byte chunks per thread and plane (2 elements fp64, 4 fp32)
+  using CH = Chunk<T, VEC>;
+  static_assert(EPT % VEC == 0, "tile / workgroup geometry");
   T py[EPT], pa[EPT];
   auto fetch = [&](long long t0) {
+    if constexpr (VL) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const int idx = e * NT + tid, row = idx / D, col = idx % D;
-      const bool ok = t0 + row < r1 && col < dim;
-      py[e] = ok ? y[(t0 + row) * dim + col] : (T)0;
-      pa[e] = ok ? a[(t0 + row) * dim + col] : (T)0;
+      for (int c = 0; c < CPT; ++c) {
+        const int idx = (c * NT + tid) * VEC, row = idx / D, col = idx % D;
+        const bool ok = t0 + row < r1 && col < dim;                // (dim % VEC == 0: a chunk is inside or outside as a whole)
+        CH vy, va;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { vy.v[v] = (T)0; va.v[v] = (T)0; }
+        if (ok) { vy = *(const CH*)(y + (t0 + row) * dim + col); va = *(const CH*)(a + (t0 + row) * dim + col); }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { py[c * VEC + v] = vy.v[v]; pa[c * VEC + v] = va.v[v]; }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int idx = e * NT + tid, row = idx / D, col = idx % D;
+        const bool ok = t0 + row < r1 && col < dim;
+        py[e] = ok ? y[(t0 + row) * dim + col] : (T)0;
+        pa[e] = ok ? a[(t0 + row) * dim + col] : (T)0;
+      }
     }
   };
   if (r0 < r1) fetch(r0);
   for (long long t0 = r0; t0 < r1; t0 += R) {
     __syncthreads();                                           // (the previous tile's operands have been read)
+    if constexpr (VL) {
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) { sy[e * NT + tid] = py[e]; sa[e * NT + tid] = pa[e]; }
+      for (int c = 0; c < CPT; ++c) {
+        CH vy, va;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { vy.v[v] = py[c * VEC + v]; va.v[v] = pa[c * VEC + v]; }
+        *(CH*)(sy + (c * NT + tid) * VEC) = vy;
+        *(CH*)(sa + (c * NT + tid) * VEC) = va;
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) { sy[e * NT + tid] = py[e]; sa[e * NT + tid] = pa[e]; }
+    }
     __syncthreads();
     if (t0 + R < r1) fetch(t0 + R);                            // in flight under this tile's MFMAs
 #pragma unroll
@@ -116,7 +145,9 @@ int outer_launch(long long batch, int dim, const void* y, const void* a, double 
   const int slabs = slabs_for(batch);
   long long rps = (batch + slabs - 1) / slabs;
   rps = (rps + 3) / 4 * 4;
-  hipLaunchKernelGGL((k_outer_partial<T, D>), dim3(slabs), dim3(D * 4), 0, st, (const T*)y, (const T*)a, batch, dim, rps, (T*)ws);
+  const bool vl = dim % MfmaTraits<T>::VEC == 0 && (((uintptr_t)y | (uintptr_t)a) & 15u) == 0;
+  if (vl) hipLaunchKernelGGL((k_outer_partial<T, D, true>), dim3(slabs), dim3(D * 4), 0, st, (const T*)y, (const T*)a, batch, dim, rps, (T*)ws);
+  else hipLaunchKernelGGL((k_outer_partial<T, D, false>), dim3(slabs), dim3(D * 4), 0, st, (const T*)y, (const T*)a, batch, dim, rps, (T*)ws);
   hipLaunchKernelGGL((k_outer_fold<T, D>), dim3((D * D + D + 255) / 256), dim3(256), 0, st, (const T*)ws, slabs, dim, (T)scale, (T*)out_w, (T*)out_b);
   MI_HIP(hipGetLastError());
   return 0;
