@@ -65,3 +65,20 @@ def theta_stage_derivatives_factored(W, b, y0, a0, h, s, tableau):
             kW = kW + np.outer(R[sigma][0], v)
         out.append((-s * kW, -s * v))
     return out
+
+
+def dense_output_fold_weights(tableau, c_mid, x):
+    """The dense output of dopri5 (interp.py:6-67 over dopri5.py:39-45's y_mid) as ONE combination of the stage derivatives:
+        y(x) = y0 + dt sum_j w_j(x) k_j,     w_j = b_j (-8x^4 + 14x^3 - 5x^2) + c_mid_j (16x^4 - 32x^3 + 16x^2)
+                                                   + [j = 0] (-2x^4 + 5x^3 - 4x^2 + x) + [j = S] (2x^4 - 3x^3 + x^2)
+    The fit is linear in (y0, y1, y_mid, f0, f1), each of which is y0 plus a combination of the k_j (y1: b = c_sol, y_mid: c_mid, f0 = k_0,
+    f1 = k_S), and the y0 terms of the x^4, x^3, x^2 coefficients cancel (-8 - 8 + 16 = 18 + 14 - 32 = -11 - 5 + 16 = 0).  This is what the
+    fused adjoint kernel forms for its parameter component (csrc/mi_ode_adjoint.h: one weight-gradient pass instead of three) and what the
+    planned linear kernel needs; `x` = (t - t0) / dt."""
+    S = len(tableau.beta)
+    x2, x3, x4 = x * x, x * x * x, x * x * x * x
+    p1 = -8 * x4 + 14 * x3 - 5 * x2
+    pm = 16 * x4 - 32 * x3 + 16 * x2
+    p0 = -2 * x4 + 5 * x3 - 4 * x2 + x
+    pS = 2 * x4 - 3 * x3 + x2
+    return [tableau.c_sol[j] * p1 + c_mid[j] * pm + (p0 if j == 0 else 0.0) + (pS if j == S else 0.0) for j in range(S + 1)]

@@ -52,3 +52,23 @@ def test_factored_stage_derivatives_equal_the_direct_ones(tableau, D, B, bias, s
         dW = sum((h * cj) * kW for cj, (kW, _) in zip(c, direct))
         fW = sum((h * cj) * qW for cj, (qW, _) in zip(c, factored))
         assert np.abs(dW - fW).max() <= 1e-12 * max(1.0, np.abs(dW).max())
+
+
+@pytest.mark.parametrize('x', [0.0, 0.137, 0.5, 0.8125, 1.0])
+def test_dense_output_as_one_combination_of_the_stage_derivatives(x):
+    """interp.py:6-67 + dopri5.py:39-45 (oracle: interp_fit_mid / interp_evaluate) against the folded weights the fused adjoint kernel
+    uses for its parameter component - float64, a nonlinear right-hand side so that the k_j are independent."""
+    rng = np.random.default_rng(3)
+    y0 = (rng.standard_normal((7, 4)),)
+    f = lambda t, y: (np.tanh(y[0] @ M) + 0.3 * np.cos(t) * y[0],)  # noqa: E731
+    M = rng.standard_normal((4, 4))
+    t0, dt = 0.3, 0.21
+    f0 = f(t0, y0)
+    y1, f1, _, k = O.runge_kutta_step(f, y0, f0, t0, dt, O.DOPRI5)
+    co = O.interp_fit_mid(y0, y1, k, dt, O.DOPRI5_C_MID)
+    ref = O.interp_evaluate(co, t0, t0 + dt, t0 + x * dt)[0]
+    w = LA.dense_output_fold_weights(O.DOPRI5, O.DOPRI5_C_MID, x)
+    got = y0[0] + sum((dt * wj) * kj for wj, kj in zip(w, k[0]))
+    assert np.abs(got - ref).max() <= 2e-14 * max(1.0, np.abs(ref).max())
+    if x == 1.0:
+        assert np.abs(got - y1[0]).max() <= 1e-15 * max(1.0, np.abs(y1[0]).max())
