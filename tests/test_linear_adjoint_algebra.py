@@ -72,3 +72,22 @@ def test_dense_output_as_one_combination_of_the_stage_derivatives(x):
     assert np.abs(got - ref).max() <= 2e-14 * max(1.0, np.abs(ref).max())
     if x == 1.0:
         assert np.abs(got - y1[0]).max() <= 1e-15 * max(1.0, np.abs(y1[0]).max())
+
+
+@pytest.mark.parametrize('act', ['tanh', 'relu', 'softplus'])
+def test_time_dependent_network_time_vjp_is_a_dot_product_with_the_bias_vjp(act):
+    """The identity the fused adjoint kernel integrates adj_t with (csrc/mi_ode_adjoint.h, round 4): for the network of
+    dense_odenet.py:79-84 - fc1 over concat([t, x]) - the first pre-activation is W1x^T x + t w_t + b1, hence
+        -a^T df/dt = dot(w_t, -a^T df/db1)        and        -a^T df/dw_t = t (-a^T df/db1)
+    checked against torch.autograd on the CPU (the reference's route: a tape over f, adjoint.py:83-95)."""
+    from tfdiffeq_amd.models import ODEFunc
+    torch.manual_seed(0)
+    func = ODEFunc(5, 12, time_dependent=True, non_linearity=act).double()
+    x = torch.randn(9, 5, dtype=torch.float64, requires_grad=True)
+    a = torch.randn(9, 5, dtype=torch.float64)
+    t = torch.tensor(0.73, dtype=torch.float64, requires_grad=True)
+    f = func(t, x)
+    g_t, g_w1, g_b1 = torch.autograd.grad(f, (t, func.fc1.weight, func.fc1.bias), -a)
+    w_t = func.fc1.weight.detach()[:, 0]                      # the column of fc1 that multiplies t ([out, in] layout; row 0 of the Keras kernel)
+    assert abs(float(torch.dot(w_t, g_b1)) - float(g_t)) <= 1e-13 * max(1.0, abs(float(g_t)))
+    assert float((g_w1[:, 0] - float(t) * g_b1).abs().max()) <= 1e-13 * max(1.0, float(g_b1.abs().max()))
