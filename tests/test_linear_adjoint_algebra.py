@@ -90,4 +90,4 @@ def test_time_dependent_network_time_vjp_is_a_dot_product_with_the_bias_vjp(act)
     g_t, g_w1, g_b1 = torch.autograd.grad(f, (t, func.fc1.weight, func.fc1.bias), -a)
     w_t = func.fc1.weight.detach()[:, 0]                      # the column of fc1 that multiplies t ([out, in] layout; row 0 of the Keras kernel)
     assert abs(float(torch.dot(w_t, g_b1)) - float(g_t)) <= 1e-13 * max(1.0, abs(float(g_t)))
-    assert float((g_w1[:, 0] - float(t) * g_b1).abs().max()) <= 1e-13 * max(1.0, float(g_b1.abs().max()))
+    assert float((g_w1[:, 0] - float(t.detach()) * g_b1).abs().max()) <= 1e-13 * max(1.0, float(g_b1.abs().max()))
