@@ -337,3 +337,28 @@ def test_linear_odefunc_descriptor_reads_the_parameters_own_storage():
     y = torch.randn(4, 5, dtype=torch.float64)
     assert torch.allclose(f(torch.tensor(0.0), y), y @ f.weight + f.bias)
     assert models.LinearODEFunc(3, bias=False).bias is None
+
+
+def test_committed_bench_line_carries_the_contract():
+    """The bench.py line committed under profiles/ (what DESIGN.md section 5 quotes) has every field of the bench contract, the metric
+    BASELINE.json names, and figures that are consistent with each other."""
+    import json
+    line = open(os.path.join(ROOT, 'profiles', 'r04_bench_config4.json')).read().strip().split('\n')[-1]
+    d = json.loads(line)
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
+              'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    base = json.load(open(os.path.join(ROOT, 'BASELINE.json')))
+    assert d['unit'] == base.get('unit', d['unit']) and d['dtype'] == 'f64' and d['data'] == 'synthetic' and d['vs_baseline'] is None
+    assert d['n_gpus'] == 1 and d['higher_is_better'] is True and 'workload' in d['config'] and 'model' not in d['config']
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] == 'mfma' and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-12
+    assert abs(d['value'] - 65536 * 128 / (d['ms_per_step'] * 1e-3)) <= 1e-6 * d['value']          # whole-job throughput = elements / wall
+    assert r['avg_launch_ms'] <= d['ms_per_step']                                                   # the kernel fits inside the step
+    assert abs(r['achieved'] - r['algorithmic_flops_per_launch'] / (r['avg_launch_ms'] * 1e-3) / 1e12) <= 1e-9 * r['achieved']
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and d['parity_max_abs_diff'] < 1e-12
