@@ -53,8 +53,9 @@ extern "C" {
 
 /* 9: mi_ode_desc.multistep (fixed-grid Adams family).  10: multistep = 3 + ms_gamma_star (variable-order Adams), the four
  * mi_ode_adams_* plane entry points.  11: family (C) mi_ode_opq_* (opaque right-hand side, device-resident controller: what a
- * captured hipGraph of an attempt needs), mi_ode_stats.clock_mhz. */
-#define MI_ODE_ABI_VERSION 12
+ * captured hipGraph of an attempt needs), mi_ode_stats.clock_mhz.
+ * 13: (A''') mi_ode_linadj_* - the backward segment of odeint_adjoint for the linear right-hand side in one launch. */
+#define MI_ODE_ABI_VERSION 13
 #define MI_ODE_MAX_STAGES 13         /* rows of the tableau (dopri8 = 13, dopri5 / tsit5 = 6, bosh3 = 3, rk4 = 3, adaptive_heun = 1) */
 #define MI_ODE_MAX_K (MI_ODE_MAX_STAGES + 1)
 #define MI_ODE_MAX_LINCOMB 14        /* stateless lincomb: up to 14 planes (dopri8: f0 + 13 stages) */
@@ -218,7 +219,7 @@ const char* mi_ode_status_string(uint32_t status_bits);   /* reference assertion
 const char* mi_ode_last_error(void);                      /* thread-local text of the last negative return */
 int64_t mi_ode_reduce_workspace_bytes(void);              /* scratch the stateless reductions need */
 int64_t mi_ode_sizeof(int32_t which);                     /* 0: mi_ode_desc, 1: mi_ode_stats, 2: mi_ode_tableau, 3: mi_ode_rhs,
-                                                             5: mi_ode_ctrl_params, 6: mi_ode_adjoint_desc, 7: mi_ode_opq_desc
+                                                             5: mi_ode_ctrl_params, 6: mi_ode_adjoint_desc, 7: mi_ode_opq_desc, 8: mi_ode_linadj_desc
                                                              (lets a foreign-language binding verify its struct layout) */
 
 /* ---- (A) fused engine ---------------------------------------------------------------------- */
@@ -346,6 +347,37 @@ int mi_ode_adjoint_dynamics_at(mi_ode_adjoint_handle h, const mi_ode_rhs* rhs, d
 int64_t mi_ode_outer_workspace_bytes(int32_t dtype, int64_t batch, int32_t dim);
 int mi_ode_outer_reduce(int32_t dtype, int64_t batch, int32_t dim, const void* y_dev, const void* a_dev, double scale,
                         void* out_w_dev, void* out_b_dev, void* workspace_dev, void* stream);
+
+/* ---- (A''') the backward segment of odeint_adjoint for the linear right-hand side, ONE launch (ABI 13) ------------- */
+/* tfdiffeq/adjoint.py:148-160: odeint(augmented_dynamics, (y, adj_y, adj_t, adj_params), [t_i, t_{i-1}]) for f(t, y) = y W + b,
+ * dopri5 over the four components with the reference's per-component error ratios, python max() of them, the initial step over all
+ * components (misc.py:183-287) and dense output at t_end (interp.py:6-67).  y and adj_y run on config 4's tile kernels (W and W^T
+ * resident in registers); adj_params needs ONE product over the batch per accepted step (csrc/mi_ode_linadj.h).  State dtype
+ * float32 or float64, 1 <= dim <= 128.  adj_params is one flat vector: W's gradient [dim, dim] in W's own [in, out] layout, then
+ * (with a bias) the dim entries of b's. */
+typedef struct mi_ode_linadj_desc {
+  int64_t batch;
+  int32_t dim;
+  int32_t dtype;              /* enum mi_ode_dtype */
+  mi_ode_tableau tableau;     /* dopri5: 6 rows, FSAL shaped, c_mid filled */
+  double rtol, atol;          /* scalars: adjoint.py passes them through to every component (dopri5.py:60-61) */
+  double safety, ifactor, dfactor;
+  int32_t order, init_order;
+  int64_t max_num_steps;
+} mi_ode_linadj_desc;
+typedef struct mi_ode_linadj* mi_ode_linadj_handle;
+int mi_ode_linadj_create(const mi_ode_linadj_desc* desc, mi_ode_linadj_handle* out);
+int mi_ode_linadj_destroy(mi_ode_linadj_handle h);
+/* One backward interval t_start -> t_end (either direction; decreasing time as misc._check_inputs handles it, misc.py:311-321).
+ * All pointers are DEVICE memory in the state dtype; w_dev [dim, dim] row-major ([in, out]: f = y W), b_dev nullable; adj_t is a
+ * device scalar.  y(t_end) is not produced (the reference discards it, adjoint.py:155-160).  Blocks until done; returns status bits
+ * (>= 0) or an error (< 0).  stats->n_launches == 1. */
+int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, const void* b_dev, const void* y_dev, const void* adj_y_dev,
+                          const void* adj_t_dev, const void* adj_params_dev, double t_start, double t_end, void* adj_y_out_dev,
+                          void* adj_t_out_dev, void* adj_params_out_dev, mi_ode_stats* stats, void* stream);
+/* where the time of the last segment went, microseconds of workgroup 0: {tile passes, adj_params combinations, hand-offs of the
+ * attempts, slab passes, folds + small products with their hand-offs, prologue, epilogue, hand-offs (count)} */
+int mi_ode_linadj_profile(mi_ode_linadj_handle h, double* out8);
 
 /* ---- function-level parity surface of the step controller ----------------------------------- */
 /* The scalar tail of one step attempt exactly as the kernels run it (csrc/mi_ode_ctrl_dev.h, ONE device thread per case):

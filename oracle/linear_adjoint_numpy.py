@@ -82,3 +82,67 @@ def dense_output_fold_weights(tableau, c_mid, x):
     p0 = -2 * x4 + 5 * x3 - 4 * x2 + x
     pS = 2 * x4 - 3 * x3 + x2
     return [tableau.c_sol[j] * p1 + c_mid[j] * pm + (p0 if j == 0 else 0.0) + (pS if j == S else 0.0) for j in range(S + 1)]
+
+
+# ---- the power form (round 5): what csrc/mi_ode_linadj.h evaluates ---------------------------------------------------------------------
+# Both systems are linear with CONSTANT matrices, so the stage inputs are polynomials in h W whose coefficients depend on the tableau
+# only:   Y_sigma = y0 R_sigma(s h W) + 1 rho_sigma,   A_sigma = a0 R_sigma(-s h W^T),   R_0 = 1,  R_sigma(z) = 1 + z sum_j beta_sigma,j R_j(z)
+# (rho_sigma = b [R_sigma(s h W) - 1] W^-1, i.e. the same coefficients shifted by one power).  With pi[sigma][p] the coefficient of z^p in
+# R_sigma, P_p = (W^T)^p, c_p = P_{p-1} b^T (c_0 = 0), G0 = y0^T a0 and g0 = sum_rows a0:
+#     Y_sigma^T A_sigma = sum_pq pi[sigma][p] pi[sigma][q] (s h)^p (-s h)^q  M_pq,        M_pq = (P_p G0 + c_p g0) P_q
+# and ANY combination over the stages (solution, error estimate, dense output at t_end) is
+#     sum_sigma (h c_sigma) k_W,sigma = -s h sum_pq K^c_pq (s h)^p (-s h)^q M_pq,         K^c_pq = sum_sigma c_sigma pi[sigma][p] pi[sigma][q]
+#     sum_sigma (h c_sigma) k_b,sigma = -s h sum_q  K^c_0q (-s h)^q (g0 P_q).
+# The M_pq depend on the step's START STATE only (not on h): one set of (S+1)^2 small products per ACCEPTED step, then an attempt costs an
+# elementwise combination.  tests/test_linear_adjoint_algebra.py holds this form to the direct one.
+
+def stage_polynomials(tableau):
+    """pi[sigma][p], sigma = 0 .. S, p = 0 .. S: the coefficient of z^p in the stage-input polynomial R_sigma(z) (rk_common.py:44-52 applied to
+    y' = y z)."""
+    S = len(tableau.beta)
+    pi = np.zeros((S + 1, S + 1))
+    pi[0, 0] = 1.0
+    for sg in range(1, S + 1):
+        pi[sg, 0] = 1.0
+        for j, bj in enumerate(tableau.beta[sg - 1]):
+            pi[sg, 1:] += bj * pi[j, :-1]
+    return pi
+
+
+def combination_table(tableau, c):
+    """K^c[p][q] = sum_sigma c_sigma pi[sigma][p] pi[sigma][q]."""
+    pi = stage_polynomials(tableau)
+    c = np.asarray(c, dtype=np.float64)
+    return np.einsum('s,sp,sq->pq', c, pi, pi)
+
+
+def start_state_products_S(W, b, G0, g0, S):
+    """(M[p][q], r[q]) of the comment above: M_pq = (P_p G0 + c_p g0) P_q  [D, D],  r_q = g0 P_q  [D], p, q = 0 .. S."""
+    D = W.shape[0]
+    P = [np.eye(D)]
+    for _ in range(S):
+        P.append(P[-1] @ W.T)
+    L = []
+    for p in range(S + 1):
+        Lp = P[p] @ G0
+        if b is not None and p >= 1:
+            Lp = Lp + np.outer(P[p - 1] @ b, g0)
+        L.append(Lp)
+    M = [[L[p] @ P[q] for q in range(S + 1)] for p in range(S + 1)]
+    r = [g0 @ P[q] for q in range(S + 1)]
+    return M, r
+
+
+def theta_combination_powers(W, b, G0, g0, h, s, tableau, c):
+    """(sum_sigma (h c_sigma) k_W,sigma, sum_sigma (h c_sigma) k_b,sigma) from the start-state products."""
+    S = len(tableau.beta)
+    K = combination_table(tableau, c)
+    M, r = start_state_products_S(W, b, G0, g0, S)
+    dW = np.zeros_like(G0)
+    db = np.zeros_like(g0)
+    for p in range(S + 1):
+        for q in range(S + 1):
+            dW = dW + (K[p, q] * (s * h) ** p * (-s * h) ** q) * M[p][q]
+    for q in range(S + 1):
+        db = db + (K[0, q] * (-s * h) ** q) * r[q]
+    return -s * h * dW, -s * h * db

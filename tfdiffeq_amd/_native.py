@@ -21,7 +21,7 @@ F32, F64 = 0, 1
 RHS_LINEAR, RHS_CUBIC_LINEAR, RHS_LOTKA_VOLTERRA, RHS_LORENZ, RHS_MLP_TANH, RHS_PLUGIN = 1, 2, 3, 4, 5, 6
 CTRL_MISC, CTRL_TSIT5 = 0, 1
 INTERP_QUARTIC_MID, INTERP_TSIT5, INTERP_TSIT5_REF = 0, 1, 2
-ABI_VERSION = 12
+ABI_VERSION = 13
 MAX_SEGMENTS = 8
 SEGMENT_ALIGN = 256
 IPC_HANDLE_BYTES = 64
@@ -83,6 +83,13 @@ class AdjointDesc(C.Structure):
                 ('time_dependent', C.c_int32), ('reserved', C.c_int32)]
 
 
+class LinAdjDesc(C.Structure):
+    """mi_ode_linadj_desc: the backward segment of odeint_adjoint for the linear right-hand side in one launch."""
+    _fields_ = [('batch', C.c_int64), ('dim', C.c_int32), ('dtype', C.c_int32), ('tableau', Tableau),
+                ('rtol', C.c_double), ('atol', C.c_double), ('safety', C.c_double), ('ifactor', C.c_double), ('dfactor', C.c_double),
+                ('order', C.c_int32), ('init_order', C.c_int32), ('max_num_steps', C.c_int64)]
+
+
 class OpqDesc(C.Structure):
     """mi_ode_opq_desc: adaptive RK over an opaque (Python) right-hand side with the controller on the device."""
     _fields_ = [('dtype', C.c_int32), ('n_comp', C.c_int32), ('n', C.c_int64 * MAX_SEGMENTS), ('tableau', Tableau),
@@ -142,6 +149,11 @@ _PROTOS = {
     'mi_ode_outer_workspace_bytes': (C.c_int64, [C.c_int32, C.c_int64, C.c_int32]),
     'mi_ode_outer_reduce': (C.c_int, [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p]),
+    'mi_ode_linadj_create': (C.c_int, [C.POINTER(LinAdjDesc), C.POINTER(C.c_void_p)]),
+    'mi_ode_linadj_destroy': (C.c_int, [C.c_void_p]),
+    'mi_ode_linadj_segment': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    'mi_ode_linadj_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     'mi_ode_opq_create': (C.c_int, [C.POINTER(OpqDesc), C.POINTER(C.c_void_p)]),
     'mi_ode_opq_destroy': (C.c_int, [C.c_void_p]),
     'mi_ode_opq_dt_dev': (C.c_void_p, [C.c_void_p]),
@@ -217,7 +229,7 @@ def load():
         fn.argtypes = args
     if lib.mi_ode_abi_version() != ABI_VERSION:
         raise NativeError('libmi_ode.so ABI version mismatch')
-    for which, st in ((0, Desc), (1, Stats), (2, Tableau), (3, Rhs), (5, CtrlParams), (6, AdjointDesc), (7, OpqDesc)):
+    for which, st in ((0, Desc), (1, Stats), (2, Tableau), (3, Rhs), (5, CtrlParams), (6, AdjointDesc), (7, OpqDesc), (8, LinAdjDesc)):
         if lib.mi_ode_sizeof(which) != C.sizeof(st):
             raise NativeError('struct layout mismatch for %s: C %d vs ctypes %d'
                               % (st.__name__, lib.mi_ode_sizeof(which), C.sizeof(st)))

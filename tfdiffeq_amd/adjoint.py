@@ -128,6 +128,87 @@ def _cached_adjoint_engine(*key):
 def clear_adjoint_engines():
     while _ENGINES:
         _ENGINES.pop(next(iter(_ENGINES))).close()
+    while _LIN_ENGINES:
+        _LIN_ENGINES.pop(next(iter(_LIN_ENGINES))).close()
+
+
+class _LinearAdjointEngine(object):
+    """Owns one mi_ode_linadj handle: the augmented system (y, adj_y, adj_t, adj_params) of adjoint.py:57-178 for f = y W + b on a
+    [batch, dim] float32 / float64 state, ONE launch per output interval (csrc/mi_ode_linadj.h)."""
+
+    def __init__(self, batch, dim, dtype, rtol, atol, safety, ifactor, dfactor, max_num_steps, device):
+        from .dopri5 import _DORMAND_PRINCE_SHAMPINE_TABLEAU, DPS_C_MID
+        from .solvers import _fill_tableau
+        self.lib = N.load()
+        self.device = torch.device(device)
+        self.dtype = dtype
+        d = N.LinAdjDesc()
+        d.batch, d.dim, d.dtype = int(batch), int(dim), N.dtype_code(dtype)
+        _fill_tableau(d.tableau, _DORMAND_PRINCE_SHAMPINE_TABLEAU, DPS_C_MID)
+        d.rtol, d.atol = float(rtol), float(atol)
+        d.safety, d.ifactor, d.dfactor = float(safety), float(ifactor), float(dfactor)
+        d.order, d.init_order = 5, 4                     # dopri5.py:68, 74
+        d.max_num_steps = int(max_num_steps)
+        self.desc = d
+        h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(self.lib.mi_ode_linadj_create(C.byref(d), C.byref(h)), 'mi_ode_linadj_create')
+        self.h = h
+        self.batch, self.dim = int(batch), int(dim)
+        self.stats = N.Stats()
+
+    def close(self):
+        if getattr(self, 'h', None):
+            self.lib.mi_ode_linadj_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def segment(self, W, b, y, adj_y, adj_t, adj_params, t_start, t_end):
+        """odeint(augmented_dynamics, (y, adj_y, adj_t, adj_params), [t_start, t_end])[..][1] (adjoint.py:148-160) without the y
+        component.  W [dim, dim] in [in, out] layout, b [dim] or None; every tensor in the state dtype on the device."""
+        y, adj_y = y.contiguous(), adj_y.contiguous()
+        a_out = torch.empty_like(adj_y)
+        t_out = torch.empty_like(adj_t)
+        p_out = torch.empty_like(adj_params)
+        with torch.cuda.device(self.device):
+            rc = N.check(self.lib.mi_ode_linadj_segment(
+                self.h, W.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(), adj_y.data_ptr(), adj_t.data_ptr(),
+                adj_params.data_ptr(), float(t_start), float(t_end), a_out.data_ptr(), t_out.data_ptr(), p_out.data_ptr(),
+                C.byref(self.stats), N.stream_ptr(self.device)), 'mi_ode_linadj_segment')
+        if rc != 0:
+            if rc & N.ST_SYNC_TIMEOUT:
+                raise HandoffTimeout(N.status_message(rc))
+            msg = N.status_message(rc)
+            if rc & N.ST_MAX_STEPS:
+                msg = 'max_num_steps exceeded ({}>={})'.format(self.desc.max_num_steps, self.desc.max_num_steps)
+            if rc & N.ST_DT_UNDERFLOW:
+                msg = 'underflow in dt {}'.format(self.stats.dt)
+            raise AssertionError(msg)                      # what the reference's solver raises (dopri5.py:85-100)
+        return a_out, t_out, p_out
+
+    def profile(self):
+        out = (C.c_double * 8)()
+        N.check(self.lib.mi_ode_linadj_profile(self.h, out), 'mi_ode_linadj_profile')
+        keys = ('tile_passes_us', 'theta_combinations_us', 'attempt_handoffs_us', 'slab_passes_us', 'small_products_us', 'prologue_us',
+                'epilogue_us', 'handoffs')
+        return dict(zip(keys, list(out)))
+
+
+_LIN_ENGINES = {}
+
+
+def _cached_linear_adjoint_engine(*key):
+    eng = _LIN_ENGINES.get(key)
+    if eng is None:
+        while len(_LIN_ENGINES) >= 4:
+            _LIN_ENGINES.pop(next(iter(_LIN_ENGINES))).close()
+        eng = _LIN_ENGINES[key] = _LinearAdjointEngine(*key)
+    return eng
 
 
 def canonical_to_module_order(base, theta):
@@ -197,6 +278,33 @@ def _linear_plan(func, n_tensors, cfg, like, f_params):
     if any(p.dtype != like.dtype or p.device != like.device or not p.is_contiguous() for p in want):
         return None
     return base
+
+
+LINEAR_ONE_LAUNCH = os.environ.get('TFDIFFEQ_AMD_LINEAR_ADJOINT', '1') != '0'   # False: the augmented dynamics on the MFMA kernels, one
+                                                                                 # Python evaluation per stage (round 4's path)
+
+
+def _linear_one_launch_plan(base, cfg, like):
+    """The mi_ode_linadj engine for this problem, or None (then `_linear_dynamics` serves it on the callable engine): dopri5 with
+    scalar tolerances and no solver options beyond max_num_steps - what the kernel's controller implements."""
+    if not LINEAR_ONE_LAUNCH or cfg['adjoint_method'] not in (None, 'dopri5'):
+        return None
+    opts = dict(cfg['adjoint_options'] or {})
+    max_num_steps = opts.pop('max_num_steps', 2 ** 31 - 1)
+    if opts or isinstance(cfg['adjoint_rtol'], (tuple, list)) or isinstance(cfg['adjoint_atol'], (tuple, list)):
+        return None
+    y1 = like[0]
+    batch = y1.numel() // base.dim
+    if batch < 1:
+        return None
+    f32 = lambda v: float(np.float32(v))                 # noqa: E731  (misc.py:137-144: python float -> float32 -> float64)
+    try:
+        return _cached_linear_adjoint_engine(batch, int(base.dim), like.dtype, float(cfg['adjoint_rtol']), float(cfg['adjoint_atol']),
+                                             f32(0.9), f32(10.0), f32(0.2), int(max_num_steps), str(like.device))
+    except N.NativeError as e:
+        import warnings
+        warnings.warn('one-launch linear adjoint engine unavailable (%s): using the callable engine' % e)
+        return None
 
 
 def _linear_dynamics(base, like):
@@ -330,6 +438,13 @@ class _OdeintAdjointMethod(torch.autograd.Function):
                                                          # (Only that: any other native / HIP failure propagates.)
                 warnings.warn('fused adjoint kernel unavailable (%s): falling back to the plane-kernel path' % e)
         lin = _linear_plan(func, n_tensors, cfg, like, f_params)
+        eng = _linear_one_launch_plan(lin, cfg, like) if lin is not None else None
+        if eng is not None:
+            try:
+                return _OdeintAdjointMethod._linear_backward(eng, lin, func, t, flat_params, ans, grad_output, like)
+            except HandoffTimeout as e:
+                import warnings
+                warnings.warn('one-launch linear adjoint kernel unavailable (%s): falling back to the callable engine' % e)
         if lin is not None:
             res = _OdeintAdjointMethod._generic_backward(func, cfg, n_tensors, t, flat_params, ans, grad_output, f_params, like,
                                                          augmented_dynamics=_linear_dynamics(lin, like))
@@ -393,6 +508,47 @@ class _OdeintAdjointMethod(torch.autograd.Function):
             grad_params = canonical_to_module_order(base, theta).to(flat_params.dtype)
         odeint_adjoint.last_backward_stats = {'engine': 'fused adjoint kernel (one launch per interval)', 'segments': segs}
         return (None, None, None, time_vjps, grad_params, adj_y)
+
+    @staticmethod
+    def _linear_backward(eng, base, func, t, flat_params, ans, grad_output, like):
+        """adjoint.py:117-178 with every interval's odeint call as ONE launch of mi_ode_linadj_segment; f(t_i, y_i) for the time
+        gradient (adjoint.py:134-140) on the MFMA stage kernel."""
+        from .fixed_grid import Euler
+        from .solvers import _FusedEngine, _cached_engine, _tableau_key
+        T = ans[0].shape[0]
+        dim = base.dim
+        y_shape = ans[0][0].shape
+        batch = ans[0][0].numel() // dim
+        W = base.weight.detach()
+        b = base.bias.detach() if base.bias is not None else None
+        proto = ans[0][0].reshape(batch, dim)
+        rhs_y = base.device_rhs()
+        key = ('rhs evaluation', rhs_y.cache_key(proto.dtype, proto.device), (batch, dim), proto.dtype, str(proto.device),
+               _tableau_key(Euler._fused_tableau, None))
+        ev = _cached_engine(key, lambda: _FusedEngine(rhs_y, proto, False, Euler._fused_tableau))
+        segs = []
+        with torch.no_grad():
+            g_out = grad_output[0]
+            adj_y = g_out[-1].reshape(batch, dim).contiguous()
+            theta = torch.zeros(dim * dim + (dim if b is not None else 0), dtype=like.dtype, device=like.device)
+            adj_time = torch.zeros((), dtype=like.dtype, device=like.device)
+            time_vjps = []
+            for i in range(T - 1, 0, -1):
+                y_i = ans[0][i].reshape(batch, dim).contiguous()
+                func_i = ev.eval_rhs(y_i)
+                dLd_cur_t = torch.dot(func_i.reshape(-1), g_out[i].reshape(-1))              # adjoint.py:134-140
+                adj_time = adj_time - dLd_cur_t
+                time_vjps.append(dLd_cur_t.reshape(1))
+                adj_y, adj_time, theta = eng.segment(W, b, y_i, adj_y, adj_time, theta, float(t[i]), float(t[i - 1]))
+                segs.append(eng.stats.as_dict())
+                _count_nfe(func, segs[-1].get('nfe', 0))
+                adj_y = adj_y + g_out[i - 1].reshape(batch, dim)
+            time_vjps.append(adj_time.reshape(1))
+            time_vjps = torch.cat(time_vjps[::-1]).to(dtype=t.dtype, device=t.device)
+            grad_params = theta.to(flat_params.dtype)
+        odeint_adjoint.last_backward_stats = {'engine': 'linear right-hand side: one launch per interval (mi_ode_linadj)', 'segments': segs,
+                                              'last_segment': segs[-1] if segs else {}}
+        return (None, None, None, time_vjps, grad_params, adj_y.reshape(y_shape))
 
     @staticmethod
     def _generic_backward(func, cfg, n_tensors, t, flat_params, ans, grad_output, f_params, like, augmented_dynamics=None):

@@ -55,6 +55,7 @@ extern "C" int64_t mi_ode_sizeof(int32_t which) {
     case 5: return (int64_t)sizeof(mi_ode_ctrl_params);
     case 6: return (int64_t)sizeof(mi_ode_adjoint_desc);
     case 7: return (int64_t)sizeof(mi_ode_opq_desc);
+    case 8: return (int64_t)sizeof(mi_ode_linadj_desc);
     default: return -1;
   }
 }

@@ -1,0 +1,689 @@
+// The backward solve of odeint_adjoint for the LINEAR right-hand side f(t, y) = y W + b in ONE launch per output interval
+// (include/mi_ode.h section A'''; tfdiffeq/adjoint.py:57-178 is the reference: odeint over the tuple (y, adj_y, adj_t, adj_params)
+// with dynamics (f, -adj_y^T df/dy, -adj_y^T df/dt, -adj_y^T df/dparams), adjoint.py:69-105).
+//
+// For this right-hand side the four components are
+//     y' = s (y W + b)          a' = -s a W^T          adj_t' = 0          theta' = -s [y^T a ; sum_rows a]        (s = -1: decreasing time)
+// Structure of the kernel - a persistent grid of G workgroups, one per CU, hand-offs as in mi_ode_persist.h:
+//   * y and a are two linear systems: workgroups [0, G/2) keep their slice of W resident and run config 4's tile pass (lin_attempt_pass,
+//     mi_ode_step_fused.h) over the y planes, workgroups [G/2, G) keep the slice of W^T (sign -s, no bias) and run it over the a planes;
+//   * theta needs NO per-stage product over the batch.  Both systems have constant matrices, so every stage input is the step's start
+//     value times a polynomial in h W whose coefficients depend on the tableau only (oracle/linear_adjoint_numpy.py, "the power form"):
+//         sum_sigma (h c_sigma) k_theta,sigma = -s h sum_pq K^c_pq (s h)^p (-s h)^q M_pq,    M_pq = ((W^T)^p G0 + c_p g0) (W^T)^q
+//     with G0 = y0^T a0, g0 = sum_rows a0 of the step's START state, c_p = (W^T)^(p-1) b^T and K^c = sum_sigma c_sigma pi_sigma pi_sigma^T
+//     (tableau constants, one table per combination: solution, error estimate, y_mid, the last stage).  Per ACCEPTED step: one slab
+//     pass over the two planes (G0, g0: the only batch-sized product), its fold, (S+1) + (S+1)^2 products of dim x dim matrices spread
+//     over the grid's wavefronts; per ATTEMPT: an elementwise combination of the M_pq, each workgroup its share of the entries;
+//   * adj_t has a zero derivative (f does not depend on t): its error estimate is 0, its norms enter the controller all the same;
+//   * the controller runs redundantly in every workgroup over the four components (misc.py:250-287: per-component ratios, python
+//     max(); misc.py:183-247 for the initial step, where h0 = +inf is the NORMAL case of this tuple - see mi_ode_adjoint.h);
+//   * adj_y(t_end) is the tile pass's speculative dense output; theta(t_end) is ONE more combination with the folded dense-output
+//     weights (oracle: dense_output_fold_weights); adj_t(t_end) the fit of a constant evaluated as the reference does.
+// The small products and theta are held in float64 whatever the state dtype (they are O(dim^2): their cost is hand-off latency, not
+// arithmetic); the slab product runs in the state dtype like the reference's own y^T a.
+// Cross-workgroup data (slab partials, G0, the small matrices): plain stores -> agent-scope release by one lane -> the hand-off record
+// -> agent-scope acquire by one lane per workgroup -> plain loads (MI355X_MICROARCH.md, "inter-workgroup visibility", valid form 1).
+#pragma once
+#include "mi_ode_persist.h"
+
+namespace mi {
+
+constexpr int kLaS = 6;                  // dopri5 (adjoint.py's default; other tableaus take the generic path)
+constexpr int kLaP = kLaS + 1;           // powers 0 .. S of W^T
+constexpr int kLaPP = kLaP * kLaP;
+constexpr int kLaMaxG = 256;             // workgroups (one per CU)
+
+struct LinAdjResult {                    // pinned host: the kernel's last act is a zero-copy store of this record
+  double t1, dt, ratio, h0;
+  long long n_attempt, n_accept;
+  unsigned status;
+  int handoffs;
+  long long prof[8];                     // 10 ns ticks of workgroup 0: tile passes / theta combinations / hand-offs of attempts / slab passes /
+                                         // folds + small products (with their hand-offs) / prologue / epilogue / -
+  long long clk_cycles, clk_ticks;
+};
+
+struct LinAdjArgs {
+  PersistArgs p;                         // p.s: tableau, rhs (W, b, sign = s), controller parameters, partials; p.s.out = adj_y(t_end)
+  const void* y_in;                      // state at t_start: y, adj_y [batch, dim]; adj_t scalar; adj_params [dim * dim (+ dim)]
+  const void* a_in;
+  const void* th_in;
+  const void* adjt_in;
+  void* th_out;
+  void* adjt_out;
+  char* planes;                          // 8 planes of batch * dim elements: y_a, y_b, fy_a, fy_b, a_a, a_b, fa_a, fa_b
+  long long stride;
+  double* pw;                            // [kLaP][D][D]       (W^T)^q, zero padded to the tile width (P_0 = identity)
+  double* cvec;                          // [kLaP][D]          c_p = (W^T)^(p-1) b^T, c_0 = 0
+  void* gpart;                           // [G][D * D + D]     slab partials of (G0 | g0), state dtype
+  double* g0;                            // [D * D + D]        G0 | g0 of the current step's start state
+  double* lmat;                          // [kLaP][D * D]      L_p = (W^T)^p G0 + c_p g0  (p >= 1; L_0 = G0 is read in place)
+  double* mmat;                          // [kLaPP][(D + 1) D] M_pq; row D: g0 (W^T)^q for p = 0, zero otherwise (the bias entries)
+  double* theta;                         // [2][D * D + D]     adj_params at the step's start / after the attempt, padded layout
+  const double* ktab;                    // device [4][kLaPP]: K^sol, K^err, K^mid, pi_S pi_S^T
+  double t_end;
+  LinAdjResult* res;
+  int has_bias;
+  int pad_;
+};
+static_assert(sizeof(LinAdjArgs) <= 4096, "kernel arguments");
+
+template <int MAXG>
+struct LaShared {
+  Ctl c;
+  PersistPub pub;
+  AttemptState st;
+  double red[80];
+  double coef[kLinCoefMax];
+  double vals[8][MAXG];                  // every workgroup's record, staged for the fixed-order folds
+  double tout[kPersistTSmall];
+  double seg_rec[4][kRec];               // combined records of (y, adj_y, adj_t, adj_params)
+  SegState seg;
+  double kq[3][kLaPP];                   // the attempt's combination weights of the M_pq: solution, error estimate, dense output
+  double adjt;                           // adj_t (constant over the segment)
+  long long prof[8], tk_prev;            // workgroup 0: where the time of a segment goes (LinAdjResult.prof)
+  int ok;
+  int skip_initb;
+};
+
+// ---- 8-value hand-off records (kPRec = 16 words: all of a record) -------------------------------------------------------------------
+__device__ __forceinline__ bool load_record8_sc1(const double* p, unsigned seq, double (&val)[8]) {
+  u64x2_t v[8];
+  asm volatile(
+      "global_load_dwordx4 %0, %8, off sc1\n\t"
+      "global_load_dwordx4 %1, %8, off offset:16 sc1\n\t"
+      "global_load_dwordx4 %2, %8, off offset:32 sc1\n\t"
+      "global_load_dwordx4 %3, %8, off offset:48 sc1\n\t"
+      "global_load_dwordx4 %4, %8, off offset:64 sc1\n\t"
+      "global_load_dwordx4 %5, %8, off offset:80 sc1\n\t"
+      "global_load_dwordx4 %6, %8, off offset:96 sc1\n\t"
+      "global_load_dwordx4 %7, %8, off offset:112 sc1\n\t"
+      "s_waitcnt vmcnt(0)"
+      : "=&v"(v[0]), "=&v"(v[1]), "=&v"(v[2]), "=&v"(v[3]), "=&v"(v[4]), "=&v"(v[5]), "=&v"(v[6]), "=&v"(v[7])
+      : "v"(p)
+      : "memory");
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    ok = ok && ((unsigned)(v[i].x >> 32) == seq) && ((unsigned)(v[i].y >> 32) == seq);
+    val[i] = __longlong_as_double((long long)((v[i].x & 0xffffffffull) | (v[i].y << 32)));
+  }
+  return ok;
+}
+
+// Grid hand-off: thread 0 publishes `mine`, every workgroup gathers all records into sh.vals.  RELEASE: this workgroup wrote data other
+// workgroups read after the hand-off; ACQUIRE: it reads such data.  Returns false (to every thread) on a time-out.
+template <class SH>
+__device__ __forceinline__ bool la_exchange(const PersistArgs& P, SH& sh, unsigned gen, const double (&mine)[8], bool release, bool acquire) {
+  const int G = (int)gridDim.x;
+  double* buf = P.s.partials + (long long)(gen & 1u) * G * kPRec;
+  const unsigned seq = P.seq_base + gen + 1u;
+  __syncthreads();                                              // every thread's stores of this phase are issued (and, being a fence, drained)
+  if (threadIdx.x == 0) {
+    if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the compiler may drop the wait behind the write-back: MI355X_MICROARCH.md)
+    double* rec = buf + (long long)blockIdx.x * kPRec;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) store_ll_sc1(rec + 2 * i, mine[i], seq);
+  }
+  const int limit = gen == 0 ? P.spin_first : P.spin_limit;
+  for (int b = threadIdx.x; b < G; b += blockDim.x) {
+    const double* p = buf + (long long)b * kPRec;
+    double v[8];
+    int spins = 0;
+    for (int i = 0; i < P.sleep_first; ++i) __builtin_amdgcn_s_sleep(1);
+    for (;;) {
+      if (load_record8_sc1(p, seq, v)) break;
+      for (int i = 0; i < P.sleep_poll; ++i) __builtin_amdgcn_s_sleep(1);
+      if (++spins > limit) { sh.ok = 0; break; }
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) sh.vals[i][b] = v[i];
+  }
+  if (acquire && threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 forgets what it held
+  __syncthreads();
+  return sh.ok != 0;
+}
+
+// wavefront 0: fixed-order fold of one record slot over workgroups [b0, b1); the result is valid in lane 0
+__device__ __forceinline__ double la_fold_sum(const double* v, int b0, int b1) {
+  double s = 0.0;
+  for (int b = b0 + (int)threadIdx.x; b < b1; b += 64) s += v[b];
+  return wave_sum(s);
+}
+__device__ __forceinline__ double la_fold_max(const double* v, int b0, int b1) {
+  double s = 0.0;
+  for (int b = b0 + (int)threadIdx.x; b < b1; b += 64) s = fmax(s, v[b]);
+  return wave_max(s);
+}
+
+// ---- small products: one wavefront = one 16 x 16 tile of C = A B (+ u v^T), float64, K = D, row-major -------------------------------
+// Lane (li, lg) feeds A[16 tm + li][lg KS + m] and B[lg KS + m][16 tn + li] at step m (any k-permutation is legal as long as both
+// operands agree; this one makes a lane's A elements contiguous).
+template <int D>
+__device__ __forceinline__ void la_tile_job(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int ldc,
+                                            int tm, int tn, const double* __restrict__ u, const double* __restrict__ v) {
+  using TR = MfmaTraits<double>;
+  constexpr int KS = D / 4, CHK = KS < 8 ? KS : 8;
+  const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  TR::acc_t acc = {0, 0, 0, 0};
+  const double* ap = A + (long long)(16 * tm + li) * D + lg * KS;
+  const double* bp = B + (long long)(lg * KS) * D + 16 * tn + li;
+#pragma unroll
+  for (int m0 = 0; m0 < KS; m0 += CHK) {
+    double av[CHK], bv[CHK];
+#pragma unroll
+    for (int m = 0; m < CHK; ++m) { av[m] = ap[m0 + m]; bv[m] = bp[(long long)(m0 + m) * D]; }
+#pragma unroll
+    for (int m = 0; m < CHK; ++m) acc = TR::mfma(av[m], bv[m], acc);
+  }
+  const int col = 16 * tn + li;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int row = 16 * tm + TR::acc_row(lane, i);
+    double c = acc[i];
+    if (u != nullptr) c = c + u[row] * v[col];
+    C[(long long)row * ldc + col] = c;
+  }
+}
+
+// ---- the slab pass: this workgroup's partial of (y^T a | sum_rows a) over rows [r0, r1) (k_outer_partial's loop, mi_ode_outer.hip) ----
+template <typename T, int D>
+__device__ __forceinline__ void la_slab_pass(const T* __restrict__ y, const T* __restrict__ a, long long r0, long long r1, int dim,
+                                             T* __restrict__ out, T* lds) {
+  using TR = MfmaTraits<T>;
+  using acc_t = typename TR::acc_t;
+  constexpr int MB = D / 16, NT = D * 4, R = 16, EPT = R * D / NT, VEC = TR::VEC, CPT = EPT / VEC;
+  using CH = Chunk<T, VEC>;
+  static_assert(EPT % VEC == 0, "tile / workgroup geometry");
+  T* sy = lds;
+  T* sa = lds + R * D;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const bool vl = dim % VEC == 0 && ((((unsigned long long)y) | ((unsigned long long)a)) & 15ull) == 0;
+  acc_t acc[MB];
+#pragma unroll
+  for (int m = 0; m < MB; ++m) acc[m] = acc_t{0, 0, 0, 0};
+  T colsum = (T)0;
+  const int ncol = 16 * w + li;
+  T py[EPT], pa[EPT];
+  auto fetch = [&](long long t0) {
+    if (vl) {
+#pragma unroll
+      for (int c = 0; c < CPT; ++c) {
+        const int idx = (c * NT + tid) * VEC, row = idx / D, col = idx % D;
+        const bool ok = t0 + row < r1 && col < dim;
+        CH vy, va;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { vy.v[v] = (T)0; va.v[v] = (T)0; }
+        if (ok) { vy = *(const CH*)(y + (t0 + row) * dim + col); va = *(const CH*)(a + (t0 + row) * dim + col); }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) { py[c * VEC + v] = vy.v[v]; pa[c * VEC + v] = va.v[v]; }
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        const int idx = (e / VEC * NT + tid) * VEC + e % VEC, row = idx / D, col = idx % D;   // (the same element -> LDS slot map as above)
+        const bool ok = t0 + row < r1 && col < dim;
+        py[e] = ok ? y[(t0 + row) * dim + col] : (T)0;
+        pa[e] = ok ? a[(t0 + row) * dim + col] : (T)0;
+      }
+    }
+  };
+  if (r0 < r1) fetch(r0);
+  for (long long t0 = r0; t0 < r1; t0 += R) {
+    __syncthreads();                                           // (the previous tile's operands have been read)
+#pragma unroll
+    for (int c = 0; c < CPT; ++c) {
+      CH vy, va;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) { vy.v[v] = py[c * VEC + v]; va.v[v] = pa[c * VEC + v]; }
+      *(CH*)(sy + (c * NT + tid) * VEC) = vy;
+      *(CH*)(sa + (c * NT + tid) * VEC) = va;
+    }
+    __syncthreads();
+    if (t0 + R < r1) fetch(t0 + R);                            // in flight under this tile's MFMAs
+#pragma unroll
+    for (int u = 0; u < R / 4; ++u) {
+      const int row = 4 * u + lg;
+      const T bv = sa[row * D + ncol];
+      colsum += bv;
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(sy[row * D + 16 * m + li], bv, acc[m]);
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) out[(16 * m + TR::acc_row(lane, i)) * D + ncol] = acc[m][i];
+  colsum += __shfl_xor(colsum, 16, 64);
+  colsum += __shfl_xor(colsum, 32, 64);
+  if (lg == 0) out[D * D + ncol] = colsum;
+  __syncthreads();                                             // the LDS tiles are free again (the tile passes use the same bytes)
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
+  constexpr int S = kLaS;
+  constexpr int NW = D / 16;                                   // wavefronts per workgroup
+  constexpr int E = D * D + D;                                 // theta entries in the padded layout: [D][D], then the bias row
+  constexpr int TJ = (D / 16) * (D / 16);                      // 16 x 16 tiles of a D x D product
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  __shared__ LaShared<kLaMaxG> sh;
+  Ctl& s_c = sh.c;
+  const int G = (int)gridDim.x, GH = G / 2;
+  const bool is_a = (int)blockIdx.x >= GH;
+  const int hb = is_a ? (int)blockIdx.x - GH : (int)blockIdx.x;
+  const int dim = A.p.s.dim;
+  const double sgn = A.p.s.rhs.sign;                           // s
+  const T* Wm = (const T*)A.p.s.rhs.w[0];
+  const T* bias = A.has_bias ? (const T*)A.p.s.rhs.b[0] : nullptr;
+  LinCtx<T, D> cx;
+  if (is_a) cx.init_matrix(Wm, nullptr, -sgn, true, (T*)smem_raw, dim);
+  else cx.init_matrix(Wm, bias, sgn, false, (T*)smem_raw, dim);
+  CtrlParams cp = A.p.s.cp;
+  cp.t_out = persist_stage_tout(A.p, sh.tout, kPersistTSmall);
+  const double* t_out = cp.t_out;
+  const long long batch = A.p.s.batch;
+  const long long n_state = batch * dim, n_theta = (long long)dim * dim + (A.has_bias ? dim : 0);
+  const int wave = (int)threadIdx.x >> 6;
+  const int gw = (int)blockIdx.x * NW + wave, ngw = G * NW;    // this wavefront among the grid's
+  const int gt = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, ngt = G * (int)blockDim.x;
+  const int EPW = (E + G - 1) / G;                             // theta entries per workgroup (a contiguous run: coalesced)
+  const int e_lo = (int)blockIdx.x * EPW, e_hi = e_lo + EPW < E ? e_lo + EPW : E;
+  auto entry_valid = [&](int e) { return e < D * D ? (e / D < dim && e % D < dim) : (A.has_bias && e - D * D < dim); };
+  unsigned gen = 0;
+  bool ok = true;
+  double mine[8];
+  auto zero_mine = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mine[i] = 0.0;
+  };
+  auto tick = [&](int slot) {                                  // workgroup 0, thread 0: where the time of a segment goes
+    if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now = (long long)wall_clock64(); sh.prof[slot] += now - sh.tk_prev; sh.tk_prev = now; }
+  };
+  if (threadIdx.x == 0) {
+    persist_init_ctl(s_c, A.p); sh.ok = 1; sh.skip_initb = 0;
+    for (int i = 0; i < 8; ++i) sh.prof[i] = 0;
+    sh.tk_prev = (long long)wall_clock64();
+    sh.adjt = (double)*(const T*)A.adjt_in;
+  }
+  __syncthreads();
+
+  T* const pl = (T*)A.planes;
+  const long long pstride = A.stride / (long long)sizeof(T);
+  T* const my_ya = pl + (is_a ? 4 : 0) * pstride;
+  T* const my_yb = my_ya + pstride;
+  T* const my_fa = my_ya + 2 * pstride;
+  T* const my_fb = my_ya + 3 * pstride;
+  const T* const my_in = is_a ? (const T*)A.a_in : (const T*)A.y_in;
+  double* const th0 = A.theta;                                 // adj_params at the step's start
+  double* const th1 = A.theta + E;                             // ... after the attempt
+  T* const my_part = (T*)A.gpart + (long long)blockIdx.x * E;
+  long long rps = (batch + G - 1) / G;                         // rows per slab, a multiple of 4
+  rps = (rps + 3) / 4 * 4;
+  const long long slab_r0 = (long long)blockIdx.x * rps < batch ? (long long)blockIdx.x * rps : batch;
+  const long long slab_r1 = slab_r0 + rps < batch ? slab_r0 + rps : batch;
+
+  // ---- the small products after a new start state (y0, a0): slab partials -> G0 | g0 -> L_p, g0 P_q -> M_pq.  Four hand-offs. ----
+  auto fold_g0 = [&]() {                                       // entries e_lo .. e_hi of G0 | g0 (fixed order: eight interleaved chains)
+    const T* part = (const T*)A.gpart;
+    for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+      double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      int g = 0;
+      for (; g + 8 <= G; g += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) q[u] += (double)part[(long long)(g + u) * E + e];
+      }
+      for (; g < G; ++g) q[0] += (double)part[(long long)g * E + e];
+      A.g0[e] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+    }
+  };
+  auto level_l = [&]() {                                       // L_p = P_p G0 + c_p g0 (p = 1..S) and the bias rows g0 P_q (q = 0..S)
+    for (int j = gw; j < S * TJ; j += ngw) {
+      const int p = 1 + j / TJ, t = j % TJ;
+      la_tile_job<D>(A.pw + (long long)p * D * D, A.g0, A.lmat + (long long)p * D * D, D, t / (D / 16), t % (D / 16),
+                     A.has_bias ? A.cvec + p * D : nullptr, A.g0 + D * D);
+    }
+    for (int j = gt; j < kLaP * D; j += ngt) {
+      const int q = j / D, c = j % D;
+      const double* P = A.pw + (long long)q * D * D;
+      double s_ = 0.0;
+      for (int k = 0; k < D; ++k) s_ = fma(A.g0[D * D + k], P[(long long)k * D + c], s_);
+      A.mmat[(long long)q * E + D * D + c] = s_;               // row D of M_0q
+    }
+  };
+  auto level_m = [&]() {                                       // M_pq = L_p P_q (L_0 = G0)
+    for (int j = gw; j < kLaPP * TJ; j += ngw) {
+      const int pq = j / TJ, t = j % TJ, p = pq / kLaP, q = pq % kLaP;
+      la_tile_job<D>(p == 0 ? A.g0 : A.lmat + (long long)p * D * D, A.pw + (long long)q * D * D, A.mmat + (long long)pq * E, D,
+                     t / (D / 16), t % (D / 16), nullptr, nullptr);
+    }
+  };
+  auto barrier_handoff = [&](bool release, bool acquire) {
+    zero_mine();
+    ok = ok && la_exchange(A.p, sh, gen++, mine, release, acquire);
+  };
+  auto products_after_slab = [&]() {                           // (the slab partials are written; the caller has not handed off yet)
+    barrier_handoff(true, true);
+    if (ok) fold_g0();
+    barrier_handoff(true, true);
+    if (ok) level_l();
+    barrier_handoff(true, true);
+    if (ok) level_m();
+    barrier_handoff(true, true);
+  };
+
+  // ---- prologue ------------------------------------------------------------------------------------------------------------------
+  // adj_params -> the padded float64 layout; P_0 = I, P_1 = W^T, c_0 = 0, c_1 = b
+  for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {     // (the entries this thread owns for the whole segment)
+    double v = 0.0;
+    if (e < D * D) { if (e / D < dim && e % D < dim) v = (double)((const T*)A.th_in)[(e / D) * dim + e % D]; }
+    else if (A.has_bias && e - D * D < dim) v = (double)((const T*)A.th_in)[dim * dim + (e - D * D)];
+    th0[e] = v;
+  }
+  for (int e = gt; e < D * D; e += ngt) {
+    const int i = e / D, j = e % D;
+    A.pw[e] = i == j ? 1.0 : 0.0;
+    A.pw[D * D + e] = (i < dim && j < dim) ? (double)Wm[(long long)j * dim + i] : 0.0;
+  }
+  for (int e = gt; e < 2 * D; e += ngt) A.cvec[e] = (e >= D && bias != nullptr && e - D < dim) ? (double)bias[e - D] : 0.0;
+  // f0 of both systems (misc.py:225-233's sums ride in the record) and the slab partials of the start state
+  Acc acc0;
+  lin_f0_pass<T, D, true>(A.p.s, my_in, my_fa, (T*)nullptr, (T*)nullptr, cx, acc0, hb, GH);
+  la_slab_pass<T, D>((const T*)A.y_in, (const T*)A.a_in, slab_r0, slab_r1, dim, my_part, (T*)smem_raw);
+  {
+    double r[5];
+    block_reduce_thread0(acc0, sh.red, r);
+    zero_mine();
+#pragma unroll
+    for (int i = 0; i < 5; ++i) mine[i] = r[i];
+    ok = la_exchange(A.p, sh, gen++, mine, true, true);
+    if (ok && threadIdx.x < 64) {                              // the y and adj_y records of the initial step
+      for (int k = 0; k < 2; ++k) {
+        const int b0 = k * GH, b1 = b0 + GH;
+        const double sa = la_fold_sum(sh.vals[R_SUMA], b0, b1), sb = la_fold_sum(sh.vals[R_SUMB], b0, b1), fl = la_fold_max(sh.vals[R_FLAG], b0, b1);
+        if (threadIdx.x == 0) {
+          double* o = sh.seg_rec[k];
+          o[R_MAXA] = 0; o[R_MAXB] = 0; o[R_SUMA] = sa; o[R_SUMB] = sb; o[R_FLAG] = fl; o[R_N] = (double)n_state; o[6] = 0; o[7] = 0;
+        }
+      }
+    }
+  }
+  // the powers of W^T by doubling (P_q = P_n P_(q-n), c_q = P_n c_(q-n), n = 1, 2, 4) next to the fold of G0
+  if (ok) fold_g0();
+  for (int n = 1; n < S; n *= 2) {
+    if (ok) {
+      const int q_hi = 2 * n < S ? 2 * n : S;
+      for (int j = gw; j < (q_hi - n) * TJ; j += ngw) {
+        const int q = n + 1 + j / TJ, t = j % TJ;
+        la_tile_job<D>(A.pw + (long long)n * D * D, A.pw + (long long)(q - n) * D * D, A.pw + (long long)q * D * D, D, t / (D / 16), t % (D / 16),
+                       nullptr, nullptr);
+      }
+      for (int j = gt; j < (q_hi - n) * D; j += ngt) {
+        const int q = n + 1 + j / D, i = j % D;
+        const double* P = A.pw + (long long)n * D * D + (long long)i * D;
+        const double* c = A.cvec + (q - n) * D;
+        double s_ = 0.0;
+        for (int k = 0; k < D; ++k) s_ = fma(P[k], c[k], s_);
+        A.cvec[q * D + i] = s_;
+      }
+    }
+    barrier_handoff(true, true);
+  }
+  if (ok) level_l();
+  barrier_handoff(true, true);
+  if (ok) level_m();
+  barrier_handoff(true, true);
+  // adj_params' share of misc._select_initial_step: f0 = -s M_00 (= -s [G0 ; g0])
+  {
+    Acc at;
+    if (ok) {
+      for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+        if (!entry_valid(e)) continue;
+        const T v0 = (T)th0[e], f0 = (T)(-sgn * A.mmat[e]);
+        const T sc = (T)cp.atol + fabs(v0) * (T)cp.rtol;       // misc.py:225
+        const double q0 = (double)(v0 / sc), q1 = (double)(f0 / sc);
+        at.suma += q0 * q0; at.sumb += q1 * q1;
+        if (!finite_(v0)) at.flag = 1;
+      }
+    }
+    double r[5];
+    block_reduce_thread0(at, sh.red, r);
+    zero_mine();
+    mine[5] = r[2]; mine[6] = r[3]; mine[7] = r[4];
+    ok = ok && la_exchange(A.p, sh, gen++, mine, false, false);
+    if (ok && threadIdx.x < 64) {
+      const double sa = la_fold_sum(sh.vals[5], 0, G), sb = la_fold_sum(sh.vals[6], 0, G), fl = la_fold_max(sh.vals[7], 0, G);
+      if (threadIdx.x == 0) {
+        double* o = sh.seg_rec[3];
+        o[R_MAXA] = 0; o[R_MAXB] = 0; o[R_SUMA] = sa; o[R_SUMB] = sb; o[R_FLAG] = fl; o[R_N] = (double)n_theta; o[6] = 0; o[7] = 0;
+        double* t_ = sh.seg_rec[2];                            // adj_t: one element, zero derivative
+        const T v0 = (T)sh.adjt;
+        const T sc = (T)cp.atol + fabs(v0) * (T)cp.rtol;
+        const double q0 = (double)(v0 / sc);
+        t_[R_MAXA] = 0; t_[R_MAXB] = 0; t_[R_SUMA] = q0 * q0; t_[R_SUMB] = 0; t_[R_FLAG] = finite_(v0) ? 0.0 : 1.0; t_[R_N] = 1.0; t_[6] = 0; t_[7] = 0;
+        controller_apply_seg(&s_c, &sh.seg, sh.seg_rec, 4, PH_F0, cp);
+        // h0 = +inf is the normal case of this tuple (adj_t has d1 = 0, misc.py:233): the second evaluation cannot change
+        // min(100 h0, h1) then - every d2 is 0 or NaN, never positive - and is skipped unless max(d1) <= 1e-15 (mi_ode_adjoint.h)
+        sh.skip_initb = (isinf(s_c.h0) && s_c.h0 > 0.0 && py_max(sh.seg.d1, 4) > 1e-15) ? 1 : 0;
+        if (sh.skip_initb) {
+          for (int k = 0; k < 4; ++k) sh.seg_rec[k][R_SUMA] = 0.0;     // d2 = 0 / inf
+          controller_apply_seg(&s_c, &sh.seg, sh.seg_rec, 4, PH_INITB, cp);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (ok && !uniform_i(sh.skip_initb)) {                       // misc.py:235-245 for a finite h0
+    Acc accb, at;
+    const double h0d = uniform_d(s_c.h0);
+    lin_initb_pass<T, D, true>(A.p.s, my_in, my_fa, (T)h0d, cx, accb, hb, GH);
+    const double hT = (double)(T)h0d, sh_ = sgn * hT;
+    for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+      if (!entry_valid(e)) continue;
+      const double m00 = A.mmat[e], m01 = A.mmat[(long long)1 * E + e], m10 = A.mmat[(long long)kLaP * E + e], m11 = A.mmat[(long long)(kLaP + 1) * E + e];
+      const T v0 = (T)th0[e], f0 = (T)(-sgn * m00);
+      const T f1 = (T)(-sgn * (m00 + sh_ * m10 - sh_ * m01 - sh_ * sh_ * m11));   // -s (I + s h W)^T [G0; g0] (I - s h W^T), bias row: p = 0 only
+      const T sc = (T)cp.atol + fabs(v0) * (T)cp.rtol;
+      const double q = (double)((f1 - f0) / sc);               // misc.py:237
+      at.suma += q * q;
+    }
+    double r[5], r2[5];
+    block_reduce_thread0(accb, sh.red, r);
+    block_reduce_thread0(at, sh.red, r2);
+    zero_mine();
+    mine[2] = r[2]; mine[5] = r2[2];
+    ok = la_exchange(A.p, sh, gen++, mine, false, false);
+    if (ok && threadIdx.x < 64) {
+      const double sy = la_fold_sum(sh.vals[2], 0, GH), sa = la_fold_sum(sh.vals[2], GH, G), st_ = la_fold_sum(sh.vals[5], 0, G);
+      if (threadIdx.x == 0) {
+        sh.seg_rec[0][R_SUMA] = sy; sh.seg_rec[1][R_SUMA] = sa; sh.seg_rec[2][R_SUMA] = 0.0; sh.seg_rec[3][R_SUMA] = st_;
+        controller_apply_seg(&s_c, &sh.seg, sh.seg_rec, 4, PH_INITB, cp);
+      }
+    }
+  }
+  auto publish = [&](const AttemptState& st) {                 // thread 0: what the next attempt needs
+    sh.pub.dt = st.dt; sh.pub.t1 = st.t1; sh.pub.accepted = st.accepted; sh.pub.done = st.done;
+    int j = st.next_out;                                       // speculative output range of the NEXT attempt (resolve_step)
+    const double t_new = st.t1 + st.dt;
+    while (j < st.n_out && !(t_out[j] > t_new)) ++j;
+    sh.pub.emit_lo = st.next_out; sh.pub.emit_hi = j;
+    sh.pub.emit_t0 = st.emit_t0; sh.pub.emit_t1 = st.emit_t1; sh.pub.emit_dt = st.emit_dt;
+  };
+  if (threadIdx.x == 0) {
+    if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
+    else set_outputs_apply(&s_c, A.p.n_out);
+    AttemptState st;
+    st.load(s_c);
+    st.accepted = 0;
+    publish(st);
+    sh.st = st;
+  }
+  __syncthreads();
+  tick(5);
+
+  // ---- the adaptive loop (dopri5.py:82-121) --------------------------------------------------------------------------------------
+  const T* cur_y = my_in;
+  T* cur_f = my_fa;
+  const double* ktab = A.ktab;
+  bool emitted = false;
+  while (!uniform_i(sh.pub.done)) {
+    StepPlanes<T, S> P;
+    const double dt_u = uniform_d(sh.pub.dt), t1_u = uniform_d(sh.pub.t1);
+    P.y0 = cur_y; P.f0 = cur_f;
+    P.y1 = (cur_y == my_ya) ? my_yb : my_ya;
+    P.f1 = (cur_f == my_fa) ? my_fb : my_fa;
+    P.hs = (T)dt_u; P.t0 = (T)t1_u;
+    P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
+    const int j_lo = uniform_i(sh.pub.emit_lo), j_hi = uniform_i(sh.pub.emit_hi);
+    P.j_lo = is_a ? j_lo : 0; P.j_hi = is_a ? j_hi : 0;        // adj_y(t_end) is wanted; the reference discards y(t_end) (adjoint.py:155-160)
+    // the weights of this attempt's combinations of the M_pq: -s h K^c_pq (s h)^p (-s h)^q, h = dt in the state dtype (rk_common.py:46)
+    {
+      const double hT = (double)P.hs;
+      for (int i = threadIdx.x; i < 2 * kLaPP; i += blockDim.x) {
+        const int c = i / kLaPP, pq = i % kLaPP, p = pq / kLaP, q = pq % kLaP;
+        double w_ = -sgn * hT * ktab[c * kLaPP + pq];
+        for (int u = 0; u < p; ++u) w_ *= sgn * hT;
+        for (int u = 0; u < q; ++u) w_ *= -sgn * hT;
+        sh.kq[c][pq] = w_;
+      }
+    }
+    Acc acc;
+    lin_attempt_pass<T, D, S, false, true>(A.p.s, P, cx, acc, t_out, (T*)sh.coef, hb, GH);   // (its first barrier also publishes sh.kq)
+    tick(0);
+    Acc at;
+    for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+      double d_sol = 0.0, d_err = 0.0;
+#pragma unroll 7
+      for (int pq = 0; pq < kLaPP; ++pq) {
+        const double m = A.mmat[(long long)pq * E + e];
+        d_sol = fma(sh.kq[0][pq], m, d_sol);
+        d_err = fma(sh.kq[1][pq], m, d_err);
+      }
+      const double v0 = th0[e], v1 = v0 + d_sol;
+      th1[e] = v1;
+      if (entry_valid(e)) {
+        at.maxa = fmax(at.maxa, fabs((double)(T)v0));
+        at.maxb = fmax(at.maxb, fabs((double)(T)v1));
+        const double er = (double)(T)d_err;
+        at.suma += er * er;
+      }
+    }
+    tick(1);
+    {
+      double r[5], r2[5];
+      block_reduce_thread0(acc, sh.red, r);
+      block_reduce_thread0(at, sh.red, r2);
+      zero_mine();
+#pragma unroll
+      for (int i = 0; i < 5; ++i) mine[i] = r[i];
+      mine[5] = r2[0]; mine[6] = r2[1]; mine[7] = r2[2];
+      // (release: an accepted attempt's y1 / a1 planes are read by OTHER workgroups' slab passes)
+      ok = la_exchange(A.p, sh, gen++, mine, true, false);
+    }
+    if (threadIdx.x < 64) {
+      if (ok) {
+        for (int k = 0; k < 2; ++k) {
+          const int b0 = k * GH, b1 = b0 + GH;
+          const double ma = la_fold_max(sh.vals[R_MAXA], b0, b1), mb = la_fold_max(sh.vals[R_MAXB], b0, b1), sa = la_fold_sum(sh.vals[R_SUMA], b0, b1);
+          if (threadIdx.x == 0) {
+            double* o = sh.seg_rec[k];
+            o[R_MAXA] = ma; o[R_MAXB] = mb; o[R_SUMA] = sa; o[R_SUMB] = 0; o[R_FLAG] = 0; o[R_N] = (double)n_state;
+          }
+        }
+        const double ma = la_fold_max(sh.vals[5], 0, G), mb = la_fold_max(sh.vals[6], 0, G), sa = la_fold_sum(sh.vals[7], 0, G);
+        if (threadIdx.x == 0) {
+          double* o = sh.seg_rec[3];
+          o[R_MAXA] = ma; o[R_MAXB] = mb; o[R_SUMA] = sa; o[R_SUMB] = 0; o[R_FLAG] = 0; o[R_N] = (double)n_theta;
+          double* t_ = sh.seg_rec[2];                          // adj_t: y0 = y1 = adj_t, error estimate 0 (misc.py:256-263 all the same)
+          const double av = fabs((double)(T)sh.adjt);
+          t_[R_MAXA] = av; t_[R_MAXB] = av; t_[R_SUMA] = 0; t_[R_SUMB] = 0; t_[R_FLAG] = 0; t_[R_N] = 1.0;
+        }
+      }
+      if (threadIdx.x == 0) {
+        AttemptState st = sh.st;
+        if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
+        else attempt_core_seg(st, sh.seg_rec, 4, cp, nullptr, nullptr);
+        publish(st);
+        sh.st = st;
+      }
+    }
+    __syncthreads();
+    tick(2);
+    if (!uniform_i(sh.pub.accepted)) continue;
+    if (uniform_i(sh.pub.done)) {                              // the accepted step covers t_end: adj_params(t_end), adj_t(t_end)
+      if (ok && j_hi > j_lo) {
+        // dense output as ONE combination (oracle: dense_output_fold_weights): K^w = p1 K^sol + pm K^mid + p0 [p = q = 0] + pS pi_S pi_S^T
+        const double hT = (double)P.hs;
+        const double x = (double)interp_x<T>(sh.pub.emit_t0, sh.pub.emit_t1, t_out[j_lo]);
+        const double x2 = x * x, x3 = x2 * x, x4 = x3 * x;
+        const double p1 = -8 * x4 + 14 * x3 - 5 * x2, pm = 16 * x4 - 32 * x3 + 16 * x2, p0 = -2 * x4 + 5 * x3 - 4 * x2 + x, pS = 2 * x4 - 3 * x3 + x2;
+        __syncthreads();
+        for (int pq = threadIdx.x; pq < kLaPP; pq += blockDim.x) {
+          const int p = pq / kLaP, q = pq % kLaP;
+          double w_ = -sgn * hT * (p1 * ktab[pq] + pm * ktab[2 * kLaPP + pq] + pS * ktab[3 * kLaPP + pq] + (pq == 0 ? p0 : 0.0));
+          for (int u = 0; u < p; ++u) w_ *= sgn * hT;
+          for (int u = 0; u < q; ++u) w_ *= -sgn * hT;
+          sh.kq[2][pq] = w_;
+        }
+        __syncthreads();
+        for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+          double d_out = 0.0;
+#pragma unroll 7
+          for (int pq = 0; pq < kLaPP; ++pq) d_out = fma(sh.kq[2][pq], A.mmat[(long long)pq * E + e], d_out);
+          const double v = th0[e] + d_out;
+          if (e < D * D) { if (e / D < dim && e % D < dim) ((T*)A.th_out)[(e / D) * dim + e % D] = (T)v; }
+          else if (A.has_bias && e - D * D < dim) ((T*)A.th_out)[dim * dim + (e - D * D)] = (T)v;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) {             // adj_t: the fit of a constant, evaluated as the reference does (interp.py:6-67)
+          const T at_ = (T)sh.adjt;
+          T co[5];
+          quartic_from_mid<T>(at_, at_, at_, (T)0, (T)0, (T)sh.pub.emit_dt, co);
+          *(T*)A.adjt_out = quartic_eval<T>(co, (T)x);
+        }
+        emitted = true;
+      }
+      tick(6);
+      break;
+    }
+    // accepted, more to come: the planes and adj_params move on; G0 | g0 and the M_pq of the new start state
+    cur_y = P.y1; cur_f = P.f1;
+    for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) th0[e] = th1[e];
+    {
+      // which y / a planes hold the accepted state: both halves flip together (same accept decisions), so the index is this half's
+      const int idx = (P.y1 == my_ya) ? 0 : 1;
+      const T* yy = pl + idx * pstride;
+      const T* aa = pl + (4 + idx) * pstride;
+      if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // other workgroups wrote these planes (their release: the
+      __syncthreads();                                                           // attempt's hand-off); rejected attempts skip the invalidate
+      la_slab_pass<T, D>(yy, aa, slab_r0, slab_r1, dim, my_part, (T*)smem_raw);
+    }
+    tick(3);
+    products_after_slab();
+    tick(4);
+    if (!ok) {
+      if (threadIdx.x == 0) { AttemptState st = sh.st; st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; publish(st); sh.st = st; }
+      __syncthreads();
+    }
+  }
+
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    AttemptState st = sh.st;
+    if (!emitted && st.status == 0) st.status |= MI_ODE_ST_SYNC_TIMEOUT;   // (cannot happen: done without a status means the output was written)
+    LinAdjResult res;
+    res.t1 = st.t1; res.dt = st.dt; res.ratio = st.ratio; res.h0 = s_c.h0;
+    res.n_attempt = st.n_attempt; res.n_accept = st.n_accept; res.status = st.status; res.handoffs = (int)gen;
+    for (int i = 0; i < 8; ++i) res.prof[i] = sh.prof[i];
+    res.clk_cycles = s_c.clk_cycles + (long long)__builtin_readcyclecounter();
+    res.clk_ticks = s_c.clk_ticks + (long long)wall_clock64();
+    const long long* src = (const long long*)&res;
+    long long* dst = (long long*)A.res;
+    for (int i = 0; i < (int)(sizeof(LinAdjResult) / sizeof(long long)); ++i)
+      __hip_atomic_store(dst + i, src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <typename T, int D>
+constexpr size_t linadj_lds_bytes() { return persist_linear_lds_bytes<T, D>(); }
+
+}  // namespace mi

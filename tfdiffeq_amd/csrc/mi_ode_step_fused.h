@@ -374,18 +374,24 @@ struct LinCtx {
 #endif
 
   __device__ __forceinline__ void init(const RhsParams& rhs, T* lds, int dim) {
+    init_matrix((const T*)rhs.w[0], (const T*)rhs.b[0], rhs.sign, false, lds, dim);
+  }
+  // f(y) = sgn (y M + bias) with M = W, or M = W^T when `transposed` (the adjoint system a' = -s a W^T of the linear right-hand side,
+  // csrc/mi_ode_linadj.h: the same resident-slice tile kernel with the other operand order of W)
+  __device__ __forceinline__ void init_matrix(const T* W, const T* bias, double sgn, bool transposed, T* lds, int dim) {
     const int tid = threadIdx.x;
     lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
     col = 16 * wave + li;
     d = dim; colok = col < dim;
-    const T* W = (const T*)rhs.w[0];
-    const T* bias = (const T*)rhs.b[0];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) bf[s] = (colok && lg * KS + s < dim) ? W[(long long)(lg * KS + s) * dim + col] : (T)0;
+    for (int s = 0; s < KS; ++s) {
+      const int kk = lg * KS + s;
+      bf[s] = (colok && kk < dim) ? (transposed ? W[(long long)col * dim + kk] : W[(long long)kk * dim + col]) : (T)0;
+    }
     has_bias = bias != nullptr;
     bias_v = (has_bias && colok) ? bias[col] : (T)0;
-    sign = (T)rhs.sign;
-    plain = bias == nullptr && rhs.sign == 1.0;
+    sign = (T)sgn;
+    plain = bias == nullptr && sgn == 1.0;
     s_ys = lds;
   }
   __device__ __forceinline__ int row_of(int i) const { return TR::acc_row(lane, i); }
@@ -481,9 +487,12 @@ __device__ __forceinline__ T stream_load(const T* p) {
 // (Round 4, measured and removed: loading a workgroup's first tile of the NEXT pass before it enters the grid hand-off.  The
 // hand-off's barriers carry a vmcnt(0) - the loads were simply waited for there: hand-offs 40 -> 57 us per call, passes unchanged.)
 // One adaptive attempt over this workgroup's tiles (tile = blockIdx.x, + gridDim.x, ...).
+// `blk` / `nblk`: this workgroup's index and the number of workgroups that share the pass (default: the whole grid; the adjoint
+// kernel of the linear system runs two such passes side by side, one per half of its grid).
 template <typename T, int D, int S, bool TS, bool SC0>
 __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPlanes<T, S>& P, LinCtx<T, D>& cx, Acc& acc,
-                                                 const double* t_out, T* coef /* LDS, kLinCoefMax */) {
+                                                 const double* t_out, T* coef /* LDS, kLinCoefMax */, int blk = (int)blockIdx.x,
+                                                 int nblk = (int)gridDim.x) {
   constexpr int R_ = LinCtx<T, D>::R_;
   using CF = LinCoef<S>;
   const long long ntiles = (A.batch + R_ - 1) / R_;
@@ -501,16 +510,16 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
       f0n[i] = ok ? stream_load<SC0>(tf + cx.off_of(i)) : (T)0;
     }
   };
-  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
+  if ((long long)blk < ntiles) fetch(blk);
   const T c_first = coef[CF::row(1)];                        // dt * beta_{1,0}: the same for every tile
   T cnx[S + 1];                                              // the coefficients of the NEXT combination (read under the MFMA chain)
 
-  for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+  for (long long tile_i = blk; tile_i < ntiles; tile_i += nblk) {
     const long long row0 = tile_i * R_;
     T y0e[4], k[S + 1][4], ys[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { y0e[i] = y0n[i]; k[0][i] = f0n[i]; }
-    if (tile_i + gridDim.x < ntiles) fetch(tile_i + gridDim.x);
+    if (tile_i + nblk < ntiles) fetch(tile_i + nblk);
 
     auto stage = [&](auto sg_c) {
       constexpr int SG = decltype(sg_c)::value;
@@ -575,7 +584,7 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
 // non-finite flag; optionally seeds a state plane and solution[0] with y0 in the same pass.
 template <typename T, int D, bool SC0>
 __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f0_out, T* copy_a, T* copy_b, LinCtx<T, D>& cx,
-                                            Acc& acc) {
+                                            Acc& acc, int blk = (int)blockIdx.x, int nblk = (int)gridDim.x) {
   constexpr int R_ = LinCtx<T, D>::R_;
   const long long ntiles = (A.batch + R_ - 1) / R_;
   T y0n[4];
@@ -585,12 +594,12 @@ __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f
 #pragma unroll
     for (int i = 0; i < 4; ++i) y0n[i] = (cx.row_of(i) < nr && cx.colok) ? stream_load<SC0>(ty + cx.off_of(i)) : (T)0;
   };
-  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
-  for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+  if ((long long)blk < ntiles) fetch(blk);
+  for (long long tile_i = blk; tile_i < ntiles; tile_i += nblk) {
     T y0e[4], kn[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) y0e[i] = y0n[i];
-    if (tile_i + gridDim.x < ntiles) fetch(tile_i + gridDim.x);
+    if (tile_i + nblk < ntiles) fetch(tile_i + nblk);
     cx.rhs_eval(y0e, kn);
     const int nr = cx.rows_here(tile_i, A.batch);
     const long long tb = tile_i * R_ * cx.d;
@@ -613,7 +622,8 @@ __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f
 
 // before_integrate, second half (misc.py:235-237): f1 = f(t0 + h0, y0 + h0 f0), sum of ((f1 - f0)/sc)^2
 template <typename T, int D, bool SC0>
-__device__ __forceinline__ void lin_initb_pass(const StepArgs& A, const T* y0, const T* f0, T h0, LinCtx<T, D>& cx, Acc& acc) {
+__device__ __forceinline__ void lin_initb_pass(const StepArgs& A, const T* y0, const T* f0, T h0, LinCtx<T, D>& cx, Acc& acc,
+                                               int blk = (int)blockIdx.x, int nblk = (int)gridDim.x) {
   constexpr int R_ = LinCtx<T, D>::R_;
   const long long ntiles = (A.batch + R_ - 1) / R_;
   T y0n[4], f0n[4];
@@ -628,12 +638,12 @@ __device__ __forceinline__ void lin_initb_pass(const StepArgs& A, const T* y0, c
       f0n[i] = ok ? stream_load<SC0>(tf + cx.off_of(i)) : (T)0;
     }
   };
-  if ((long long)blockIdx.x < ntiles) fetch(blockIdx.x);
-  for (long long tile_i = blockIdx.x; tile_i < ntiles; tile_i += gridDim.x) {
+  if ((long long)blk < ntiles) fetch(blk);
+  for (long long tile_i = blk; tile_i < ntiles; tile_i += nblk) {
     T y0e[4], f0e[4], ys[4], kn[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { y0e[i] = y0n[i]; f0e[i] = f0n[i]; ys[i] = y0e[i] + h0 * f0e[i]; }   // misc.py:235
-    if (tile_i + gridDim.x < ntiles) fetch(tile_i + gridDim.x);
+    if (tile_i + nblk < ntiles) fetch(tile_i + nblk);
     cx.rhs_eval(ys, kn);
     const int nr = cx.rows_here(tile_i, A.batch);
 #pragma unroll
