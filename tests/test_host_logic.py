@@ -36,7 +36,7 @@ def test_library_exports_every_declared_symbol_and_layout_matches():
     assert declared == list(N.EXPORTED_SYMBOLS), (declared, N.EXPORTED_SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mi_ode_abi_version() == N.ABI_VERSION == 12
+    assert lib.mi_ode_abi_version() == N.ABI_VERSION == 13
     assert lib.mi_ode_sizeof(0) == C.sizeof(N.Desc) and lib.mi_ode_sizeof(1) == C.sizeof(N.Stats)
     assert lib.mi_ode_status_string(N.ST_MAX_STEPS).decode().startswith('max_num_steps exceeded')
     assert lib.mi_ode_status_string(N.ST_DT_UNDERFLOW).decode().startswith('underflow in dt')

@@ -5,8 +5,9 @@
 // For this right-hand side the four components are
 //     y' = s (y W + b)          a' = -s a W^T          adj_t' = 0          theta' = -s [y^T a ; sum_rows a]        (s = -1: decreasing time)
 // Structure of the kernel - a persistent grid of G workgroups, one per CU, hand-offs as in mi_ode_persist.h:
-//   * y and a are two linear systems: workgroups [0, G/2) keep their slice of W resident and run config 4's tile pass (lin_attempt_pass,
-//     mi_ode_step_fused.h) over the y planes, workgroups [G/2, G) keep the slice of W^T (sign -s, no bias) and run it over the a planes;
+//   * y and a are two linear systems: every workgroup runs config 4's tile pass (lin_attempt_pass, mi_ode_step_fused.h) over its tiles
+//     of the y planes with its slice of W resident, reloads the slice of W^T (sign -s, no bias) and runs it over the same tiles of the a
+//     planes - so the rows of (y1, a1) a workgroup needs for the slab product below are rows it wrote itself;
 //   * theta needs NO per-stage product over the batch.  Both systems have constant matrices, so every stage input is the step's start
 //     value times a polynomial in h W whose coefficients depend on the tableau only (oracle/linear_adjoint_numpy.py, "the power form"):
 //         sum_sigma (h c_sigma) k_theta,sigma = -s h sum_pq K^c_pq (s h)^p (-s h)^q M_pq,    M_pq = ((W^T)^p G0 + c_p g0) (W^T)^q
@@ -38,7 +39,7 @@ struct LinAdjResult {                    // pinned host: the kernel's last act i
   long long n_attempt, n_accept;
   unsigned status;
   int handoffs;
-  long long prof[8];                     // 10 ns ticks of workgroup 0: tile passes / theta combinations / hand-offs of attempts / slab passes /
+  long long prof[16];                    // 10 ns ticks of workgroup 0: tile passes / theta combinations / hand-offs of attempts / slab passes /
                                          // folds + small products (with their hand-offs) / prologue / epilogue / -
   long long clk_cycles, clk_ticks;
 };
@@ -60,6 +61,7 @@ struct LinAdjArgs {
   double* lmat;                          // [kLaP][D * D]      L_p = (W^T)^p G0 + c_p g0  (p >= 1; L_0 = G0 is read in place)
   double* mmat;                          // [kLaPP][(D + 1) D] M_pq; row D: g0 (W^T)^q for p = 0, zero otherwise (the bias entries)
   double* theta;                         // [2][D * D + D]     adj_params at the step's start / after the attempt, padded layout
+  void* wpad;                            // [2][D][D]          W and W^T zero padded to the tile width, state dtype (what the tile passes keep resident)
   const double* ktab;                    // device [4][kLaPP]: K^sol, K^err, K^mid, pi_S pi_S^T
   double t_end;
   LinAdjResult* res;
@@ -81,7 +83,9 @@ struct LaShared {
   SegState seg;
   double kq[3][kLaPP];                   // the attempt's combination weights of the M_pq: solution, error estimate, dense output
   double adjt;                           // adj_t (constant over the segment)
-  long long prof[8], tk_prev;            // workgroup 0: where the time of a segment goes (LinAdjResult.prof)
+  double th0_max;                        // max |adj_params| at the step's start (thread 0)
+  double mine[8];                        // thread 0: this workgroup's record while its passes run
+  long long prof[16], tk_prev;            // workgroup 0: where the time of a segment goes (LinAdjResult.prof)
   int ok;
   int skip_initb;
 };
@@ -164,7 +168,7 @@ template <int D>
 __device__ __forceinline__ void la_tile_job(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int ldc,
                                             int tm, int tn, const double* __restrict__ u, const double* __restrict__ v) {
   using TR = MfmaTraits<double>;
-  constexpr int KS = D / 4, CHK = KS < 8 ? KS : 8;
+  constexpr int KS = D / 4, CHK = KS;                          // every operand of the product in flight at once (one wait)
   const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
   TR::acc_t acc = {0, 0, 0, 0};
   const double* ap = A + (long long)(16 * tm + li) * D + lg * KS;
@@ -174,6 +178,7 @@ __device__ __forceinline__ void la_tile_job(const double* __restrict__ A, const 
     double av[CHK], bv[CHK];
 #pragma unroll
     for (int m = 0; m < CHK; ++m) { av[m] = ap[m0 + m]; bv[m] = bp[(long long)(m0 + m) * D]; }
+    __builtin_amdgcn_sched_barrier(0);                         // all loads first, ONE wait, then the chain (the scheduler would interleave a wait per step)
 #pragma unroll
     for (int m = 0; m < CHK; ++m) acc = TR::mfma(av[m], bv[m], acc);
   }
@@ -187,31 +192,52 @@ __device__ __forceinline__ void la_tile_job(const double* __restrict__ A, const 
   }
 }
 
-// ---- the slab pass: this workgroup's partial of (y^T a | sum_rows a) over rows [r0, r1) (k_outer_partial's loop, mi_ode_outer.hip) ----
+// seven lanes share one entry of the folds / the combinations (49 = 7 x 7 terms; nine groups per wavefront, lane 63 idles): every lane
+// of a group ends up with the group's sum, formed in a fixed order
+__device__ __forceinline__ double group7_sum(double v, int lane) {
+  const int base = lane / 7 * 7;
+  double s_ = 0.0;
+#pragma unroll
+  for (int k = 0; k < 7; ++k) s_ += __shfl(v, base + k < 64 ? base + k : 63, 64);
+  return s_;
+}
+// eight lanes share one output of the small vector jobs: every lane ends up with the group's sum
+__device__ __forceinline__ double group8_sum(double v) {
+  v += __shfl_xor(v, 1, 64);
+  v += __shfl_xor(v, 2, 64);
+  v += __shfl_xor(v, 4, 64);
+  return v;
+}
+
+// ---- the slab pass: this workgroup's partial of (y^T a | sum_rows a) over ITS OWN 16-row tiles (tile = blk, blk + nblk, ...: the rows
+// its tile passes wrote - no other workgroup's stores are read).  k_outer_partial's loop (mi_ode_outer.hip). ----
 template <typename T, int D>
-__device__ __forceinline__ void la_slab_pass(const T* __restrict__ y, const T* __restrict__ a, long long r0, long long r1, int dim,
+__device__ __forceinline__ void la_slab_pass(const T* __restrict__ y, const T* __restrict__ a, long long batch, int dim, int blk, int nblk,
                                              T* __restrict__ out, T* lds) {
   using TR = MfmaTraits<T>;
   using acc_t = typename TR::acc_t;
   constexpr int MB = D / 16, NT = D * 4, R = 16, EPT = R * D / NT, VEC = TR::VEC, CPT = EPT / VEC;
   using CH = Chunk<T, VEC>;
   static_assert(EPT % VEC == 0, "tile / workgroup geometry");
+  constexpr int LDP = D + 16;                                  // row stride: the four row groups of an MFMA operand read land in different banks
   T* sy = lds;
-  T* sa = lds + R * D;
+  T* sa = lds + R * LDP;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
   const bool vl = dim % VEC == 0 && ((((unsigned long long)y) | ((unsigned long long)a)) & 15ull) == 0;
+  const long long ntiles = (batch + R - 1) / R;
   acc_t acc[MB];
 #pragma unroll
   for (int m = 0; m < MB; ++m) acc[m] = acc_t{0, 0, 0, 0};
   T colsum = (T)0;
   const int ncol = 16 * w + li;
-  T py[EPT], pa[EPT];
-  auto fetch = [&](long long t0) {
+  T py[EPT], pa[EPT], qy[EPT], qa[EPT];                        // the next tile and the one after it (two tiles in flight)
+  auto fetch = [&](long long tile_i, T (&py)[EPT], T (&pa)[EPT]) {
+    const long long t0 = tile_i * R;
     if (vl) {
 #pragma unroll
       for (int c = 0; c < CPT; ++c) {
         const int idx = (c * NT + tid) * VEC, row = idx / D, col = idx % D;
-        const bool ok = t0 + row < r1 && col < dim;
+        const bool ok = t0 + row < batch && col < dim;
         CH vy, va;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) { vy.v[v] = (T)0; va.v[v] = (T)0; }
@@ -223,32 +249,36 @@ __device__ __forceinline__ void la_slab_pass(const T* __restrict__ y, const T* _
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
         const int idx = (e / VEC * NT + tid) * VEC + e % VEC, row = idx / D, col = idx % D;   // (the same element -> LDS slot map as above)
-        const bool ok = t0 + row < r1 && col < dim;
+        const bool ok = t0 + row < batch && col < dim;
         py[e] = ok ? y[(t0 + row) * dim + col] : (T)0;
         pa[e] = ok ? a[(t0 + row) * dim + col] : (T)0;
       }
     }
   };
-  if (r0 < r1) fetch(r0);
-  for (long long t0 = r0; t0 < r1; t0 += R) {
+  if ((long long)blk < ntiles) fetch(blk, py, pa);
+  if ((long long)blk + nblk < ntiles) fetch((long long)blk + nblk, qy, qa);
+  for (long long tile_i = blk; tile_i < ntiles; tile_i += nblk) {
     __syncthreads();                                           // (the previous tile's operands have been read)
 #pragma unroll
     for (int c = 0; c < CPT; ++c) {
       CH vy, va;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) { vy.v[v] = py[c * VEC + v]; va.v[v] = pa[c * VEC + v]; }
-      *(CH*)(sy + (c * NT + tid) * VEC) = vy;
-      *(CH*)(sa + (c * NT + tid) * VEC) = va;
+      const int idx = (c * NT + tid) * VEC;
+      *(CH*)(sy + idx / D * LDP + idx % D) = vy;
+      *(CH*)(sa + idx / D * LDP + idx % D) = va;
     }
     __syncthreads();
-    if (t0 + R < r1) fetch(t0 + R);                            // in flight under this tile's MFMAs
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) { py[e] = qy[e]; pa[e] = qa[e]; }
+    if (tile_i + 2 * (long long)nblk < ntiles) fetch(tile_i + 2 * (long long)nblk, qy, qa);   // in flight under two tiles' MFMAs
 #pragma unroll
     for (int u = 0; u < R / 4; ++u) {
       const int row = 4 * u + lg;
-      const T bv = sa[row * D + ncol];
+      const T bv = sa[row * LDP + ncol];
       colsum += bv;
 #pragma unroll
-      for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(sy[row * D + 16 * m + li], bv, acc[m]);
+      for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(sy[row * LDP + 16 * m + li], bv, acc[m]);
     }
   }
 #pragma unroll
@@ -270,26 +300,34 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ LaShared<kLaMaxG> sh;
   Ctl& s_c = sh.c;
-  const int G = (int)gridDim.x, GH = G / 2;
-  const bool is_a = (int)blockIdx.x >= GH;
-  const int hb = is_a ? (int)blockIdx.x - GH : (int)blockIdx.x;
+  const int G = (int)gridDim.x, blk = (int)blockIdx.x;
   const int dim = A.p.s.dim;
   const double sgn = A.p.s.rhs.sign;                           // s
   const T* Wm = (const T*)A.p.s.rhs.w[0];
   const T* bias = A.has_bias ? (const T*)A.p.s.rhs.b[0] : nullptr;
+  // every workgroup runs BOTH systems over its own tiles, one after the other, and reloads its resident matrix slice in between
+  // (128 KB from L2 per switch at dim 128: microseconds against the 200 of a pass) - so that the rows of y1 and a1 a workgroup needs for
+  // its slab partial are rows it wrote itself, and every workgroup does the same amount of work per pass (no half waits for the other)
   LinCtx<T, D> cx;
-  if (is_a) cx.init_matrix(Wm, nullptr, -sgn, true, (T*)smem_raw, dim);
-  else cx.init_matrix(Wm, bias, sgn, false, (T*)smem_raw, dim);
+  bool padded_ready = false;                                   // (A.wpad is written in the prologue: readable after the first hand-off)
+  auto load_system = [&](int sys) {                            // 0: y' = s (y W + b);  1: a' = -s a W^T
+    if (padded_ready) cx.init_padded((const T*)A.wpad + (long long)sys * D * D, sys == 0 ? bias : (const T*)nullptr, sys == 0 ? sgn : -sgn, (T*)smem_raw, dim);
+    else cx.init_matrix(Wm, sys == 0 ? bias : (const T*)nullptr, sys == 0 ? sgn : -sgn, sys != 0, (T*)smem_raw, dim);
+  };
   CtrlParams cp = A.p.s.cp;
   cp.t_out = persist_stage_tout(A.p, sh.tout, kPersistTSmall);
   const double* t_out = cp.t_out;
   const long long batch = A.p.s.batch;
   const long long n_state = batch * dim, n_theta = (long long)dim * dim + (A.has_bias ? dim : 0);
-  const int wave = (int)threadIdx.x >> 6;
-  const int gw = (int)blockIdx.x * NW + wave, ngw = G * NW;    // this wavefront among the grid's
-  const int gt = (int)blockIdx.x * (int)blockDim.x + (int)threadIdx.x, ngt = G * (int)blockDim.x;
+  const int tid = (int)threadIdx.x, nthr = (int)blockDim.x;
+  const int wave = tid >> 6;
+  const int gw = blk * NW + wave, ngw = G * NW;                // this wavefront among the grid's
+  const int gt = blk * nthr + tid, ngt = G * nthr;
+  const int gg = gt >> 3, ngg = ngt >> 3, part8 = tid & 7;     // groups of eight lanes (one output of a vector job each)
+  const int lane = tid & 63, part7 = lane % 7;                 // groups of seven lanes (one entry of a fold / combination each)
+  const int grp7 = lane < 63 ? wave * 9 + lane / 7 : -1, ngrp7 = NW * 9;
   const int EPW = (E + G - 1) / G;                             // theta entries per workgroup (a contiguous run: coalesced)
-  const int e_lo = (int)blockIdx.x * EPW, e_hi = e_lo + EPW < E ? e_lo + EPW : E;
+  const int e_lo = blk * EPW, e_hi = e_lo + EPW < E ? e_lo + EPW : E;
   auto entry_valid = [&](int e) { return e < D * D ? (e / D < dim && e % D < dim) : (A.has_bias && e - D * D < dim); };
   unsigned gen = 0;
   bool ok = true;
@@ -299,11 +337,11 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     for (int i = 0; i < 8; ++i) mine[i] = 0.0;
   };
   auto tick = [&](int slot) {                                  // workgroup 0, thread 0: where the time of a segment goes
-    if (blockIdx.x == 0 && threadIdx.x == 0) { const long long now = (long long)wall_clock64(); sh.prof[slot] += now - sh.tk_prev; sh.tk_prev = now; }
+    if (blk == 0 && tid == 0) { const long long now = (long long)wall_clock64(); sh.prof[slot] += now - sh.tk_prev; sh.tk_prev = now; }
   };
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     persist_init_ctl(s_c, A.p); sh.ok = 1; sh.skip_initb = 0;
-    for (int i = 0; i < 8; ++i) sh.prof[i] = 0;
+    for (int i = 0; i < 16; ++i) sh.prof[i] = 0;
     sh.tk_prev = (long long)wall_clock64();
     sh.adjt = (double)*(const T*)A.adjt_in;
   }
@@ -311,31 +349,29 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
 
   T* const pl = (T*)A.planes;
   const long long pstride = A.stride / (long long)sizeof(T);
-  T* const my_ya = pl + (is_a ? 4 : 0) * pstride;
-  T* const my_yb = my_ya + pstride;
-  T* const my_fa = my_ya + 2 * pstride;
-  T* const my_fb = my_ya + 3 * pstride;
-  const T* const my_in = is_a ? (const T*)A.a_in : (const T*)A.y_in;
+  T* const y_pa = pl; T* const y_pb = pl + pstride; T* const y_fa = pl + 2 * pstride; T* const y_fb = pl + 3 * pstride;
+  T* const a_pa = pl + 4 * pstride; T* const a_pb = pl + 5 * pstride; T* const a_fa = pl + 6 * pstride; T* const a_fb = pl + 7 * pstride;
   double* const th0 = A.theta;                                 // adj_params at the step's start
   double* const th1 = A.theta + E;                             // ... after the attempt
-  T* const my_part = (T*)A.gpart + (long long)blockIdx.x * E;
-  long long rps = (batch + G - 1) / G;                         // rows per slab, a multiple of 4
-  rps = (rps + 3) / 4 * 4;
-  const long long slab_r0 = (long long)blockIdx.x * rps < batch ? (long long)blockIdx.x * rps : batch;
-  const long long slab_r1 = slab_r0 + rps < batch ? slab_r0 + rps : batch;
+  T* const my_part = (T*)A.gpart + (long long)blk * E;
 
-  // ---- the small products after a new start state (y0, a0): slab partials -> G0 | g0 -> L_p, g0 P_q -> M_pq.  Four hand-offs. ----
-  auto fold_g0 = [&]() {                                       // entries e_lo .. e_hi of G0 | g0 (fixed order: eight interleaved chains)
-    const T* part = (const T*)A.gpart;
-    for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+  // ---- the small products after a new start state (y0, a0): slab partials -> G0 | g0 -> L_p, g0 P_q -> M_pq ----------------------
+  auto fold_g0 = [&]() {                                       // entries e_lo .. e_hi of G0 | g0: seven lanes per entry, lane j sums the
+    const T* part = (const T*)A.gpart;                         // slabs j, j + 7, ... in eight interleaved chains (a fixed order)
+    for (int e0 = e_lo; e0 < e_hi; e0 += ngrp7) {              // (uniform trip count: the shuffles need every lane)
+      const int e = e0 + grp7;
+      const bool live = grp7 >= 0 && e < e_hi;
       double q[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-      int g = 0;
-      for (; g + 8 <= G; g += 8) {
+      if (live) {
+        int g = part7;
+        for (; g + 49 < G; g += 56) {
 #pragma unroll
-        for (int u = 0; u < 8; ++u) q[u] += (double)part[(long long)(g + u) * E + e];
+          for (int u = 0; u < 8; ++u) q[u] += (double)part[(long long)(g + 7 * u) * E + e];
+        }
+        for (; g < G; g += 7) q[0] += (double)part[(long long)g * E + e];
       }
-      for (; g < G; ++g) q[0] += (double)part[(long long)g * E + e];
-      A.g0[e] = ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7]));
+      const double s_ = group7_sum(((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7])), lane);
+      if (live && part7 == 0) A.g0[e] = s_;
     }
   };
   auto level_l = [&]() {                                       // L_p = P_p G0 + c_p g0 (p = 1..S) and the bias rows g0 P_q (q = 0..S)
@@ -344,12 +380,14 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       la_tile_job<D>(A.pw + (long long)p * D * D, A.g0, A.lmat + (long long)p * D * D, D, t / (D / 16), t % (D / 16),
                      A.has_bias ? A.cvec + p * D : nullptr, A.g0 + D * D);
     }
-    for (int j = gt; j < kLaP * D; j += ngt) {
+    for (int j = gg; j < kLaP * D; j += ngg) {                 // row D of M_0q: g0 P_q
       const int q = j / D, c = j % D;
       const double* P = A.pw + (long long)q * D * D;
       double s_ = 0.0;
-      for (int k = 0; k < D; ++k) s_ = fma(A.g0[D * D + k], P[(long long)k * D + c], s_);
-      A.mmat[(long long)q * E + D * D + c] = s_;               // row D of M_0q
+#pragma unroll
+      for (int k = part8; k < D; k += 8) s_ = fma(A.g0[D * D + k], P[(long long)k * D + c], s_);
+      s_ = group8_sum(s_);
+      if (part8 == 0) A.mmat[(long long)q * E + D * D + c] = s_;
     }
   };
   auto level_m = [&]() {                                       // M_pq = L_p P_q (L_0 = G0)
@@ -359,23 +397,14 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
                      t / (D / 16), t % (D / 16), nullptr, nullptr);
     }
   };
-  auto barrier_handoff = [&](bool release, bool acquire) {
+  auto barrier_handoff = [&]() {
     zero_mine();
-    ok = ok && la_exchange(A.p, sh, gen++, mine, release, acquire);
-  };
-  auto products_after_slab = [&]() {                           // (the slab partials are written; the caller has not handed off yet)
-    barrier_handoff(true, true);
-    if (ok) fold_g0();
-    barrier_handoff(true, true);
-    if (ok) level_l();
-    barrier_handoff(true, true);
-    if (ok) level_m();
-    barrier_handoff(true, true);
+    ok = ok && la_exchange(A.p, sh, gen++, mine, true, true);
   };
 
   // ---- prologue ------------------------------------------------------------------------------------------------------------------
   // adj_params -> the padded float64 layout; P_0 = I, P_1 = W^T, c_0 = 0, c_1 = b
-  for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {     // (the entries this thread owns for the whole segment)
+  for (int e = e_lo + tid; e < e_hi; e += nthr) {              // (the entries this workgroup owns for the whole segment)
     double v = 0.0;
     if (e < D * D) { if (e / D < dim && e % D < dim) v = (double)((const T*)A.th_in)[(e / D) * dim + e % D]; }
     else if (A.has_bias && e - D * D < dim) v = (double)((const T*)A.th_in)[dim * dim + (e - D * D)];
@@ -384,25 +413,35 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
   for (int e = gt; e < D * D; e += ngt) {
     const int i = e / D, j = e % D;
     A.pw[e] = i == j ? 1.0 : 0.0;
-    A.pw[D * D + e] = (i < dim && j < dim) ? (double)Wm[(long long)j * dim + i] : 0.0;
+    const T wt = (i < dim && j < dim) ? Wm[(long long)j * dim + i] : (T)0;
+    A.pw[D * D + e] = (double)wt;
+    ((T*)A.wpad)[e] = (i < dim && j < dim) ? Wm[(long long)i * dim + j] : (T)0;
+    ((T*)A.wpad)[D * D + e] = wt;
   }
   for (int e = gt; e < 2 * D; e += ngt) A.cvec[e] = (e >= D && bias != nullptr && e - D < dim) ? (double)bias[e - D] : 0.0;
-  // f0 of both systems (misc.py:225-233's sums ride in the record) and the slab partials of the start state
-  Acc acc0;
-  lin_f0_pass<T, D, true>(A.p.s, my_in, my_fa, (T*)nullptr, (T*)nullptr, cx, acc0, hb, GH);
-  la_slab_pass<T, D>((const T*)A.y_in, (const T*)A.a_in, slab_r0, slab_r1, dim, my_part, (T*)smem_raw);
+  // f0 of both systems (misc.py:225-233's sums ride in the record) and the slab partial of the start state
   {
-    double r[5];
-    block_reduce_thread0(acc0, sh.red, r);
+#pragma clang loop unroll(disable)
+    for (int sys = 0; sys < 2; ++sys) {                        // (one instance of the pass in the code: the systems differ in pointers only)
+      Acc acc;
+      load_system(sys);
+      lin_f0_pass<T, D, true>(A.p.s, sys == 0 ? (const T*)A.y_in : (const T*)A.a_in, sys == 0 ? y_fa : a_fa, (T*)nullptr, (T*)nullptr, cx, acc);
+      double r[5];
+      block_reduce_thread0(acc, sh.red, r);
+      if (tid == 0) { sh.mine[3 * sys] = r[2]; sh.mine[3 * sys + 1] = r[3]; sh.mine[3 * sys + 2] = r[4]; }
+    }
+    la_slab_pass<T, D>((const T*)A.y_in, (const T*)A.a_in, batch, dim, blk, G, my_part, (T*)smem_raw);
     zero_mine();
+    if (tid == 0) {
 #pragma unroll
-    for (int i = 0; i < 5; ++i) mine[i] = r[i];
+      for (int i = 0; i < 6; ++i) mine[i] = sh.mine[i];
+    }
     ok = la_exchange(A.p, sh, gen++, mine, true, true);
-    if (ok && threadIdx.x < 64) {                              // the y and adj_y records of the initial step
+    padded_ready = true;
+    if (ok && tid < 64) {                                      // the y and adj_y records of the initial step
       for (int k = 0; k < 2; ++k) {
-        const int b0 = k * GH, b1 = b0 + GH;
-        const double sa = la_fold_sum(sh.vals[R_SUMA], b0, b1), sb = la_fold_sum(sh.vals[R_SUMB], b0, b1), fl = la_fold_max(sh.vals[R_FLAG], b0, b1);
-        if (threadIdx.x == 0) {
+        const double sa = la_fold_sum(sh.vals[3 * k], 0, G), sb = la_fold_sum(sh.vals[3 * k + 1], 0, G), fl = la_fold_max(sh.vals[3 * k + 2], 0, G);
+        if (tid == 0) {
           double* o = sh.seg_rec[k];
           o[R_MAXA] = 0; o[R_MAXB] = 0; o[R_SUMA] = sa; o[R_SUMB] = sb; o[R_FLAG] = fl; o[R_N] = (double)n_state; o[6] = 0; o[7] = 0;
         }
@@ -419,42 +458,47 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
         la_tile_job<D>(A.pw + (long long)n * D * D, A.pw + (long long)(q - n) * D * D, A.pw + (long long)q * D * D, D, t / (D / 16), t % (D / 16),
                        nullptr, nullptr);
       }
-      for (int j = gt; j < (q_hi - n) * D; j += ngt) {
+      for (int j = gg; j < (q_hi - n) * D; j += ngg) {
         const int q = n + 1 + j / D, i = j % D;
         const double* P = A.pw + (long long)n * D * D + (long long)i * D;
         const double* c = A.cvec + (q - n) * D;
         double s_ = 0.0;
-        for (int k = 0; k < D; ++k) s_ = fma(P[k], c[k], s_);
-        A.cvec[q * D + i] = s_;
+#pragma unroll
+        for (int k = part8; k < D; k += 8) s_ = fma(P[k], c[k], s_);
+        s_ = group8_sum(s_);
+        if (part8 == 0) A.cvec[q * D + i] = s_;
       }
     }
-    barrier_handoff(true, true);
+    barrier_handoff();
   }
   if (ok) level_l();
-  barrier_handoff(true, true);
+  barrier_handoff();
   if (ok) level_m();
-  barrier_handoff(true, true);
+  barrier_handoff();
   // adj_params' share of misc._select_initial_step: f0 = -s M_00 (= -s [G0 ; g0])
   {
     Acc at;
     if (ok) {
-      for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+      for (int e = e_lo + tid; e < e_hi; e += nthr) {
         if (!entry_valid(e)) continue;
         const T v0 = (T)th0[e], f0 = (T)(-sgn * A.mmat[e]);
         const T sc = (T)cp.atol + fabs(v0) * (T)cp.rtol;       // misc.py:225
         const double q0 = (double)(v0 / sc), q1 = (double)(f0 / sc);
         at.suma += q0 * q0; at.sumb += q1 * q1;
+        at.maxa = fmax(at.maxa, fabs((double)v0));
         if (!finite_(v0)) at.flag = 1;
       }
     }
     double r[5];
     block_reduce_thread0(at, sh.red, r);
     zero_mine();
-    mine[5] = r[2]; mine[6] = r[3]; mine[7] = r[4];
+    mine[0] = r[2]; mine[1] = r[3]; mine[2] = r[4]; mine[3] = r[0];
     ok = ok && la_exchange(A.p, sh, gen++, mine, false, false);
-    if (ok && threadIdx.x < 64) {
-      const double sa = la_fold_sum(sh.vals[5], 0, G), sb = la_fold_sum(sh.vals[6], 0, G), fl = la_fold_max(sh.vals[7], 0, G);
-      if (threadIdx.x == 0) {
+    if (ok && tid < 64) {
+      const double sa = la_fold_sum(sh.vals[0], 0, G), sb = la_fold_sum(sh.vals[1], 0, G), fl = la_fold_max(sh.vals[2], 0, G);
+      const double m0 = la_fold_max(sh.vals[3], 0, G);
+      if (tid == 0) {
+        sh.th0_max = m0;
         double* o = sh.seg_rec[3];
         o[R_MAXA] = 0; o[R_MAXB] = 0; o[R_SUMA] = sa; o[R_SUMB] = sb; o[R_FLAG] = fl; o[R_N] = (double)n_theta; o[6] = 0; o[7] = 0;
         double* t_ = sh.seg_rec[2];                            // adj_t: one element, zero derivative
@@ -475,11 +519,19 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     __syncthreads();
   }
   if (ok && !uniform_i(sh.skip_initb)) {                       // misc.py:235-245 for a finite h0
-    Acc accb, at;
+    Acc at;
     const double h0d = uniform_d(s_c.h0);
-    lin_initb_pass<T, D, true>(A.p.s, my_in, my_fa, (T)h0d, cx, accb, hb, GH);
+#pragma clang loop unroll(disable)
+    for (int sys = 0; sys < 2; ++sys) {
+      Acc acc;
+      load_system(sys);
+      lin_initb_pass<T, D, true>(A.p.s, sys == 0 ? (const T*)A.y_in : (const T*)A.a_in, sys == 0 ? y_fa : a_fa, (T)h0d, cx, acc);
+      double r[5];
+      block_reduce_thread0(acc, sh.red, r);
+      if (tid == 0) sh.mine[sys] = r[2];
+    }
     const double hT = (double)(T)h0d, sh_ = sgn * hT;
-    for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+    for (int e = e_lo + tid; e < e_hi; e += nthr) {
       if (!entry_valid(e)) continue;
       const double m00 = A.mmat[e], m01 = A.mmat[(long long)1 * E + e], m10 = A.mmat[(long long)kLaP * E + e], m11 = A.mmat[(long long)(kLaP + 1) * E + e];
       const T v0 = (T)th0[e], f0 = (T)(-sgn * m00);
@@ -488,15 +540,14 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       const double q = (double)((f1 - f0) / sc);               // misc.py:237
       at.suma += q * q;
     }
-    double r[5], r2[5];
-    block_reduce_thread0(accb, sh.red, r);
-    block_reduce_thread0(at, sh.red, r2);
+    double r3[5];
+    block_reduce_thread0(at, sh.red, r3);
     zero_mine();
-    mine[2] = r[2]; mine[5] = r2[2];
+    if (tid == 0) { mine[0] = sh.mine[0]; mine[1] = sh.mine[1]; mine[2] = r3[2]; }
     ok = la_exchange(A.p, sh, gen++, mine, false, false);
-    if (ok && threadIdx.x < 64) {
-      const double sy = la_fold_sum(sh.vals[2], 0, GH), sa = la_fold_sum(sh.vals[2], GH, G), st_ = la_fold_sum(sh.vals[5], 0, G);
-      if (threadIdx.x == 0) {
+    if (ok && tid < 64) {
+      const double sy = la_fold_sum(sh.vals[0], 0, G), sa = la_fold_sum(sh.vals[1], 0, G), st_ = la_fold_sum(sh.vals[2], 0, G);
+      if (tid == 0) {
         sh.seg_rec[0][R_SUMA] = sy; sh.seg_rec[1][R_SUMA] = sa; sh.seg_rec[2][R_SUMA] = 0.0; sh.seg_rec[3][R_SUMA] = st_;
         controller_apply_seg(&s_c, &sh.seg, sh.seg_rec, 4, PH_INITB, cp);
       }
@@ -510,7 +561,7 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     sh.pub.emit_lo = st.next_out; sh.pub.emit_hi = j;
     sh.pub.emit_t0 = st.emit_t0; sh.pub.emit_t1 = st.emit_t1; sh.pub.emit_dt = st.emit_dt;
   };
-  if (threadIdx.x == 0) {
+  if (tid == 0) {
     if (!ok) { s_c.status |= MI_ODE_ST_SYNC_TIMEOUT; s_c.done = 1; }
     else set_outputs_apply(&s_c, A.p.n_out);
     AttemptState st;
@@ -523,24 +574,29 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
   tick(5);
 
   // ---- the adaptive loop (dopri5.py:82-121) --------------------------------------------------------------------------------------
-  const T* cur_y = my_in;
-  T* cur_f = my_fa;
+  int cur = -1, cur_f = 0;                                     // state: -1 the caller's (y_in, a_in), 0 / 1 planes a / b; derivative: plane fa / fb
   const double* ktab = A.ktab;
   bool emitted = false;
   while (!uniform_i(sh.pub.done)) {
-    StepPlanes<T, S> P;
     const double dt_u = uniform_d(sh.pub.dt), t1_u = uniform_d(sh.pub.t1);
-    P.y0 = cur_y; P.f0 = cur_f;
-    P.y1 = (cur_y == my_ya) ? my_yb : my_ya;
-    P.f1 = (cur_f == my_fa) ? my_fb : my_fa;
-    P.hs = (T)dt_u; P.t0 = (T)t1_u;
-    P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
+    const int nxt = cur == 0 ? 1 : 0;
     const int j_lo = uniform_i(sh.pub.emit_lo), j_hi = uniform_i(sh.pub.emit_hi);
-    P.j_lo = is_a ? j_lo : 0; P.j_hi = is_a ? j_hi : 0;        // adj_y(t_end) is wanted; the reference discards y(t_end) (adjoint.py:155-160)
+    const T hs_T = (T)dt_u;
+    auto planes_of = [&](int sys, StepPlanes<T, S>& P) {       // state / derivative planes of system `sys` for this attempt
+      T* const pa = sys == 0 ? y_pa : a_pa; T* const pb = sys == 0 ? y_pb : a_pb;
+      T* const fa = sys == 0 ? y_fa : a_fa; T* const fb = sys == 0 ? y_fb : a_fb;
+      const T* const in = sys == 0 ? (const T*)A.y_in : (const T*)A.a_in;
+      P.y0 = cur < 0 ? in : (cur == 0 ? pa : pb); P.f0 = cur_f == 0 ? fa : fb;
+      P.y1 = nxt == 0 ? pa : pb; P.f1 = cur_f == 0 ? fb : fa;
+      P.hs = hs_T; P.t0 = (T)t1_u;
+      P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
+      // adj_y(t_end) is the tile pass's speculative dense output; the reference discards y(t_end) (adjoint.py:155-160)
+      P.j_lo = sys == 0 ? 0 : j_lo; P.j_hi = sys == 0 ? 0 : j_hi;
+    };
     // the weights of this attempt's combinations of the M_pq: -s h K^c_pq (s h)^p (-s h)^q, h = dt in the state dtype (rk_common.py:46)
     {
-      const double hT = (double)P.hs;
-      for (int i = threadIdx.x; i < 2 * kLaPP; i += blockDim.x) {
+      const double hT = (double)hs_T;
+      for (int i = tid; i < 2 * kLaPP; i += nthr) {
         const int c = i / kLaPP, pq = i % kLaPP, p = pq / kLaP, q = pq % kLaP;
         double w_ = -sgn * hT * ktab[c * kLaPP + pq];
         for (int u = 0; u < p; ++u) w_ *= sgn * hT;
@@ -548,62 +604,83 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
         sh.kq[c][pq] = w_;
       }
     }
-    Acc acc;
-    lin_attempt_pass<T, D, S, false, true>(A.p.s, P, cx, acc, t_out, (T*)sh.coef, hb, GH);   // (its first barrier also publishes sh.kq)
-    tick(0);
+#pragma clang loop unroll(disable)
+    for (int sys = 0; sys < 2; ++sys) {
+      StepPlanes<T, S> P;
+      planes_of(sys, P);
+      Acc acc;
+      tick(7);
+      load_system(sys);
+      tick(8);
+      lin_attempt_pass<T, D, S, false, true>(A.p.s, P, cx, acc, t_out, (T*)sh.coef);   // (its first barrier also publishes sh.kq)
+      tick(0);
+      double r[5];
+      block_reduce_thread0(acc, sh.red, r);
+      if (tid == 0) { sh.mine[3 * sys] = r[0]; sh.mine[3 * sys + 1] = r[1]; sh.mine[3 * sys + 2] = r[2]; }
+      tick(9);
+    }
     Acc at;
-    for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+    for (int e0 = e_lo; e0 < e_hi; e0 += ngrp7) {              // seven lanes per entry, lane j the terms pq = 7 j .. 7 j + 6
+      const int e = e0 + grp7;
+      const bool live = grp7 >= 0 && e < e_hi;
       double d_sol = 0.0, d_err = 0.0;
-#pragma unroll 7
-      for (int pq = 0; pq < kLaPP; ++pq) {
-        const double m = A.mmat[(long long)pq * E + e];
-        d_sol = fma(sh.kq[0][pq], m, d_sol);
-        d_err = fma(sh.kq[1][pq], m, d_err);
+      if (live) {
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+          const int pq = 7 * part7 + u;
+          const double m = A.mmat[(long long)pq * E + e];
+          d_sol = fma(sh.kq[0][pq], m, d_sol);
+          d_err = fma(sh.kq[1][pq], m, d_err);
+        }
       }
-      const double v0 = th0[e], v1 = v0 + d_sol;
-      th1[e] = v1;
-      if (entry_valid(e)) {
-        at.maxa = fmax(at.maxa, fabs((double)(T)v0));
-        at.maxb = fmax(at.maxb, fabs((double)(T)v1));
-        const double er = (double)(T)d_err;
-        at.suma += er * er;
+      d_sol = group7_sum(d_sol, lane); d_err = group7_sum(d_err, lane);
+      if (live && part7 == 0) {
+        const double v1 = th0[e] + d_sol;
+        th1[e] = v1;
+        if (entry_valid(e)) {
+          at.maxb = fmax(at.maxb, fabs((double)(T)v1));
+          const double er = (double)(T)d_err;
+          at.suma += er * er;
+        }
       }
     }
     tick(1);
     {
-      double r[5], r2[5];
-      block_reduce_thread0(acc, sh.red, r);
-      block_reduce_thread0(at, sh.red, r2);
+      double r3[5];
+      block_reduce_thread0(at, sh.red, r3);
       zero_mine();
+      if (tid == 0) {
 #pragma unroll
-      for (int i = 0; i < 5; ++i) mine[i] = r[i];
-      mine[5] = r2[0]; mine[6] = r2[1]; mine[7] = r2[2];
-      // (release: an accepted attempt's y1 / a1 planes are read by OTHER workgroups' slab passes)
-      ok = la_exchange(A.p, sh, gen++, mine, true, false);
+        for (int i = 0; i < 6; ++i) mine[i] = sh.mine[i];
+        mine[6] = r3[1]; mine[7] = r3[2];
+      }
+      ok = la_exchange(A.p, sh, gen++, mine, false, false);
     }
-    if (threadIdx.x < 64) {
+    if (tid < 64) {
+      double th1_max = 0.0;
       if (ok) {
         for (int k = 0; k < 2; ++k) {
-          const int b0 = k * GH, b1 = b0 + GH;
-          const double ma = la_fold_max(sh.vals[R_MAXA], b0, b1), mb = la_fold_max(sh.vals[R_MAXB], b0, b1), sa = la_fold_sum(sh.vals[R_SUMA], b0, b1);
-          if (threadIdx.x == 0) {
+          const double ma = la_fold_max(sh.vals[3 * k], 0, G), mb = la_fold_max(sh.vals[3 * k + 1], 0, G), sa = la_fold_sum(sh.vals[3 * k + 2], 0, G);
+          if (tid == 0) {
             double* o = sh.seg_rec[k];
             o[R_MAXA] = ma; o[R_MAXB] = mb; o[R_SUMA] = sa; o[R_SUMB] = 0; o[R_FLAG] = 0; o[R_N] = (double)n_state;
           }
         }
-        const double ma = la_fold_max(sh.vals[5], 0, G), mb = la_fold_max(sh.vals[6], 0, G), sa = la_fold_sum(sh.vals[7], 0, G);
-        if (threadIdx.x == 0) {
-          double* o = sh.seg_rec[3];
-          o[R_MAXA] = ma; o[R_MAXB] = mb; o[R_SUMA] = sa; o[R_SUMB] = 0; o[R_FLAG] = 0; o[R_N] = (double)n_theta;
+        const double mb = la_fold_max(sh.vals[6], 0, G), sa = la_fold_sum(sh.vals[7], 0, G);
+        if (tid == 0) {
+          th1_max = mb;
+          double* o = sh.seg_rec[3];                           // (max |theta0| is the previous accepted attempt's max |theta1|)
+          o[R_MAXA] = sh.th0_max; o[R_MAXB] = mb; o[R_SUMA] = sa; o[R_SUMB] = 0; o[R_FLAG] = 0; o[R_N] = (double)n_theta;
           double* t_ = sh.seg_rec[2];                          // adj_t: y0 = y1 = adj_t, error estimate 0 (misc.py:256-263 all the same)
           const double av = fabs((double)(T)sh.adjt);
           t_[R_MAXA] = av; t_[R_MAXB] = av; t_[R_SUMA] = 0; t_[R_SUMB] = 0; t_[R_FLAG] = 0; t_[R_N] = 1.0;
         }
       }
-      if (threadIdx.x == 0) {
+      if (tid == 0) {
         AttemptState st = sh.st;
         if (!ok) { st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; st.accepted = 0; }
         else attempt_core_seg(st, sh.seg_rec, 4, cp, nullptr, nullptr);
+        if (st.accepted) sh.th0_max = th1_max;
         publish(st);
         sh.st = st;
       }
@@ -614,12 +691,11 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     if (uniform_i(sh.pub.done)) {                              // the accepted step covers t_end: adj_params(t_end), adj_t(t_end)
       if (ok && j_hi > j_lo) {
         // dense output as ONE combination (oracle: dense_output_fold_weights): K^w = p1 K^sol + pm K^mid + p0 [p = q = 0] + pS pi_S pi_S^T
-        const double hT = (double)P.hs;
+        const double hT = (double)hs_T;
         const double x = (double)interp_x<T>(sh.pub.emit_t0, sh.pub.emit_t1, t_out[j_lo]);
         const double x2 = x * x, x3 = x2 * x, x4 = x3 * x;
         const double p1 = -8 * x4 + 14 * x3 - 5 * x2, pm = 16 * x4 - 32 * x3 + 16 * x2, p0 = -2 * x4 + 5 * x3 - 4 * x2 + x, pS = 2 * x4 - 3 * x3 + x2;
-        __syncthreads();
-        for (int pq = threadIdx.x; pq < kLaPP; pq += blockDim.x) {
+        for (int pq = tid; pq < kLaPP; pq += nthr) {
           const int p = pq / kLaP, q = pq % kLaP;
           double w_ = -sgn * hT * (p1 * ktab[pq] + pm * ktab[2 * kLaPP + pq] + pS * ktab[3 * kLaPP + pq] + (pq == 0 ? p0 : 0.0));
           for (int u = 0; u < p; ++u) w_ *= sgn * hT;
@@ -627,15 +703,22 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
           sh.kq[2][pq] = w_;
         }
         __syncthreads();
-        for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) {
+        for (int e0 = e_lo; e0 < e_hi; e0 += ngrp7) {
+          const int e = e0 + grp7;
+          const bool live = grp7 >= 0 && e < e_hi;
           double d_out = 0.0;
-#pragma unroll 7
-          for (int pq = 0; pq < kLaPP; ++pq) d_out = fma(sh.kq[2][pq], A.mmat[(long long)pq * E + e], d_out);
-          const double v = th0[e] + d_out;
-          if (e < D * D) { if (e / D < dim && e % D < dim) ((T*)A.th_out)[(e / D) * dim + e % D] = (T)v; }
-          else if (A.has_bias && e - D * D < dim) ((T*)A.th_out)[dim * dim + (e - D * D)] = (T)v;
+          if (live) {
+#pragma unroll
+            for (int u = 0; u < 7; ++u) d_out = fma(sh.kq[2][7 * part7 + u], A.mmat[(long long)(7 * part7 + u) * E + e], d_out);
+          }
+          d_out = group7_sum(d_out, lane);
+          if (live && part7 == 0) {
+            const double v = th0[e] + d_out;
+            if (e < D * D) { if (e / D < dim && e % D < dim) ((T*)A.th_out)[(e / D) * dim + e % D] = (T)v; }
+            else if (A.has_bias && e - D * D < dim) ((T*)A.th_out)[dim * dim + (e - D * D)] = (T)v;
+          }
         }
-        if (blockIdx.x == 0 && threadIdx.x == 0) {             // adj_t: the fit of a constant, evaluated as the reference does (interp.py:6-67)
+        if (blk == 0 && tid == 0) {                            // adj_t: the fit of a constant, evaluated as the reference does (interp.py:6-67)
           const T at_ = (T)sh.adjt;
           T co[5];
           quartic_from_mid<T>(at_, at_, at_, (T)0, (T)0, (T)sh.pub.emit_dt, co);
@@ -647,33 +730,37 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       break;
     }
     // accepted, more to come: the planes and adj_params move on; G0 | g0 and the M_pq of the new start state
-    cur_y = P.y1; cur_f = P.f1;
-    for (int e = e_lo + (int)threadIdx.x; e < e_hi; e += (int)blockDim.x) th0[e] = th1[e];
-    {
-      // which y / a planes hold the accepted state: both halves flip together (same accept decisions), so the index is this half's
-      const int idx = (P.y1 == my_ya) ? 0 : 1;
-      const T* yy = pl + idx * pstride;
-      const T* aa = pl + (4 + idx) * pstride;
-      if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // other workgroups wrote these planes (their release: the
-      __syncthreads();                                                           // attempt's hand-off); rejected attempts skip the invalidate
-      la_slab_pass<T, D>(yy, aa, slab_r0, slab_r1, dim, my_part, (T*)smem_raw);
-    }
+    cur = nxt; cur_f ^= 1;
+    for (int e = e_lo + tid; e < e_hi; e += nthr) th0[e] = th1[e];
+    la_slab_pass<T, D>(nxt == 0 ? y_pa : y_pb, nxt == 0 ? a_pa : a_pb, batch, dim, blk, G, my_part, (T*)smem_raw);   // (rows this workgroup wrote itself: no fence)
     tick(3);
-    products_after_slab();
-    tick(4);
+    barrier_handoff();
+    tick(10);
+    if (ok) fold_g0();
+    tick(11);
+    barrier_handoff();
+    tick(10);
+    if (ok) level_l();
+    tick(12);
+    barrier_handoff();
+    tick(10);
+    if (ok) level_m();
+    tick(13);
+    barrier_handoff();
+    tick(10);
     if (!ok) {
-      if (threadIdx.x == 0) { AttemptState st = sh.st; st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; publish(st); sh.st = st; }
+      if (tid == 0) { AttemptState st = sh.st; st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; publish(st); sh.st = st; }
       __syncthreads();
     }
   }
 
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (blk == 0 && tid == 0) {
     AttemptState st = sh.st;
     if (!emitted && st.status == 0) st.status |= MI_ODE_ST_SYNC_TIMEOUT;   // (cannot happen: done without a status means the output was written)
     LinAdjResult res;
     res.t1 = st.t1; res.dt = st.dt; res.ratio = st.ratio; res.h0 = s_c.h0;
     res.n_attempt = st.n_attempt; res.n_accept = st.n_accept; res.status = st.status; res.handoffs = (int)gen;
-    for (int i = 0; i < 8; ++i) res.prof[i] = sh.prof[i];
+    for (int i = 0; i < 16; ++i) res.prof[i] = sh.prof[i];
     res.clk_cycles = s_c.clk_cycles + (long long)__builtin_readcyclecounter();
     res.clk_ticks = s_c.clk_ticks + (long long)wall_clock64();
     const long long* src = (const long long*)&res;
@@ -684,6 +771,8 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
 }
 
 template <typename T, int D>
-constexpr size_t linadj_lds_bytes() { return persist_linear_lds_bytes<T, D>(); }
+constexpr size_t linadj_lds_bytes() {                        // the tile passes' two stage tiles | the slab pass' two operand tiles (padded rows)
+  return persist_linear_lds_bytes<T, D>() > (size_t)2 * 16 * (D + 16) * sizeof(T) ? persist_linear_lds_bytes<T, D>() : (size_t)2 * 16 * (D + 16) * sizeof(T);
+}
 
 }  // namespace mi

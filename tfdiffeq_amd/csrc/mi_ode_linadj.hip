@@ -22,7 +22,7 @@ struct mi_ode_linadj {
   char* planes;                // 8 state planes
   long long stride;
   double *pw, *cvec, *g0, *lmat, *mmat, *theta, *ktab;
-  void* gpart;
+  void *gpart, *wpad;
   double* partials;            // hand-off records (2 parities)
   Ctl* ctl_dev;
   LinAdjResult* res;           // pinned host
@@ -72,6 +72,7 @@ extern "C" int mi_ode_linadj_destroy(mi_ode_linadj_handle h) {
   if (h->theta) (void)hipFree(h->theta);
   if (h->ktab) (void)hipFree(h->ktab);
   if (h->gpart) (void)hipFree(h->gpart);
+  if (h->wpad) (void)hipFree(h->wpad);
   if (h->partials) (void)hipFree(h->partials);
   if (h->ctl_dev) (void)hipFree(h->ctl_dev);
   if (h->res) (void)hipHostFree(h->res);
@@ -108,12 +109,12 @@ extern "C" int mi_ode_linadj_create(const mi_ode_linadj_desc* desc, mi_ode_linad
     mi_set_error("linear adjoint kernel does not fit a compute unit (LDS %zu bytes, %d threads)", h->lds, h->block);
     delete h; return MI_ODE_E_HIP;
   }
-  long long gh = h->ntiles;                      // workgroups per half: every workgroup co-resident (the hand-offs spin), one per CU
-  if (gh > cus / 2) gh = cus / 2;
-  if (gh > kLaMaxG / 2) gh = kLaMaxG / 2;
-  if (gh < 1) gh = 1;
-  if (const char* eg = getenv("MI_ODE_LINADJ_GRID")) { const int v = atoi(eg) / 2; if (v >= 1 && v <= gh) gh = v; }   // tests: small grids
-  h->grid = (int)(2 * gh);
+  long long g = h->ntiles;                       // every workgroup co-resident (the hand-offs spin): at most one per CU
+  if (g > cus) g = cus;
+  if (g > kLaMaxG) g = kLaMaxG;
+  if (g < 1) g = 1;
+  if (const char* eg = getenv("MI_ODE_LINADJ_GRID")) { const int v = atoi(eg); if (v >= 1 && v <= g) g = v; }   // tests: other grids
+  h->grid = (int)g;
   const size_t D = (size_t)h->dp, E = D * D + D;
   const size_t n = (size_t)desc->batch * (size_t)desc->dim;
   h->stride = (long long)((n * h->elt + 255) / 256 * 256);
@@ -126,6 +127,7 @@ extern "C" int mi_ode_linadj_create(const mi_ode_linadj_desc* desc, mi_ode_linad
   if (e == hipSuccess) e = hipMalloc((void**)&h->theta, 2 * E * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&h->ktab, 4 * kLaPP * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&h->gpart, (size_t)h->grid * E * h->elt);
+  if (e == hipSuccess) e = hipMalloc((void**)&h->wpad, 2 * D * D * h->elt);
   if (e == hipSuccess) e = hipMalloc((void**)&h->partials, (size_t)kMaxBlocks * kRec * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&h->ctl_dev, sizeof(Ctl));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->res, sizeof(LinAdjResult), hipHostMallocDefault);
@@ -212,7 +214,7 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
   A.y_in = y_dev; A.a_in = adj_y_dev; A.th_in = adj_params_dev; A.adjt_in = adj_t_dev;
   A.th_out = adj_params_out_dev; A.adjt_out = adj_t_out_dev;
   A.planes = h->planes; A.stride = h->stride;
-  A.pw = h->pw; A.cvec = h->cvec; A.gpart = h->gpart; A.g0 = h->g0; A.lmat = h->lmat; A.mmat = h->mmat; A.theta = h->theta; A.ktab = h->ktab;
+  A.pw = h->pw; A.cvec = h->cvec; A.gpart = h->gpart; A.g0 = h->g0; A.lmat = h->lmat; A.mmat = h->mmat; A.theta = h->theta; A.ktab = h->ktab; A.wpad = h->wpad;
   A.res = h->res;
   A.has_bias = b_dev != nullptr ? 1 : 0;
   memset(h->res, 0, sizeof(LinAdjResult));
@@ -226,9 +228,10 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
   h->seq += (unsigned)(r.handoffs > 0 ? r.handoffs : 64) + 16u;
   if (h->seq >= 0xE0000000u) h->seq = 0;
   if (getenv("MI_ODE_LINADJ_PROF") != nullptr)
-    fprintf(stderr, "[linadj prof] attempts %lld (accepted %lld) hand-offs %d  us: tile passes %.1f  theta combinations %.1f  attempt hand-offs %.1f  slab passes %.1f  "
-            "folds + small products %.1f  prologue %.1f  epilogue %.1f\n", r.n_attempt, r.n_accept, r.handoffs, 0.01 * r.prof[0], 0.01 * r.prof[1], 0.01 * r.prof[2],
-            0.01 * r.prof[3], 0.01 * r.prof[4], 0.01 * r.prof[5], 0.01 * r.prof[6]);
+    fprintf(stderr, "[linadj prof] attempts %lld (accepted %lld) hand-offs %d  us: tile passes %.1f (matrix loads %.1f, before %.1f, block reduce %.1f)  theta combinations %.1f  "
+            "attempt hand-offs %.1f  slab passes %.1f  small products: hand-offs %.1f fold %.1f L %.1f M %.1f  prologue %.1f  epilogue %.1f\n", r.n_attempt, r.n_accept,
+            r.handoffs, 0.01 * r.prof[0], 0.01 * r.prof[8], 0.01 * r.prof[7], 0.01 * r.prof[9], 0.01 * r.prof[1], 0.01 * r.prof[2], 0.01 * r.prof[3], 0.01 * r.prof[10],
+            0.01 * r.prof[11], 0.01 * r.prof[12], 0.01 * r.prof[13], 0.01 * r.prof[5], 0.01 * r.prof[6]);
   if (stats != nullptr) {
     memset(stats, 0, sizeof(*stats));
     stats->n_attempts = r.n_attempt; stats->n_accepted = r.n_accept; stats->n_rejected = r.n_attempt - r.n_accept;
@@ -242,7 +245,11 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
 
 extern "C" int mi_ode_linadj_profile(mi_ode_linadj_handle h, double* out8) {
   if (h == nullptr || out8 == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
-  for (int i = 0; i < 7; ++i) out8[i] = 0.01 * (double)h->res->prof[i];
-  out8[7] = (double)h->res->handoffs;
+  const LinAdjResult& r = *h->res;
+  out8[0] = 0.01 * (double)(r.prof[0] + r.prof[7] + r.prof[8] + r.prof[9]);
+  out8[1] = 0.01 * (double)r.prof[1]; out8[2] = 0.01 * (double)r.prof[2]; out8[3] = 0.01 * (double)r.prof[3];
+  out8[4] = 0.01 * (double)(r.prof[10] + r.prof[11] + r.prof[12] + r.prof[13]);
+  out8[5] = 0.01 * (double)r.prof[5]; out8[6] = 0.01 * (double)r.prof[6];
+  out8[7] = (double)r.handoffs;
   return 0;
 }

@@ -383,11 +383,29 @@ struct LinCtx {
     lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
     col = 16 * wave + li;
     d = dim; colok = col < dim;
+    // (every lane loads from a valid address and selects afterwards: a load under a per-element condition is a branch and a wait per
+    // element - ten microseconds per call where the adjoint kernel switches matrices twice per attempt)
+    const int cc = colok ? col : 0;
 #pragma unroll
     for (int s = 0; s < KS; ++s) {
-      const int kk = lg * KS + s;
-      bf[s] = (colok && kk < dim) ? (transposed ? W[(long long)col * dim + kk] : W[(long long)kk * dim + col]) : (T)0;
+      const int kk = lg * KS + s, kc = kk < dim ? kk : 0;
+      const T v = transposed ? W[(long long)cc * dim + kc] : W[(long long)kc * dim + cc];
+      bf[s] = (colok && kk < dim) ? v : (T)0;
     }
+    has_bias = bias != nullptr;
+    bias_v = (has_bias && colok) ? bias[col] : (T)0;
+    sign = (T)sgn;
+    plain = bias == nullptr && sgn == 1.0;
+    s_ys = lds;
+  }
+  // ... from a matrix already zero padded to [D, D] (row stride D): no bounds, every load coalesced over the sixteen lanes of a group
+  __device__ __forceinline__ void init_padded(const T* Mpad, const T* bias, double sgn, T* lds, int dim) {
+    const int tid = threadIdx.x;
+    lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
+    col = 16 * wave + li;
+    d = dim; colok = col < dim;
+#pragma unroll
+    for (int s = 0; s < KS; ++s) bf[s] = Mpad[(lg * KS + s) * D + col];
     has_bias = bias != nullptr;
     bias_v = (has_bias && colok) ? bias[col] : (T)0;
     sign = (T)sgn;
