@@ -146,3 +146,21 @@ def theta_combination_powers(W, b, G0, g0, h, s, tableau, c):
     for q in range(S + 1):
         db = db + (K[0, q] * (-s * h) ** q) * r[q]
     return -s * h * dW, -s * h * db
+
+
+def end_state_products_powers(W, b, G0, g0, h, s, tableau):
+    """(y1^T a1, sum_rows a1) of the step's END state from the start-state products alone: for an FSAL-shaped tableau y1 = Y_S and a1 = A_S are
+    the last stage inputs, so  y1^T a1 = sum_pq pi[S][p] pi[S][q] (s h)^p (-s h)^q M_pq  and  sum_rows a1 = sum_q pi[S][q] (-s h)^q (g0 P_q) -
+    the combination of the M_pq with the table pi_S pi_S^T and NO factor -s h.  csrc/mi_ode_linadj.h carries G0 | g0 from step to step this
+    way: one product over the batch per backward INTERVAL (at its start state), none per step."""
+    S = len(tableau.beta)
+    pi = stage_polynomials(tableau)
+    M, r = start_state_products_S(W, b, G0, g0, S)
+    G1 = np.zeros_like(G0)
+    g1 = np.zeros_like(g0)
+    for p in range(S + 1):
+        for q in range(S + 1):
+            G1 = G1 + (pi[S, p] * pi[S, q] * (s * h) ** p * (-s * h) ** q) * M[p][q]
+    for q in range(S + 1):
+        g1 = g1 + (pi[S, q] * (-s * h) ** q) * r[q]
+    return G1, g1

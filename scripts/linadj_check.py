@@ -53,6 +53,9 @@ if __name__ == '__main__':
     case(5000, 128, True, torch.float64, [0.0, 0.4, 1.0], tol64)
     case(300, 16, True, torch.float32, [0.0, 0.4, 1.0], dict(rtol=1e-4, atol=1e-5, method='dopri5'))
     case(70001, 128, True, torch.float64, [0.0, 1.0], dict(rtol=1e-6, atol=1e-9, method='dopri5'))
+    case(70001, 128, False, torch.float64, [0.0, 1.0], dict(rtol=1e-6, atol=1e-9, method='dopri5'))
+    case(3000, 64, True, torch.float64, [0.0, 1.0], dict(rtol=1e-6, atol=1e-9, method='dopri5'))
+    case(4100, 100, True, torch.float64, [0.0, 1.0], dict(rtol=1e-6, atol=1e-9, method='dopri5'))
     if '--time' in sys.argv:
         torch.manual_seed(0)
         func = models.LinearODEFunc(128, bias=False).to(dev)

@@ -26,6 +26,9 @@
 // -> agent-scope acquire by one lane per workgroup -> plain loads (MI355X_MICROARCH.md, "inter-workgroup visibility", valid form 1).
 #pragma once
 #include "mi_ode_persist.h"
+#ifndef MI_LA_CHK
+#define MI_LA_CHK 16      // operand pairs of a small product in flight at once (32 - every operand of a dim-128 product, 48 loads - gave WRONG products in this kernel: stale accumulator rows; 8 and 16 are right)
+#endif
 
 namespace mi {
 
@@ -57,7 +60,7 @@ struct LinAdjArgs {
   double* pw;                            // [kLaP][D][D]       (W^T)^q, zero padded to the tile width (P_0 = identity)
   double* cvec;                          // [kLaP][D]          c_p = (W^T)^(p-1) b^T, c_0 = 0
   void* gpart;                           // [G][D * D + D]     slab partials of (G0 | g0), state dtype
-  double* g0;                            // [D * D + D]        G0 | g0 of the current step's start state
+  double* g0;                            // [2][D * D + D]     G0 | g0 of the current step's start state / of the attempt's end state
   double* lmat;                          // [kLaP][D * D]      L_p = (W^T)^p G0 + c_p g0  (p >= 1; L_0 = G0 is read in place)
   double* mmat;                          // [kLaPP][(D + 1) D] M_pq; row D: g0 (W^T)^q for p = 0, zero otherwise (the bias entries)
   double* theta;                         // [2][D * D + D]     adj_params at the step's start / after the attempt, padded layout
@@ -66,7 +69,7 @@ struct LinAdjArgs {
   double t_end;
   LinAdjResult* res;
   int has_bias;
-  int pad_;
+  int dbg;                               // tuning / bisecting aid (MI_ODE_LINADJ_DBG): bit 0: the chain of small products right after the accept, not between the passes
 };
 static_assert(sizeof(LinAdjArgs) <= 4096, "kernel arguments");
 
@@ -81,7 +84,7 @@ struct LaShared {
   double tout[kPersistTSmall];
   double seg_rec[4][kRec];               // combined records of (y, adj_y, adj_t, adj_params)
   SegState seg;
-  double kq[3][kLaPP];                   // the attempt's combination weights of the M_pq: solution, error estimate, dense output
+  double kq[3][kLaPP];                   // the attempt's combination weights of the M_pq: solution, error estimate, G0 | g0 of the end state (or: dense output)
   double adjt;                           // adj_t (constant over the segment)
   double th0_max;                        // max |adj_params| at the step's start (thread 0)
   double mine[8];                        // thread 0: this workgroup's record while its passes run
@@ -115,14 +118,17 @@ __device__ __forceinline__ bool load_record8_sc1(const double* p, unsigned seq, 
   return ok;
 }
 
-// Grid hand-off: thread 0 publishes `mine`, every workgroup gathers all records into sh.vals.  RELEASE: this workgroup wrote data other
-// workgroups read after the hand-off; ACQUIRE: it reads such data.  Returns false (to every thread) on a time-out.
-template <class SH>
-__device__ __forceinline__ bool la_exchange(const PersistArgs& P, SH& sh, unsigned gen, const double (&mine)[8], bool release, bool acquire) {
+// Grid hand-off in two halves: thread 0 publishes `mine` (la_publish), every workgroup gathers all records into sh.vals (la_gather).
+// RELEASE: this workgroup wrote data other workgroups read after the hand-off; ACQUIRE: it reads such data.
+__device__ __forceinline__ void la_publish(const PersistArgs& P, unsigned gen, const double (&mine)[8], bool release) {
   const int G = (int)gridDim.x;
   double* buf = P.s.partials + (long long)(gen & 1u) * G * kPRec;
   const unsigned seq = P.seq_base + gen + 1u;
-  __syncthreads();                                              // every thread's stores of this phase are issued (and, being a fence, drained)
+  // EVERY wavefront drains its own stores before the barrier: a workgroup-scope fence (what __syncthreads() carries) does not wait for
+  // global stores on this target (one CU, one L1: nothing to wait for at THAT scope), and a line that reaches the L2 after thread 0's
+  // write-back below stays dirty there - invisible to the other XCDs until it is evicted (observed: stale G0 rows, two steps old)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
   if (threadIdx.x == 0) {
     if (release) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // (the compiler may drop the wait behind the write-back: MI355X_MICROARCH.md)
@@ -130,6 +136,13 @@ __device__ __forceinline__ bool la_exchange(const PersistArgs& P, SH& sh, unsign
 #pragma unroll
     for (int i = 0; i < 8; ++i) store_ll_sc1(rec + 2 * i, mine[i], seq);
   }
+}
+// Returns false (to every thread) on a time-out.
+template <class SH>
+__device__ __forceinline__ bool la_gather(const PersistArgs& P, SH& sh, unsigned gen, bool acquire) {
+  const int G = (int)gridDim.x;
+  const double* buf = P.s.partials + (long long)(gen & 1u) * G * kPRec;
+  const unsigned seq = P.seq_base + gen + 1u;
   const int limit = gen == 0 ? P.spin_first : P.spin_limit;
   for (int b = threadIdx.x; b < G; b += blockDim.x) {
     const double* p = buf + (long long)b * kPRec;
@@ -144,7 +157,49 @@ __device__ __forceinline__ bool la_exchange(const PersistArgs& P, SH& sh, unsign
 #pragma unroll
     for (int i = 0; i < 8; ++i) sh.vals[i][b] = v[i];
   }
-  if (acquire && threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 forgets what it held
+  if (acquire) {                                                // the invalidate must come after the LAST record was seen (any wavefront's)
+    __syncthreads();
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // this CU's L1 forgets what it held
+  }
+  __syncthreads();
+  return sh.ok != 0;
+}
+template <class SH>
+__device__ __forceinline__ bool la_exchange(const PersistArgs& P, SH& sh, unsigned gen, const double (&mine)[8], bool release, bool acquire) {
+  la_publish(P, gen, mine, release);
+  return la_gather(P, sh, gen, acquire);
+}
+
+// "My share of phase `which` (0: the L_p, 1: the M_pq) of the `cgen`-th accepted step is written": one stamped 16-byte word per workgroup,
+// phase and parity of cgen, behind the grid records in the same allocation.  Set with a release, waited for with an acquire.  A workgroup
+// sets its word, goes through a whole tile pass and only then waits for everybody's - by then they have long been set: the wait is one
+// poll round, not a rendez-vous (and a workgroup that IS late is simply waited for).
+__device__ __forceinline__ double* la_flag_words(const PersistArgs& P, int which, unsigned cgen) {
+  return P.s.partials + 2 * kLaMaxG * kPRec + (long long)((which * 2 + (int)(cgen & 1u)) * kLaMaxG) * 2;
+}
+__device__ __forceinline__ void la_flag_set(const PersistArgs& P, int which, unsigned cgen) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (as in la_publish: every wavefront's stores are in the L2 before the write-back)
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    store_ll_sc1(la_flag_words(P, which, cgen) + 2 * blockIdx.x, 0.0, P.seq_base + cgen + 1u);
+  }
+}
+template <class SH>
+__device__ __forceinline__ bool la_flag_wait(const PersistArgs& P, SH& sh, int which, unsigned cgen) {
+  const unsigned seq = P.seq_base + cgen + 1u;
+  const double* w = la_flag_words(P, which, cgen);
+  for (int b = threadIdx.x; b < (int)gridDim.x; b += blockDim.x) {
+    double v;
+    int spins = 0;
+    while (!load_ll_sc1(w + 2 * b, seq, v)) {
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > P.spin_limit) { sh.ok = 0; break; }
+    }
+  }
+  __syncthreads();                                              // (the invalidate after the last flag was seen)
+  if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   __syncthreads();
   return sh.ok != 0;
 }
@@ -168,7 +223,7 @@ template <int D>
 __device__ __forceinline__ void la_tile_job(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int ldc,
                                             int tm, int tn, const double* __restrict__ u, const double* __restrict__ v) {
   using TR = MfmaTraits<double>;
-  constexpr int KS = D / 4, CHK = KS;                          // every operand of the product in flight at once (one wait)
+  constexpr int KS = D / 4, CHK = (MI_LA_CHK) < KS ? (MI_LA_CHK) : KS;
   const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
   TR::acc_t acc = {0, 0, 0, 0};
   const double* ap = A + (long long)(16 * tm + li) * D + lg * KS;
@@ -374,26 +429,26 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       if (live && part7 == 0) A.g0[e] = s_;
     }
   };
-  auto level_l = [&]() {                                       // L_p = P_p G0 + c_p g0 (p = 1..S) and the bias rows g0 P_q (q = 0..S)
+  auto level_l = [&](const double* g0c) {                      // L_p = P_p G0 + c_p g0 (p = 1..S) and the bias rows g0 P_q (q = 0..S)
     for (int j = gw; j < S * TJ; j += ngw) {
       const int p = 1 + j / TJ, t = j % TJ;
-      la_tile_job<D>(A.pw + (long long)p * D * D, A.g0, A.lmat + (long long)p * D * D, D, t / (D / 16), t % (D / 16),
-                     A.has_bias ? A.cvec + p * D : nullptr, A.g0 + D * D);
+      la_tile_job<D>(A.pw + (long long)p * D * D, g0c, A.lmat + (long long)p * D * D, D, t / (D / 16), t % (D / 16),
+                     A.has_bias ? A.cvec + p * D : nullptr, g0c + D * D);
     }
     for (int j = gg; j < kLaP * D; j += ngg) {                 // row D of M_0q: g0 P_q
       const int q = j / D, c = j % D;
       const double* P = A.pw + (long long)q * D * D;
       double s_ = 0.0;
 #pragma unroll
-      for (int k = part8; k < D; k += 8) s_ = fma(A.g0[D * D + k], P[(long long)k * D + c], s_);
+      for (int k = part8; k < D; k += 8) s_ = fma(g0c[D * D + k], P[(long long)k * D + c], s_);
       s_ = group8_sum(s_);
       if (part8 == 0) A.mmat[(long long)q * E + D * D + c] = s_;
     }
   };
-  auto level_m = [&]() {                                       // M_pq = L_p P_q (L_0 = G0)
+  auto level_m = [&](const double* g0c) {                      // M_pq = L_p P_q (L_0 = G0)
     for (int j = gw; j < kLaPP * TJ; j += ngw) {
       const int pq = j / TJ, t = j % TJ, p = pq / kLaP, q = pq % kLaP;
-      la_tile_job<D>(p == 0 ? A.g0 : A.lmat + (long long)p * D * D, A.pw + (long long)q * D * D, A.mmat + (long long)pq * E, D,
+      la_tile_job<D>(p == 0 ? g0c : A.lmat + (long long)p * D * D, A.pw + (long long)q * D * D, A.mmat + (long long)pq * E, D,
                      t / (D / 16), t % (D / 16), nullptr, nullptr);
     }
   };
@@ -471,9 +526,9 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     }
     barrier_handoff();
   }
-  if (ok) level_l();
+  if (ok) level_l(A.g0);
   barrier_handoff();
-  if (ok) level_m();
+  if (ok) level_m(A.g0);
   barrier_handoff();
   // adj_params' share of misc._select_initial_step: f0 = -s M_00 (= -s [G0 ; g0])
   {
@@ -575,6 +630,10 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
 
   // ---- the adaptive loop (dopri5.py:82-121) --------------------------------------------------------------------------------------
   int cur = -1, cur_f = 0;                                     // state: -1 the caller's (y_in, a_in), 0 / 1 planes a / b; derivative: plane fa / fb
+  int gcur = 0;                                                // which half of A.g0 holds G0 | g0 of the step's start state
+  unsigned cgen = 0;                                           // accepted steps so far (uniform over the grid): stamps the chain's flags
+  int chain = 0;                                               // 1: the L_p of the new start state are being written (my flag is set), the M_pq
+                                                               // follow after the next y pass; 2: ... the M_pq are being written; 0: M_pq valid
   const double* ktab = A.ktab;
   bool emitted = false;
   while (!uniform_i(sh.pub.done)) {
@@ -582,6 +641,8 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     const int nxt = cur == 0 ? 1 : 0;
     const int j_lo = uniform_i(sh.pub.emit_lo), j_hi = uniform_i(sh.pub.emit_hi);
     const T hs_T = (T)dt_u;
+    double* const g0c = A.g0 + (long long)gcur * E;           // G0 | g0 of the start state ...
+    double* const g0n = A.g0 + (long long)(1 - gcur) * E;     // ... of this attempt's end state
     auto planes_of = [&](int sys, StepPlanes<T, S>& P) {       // state / derivative planes of system `sys` for this attempt
       T* const pa = sys == 0 ? y_pa : a_pa; T* const pb = sys == 0 ? y_pb : a_pb;
       T* const fa = sys == 0 ? y_fa : a_fa; T* const fb = sys == 0 ? y_fb : a_fb;
@@ -593,12 +654,15 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       // adj_y(t_end) is the tile pass's speculative dense output; the reference discards y(t_end) (adjoint.py:155-160)
       P.j_lo = sys == 0 ? 0 : j_lo; P.j_hi = sys == 0 ? 0 : j_hi;
     };
-    // the weights of this attempt's combinations of the M_pq: -s h K^c_pq (s h)^p (-s h)^q, h = dt in the state dtype (rk_common.py:46)
+    // the weights of this attempt's combinations of the M_pq, h = dt in the state dtype (rk_common.py:46): -s h K^c_pq (s h)^p (-s h)^q for
+    // the solution and the error estimate; pi_S[p] pi_S[q] (s h)^p (-s h)^q - no factor -s h - for G0 | g0 of the END state: y1 and a1 are the
+    // last stage inputs, so y1^T a1 follows from the start state's products like everything else (oracle: end_state_products_powers) and
+    // the only product over the batch of a whole backward interval is the prologue's
     {
       const double hT = (double)hs_T;
-      for (int i = tid; i < 2 * kLaPP; i += nthr) {
+      for (int i = tid; i < 3 * kLaPP; i += nthr) {
         const int c = i / kLaPP, pq = i % kLaPP, p = pq / kLaP, q = pq % kLaP;
-        double w_ = -sgn * hT * ktab[c * kLaPP + pq];
+        double w_ = c < 2 ? -sgn * hT * ktab[c * kLaPP + pq] : ktab[3 * kLaPP + pq];
         for (int u = 0; u < p; ++u) w_ *= sgn * hT;
         for (int u = 0; u < q; ++u) w_ *= -sgn * hT;
         sh.kq[c][pq] = w_;
@@ -618,12 +682,23 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       block_reduce_thread0(acc, sh.red, r);
       if (tid == 0) { sh.mine[3 * sys] = r[0]; sh.mine[3 * sys + 1] = r[1]; sh.mine[3 * sys + 2] = r[2]; }
       tick(9);
+      // the chain of small products of an accepted step rides between the tile passes of the next attempt: every workgroup wrote its
+      // share of the L_p before its y pass, of the M_pq before its a pass - when it asks for everybody's, they have been there for 200 us
+      if (chain == 1 && sys == 0) {
+        ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);
+        tick(10);
+        if (ok) level_m(g0c);
+        la_flag_set(A.p, 1, cgen - 1u);
+        chain = 2;
+        tick(13);
+      }
     }
+    if (chain == 2) { ok = ok && la_flag_wait(A.p, sh, 1, cgen - 1u); chain = 0; tick(10); }
     Acc at;
     for (int e0 = e_lo; e0 < e_hi; e0 += ngrp7) {              // seven lanes per entry, lane j the terms pq = 7 j .. 7 j + 6
       const int e = e0 + grp7;
       const bool live = grp7 >= 0 && e < e_hi;
-      double d_sol = 0.0, d_err = 0.0;
+      double d_sol = 0.0, d_err = 0.0, d_nxt = 0.0;
       if (live) {
 #pragma unroll
         for (int u = 0; u < 7; ++u) {
@@ -631,12 +706,14 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
           const double m = A.mmat[(long long)pq * E + e];
           d_sol = fma(sh.kq[0][pq], m, d_sol);
           d_err = fma(sh.kq[1][pq], m, d_err);
+          d_nxt = fma(sh.kq[2][pq], m, d_nxt);
         }
       }
-      d_sol = group7_sum(d_sol, lane); d_err = group7_sum(d_err, lane);
+      d_sol = group7_sum(d_sol, lane); d_err = group7_sum(d_err, lane); d_nxt = group7_sum(d_nxt, lane);
       if (live && part7 == 0) {
         const double v1 = th0[e] + d_sol;
         th1[e] = v1;
+        g0n[e] = d_nxt;
         if (entry_valid(e)) {
           at.maxb = fmax(at.maxb, fabs((double)(T)v1));
           const double er = (double)(T)d_err;
@@ -654,7 +731,7 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
         for (int i = 0; i < 6; ++i) mine[i] = sh.mine[i];
         mine[6] = r3[1]; mine[7] = r3[2];
       }
-      ok = la_exchange(A.p, sh, gen++, mine, false, false);
+      ok = la_exchange(A.p, sh, gen++, mine, true, true) && ok;   // (release / acquire: G0 | g0 of the end state, read by the L_p products)
     }
     if (tid < 64) {
       double th1_max = 0.0;
@@ -729,25 +806,21 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       tick(6);
       break;
     }
-    // accepted, more to come: the planes and adj_params move on; G0 | g0 and the M_pq of the new start state
-    cur = nxt; cur_f ^= 1;
+    // accepted, more to come: the planes, adj_params and G0 | g0 move on; the chain L_p -> M_pq of the new start state begins here and
+    // ends between the tile passes of the next attempt
+    cur = nxt; cur_f ^= 1; gcur ^= 1;
     for (int e = e_lo + tid; e < e_hi; e += nthr) th0[e] = th1[e];
-    la_slab_pass<T, D>(nxt == 0 ? y_pa : y_pb, nxt == 0 ? a_pa : a_pb, batch, dim, blk, G, my_part, (T*)smem_raw);   // (rows this workgroup wrote itself: no fence)
-    tick(3);
-    barrier_handoff();
-    tick(10);
-    if (ok) fold_g0();
-    tick(11);
-    barrier_handoff();
-    tick(10);
-    if (ok) level_l();
+    if (ok) level_l(g0n);                                      // (g0n of this attempt = the new start state's)
+    la_flag_set(A.p, 0, cgen);
+    cgen += 1u; chain = 1;
     tick(12);
-    barrier_handoff();
-    tick(10);
-    if (ok) level_m();
-    tick(13);
-    barrier_handoff();
-    tick(10);
+    if (A.dbg & 1) {
+      ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);
+      if (ok) level_m(g0n);
+      la_flag_set(A.p, 1, cgen - 1u);
+      ok = ok && la_flag_wait(A.p, sh, 1, cgen - 1u);
+      chain = 0;
+    }
     if (!ok) {
       if (tid == 0) { AttemptState st = sh.st; st.status |= MI_ODE_ST_SYNC_TIMEOUT; st.done = 1; publish(st); sh.st = st; }
       __syncthreads();

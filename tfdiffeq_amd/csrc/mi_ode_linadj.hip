@@ -121,7 +121,7 @@ extern "C" int mi_ode_linadj_create(const mi_ode_linadj_desc* desc, mi_ode_linad
   hipError_t e = hipMalloc((void**)&h->planes, 8 * (size_t)h->stride);
   if (e == hipSuccess) e = hipMalloc((void**)&h->pw, kLaP * D * D * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&h->cvec, kLaP * D * sizeof(double));
-  if (e == hipSuccess) e = hipMalloc((void**)&h->g0, E * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->g0, 2 * E * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&h->lmat, kLaP * D * D * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&h->mmat, kLaPP * E * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&h->theta, 2 * E * sizeof(double));
@@ -217,6 +217,7 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
   A.pw = h->pw; A.cvec = h->cvec; A.gpart = h->gpart; A.g0 = h->g0; A.lmat = h->lmat; A.mmat = h->mmat; A.theta = h->theta; A.ktab = h->ktab; A.wpad = h->wpad;
   A.res = h->res;
   A.has_bias = b_dev != nullptr ? 1 : 0;
+  if (const char* ed = getenv("MI_ODE_LINADJ_DBG")) A.dbg = atoi(ed);
   memset(h->res, 0, sizeof(LinAdjResult));
   h->res->status = MI_ODE_ST_SYNC_TIMEOUT;       // (overwritten by the kernel's result record)
   void* args[] = {(void*)&A};
@@ -232,6 +233,21 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
             "attempt hand-offs %.1f  slab passes %.1f  small products: hand-offs %.1f fold %.1f L %.1f M %.1f  prologue %.1f  epilogue %.1f\n", r.n_attempt, r.n_accept,
             r.handoffs, 0.01 * r.prof[0], 0.01 * r.prof[8], 0.01 * r.prof[7], 0.01 * r.prof[9], 0.01 * r.prof[1], 0.01 * r.prof[2], 0.01 * r.prof[3], 0.01 * r.prof[10],
             0.01 * r.prof[11], 0.01 * r.prof[12], 0.01 * r.prof[13], 0.01 * r.prof[5], 0.01 * r.prof[6]);
+  if (const char* dd = getenv("MI_ODE_LINADJ_DUMP")) {       // debugging aid: the small matrices of the last step, raw float64
+    const size_t D = (size_t)h->dp, E = D * D + D;
+    struct { const char* name; const void* p; size_t n; } items[] = {{"g0", h->g0, 2 * E}, {"lmat", h->lmat, kLaP * D * D}, {"mmat", h->mmat, kLaPP * E},
+                                                                       {"pw", h->pw, kLaP * D * D}, {"theta", h->theta, 2 * E}, {"cvec", h->cvec, kLaP * D}};
+    for (auto& it : items) {
+      char path[512];
+      snprintf(path, sizeof(path), "%s/%s.bin", dd, it.name);
+      double* host = (double*)malloc(it.n * sizeof(double));
+      if (host != nullptr && hipMemcpy(host, it.p, it.n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
+        FILE* f = fopen(path, "wb");
+        if (f) { fwrite(host, sizeof(double), it.n, f); fclose(f); }
+      }
+      free(host);
+    }
+  }
   if (stats != nullptr) {
     memset(stats, 0, sizeof(*stats));
     stats->n_attempts = r.n_attempt; stats->n_accepted = r.n_accept; stats->n_rejected = r.n_attempt - r.n_accept;
