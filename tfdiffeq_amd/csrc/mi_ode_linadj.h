@@ -69,6 +69,7 @@ struct LinAdjArgs {
   double t_end;
   LinAdjResult* res;
   int has_bias;
+  long long* skew;                       // device [32][G][2] or null (MI_ODE_LINADJ_PROF): every workgroup's arrival at / departure from the first 32 hand-offs
   int dbg;                               // tuning / bisecting aid (MI_ODE_LINADJ_DBG): bit 0: the chain of small products right after the accept, not between the passes
 };
 static_assert(sizeof(LinAdjArgs) <= 4096, "kernel arguments");
@@ -117,6 +118,11 @@ __device__ __forceinline__ bool load_record8_sc1(const double* p, unsigned seq, 
   }
   return ok;
 }
+
+// Cross-workgroup data of the small products (G0 | g0, L_p, M_pq: kilobytes per workgroup) is stored WRITE-THROUGH (sc1): it is in memory
+// when the storing wavefront's vmcnt drains, and the publishing side needs no write-back of its XCD's L2 - which, behind a tile pass,
+// holds megabytes of dirty state planes (a `buffer_wbl2` there costs the hand-off several microseconds for a few kilobytes of payload).
+__device__ __forceinline__ void st_wt(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // Grid hand-off in two halves: thread 0 publishes `mine` (la_publish), every workgroup gathers all records into sh.vals (la_gather).
 // RELEASE: this workgroup wrote data other workgroups read after the hand-off; ACQUIRE: it reads such data.
@@ -170,21 +176,18 @@ __device__ __forceinline__ bool la_exchange(const PersistArgs& P, SH& sh, unsign
   return la_gather(P, sh, gen, acquire);
 }
 
-// "My share of phase `which` (0: the L_p, 1: the M_pq) of the `cgen`-th accepted step is written": one stamped 16-byte word per workgroup,
-// phase and parity of cgen, behind the grid records in the same allocation.  Set with a release, waited for with an acquire.  A workgroup
+// "My share of the `cgen`-th flag round is written" (write-through stores, drained): one stamped 16-byte word per workgroup and parity of
+// cgen, behind the grid records in the same allocation; waited for with an acquire.  Every workgroup takes part in every round, in order:
+// who has seen all flags of round r knows that nobody still polls round r - 1, whose words round r + 1 overwrites.  A workgroup
 // sets its word, goes through a whole tile pass and only then waits for everybody's - by then they have long been set: the wait is one
 // poll round, not a rendez-vous (and a workgroup that IS late is simply waited for).
 __device__ __forceinline__ double* la_flag_words(const PersistArgs& P, int which, unsigned cgen) {
   return P.s.partials + 2 * kLaMaxG * kPRec + (long long)((which * 2 + (int)(cgen & 1u)) * kLaMaxG) * 2;
 }
 __device__ __forceinline__ void la_flag_set(const PersistArgs& P, int which, unsigned cgen) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (as in la_publish: every wavefront's stores are in the L2 before the write-back)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // every wavefront's write-through stores have landed
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    store_ll_sc1(la_flag_words(P, which, cgen) + 2 * blockIdx.x, 0.0, P.seq_base + cgen + 1u);
-  }
+  if (threadIdx.x == 0) store_ll_sc1(la_flag_words(P, which, cgen) + 2 * blockIdx.x, 0.0, P.seq_base + cgen + 1u);
 }
 template <class SH>
 __device__ __forceinline__ bool la_flag_wait(const PersistArgs& P, SH& sh, int which, unsigned cgen) {
@@ -243,7 +246,7 @@ __device__ __forceinline__ void la_tile_job(const double* __restrict__ A, const 
     const int row = 16 * tm + TR::acc_row(lane, i);
     double c = acc[i];
     if (u != nullptr) c = c + u[row] * v[col];
-    C[(long long)row * ldc + col] = c;
+    st_wt(C + (long long)row * ldc + col, c);
   }
 }
 
@@ -426,7 +429,7 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
         for (; g < G; g += 7) q[0] += (double)part[(long long)g * E + e];
       }
       const double s_ = group7_sum(((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7])), lane);
-      if (live && part7 == 0) A.g0[e] = s_;
+      if (live && part7 == 0) st_wt(A.g0 + e, s_);
     }
   };
   auto level_l = [&](const double* g0c) {                      // L_p = P_p G0 + c_p g0 (p = 1..S) and the bias rows g0 P_q (q = 0..S)
@@ -442,23 +445,28 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
 #pragma unroll
       for (int k = part8; k < D; k += 8) s_ = fma(g0c[D * D + k], P[(long long)k * D + c], s_);
       s_ = group8_sum(s_);
-      if (part8 == 0) A.mmat[(long long)q * E + D * D + c] = s_;
+      if (part8 == 0) st_wt(A.mmat + (long long)q * E + D * D + c, s_);
     }
   };
   auto level_m = [&](const double* g0c) {                      // M_pq = L_p P_q (L_0 = G0)
-    for (int j = gw; j < kLaPP * TJ; j += ngw) {
+    // the jobs of a chain are dealt round-robin over BOTH levels: the wavefronts that had an L_p product start one M_pq product later, so
+    // every wavefront ends up with the same number of products per accepted step (to one) - the workgroups reach the attempt's hand-off
+    // together (measured before: the 48 workgroups with L_p products arrived 20 us after the others)
+    for (int pos = gw; pos < (S + kLaPP) * TJ; pos += ngw) {
+      if (pos < S * TJ) continue;
+      const int j = pos - S * TJ;
       const int pq = j / TJ, t = j % TJ, p = pq / kLaP, q = pq % kLaP;
       la_tile_job<D>(p == 0 ? g0c : A.lmat + (long long)p * D * D, A.pw + (long long)q * D * D, A.mmat + (long long)pq * E, D,
                      t / (D / 16), t % (D / 16), nullptr, nullptr);
     }
   };
-  auto barrier_handoff = [&]() {
+  auto barrier_handoff = [&]() {                               // (the small products' outputs are write-through stores: no release)
     zero_mine();
-    ok = ok && la_exchange(A.p, sh, gen++, mine, true, true);
+    ok = ok && la_exchange(A.p, sh, gen++, mine, false, true);
   };
 
   // ---- prologue ------------------------------------------------------------------------------------------------------------------
-  // adj_params -> the padded float64 layout; P_0 = I, P_1 = W^T, c_0 = 0, c_1 = b
+  // adj_params -> the padded float64 layout; P_0 = I, P_1 = W^T, c_0 = 0, c_1 = b; W and W^T zero padded in the state dtype
   for (int e = e_lo + tid; e < e_hi; e += nthr) {              // (the entries this workgroup owns for the whole segment)
     double v = 0.0;
     if (e < D * D) { if (e / D < dim && e % D < dim) v = (double)((const T*)A.th_in)[(e / D) * dim + e % D]; }
@@ -467,14 +475,41 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
   }
   for (int e = gt; e < D * D; e += ngt) {
     const int i = e / D, j = e % D;
-    A.pw[e] = i == j ? 1.0 : 0.0;
+    st_wt(A.pw + e, i == j ? 1.0 : 0.0);
     const T wt = (i < dim && j < dim) ? Wm[(long long)j * dim + i] : (T)0;
-    A.pw[D * D + e] = (double)wt;
-    ((T*)A.wpad)[e] = (i < dim && j < dim) ? Wm[(long long)i * dim + j] : (T)0;
-    ((T*)A.wpad)[D * D + e] = wt;
+    st_wt(A.pw + D * D + e, (double)wt);
+    const T wn = (i < dim && j < dim) ? Wm[(long long)i * dim + j] : (T)0;
+    if constexpr (sizeof(T) == 8) { st_wt((double*)A.wpad + e, (double)wn); st_wt((double*)A.wpad + D * D + e, (double)wt); }
+    else {
+      __hip_atomic_store((float*)A.wpad + e, (float)wn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store((float*)A.wpad + D * D + e, (float)wt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
   }
-  for (int e = gt; e < 2 * D; e += ngt) A.cvec[e] = (e >= D && bias != nullptr && e - D < dim) ? (double)bias[e - D] : 0.0;
-  // f0 of both systems (misc.py:225-233's sums ride in the record) and the slab partial of the start state
+  for (int e = gt; e < 2 * D; e += ngt) st_wt(A.cvec + e, (e >= D && bias != nullptr && e - D < dim) ? (double)bias[e - D] : 0.0);
+  // The powers of W^T by doubling (P_q = P_n P_(q-n), c_q = P_n c_(q-n), n = 1, 2, 4) ride BETWEEN the three batch-sized passes of the
+  // prologue, like the chain of an accepted step between the tile passes: a workgroup writes its share of a level, flags it, runs a pass
+  // and only then asks for everybody's flags.
+  unsigned cgen = 0;                                           // flag rounds so far (uniform over the grid)
+  auto power_level = [&](int n) {
+    const int q_hi = 2 * n < S ? 2 * n : S;
+    for (int j = gw; j < (q_hi - n) * TJ; j += ngw) {
+      const int q = n + 1 + j / TJ, t = j % TJ;
+      la_tile_job<D>(A.pw + (long long)n * D * D, A.pw + (long long)(q - n) * D * D, A.pw + (long long)q * D * D, D, t / (D / 16), t % (D / 16),
+                     nullptr, nullptr);
+    }
+    for (int j = gg; j < (q_hi - n) * D; j += ngg) {
+      const int q = n + 1 + j / D, i = j % D;
+      const double* P = A.pw + (long long)n * D * D + (long long)i * D;
+      const double* c = A.cvec + (q - n) * D;
+      double s_ = 0.0;
+#pragma unroll
+      for (int k = part8; k < D; k += 8) s_ = fma(P[k], c[k], s_);
+      s_ = group8_sum(s_);
+      if (part8 == 0) st_wt(A.cvec + q * D + i, s_);
+    }
+  };
+  la_flag_set(A.p, 0, cgen++);                                 // P_0, P_1, c_1, the padded matrices
+  // f0 of both systems (misc.py:225-233's sums ride in the record), the slab partial of the start state
   {
 #pragma clang loop unroll(disable)
     for (int sys = 0; sys < 2; ++sys) {                        // (one instance of the pass in the code: the systems differ in pointers only)
@@ -484,15 +519,20 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       double r[5];
       block_reduce_thread0(acc, sh.red, r);
       if (tid == 0) { sh.mine[3 * sys] = r[2]; sh.mine[3 * sys + 1] = r[3]; sh.mine[3 * sys + 2] = r[4]; }
+      ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);          // (set a whole pass ago)
+      padded_ready = true;
+      if (ok) power_level(sys == 0 ? 1 : 2);                   // P_2 ; P_3, P_4
+      la_flag_set(A.p, 0, cgen++);
     }
     la_slab_pass<T, D>((const T*)A.y_in, (const T*)A.a_in, batch, dim, blk, G, my_part, (T*)smem_raw);
+    ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);
+    if (ok) power_level(4);                                    // P_5, P_6 (visible after the hand-off below)
     zero_mine();
     if (tid == 0) {
 #pragma unroll
       for (int i = 0; i < 6; ++i) mine[i] = sh.mine[i];
     }
-    ok = la_exchange(A.p, sh, gen++, mine, true, true);
-    padded_ready = true;
+    ok = la_exchange(A.p, sh, gen++, mine, true, true) && ok;  // (release: the slab partials are plain stores)
     if (ok && tid < 64) {                                      // the y and adj_y records of the initial step
       for (int k = 0; k < 2; ++k) {
         const double sa = la_fold_sum(sh.vals[3 * k], 0, G), sb = la_fold_sum(sh.vals[3 * k + 1], 0, G), fl = la_fold_max(sh.vals[3 * k + 2], 0, G);
@@ -503,29 +543,8 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       }
     }
   }
-  // the powers of W^T by doubling (P_q = P_n P_(q-n), c_q = P_n c_(q-n), n = 1, 2, 4) next to the fold of G0
   if (ok) fold_g0();
-  for (int n = 1; n < S; n *= 2) {
-    if (ok) {
-      const int q_hi = 2 * n < S ? 2 * n : S;
-      for (int j = gw; j < (q_hi - n) * TJ; j += ngw) {
-        const int q = n + 1 + j / TJ, t = j % TJ;
-        la_tile_job<D>(A.pw + (long long)n * D * D, A.pw + (long long)(q - n) * D * D, A.pw + (long long)q * D * D, D, t / (D / 16), t % (D / 16),
-                       nullptr, nullptr);
-      }
-      for (int j = gg; j < (q_hi - n) * D; j += ngg) {
-        const int q = n + 1 + j / D, i = j % D;
-        const double* P = A.pw + (long long)n * D * D + (long long)i * D;
-        const double* c = A.cvec + (q - n) * D;
-        double s_ = 0.0;
-#pragma unroll
-        for (int k = part8; k < D; k += 8) s_ = fma(P[k], c[k], s_);
-        s_ = group8_sum(s_);
-        if (part8 == 0) A.cvec[q * D + i] = s_;
-      }
-    }
-    barrier_handoff();
-  }
+  barrier_handoff();
   if (ok) level_l(A.g0);
   barrier_handoff();
   if (ok) level_m(A.g0);
@@ -631,7 +650,6 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
   // ---- the adaptive loop (dopri5.py:82-121) --------------------------------------------------------------------------------------
   int cur = -1, cur_f = 0;                                     // state: -1 the caller's (y_in, a_in), 0 / 1 planes a / b; derivative: plane fa / fb
   int gcur = 0;                                                // which half of A.g0 holds G0 | g0 of the step's start state
-  unsigned cgen = 0;                                           // accepted steps so far (uniform over the grid): stamps the chain's flags
   int chain = 0;                                               // 1: the L_p of the new start state are being written (my flag is set), the M_pq
                                                                // follow after the next y pass; 2: ... the M_pq are being written; 0: M_pq valid
   const double* ktab = A.ktab;
@@ -688,12 +706,12 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
         ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);
         tick(10);
         if (ok) level_m(g0c);
-        la_flag_set(A.p, 1, cgen - 1u);
+        la_flag_set(A.p, 0, cgen++);
         chain = 2;
         tick(13);
       }
     }
-    if (chain == 2) { ok = ok && la_flag_wait(A.p, sh, 1, cgen - 1u); chain = 0; tick(10); }
+    if (chain == 2) { ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u); chain = 0; tick(10); }
     Acc at;
     for (int e0 = e_lo; e0 < e_hi; e0 += ngrp7) {              // seven lanes per entry, lane j the terms pq = 7 j .. 7 j + 6
       const int e = e0 + grp7;
@@ -713,7 +731,7 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       if (live && part7 == 0) {
         const double v1 = th0[e] + d_sol;
         th1[e] = v1;
-        g0n[e] = d_nxt;
+        st_wt(g0n + e, d_nxt);
         if (entry_valid(e)) {
           at.maxb = fmax(at.maxb, fabs((double)(T)v1));
           const double er = (double)(T)d_err;
@@ -731,7 +749,9 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
         for (int i = 0; i < 6; ++i) mine[i] = sh.mine[i];
         mine[6] = r3[1]; mine[7] = r3[2];
       }
-      ok = la_exchange(A.p, sh, gen++, mine, true, true) && ok;   // (release / acquire: G0 | g0 of the end state, read by the L_p products)
+      if (A.skew != nullptr && tid == 0 && gen < 32u) A.skew[((long long)gen * G + blk) * 2] = (long long)wall_clock64();
+      ok = la_exchange(A.p, sh, gen++, mine, false, true) && ok;  // (acquire: G0 | g0 of the end state - write-through stores - read by the L_p products)
+      if (A.skew != nullptr && tid == 0 && gen <= 32u) A.skew[((long long)(gen - 1u) * G + blk) * 2 + 1] = (long long)wall_clock64();
     }
     if (tid < 64) {
       double th1_max = 0.0;
@@ -811,14 +831,14 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     cur = nxt; cur_f ^= 1; gcur ^= 1;
     for (int e = e_lo + tid; e < e_hi; e += nthr) th0[e] = th1[e];
     if (ok) level_l(g0n);                                      // (g0n of this attempt = the new start state's)
-    la_flag_set(A.p, 0, cgen);
-    cgen += 1u; chain = 1;
+    la_flag_set(A.p, 0, cgen++);
+    chain = 1;
     tick(12);
     if (A.dbg & 1) {
       ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);
       if (ok) level_m(g0n);
-      la_flag_set(A.p, 1, cgen - 1u);
-      ok = ok && la_flag_wait(A.p, sh, 1, cgen - 1u);
+      la_flag_set(A.p, 0, cgen++);
+      ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);
       chain = 0;
     }
     if (!ok) {
@@ -832,7 +852,7 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     if (!emitted && st.status == 0) st.status |= MI_ODE_ST_SYNC_TIMEOUT;   // (cannot happen: done without a status means the output was written)
     LinAdjResult res;
     res.t1 = st.t1; res.dt = st.dt; res.ratio = st.ratio; res.h0 = s_c.h0;
-    res.n_attempt = st.n_attempt; res.n_accept = st.n_accept; res.status = st.status; res.handoffs = (int)gen;
+    res.n_attempt = st.n_attempt; res.n_accept = st.n_accept; res.status = st.status; res.handoffs = (int)(gen > cgen ? gen : cgen);
     for (int i = 0; i < 16; ++i) res.prof[i] = sh.prof[i];
     res.clk_cycles = s_c.clk_cycles + (long long)__builtin_readcyclecounter();
     res.clk_ticks = s_c.clk_ticks + (long long)wall_clock64();

@@ -23,6 +23,7 @@ struct mi_ode_linadj {
   long long stride;
   double *pw, *cvec, *g0, *lmat, *mmat, *theta, *ktab;
   void *gpart, *wpad;
+  long long* skew;
   double* partials;            // hand-off records (2 parities)
   Ctl* ctl_dev;
   LinAdjResult* res;           // pinned host
@@ -73,6 +74,7 @@ extern "C" int mi_ode_linadj_destroy(mi_ode_linadj_handle h) {
   if (h->ktab) (void)hipFree(h->ktab);
   if (h->gpart) (void)hipFree(h->gpart);
   if (h->wpad) (void)hipFree(h->wpad);
+  if (h->skew) (void)hipFree(h->skew);
   if (h->partials) (void)hipFree(h->partials);
   if (h->ctl_dev) (void)hipFree(h->ctl_dev);
   if (h->res) (void)hipHostFree(h->res);
@@ -131,6 +133,7 @@ extern "C" int mi_ode_linadj_create(const mi_ode_linadj_desc* desc, mi_ode_linad
   if (e == hipSuccess) e = hipMalloc((void**)&h->partials, (size_t)kMaxBlocks * kRec * sizeof(double));
   if (e == hipSuccess) e = hipMalloc((void**)&h->ctl_dev, sizeof(Ctl));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->res, sizeof(LinAdjResult), hipHostMallocDefault);
+  if (e == hipSuccess && getenv("MI_ODE_LINADJ_PROF") != nullptr) e = hipMalloc((void**)&h->skew, 32 * (size_t)kLaMaxG * 2 * sizeof(long long));
   if (e == hipSuccess) e = hipMemset(h->partials, 0, (size_t)kMaxBlocks * kRec * sizeof(double));
   if (e == hipSuccess) e = hipMemset(h->mmat, 0, kLaPP * E * sizeof(double));      // the bias rows of M_pq, p > 0, stay zero
   if (e == hipSuccess) e = hipMemset(h->cvec, 0, kLaP * D * sizeof(double));
@@ -217,6 +220,8 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
   A.pw = h->pw; A.cvec = h->cvec; A.gpart = h->gpart; A.g0 = h->g0; A.lmat = h->lmat; A.mmat = h->mmat; A.theta = h->theta; A.ktab = h->ktab; A.wpad = h->wpad;
   A.res = h->res;
   A.has_bias = b_dev != nullptr ? 1 : 0;
+  A.skew = h->skew;
+  if (h->skew) (void)hipMemsetAsync(h->skew, 0, 32 * (size_t)kLaMaxG * 2 * sizeof(long long), st);
   if (const char* ed = getenv("MI_ODE_LINADJ_DBG")) A.dbg = atoi(ed);
   memset(h->res, 0, sizeof(LinAdjResult));
   h->res->status = MI_ODE_ST_SYNC_TIMEOUT;       // (overwritten by the kernel's result record)
@@ -246,6 +251,28 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
         if (f) { fwrite(host, sizeof(double), it.n, f); fclose(f); }
       }
       free(host);
+    }
+  }
+  if (h->skew != nullptr && getenv("MI_ODE_LINADJ_PROF") != nullptr) {
+    static long long stamps[32 * kLaMaxG * 2];
+    const int G = h->grid;
+    if (hipMemcpy(stamps, h->skew, sizeof(long long) * 32 * G * 2, hipMemcpyDeviceToHost) == hipSuccess) {
+      for (int g = 0; g < 32; ++g) {
+        long long a_min = (1LL << 62), a_max = 0, l_min = (1LL << 62), l_max = 0; double a_sum = 0; int n = 0, last = -1;
+        for (int b = 0; b < G; ++b) {
+          const long long a = stamps[(g * G + b) * 2], l = stamps[(g * G + b) * 2 + 1];
+          if (a == 0) continue;
+          ++n;
+          if (a < a_min) a_min = a;
+          if (a > a_max) { a_max = a; last = b; }
+          if (l < l_min) l_min = l;
+          if (l > l_max) l_max = l;
+          a_sum += (double)a;
+        }
+        if (n > 0)
+          fprintf(stderr, "[linadj skew] hand-off %d: arrivals spread %.2f us (mean arrives %.2f us before the last, workgroup %d), first leaves %.2f us / last leaves %.2f us after the last arrival\n",
+                  g, 0.01 * (a_max - a_min), 0.01 * ((double)a_max - a_sum / n), last, 0.01 * (l_min - a_max), 0.01 * (l_max - a_max));
+      }
     }
   }
   if (stats != nullptr) {
