@@ -370,11 +370,15 @@ int mi_ode_linadj_create(const mi_ode_linadj_desc* desc, mi_ode_linadj_handle* o
 int mi_ode_linadj_destroy(mi_ode_linadj_handle h);
 /* One backward interval t_start -> t_end (either direction; decreasing time as misc._check_inputs handles it, misc.py:311-321).
  * All pointers are DEVICE memory in the state dtype; w_dev [dim, dim] row-major ([in, out]: f = y W), b_dev nullable; adj_t is a
- * device scalar.  y(t_end) is not produced (the reference discards it, adjoint.py:155-160).  Blocks until done; returns status bits
- * (>= 0) or an error (< 0).  stats->n_launches == 1. */
+ * device scalar.  grad_out_dev (nullable): grad_output at t_start, [batch, dim] - the segment then starts from
+ * adj_t - f(t_start, y) . grad_out (the time gradient of the measurement point, adjoint.py:134-140; f(t_start, y) is the kernel's own first
+ * evaluation) and stores that dot product in dldt_out_dev (nullable device scalar).  host_scalars (nullable): {the dot product,
+ * adj_t(t_end)} as doubles, for a caller that assembles the time gradients on the host.  y(t_end) is not produced (the reference
+ * discards it, adjoint.py:155-160).  Blocks until done; returns status bits (>= 0) or an error (< 0).  stats->n_launches == 1. */
 int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, const void* b_dev, const void* y_dev, const void* adj_y_dev,
-                          const void* adj_t_dev, const void* adj_params_dev, double t_start, double t_end, void* adj_y_out_dev,
-                          void* adj_t_out_dev, void* adj_params_out_dev, mi_ode_stats* stats, void* stream);
+                          const void* adj_t_dev, const void* adj_params_dev, const void* grad_out_dev, double t_start, double t_end,
+                          void* adj_y_out_dev, void* adj_t_out_dev, void* adj_params_out_dev, void* dldt_out_dev, double* host_scalars,
+                          mi_ode_stats* stats, void* stream);
 /* where the time of the last segment went, microseconds of workgroup 0: {tile passes, adj_params combinations, hand-offs of the
  * attempts, slab passes, folds + small products with their hand-offs, prologue, epilogue, hand-offs (count)} */
 int mi_ode_linadj_profile(mi_ode_linadj_handle h, double* out8);

@@ -151,8 +151,8 @@ _PROTOS = {
                                       C.c_void_p, C.c_void_p]),
     'mi_ode_linadj_create': (C.c_int, [C.POINTER(LinAdjDesc), C.POINTER(C.c_void_p)]),
     'mi_ode_linadj_destroy': (C.c_int, [C.c_void_p]),
-    'mi_ode_linadj_segment': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double,
-                                        C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Stats), C.c_void_p]),
+    'mi_ode_linadj_segment': (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double,
+                                        C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_double), C.POINTER(Stats), C.c_void_p]),
     'mi_ode_linadj_profile': (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     'mi_ode_opq_create': (C.c_int, [C.POINTER(OpqDesc), C.POINTER(C.c_void_p)]),
     'mi_ode_opq_destroy': (C.c_int, [C.c_void_p]),

@@ -156,6 +156,8 @@ class _LinearAdjointEngine(object):
         self.h = h
         self.batch, self.dim = int(batch), int(dim)
         self.stats = N.Stats()
+        self._scalars = (C.c_double * 2)()
+        self.scalars = (0.0, 0.0)
 
     def close(self):
         if getattr(self, 'h', None):
@@ -168,18 +170,23 @@ class _LinearAdjointEngine(object):
         except Exception:
             pass
 
-    def segment(self, W, b, y, adj_y, adj_t, adj_params, t_start, t_end):
+    def segment(self, W, b, y, adj_y, adj_t, adj_params, t_start, t_end, grad_out=None):
         """odeint(augmented_dynamics, (y, adj_y, adj_t, adj_params), [t_start, t_end])[..][1] (adjoint.py:148-160) without the y
-        component.  W [dim, dim] in [in, out] layout, b [dim] or None; every tensor in the state dtype on the device."""
+        component.  W [dim, dim] in [in, out] layout, b [dim] or None; every tensor in the state dtype on the device.  grad_out: the
+        gradient at t_start - the kernel then subtracts f(t_start, y) . grad_out from adj_t first (adjoint.py:134-140; its own first evaluation
+        IS f(t_start, y)) and `self.scalars` holds (that dot product, adj_t(t_end)) as Python floats."""
         y, adj_y = y.contiguous(), adj_y.contiguous()
         a_out = torch.empty_like(adj_y)
         t_out = torch.empty_like(adj_t)
         p_out = torch.empty_like(adj_params)
+        if grad_out is not None:
+            grad_out = grad_out.contiguous()
         with torch.cuda.device(self.device):
             rc = N.check(self.lib.mi_ode_linadj_segment(
                 self.h, W.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(), adj_y.data_ptr(), adj_t.data_ptr(),
-                adj_params.data_ptr(), float(t_start), float(t_end), a_out.data_ptr(), t_out.data_ptr(), p_out.data_ptr(),
-                C.byref(self.stats), N.stream_ptr(self.device)), 'mi_ode_linadj_segment')
+                adj_params.data_ptr(), grad_out.data_ptr() if grad_out is not None else None, float(t_start), float(t_end), a_out.data_ptr(),
+                t_out.data_ptr(), p_out.data_ptr(), None, self._scalars, C.byref(self.stats), N.stream_ptr(self.device)), 'mi_ode_linadj_segment')
+        self.scalars = (float(self._scalars[0]), float(self._scalars[1]))
         if rc != 0:
             if rc & N.ST_SYNC_TIMEOUT:
                 raise HandoffTimeout(N.status_message(rc))
@@ -511,40 +518,34 @@ class _OdeintAdjointMethod(torch.autograd.Function):
 
     @staticmethod
     def _linear_backward(eng, base, func, t, flat_params, ans, grad_output, like):
-        """adjoint.py:117-178 with every interval's odeint call as ONE launch of mi_ode_linadj_segment; f(t_i, y_i) for the time
-        gradient (adjoint.py:134-140) on the MFMA stage kernel."""
-        from .fixed_grid import Euler
-        from .solvers import _FusedEngine, _cached_engine, _tableau_key
+        """adjoint.py:117-178 with every interval's odeint call - and the time gradient of its start point (adjoint.py:134-140) - as ONE
+        launch of mi_ode_linadj_segment."""
         T = ans[0].shape[0]
         dim = base.dim
         y_shape = ans[0][0].shape
         batch = ans[0][0].numel() // dim
         W = base.weight.detach()
         b = base.bias.detach() if base.bias is not None else None
-        proto = ans[0][0].reshape(batch, dim)
-        rhs_y = base.device_rhs()
-        key = ('rhs evaluation', rhs_y.cache_key(proto.dtype, proto.device), (batch, dim), proto.dtype, str(proto.device),
-               _tableau_key(Euler._fused_tableau, None))
-        ev = _cached_engine(key, lambda: _FusedEngine(rhs_y, proto, False, Euler._fused_tableau))
         segs = []
         with torch.no_grad():
             g_out = grad_output[0]
-            adj_y = g_out[-1].reshape(batch, dim).contiguous()
+            adj_y = g_out[-1].reshape(batch, dim)
             theta = torch.zeros(dim * dim + (dim if b is not None else 0), dtype=like.dtype, device=like.device)
             adj_time = torch.zeros((), dtype=like.dtype, device=like.device)
-            time_vjps = []
+            time_vjps = []                                   # (host floats: the kernel hands f(t_i, y_i) . grad_output_i and adj_t(t_end) back)
             for i in range(T - 1, 0, -1):
-                y_i = ans[0][i].reshape(batch, dim).contiguous()
-                func_i = ev.eval_rhs(y_i)
-                dLd_cur_t = torch.dot(func_i.reshape(-1), g_out[i].reshape(-1))              # adjoint.py:134-140
-                adj_time = adj_time - dLd_cur_t
-                time_vjps.append(dLd_cur_t.reshape(1))
-                adj_y, adj_time, theta = eng.segment(W, b, y_i, adj_y, adj_time, theta, float(t[i]), float(t[i - 1]))
+                y_i = ans[0][i].reshape(batch, dim)
+                # adjoint.py:134-140 (dLd_cur_t, adj_time -= dLd_cur_t) happens inside the segment: f(t_i, y_i) is its first evaluation
+                adj_y, adj_time, theta = eng.segment(W, b, y_i, adj_y, adj_time, theta, float(t[i]), float(t[i - 1]), grad_out=g_out[i].reshape(batch, dim))
+                time_vjps.append(eng.scalars[0])
                 segs.append(eng.stats.as_dict())
                 _count_nfe(func, segs[-1].get('nfe', 0))
-                adj_y = adj_y + g_out[i - 1].reshape(batch, dim)
-            time_vjps.append(adj_time.reshape(1))
-            time_vjps = torch.cat(time_vjps[::-1]).to(dtype=t.dtype, device=t.device)
+                if i > 1:
+                    adj_y = adj_y + g_out[i - 1].reshape(batch, dim)
+                else:
+                    adj_y.add_(g_out[0].reshape(batch, dim))
+            time_vjps.append(eng.scalars[1] if T > 1 else 0.0)
+            time_vjps = torch.tensor(time_vjps[::-1], dtype=t.dtype, device=t.device)
             grad_params = theta.to(flat_params.dtype)
         odeint_adjoint.last_backward_stats = {'engine': 'linear right-hand side: one launch per interval (mi_ode_linadj)', 'segments': segs,
                                               'last_segment': segs[-1] if segs else {}}

@@ -45,6 +45,7 @@ struct LinAdjResult {                    // pinned host: the kernel's last act i
   long long prof[16];                    // 10 ns ticks of workgroup 0: tile passes / theta combinations / hand-offs of attempts / slab passes /
                                          // folds + small products (with their hand-offs) / prologue / epilogue / -
   long long clk_cycles, clk_ticks;
+  double dldt, adjt_end;                 // f(t_start, y) . grad_out (0 without grad_out) and adj_t(t_end), for the host's time gradients
 };
 
 struct LinAdjArgs {
@@ -53,6 +54,8 @@ struct LinAdjArgs {
   const void* a_in;
   const void* th_in;
   const void* adjt_in;
+  const void* grad_in;                   // nullable: grad_output at t_start [batch, dim] - adj_t starts at adjt_in - f(t_start, y) . grad_in (adjoint.py:134-140)
+  void* dldt_out;                        // nullable: that dot product
   void* th_out;
   void* adjt_out;
   char* planes;                          // 8 planes of batch * dim elements: y_a, y_b, fy_a, fy_b, a_a, a_b, fa_a, fa_b
@@ -88,6 +91,7 @@ struct LaShared {
   double kq[3][kLaPP];                   // the attempt's combination weights of the M_pq: solution, error estimate, G0 | g0 of the end state (or: dense output)
   double adjt;                           // adj_t (constant over the segment)
   double th0_max;                        // max |adj_params| at the step's start (thread 0)
+  double dldt, adjt_end;
   double mine[8];                        // thread 0: this workgroup's record while its passes run
   long long prof[16], tk_prev;            // workgroup 0: where the time of a segment goes (LinAdjResult.prof)
   int ok;
@@ -250,6 +254,50 @@ __device__ __forceinline__ void la_tile_job(const double* __restrict__ A, const 
   }
 }
 
+// The same tile by KSPLIT wavefronts of ONE workgroup, wavefront `part` taking the k-steps [part KS / KSPLIT, (part + 1) KS / KSPLIT): a
+// quarter of the operand loads per wavefront, all in flight at once - ONE memory round trip where the whole-K job needs two (its operands
+// are freshly written by other XCDs: every load goes to memory).  The partial tiles meet in LDS ([slot][part][64 lanes][4]), part 0 adds
+// them in a fixed order and stores.  Called by every wavefront of the workgroup together (`active`: this slot has a job this round).
+template <int D, int KSPLIT>
+__device__ __forceinline__ void la_tile_job_split(const double* __restrict__ A, const double* __restrict__ B, double* __restrict__ C, int ldc,
+                                                  int tm, int tn, const double* __restrict__ u, const double* __restrict__ v, bool active,
+                                                  int slot, int part, double* lds) {
+  using TR = MfmaTraits<double>;
+  constexpr int KS = D / 4, KQ = KS / KSPLIT;
+  static_assert(KS % KSPLIT == 0 && KQ >= 1, "k-steps per wavefront");
+  const int lane = threadIdx.x & 63, li = lane & 15, lg = lane >> 4;
+  TR::acc_t acc = {0, 0, 0, 0};
+  if (active) {
+    const double* ap = A + (long long)(16 * tm + li) * D + lg * KS + part * KQ;
+    const double* bp = B + (long long)(lg * KS + part * KQ) * D + 16 * tn + li;
+    double av[KQ], bv[KQ];
+#pragma unroll
+    for (int m = 0; m < KQ; ++m) { av[m] = ap[m]; bv[m] = bp[(long long)m * D]; }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int m = 0; m < KQ; ++m) acc = TR::mfma(av[m], bv[m], acc);
+    if (KSPLIT > 1 && part > 0) {
+      double* o = lds + ((long long)(slot * KSPLIT + part) * 64 + lane) * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = acc[i];
+    }
+  }
+  if (KSPLIT > 1) __syncthreads();
+  if (active && part == 0) {
+    const int col = 16 * tn + li;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 16 * tm + TR::acc_row(lane, i);
+      double c = acc[i];
+#pragma unroll
+      for (int k = 1; k < KSPLIT; ++k) c += lds[((long long)(slot * KSPLIT + k) * 64 + lane) * 4 + i];
+      if (u != nullptr) c = c + u[row] * v[col];
+      st_wt(C + (long long)row * ldc + col, c);
+    }
+  }
+  if (KSPLIT > 1) __syncthreads();                             // (the LDS slots are free for the next round)
+}
+
 // seven lanes share one entry of the folds / the combinations (49 = 7 x 7 terms; nine groups per wavefront, lane 63 idles): every lane
 // of a group ends up with the group's sum, formed in a fixed order
 __device__ __forceinline__ double group7_sum(double v, int lane) {
@@ -330,13 +378,20 @@ __device__ __forceinline__ void la_slab_pass(const T* __restrict__ y, const T* _
 #pragma unroll
     for (int e = 0; e < EPT; ++e) { py[e] = qy[e]; pa[e] = qa[e]; }
     if (tile_i + 2 * (long long)nblk < ntiles) fetch(tile_i + 2 * (long long)nblk, qy, qa);   // in flight under two tiles' MFMAs
-#pragma unroll
+    T ay[R / 4][MB], bv[R / 4];                                // every operand of the tile out of LDS first, then the chain (the scheduler would
+#pragma unroll                                                 // otherwise put an LDS wait in front of every MFMA)
     for (int u = 0; u < R / 4; ++u) {
       const int row = 4 * u + lg;
-      const T bv = sa[row * LDP + ncol];
-      colsum += bv;
+      bv[u] = sa[row * LDP + ncol];
 #pragma unroll
-      for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(sy[row * LDP + 16 * m + li], bv, acc[m]);
+      for (int m = 0; m < MB; ++m) ay[u][m] = sy[row * LDP + 16 * m + li];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < R / 4; ++u) {
+      colsum += bv[u];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(ay[u][m], bv[u], acc[m]);
     }
   }
 #pragma unroll
@@ -433,10 +488,16 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     }
   };
   auto level_l = [&](const double* g0c) {                      // L_p = P_p G0 + c_p g0 (p = 1..S) and the bias rows g0 P_q (q = 0..S)
-    for (int j = gw; j < S * TJ; j += ngw) {
-      const int p = 1 + j / TJ, t = j % TJ;
-      la_tile_job<D>(A.pw + (long long)p * D * D, g0c, A.lmat + (long long)p * D * D, D, t / (D / 16), t % (D / 16),
-                     A.has_bias ? A.cvec + p * D : nullptr, g0c + D * D);
+    // (this level starts the moment an attempt is accepted and nothing else runs beside it: its latency is the step's - every product is
+    // split over KSPLIT wavefronts of a workgroup, one memory round trip each)
+    constexpr int KSPLIT = NW >= 4 ? 4 : NW, JPW = NW / KSPLIT;
+    const int slot = wave / KSPLIT, kpart = wave % KSPLIT;
+    for (int j0 = 0; j0 < S * TJ; j0 += G * JPW) {             // (uniform trip count: the job synchronises the workgroup)
+      const int j = j0 + blk * JPW + slot;
+      const bool active = j < S * TJ;
+      const int p = active ? 1 + j / TJ : 1, t = active ? j % TJ : 0;
+      la_tile_job_split<D, KSPLIT>(A.pw + (long long)p * D * D, g0c, A.lmat + (long long)p * D * D, D, t / (D / 16), t % (D / 16),
+                                   A.has_bias ? A.cvec + p * D : nullptr, g0c + D * D, active, slot, kpart, (double*)smem_raw);
     }
     for (int j = gg; j < kLaP * D; j += ngg) {                 // row D of M_0q: g0 P_q
       const int q = j / D, c = j % D;
@@ -449,12 +510,7 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     }
   };
   auto level_m = [&](const double* g0c) {                      // M_pq = L_p P_q (L_0 = G0)
-    // the jobs of a chain are dealt round-robin over BOTH levels: the wavefronts that had an L_p product start one M_pq product later, so
-    // every wavefront ends up with the same number of products per accepted step (to one) - the workgroups reach the attempt's hand-off
-    // together (measured before: the 48 workgroups with L_p products arrived 20 us after the others)
-    for (int pos = gw; pos < (S + kLaPP) * TJ; pos += ngw) {
-      if (pos < S * TJ) continue;
-      const int j = pos - S * TJ;
+    for (int j = gw; j < kLaPP * TJ; j += ngw) {
       const int pq = j / TJ, t = j % TJ, p = pq / kLaP, q = pq % kLaP;
       la_tile_job<D>(p == 0 ? g0c : A.lmat + (long long)p * D * D, A.pw + (long long)q * D * D, A.mmat + (long long)pq * E, D,
                      t / (D / 16), t % (D / 16), nullptr, nullptr);
@@ -509,31 +565,52 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     }
   };
   la_flag_set(A.p, 0, cgen++);                                 // P_0, P_1, c_1, the padded matrices
+  tick(5);
   // f0 of both systems (misc.py:225-233's sums ride in the record), the slab partial of the start state
   {
 #pragma clang loop unroll(disable)
     for (int sys = 0; sys < 2; ++sys) {                        // (one instance of the pass in the code: the systems differ in pointers only)
       Acc acc;
       load_system(sys);
-      lin_f0_pass<T, D, true>(A.p.s, sys == 0 ? (const T*)A.y_in : (const T*)A.a_in, sys == 0 ? y_fa : a_fa, (T*)nullptr, (T*)nullptr, cx, acc);
+      double dsum = 0.0;
+      if (sys == 0 && A.grad_in != nullptr)
+        lin_f0_pass<T, D, true, true>(A.p.s, (const T*)A.y_in, y_fa, (T*)nullptr, (T*)nullptr, cx, acc, blk, G, (const T*)A.grad_in, &dsum);
+      else
+        lin_f0_pass<T, D, true>(A.p.s, sys == 0 ? (const T*)A.y_in : (const T*)A.a_in, sys == 0 ? y_fa : a_fa, (T*)nullptr, (T*)nullptr, cx, acc);
       double r[5];
       block_reduce_thread0(acc, sh.red, r);
       if (tid == 0) { sh.mine[3 * sys] = r[2]; sh.mine[3 * sys + 1] = r[3]; sh.mine[3 * sys + 2] = r[4]; }
+      if (sys == 0) {                                          // the dot product's block sum (a sum: the sumb slot of a second reduction)
+        Acc ad; ad.sumb = dsum;
+        block_reduce_thread0(ad, sh.red, r);
+        if (tid == 0) sh.mine[6] = r[3];
+      }
+      tick(14);
       ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);          // (set a whole pass ago)
       padded_ready = true;
       if (ok) power_level(sys == 0 ? 1 : 2);                   // P_2 ; P_3, P_4
       la_flag_set(A.p, 0, cgen++);
+      tick(15);
     }
     la_slab_pass<T, D>((const T*)A.y_in, (const T*)A.a_in, batch, dim, blk, G, my_part, (T*)smem_raw);
+    tick(3);
     ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);
     if (ok) power_level(4);                                    // P_5, P_6 (visible after the hand-off below)
+    tick(15);
     zero_mine();
     if (tid == 0) {
 #pragma unroll
-      for (int i = 0; i < 6; ++i) mine[i] = sh.mine[i];
+      for (int i = 0; i < 7; ++i) mine[i] = sh.mine[i];
     }
     ok = la_exchange(A.p, sh, gen++, mine, true, true) && ok;  // (release: the slab partials are plain stores)
     if (ok && tid < 64) {                                      // the y and adj_y records of the initial step
+      const double dsum = la_fold_sum(sh.vals[6], 0, G);
+      if (tid == 0) {                                          // adjoint.py:134-140: adj_t -= f(t_i, y_i) . grad_output_i (f0 carries the time-reversal sign)
+        const T dl = (T)(sgn * dsum);
+        sh.dldt = A.grad_in != nullptr ? (double)dl : 0.0;
+        if (A.grad_in != nullptr) sh.adjt = (double)((T)sh.adjt - dl);
+        if (blk == 0 && A.dldt_out != nullptr) *(T*)A.dldt_out = A.grad_in != nullptr ? dl : (T)0;
+      }
       for (int k = 0; k < 2; ++k) {
         const double sa = la_fold_sum(sh.vals[3 * k], 0, G), sb = la_fold_sum(sh.vals[3 * k + 1], 0, G), fl = la_fold_max(sh.vals[3 * k + 2], 0, G);
         if (tid == 0) {
@@ -543,19 +620,19 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       }
     }
   }
+  tick(4);
   if (ok) fold_g0();
+  tick(11);
   barrier_handoff();
-  if (ok) level_l(A.g0);
-  barrier_handoff();
-  if (ok) level_m(A.g0);
-  barrier_handoff();
-  // adj_params' share of misc._select_initial_step: f0 = -s M_00 (= -s [G0 ; g0])
+  tick(4);
+  // adj_params' share of misc._select_initial_step: f0 = -s M_00 = -s [G0 ; g0] - the fold's output itself.  The products L_p, M_pq of the
+  // start state are not needed before the first attempt's combinations: they ride between ITS tile passes like every later step's.
   {
     Acc at;
     if (ok) {
       for (int e = e_lo + tid; e < e_hi; e += nthr) {
         if (!entry_valid(e)) continue;
-        const T v0 = (T)th0[e], f0 = (T)(-sgn * A.mmat[e]);
+        const T v0 = (T)th0[e], f0 = (T)(-sgn * A.g0[e]);
         const T sc = (T)cp.atol + fabs(v0) * (T)cp.rtol;       // misc.py:225
         const double q0 = (double)(v0 / sc), q1 = (double)(f0 / sc);
         at.suma += q0 * q0; at.sumb += q1 * q1;
@@ -592,7 +669,17 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     }
     __syncthreads();
   }
-  if (ok && !uniform_i(sh.skip_initb)) {                       // misc.py:235-245 for a finite h0
+  int chain = 0;                                               // 1: the L_p of the new start state are being written (my flag is set), the M_pq
+                                                               // follow after the next y pass; 2: ... the M_pq are being written; 0: M_pq valid
+  if (ok) level_l(A.g0);
+  la_flag_set(A.p, 0, cgen++);
+  chain = 1;
+  if (ok && !uniform_i(sh.skip_initb)) {                       // misc.py:235-245 for a finite h0 (rare: adj_t = 0): the M_pq right away
+    ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);
+    if (ok) level_m(A.g0);
+    la_flag_set(A.p, 0, cgen++);
+    ok = ok && la_flag_wait(A.p, sh, 0, cgen - 1u);
+    chain = 0;
     Acc at;
     const double h0d = uniform_d(s_c.h0);
 #pragma clang loop unroll(disable)
@@ -650,8 +737,6 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
   // ---- the adaptive loop (dopri5.py:82-121) --------------------------------------------------------------------------------------
   int cur = -1, cur_f = 0;                                     // state: -1 the caller's (y_in, a_in), 0 / 1 planes a / b; derivative: plane fa / fb
   int gcur = 0;                                                // which half of A.g0 holds G0 | g0 of the step's start state
-  int chain = 0;                                               // 1: the L_p of the new start state are being written (my flag is set), the M_pq
-                                                               // follow after the next y pass; 2: ... the M_pq are being written; 0: M_pq valid
   const double* ktab = A.ktab;
   bool emitted = false;
   while (!uniform_i(sh.pub.done)) {
@@ -819,7 +904,9 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
           const T at_ = (T)sh.adjt;
           T co[5];
           quartic_from_mid<T>(at_, at_, at_, (T)0, (T)0, (T)sh.pub.emit_dt, co);
-          *(T*)A.adjt_out = quartic_eval<T>(co, (T)x);
+          const T ae = quartic_eval<T>(co, (T)x);
+          *(T*)A.adjt_out = ae;
+          sh.adjt_end = (double)ae;
         }
         emitted = true;
       }
@@ -856,6 +943,7 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
     for (int i = 0; i < 16; ++i) res.prof[i] = sh.prof[i];
     res.clk_cycles = s_c.clk_cycles + (long long)__builtin_readcyclecounter();
     res.clk_ticks = s_c.clk_ticks + (long long)wall_clock64();
+    res.dldt = sh.dldt; res.adjt_end = sh.adjt_end;
     const long long* src = (const long long*)&res;
     long long* dst = (long long*)A.res;
     for (int i = 0; i < (int)(sizeof(LinAdjResult) / sizeof(long long)); ++i)

@@ -171,8 +171,9 @@ extern "C" int mi_ode_linadj_create(const mi_ode_linadj_desc* desc, mi_ode_linad
 }
 
 extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, const void* b_dev, const void* y_dev, const void* adj_y_dev,
-                                     const void* adj_t_dev, const void* adj_params_dev, double t_start, double t_end, void* adj_y_out_dev,
-                                     void* adj_t_out_dev, void* adj_params_out_dev, mi_ode_stats* stats, void* stream) {
+                                     const void* adj_t_dev, const void* adj_params_dev, const void* grad_out_dev, double t_start, double t_end,
+                                     void* adj_y_out_dev, void* adj_t_out_dev, void* adj_params_out_dev, void* dldt_out_dev, double* host_scalars,
+                                     mi_ode_stats* stats, void* stream) {
   if (h == nullptr || w_dev == nullptr || y_dev == nullptr || adj_y_dev == nullptr || adj_t_dev == nullptr || adj_params_dev == nullptr ||
       adj_y_out_dev == nullptr || adj_t_out_dev == nullptr || adj_params_out_dev == nullptr) { mi_set_error("null argument"); return MI_ODE_E_INVALID; }
   if (!(t_end != t_start)) {                      // _assert_increasing on the (possibly negated) pair (misc.py:158-159)
@@ -216,6 +217,7 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
   A.p.sleep_first = h->sleep_first; A.p.sleep_poll = h->sleep_poll;
   A.y_in = y_dev; A.a_in = adj_y_dev; A.th_in = adj_params_dev; A.adjt_in = adj_t_dev;
   A.th_out = adj_params_out_dev; A.adjt_out = adj_t_out_dev;
+  A.grad_in = grad_out_dev; A.dldt_out = dldt_out_dev;
   A.planes = h->planes; A.stride = h->stride;
   A.pw = h->pw; A.cvec = h->cvec; A.gpart = h->gpart; A.g0 = h->g0; A.lmat = h->lmat; A.mmat = h->mmat; A.theta = h->theta; A.ktab = h->ktab; A.wpad = h->wpad;
   A.res = h->res;
@@ -235,24 +237,9 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
   if (h->seq >= 0xE0000000u) h->seq = 0;
   if (getenv("MI_ODE_LINADJ_PROF") != nullptr)
     fprintf(stderr, "[linadj prof] attempts %lld (accepted %lld) hand-offs %d  us: tile passes %.1f (matrix loads %.1f, before %.1f, block reduce %.1f)  theta combinations %.1f  "
-            "attempt hand-offs %.1f  slab passes %.1f  small products: hand-offs %.1f fold %.1f L %.1f M %.1f  prologue %.1f  epilogue %.1f\n", r.n_attempt, r.n_accept,
-            r.handoffs, 0.01 * r.prof[0], 0.01 * r.prof[8], 0.01 * r.prof[7], 0.01 * r.prof[9], 0.01 * r.prof[1], 0.01 * r.prof[2], 0.01 * r.prof[3], 0.01 * r.prof[10],
-            0.01 * r.prof[11], 0.01 * r.prof[12], 0.01 * r.prof[13], 0.01 * r.prof[5], 0.01 * r.prof[6]);
-  if (const char* dd = getenv("MI_ODE_LINADJ_DUMP")) {       // debugging aid: the small matrices of the last step, raw float64
-    const size_t D = (size_t)h->dp, E = D * D + D;
-    struct { const char* name; const void* p; size_t n; } items[] = {{"g0", h->g0, 2 * E}, {"lmat", h->lmat, kLaP * D * D}, {"mmat", h->mmat, kLaPP * E},
-                                                                       {"pw", h->pw, kLaP * D * D}, {"theta", h->theta, 2 * E}, {"cvec", h->cvec, kLaP * D}};
-    for (auto& it : items) {
-      char path[512];
-      snprintf(path, sizeof(path), "%s/%s.bin", dd, it.name);
-      double* host = (double*)malloc(it.n * sizeof(double));
-      if (host != nullptr && hipMemcpy(host, it.p, it.n * sizeof(double), hipMemcpyDeviceToHost) == hipSuccess) {
-        FILE* f = fopen(path, "wb");
-        if (f) { fwrite(host, sizeof(double), it.n, f); fclose(f); }
-      }
-      free(host);
-    }
-  }
+            "attempt hand-offs %.1f  small products: flag waits %.1f L %.1f M %.1f | prologue: init + first step size + first L_p %.1f f0 passes %.1f power levels %.1f slab %.1f first hand-off + barrier %.1f fold %.1f rest %.1f | epilogue %.1f\n",
+            r.n_attempt, r.n_accept, r.handoffs, 0.01 * r.prof[0], 0.01 * r.prof[8], 0.01 * r.prof[7], 0.01 * r.prof[9], 0.01 * r.prof[1], 0.01 * r.prof[2], 0.01 * r.prof[10],
+            0.01 * r.prof[12], 0.01 * r.prof[13], 0.01 * r.prof[5], 0.01 * r.prof[14], 0.01 * r.prof[15], 0.01 * r.prof[3], 0.01 * r.prof[4], 0.01 * r.prof[11], 0.0, 0.01 * r.prof[6]);
   if (h->skew != nullptr && getenv("MI_ODE_LINADJ_PROF") != nullptr) {
     static long long stamps[32 * kLaMaxG * 2];
     const int G = h->grid;
@@ -275,6 +262,7 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
       }
     }
   }
+  if (host_scalars != nullptr) { host_scalars[0] = r.dldt; host_scalars[1] = r.adjt_end; }
   if (stats != nullptr) {
     memset(stats, 0, sizeof(*stats));
     stats->n_attempts = r.n_attempt; stats->n_accepted = r.n_accept; stats->n_rejected = r.n_attempt - r.n_accept;

@@ -600,23 +600,30 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
 
 // before_integrate, first half (dopri5.py:71 + misc.py:225-233): f0 = f(t0, y0), sums of (y0/sc)^2 and (f0/sc)^2, the
 // non-finite flag; optionally seeds a state plane and solution[0] with y0 in the same pass.
-template <typename T, int D, bool SC0>
+// DOT (the adjoint kernel of the linear system): also sum f0 . gdot over the tiles into *dot - the time gradient of adjoint.py:134-140
+// needs f(t_i, y_i) . grad_output_i, and f(t_i, y_i) is this pass's f0.
+template <typename T, int D, bool SC0, bool DOT = false>
 __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f0_out, T* copy_a, T* copy_b, LinCtx<T, D>& cx,
-                                            Acc& acc, int blk = (int)blockIdx.x, int nblk = (int)gridDim.x) {
+                                            Acc& acc, int blk = (int)blockIdx.x, int nblk = (int)gridDim.x, const T* gdot = nullptr,
+                                            double* dot = nullptr) {
   constexpr int R_ = LinCtx<T, D>::R_;
   const long long ntiles = (A.batch + R_ - 1) / R_;
-  T y0n[4];
+  T y0n[4], gn[DOT ? 4 : 1];
   auto fetch = [&](long long t_i) {
     const T* ty = y0 + t_i * R_ * cx.d;
     const int nr = cx.rows_here(t_i, A.batch);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y0n[i] = (cx.row_of(i) < nr && cx.colok) ? stream_load<SC0>(ty + cx.off_of(i)) : (T)0;
+    for (int i = 0; i < 4; ++i) {
+      const bool ok = cx.row_of(i) < nr && cx.colok;
+      y0n[i] = ok ? stream_load<SC0>(ty + cx.off_of(i)) : (T)0;
+      if constexpr (DOT) gn[i] = ok ? (gdot + t_i * R_ * cx.d)[cx.off_of(i)] : (T)0;
+    }
   };
   if ((long long)blk < ntiles) fetch(blk);
   for (long long tile_i = blk; tile_i < ntiles; tile_i += nblk) {
-    T y0e[4], kn[4];
+    T y0e[4], kn[4], ge[DOT ? 4 : 1];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) y0e[i] = y0n[i];
+    for (int i = 0; i < 4; ++i) { y0e[i] = y0n[i]; if constexpr (DOT) ge[i] = gn[i]; }
     if (tile_i + nblk < ntiles) fetch(tile_i + nblk);
     cx.rhs_eval(y0e, kn);
     const int nr = cx.rows_here(tile_i, A.batch);
@@ -633,6 +640,7 @@ __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f
         if (!finite_(y0e[i])) acc.flag = 1;
         const double q1 = (double)(kn[i] / sc);
         acc.sumb += q1 * q1;                                         // misc.py:228
+        if constexpr (DOT) *dot += (double)kn[i] * (double)ge[i];
       }
     }
   }
