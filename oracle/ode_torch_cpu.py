@@ -31,7 +31,13 @@ DPS_C_MID = [6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -26
 
 
 def _scalar(x, like):
-    """tf.cast / tf.convert_to_tensor of a scalar to the state dtype: a 0-d tensor (a scalar op in TF eager)."""
+    """tf.cast / tf.convert_to_tensor of a scalar to the state dtype: a 0-d tensor (a scalar op in TF eager).
+    DELIBERATELY detached: the step size and the stage times are controller outputs, and the gradient checker differentiates the
+    DISCRETE flow at the step sequence the controller chose - d(dt)/d(y0) is not part of it (the adjoint method does not see it either:
+    it integrates the continuous sensitivity).  At the tolerances the gradient tests run this checker (rtol <= 1e-9) the two agree to the
+    solve's own accuracy; the detach is what makes that statement exact instead of approximately true."""
+    if isinstance(x, torch.Tensor):
+        x = x.detach()
     return torch.tensor(float(x), dtype=like.dtype)
 
 

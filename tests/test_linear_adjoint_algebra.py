@@ -91,3 +91,39 @@ def test_time_dependent_network_time_vjp_is_a_dot_product_with_the_bias_vjp(act)
     w_t = func.fc1.weight.detach()[:, 0]                      # the column of fc1 that multiplies t ([out, in] layout; row 0 of the Keras kernel)
     assert abs(float(torch.dot(w_t, g_b1)) - float(g_t)) <= 1e-13 * max(1.0, abs(float(g_t)))
     assert float((g_w1[:, 0] - float(t.detach()) * g_b1).abs().max()) <= 1e-13 * max(1.0, float(g_b1.abs().max()))
+
+
+@pytest.mark.parametrize('tableau', ['DOPRI5', 'BOSH3'])
+@pytest.mark.parametrize('D,B,bias,s,h', [(3, 7, True, 1.0, 0.2), (6, 50, False, -1.0, 0.35), (16, 300, True, -1.0, 0.1), (64, 500, True, -1.0, 0.25), (5, 1, True, -1.0, 0.8)])
+def test_power_form_of_the_parameter_combinations(tableau, D, B, bias, s, h):
+    """What csrc/mi_ode_linadj.h evaluates (round 5): any combination over the stages from the start state's (S + 1)^2 small products M_pq - held
+    to the direct form (the stage inputs of the whole batch) at 1e-13 of the terms' scale; the ERROR ESTIMATE, a difference of O(1) terms that
+    is itself O(h^5), keeps an absolute error of 1e-15 of that scale."""
+    tb = getattr(O, tableau)
+    W, b, y0, a0 = _problem(D, B, bias, 5 * D + B)
+    direct = LA.theta_stage_derivatives_direct(W, b, y0, a0, h, s, tb)
+    scale = h * max(np.abs(kW).max() for kW, _ in direct)
+    scale_b = h * max(max(np.abs(kb).max() for _, kb in direct), 1e-300)
+    for c in (tb.c_sol, tb.c_error):
+        dW = sum((h * cj) * kW for cj, (kW, _) in zip(c, direct))
+        db = sum((h * cj) * kb for cj, (_, kb) in zip(c, direct))
+        pW, pb = LA.theta_combination_powers(W, b, y0.T @ a0, a0.sum(0), h, s, tb, c)
+        assert np.abs(dW - pW).max() <= 1e-13 * scale
+        assert np.abs(db - pb).max() <= 1e-13 * scale_b
+
+
+@pytest.mark.parametrize('D,B,bias,s,h', [(6, 50, True, -1.0, 0.3), (32, 400, True, -1.0, 0.2), (16, 300, False, 1.0, 0.1)])
+def test_the_product_over_the_batch_is_carried_from_step_to_step(D, B, bias, s, h):
+    """G0 = y^T a and g0 = sum_rows a of a step's END state from its START state's small products (oracle: end_state_products_powers) - the
+    kernel forms the product over the batch once per backward interval; after eight steps of propagation it still equals the product of the
+    actual states to 1e-13."""
+    W, b, y, a = _problem(D, B, bias, 7 * D + B)
+    G, g = y.T @ a, a.sum(0)
+    fy = (lambda y_: s * (y_ @ W + b)) if bias else (lambda y_: s * (y_ @ W))
+    for _ in range(8):
+        Ys, _k = LA.stage_inputs(fy, y, h, O.DOPRI5)
+        As, _k = LA.stage_inputs(lambda a_: -s * (a_ @ W.T), a, h, O.DOPRI5)
+        G, g = LA.end_state_products_powers(W, b, G, g, h, s, O.DOPRI5)
+        y, a = Ys[-1], As[-1]                                    # FSAL shaped: y1 = the last stage input (rk_common.py:54-58)
+    assert np.abs(G - y.T @ a).max() <= 1e-13 * max(1.0, np.abs(G).max())
+    assert np.abs(g - a.sum(0)).max() <= 1e-13 * max(1.0, np.abs(g).max())
