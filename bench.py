@@ -57,6 +57,71 @@ CPU_LEG_BUDGET_S = 10.0
 CPU_PLAN = ((8, 3), (32, 2), (1, 1))    # (pinned threads, timed runs after one warm-up) of the CPU baseline, full shard each
 
 
+class Hwmon(object):
+    """Power, clocks and temperatures of the visible GPU(s) from the amdgpu hwmon files (what rocm-smi reads; a read costs ~0.1 ms, so the
+    part can be sampled while it works).  One entry per card that exposes the files (a one-GPU box: one).  Fields: socket power and its
+    cap (W), sclk / mclk (MHz), junction / memory temperature (C).  `clock_mhz` of the bench line is the kernel's own cycle counter;
+    this is what the driver reports beside it - so that a box that grants 2150-2250 MHz can be told apart from a kernel that trips a
+    power cap (round-4 review, item 2a)."""
+    FILES = (('power_w', 'power1_input', 1e-6), ('power_cap_w', 'power1_cap', 1e-6), ('sclk_mhz', 'freq1_input', 1e-6), ('mclk_mhz', 'freq2_input', 1e-6),
+             ('temp_junction_c', 'temp2_input', 1e-3), ('temp_memory_c', 'temp3_input', 1e-3))
+
+    def __init__(self, device_index=None):
+        import glob
+        self.dirs = [d for d in sorted(glob.glob('/sys/class/drm/card*/device/hwmon/hwmon*')) if os.path.exists(os.path.join(d, 'power1_input'))]
+        self.note = '%d card(s) expose hwmon files' % len(self.dirs)
+        # a node shows the files of ALL its GPUs (other tenants' included): keep the card this process computes on, found by its PCI address
+        try:
+            pr = torch.cuda.get_device_properties(torch.cuda.current_device() if device_index is None else device_index)
+            bdf = '%04x:%02x:%02x.' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+            mine = [d for d in self.dirs if bdf in os.path.realpath(os.path.join(d, '..', '..'))]
+            if len(mine) == 1:
+                self.dirs = mine
+                self.note += '; this device: PCI %s0' % bdf
+        except Exception as e:                                # (older torch without the PCI fields: every card is reported)
+            self.note += '; device not identified (%s)' % type(e).__name__
+
+    def read(self):
+        out = []
+        for d in self.dirs:
+            rec = {}
+            for key, name, scale in self.FILES:
+                try:
+                    rec[key] = round(float(open(os.path.join(d, name)).read()) * scale, 2)
+                except (OSError, ValueError):
+                    rec[key] = None
+            out.append(rec)
+        return out
+
+    def sample_while(self, fn, seconds, period=0.01):
+        """Call fn() in a loop for `seconds` while a thread reads the files every `period`: per card, mean / min / max of every field."""
+        import threading
+        rows, stop = [], threading.Event()
+
+        def run():
+            while not stop.is_set():
+                rows.append(self.read())
+                stop.wait(period)
+        th = threading.Thread(target=run, daemon=True)
+        t0 = time.perf_counter()
+        th.start()
+        n = 0
+        while time.perf_counter() - t0 < seconds:
+            fn()
+            n += 1
+        torch.cuda.synchronize()
+        stop.set()
+        th.join()
+        cards = []
+        for c in range(len(self.dirs)):
+            agg = {}
+            for key, _, _ in self.FILES:
+                vals = [r[c][key] for r in rows if r[c].get(key) is not None]
+                agg[key] = {'mean': round(sum(vals) / len(vals), 1), 'min': min(vals), 'max': max(vals)} if vals else None
+            cards.append(agg)
+        return {'seconds': round(time.perf_counter() - t0, 2), 'calls': n, 'samples': len(rows), 'cards': cards}
+
+
 def pmc_traffic(kernel_substr):
     """HBM bytes per launch of a kernel from the committed PMC summary (scripts/pmc_summary.py), or (None, None)."""
     import glob
@@ -303,6 +368,25 @@ def main():
         return
     if args.transport != 'auto':
         os.environ['TFDIFFEQ_AMD_XRANK'] = args.transport          # (read when the engine is created, on every rank)
+    # A run that cannot be what was asked for ends at once, with ONE line that says why (non-zero exit status): fewer devices than ranks
+    # would otherwise surface as N stack traces from the launcher, or as a hang inside the first collective.
+    share_gpu = os.environ.get('BENCH_SHARE_GPU') == '1'
+    n_dev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if n_dev < 1 or (args.gpus > n_dev and not share_gpu):
+        sys.stderr.write('bench.py: --gpus %d but %d device(s) visible (there is no CPU path; BENCH_SHARE_GPU=1 lets several ranks share device 0 '
+                         'for plumbing tests)\n' % (args.gpus, n_dev))
+        sys.exit(3)
+    # ... and a run that hangs (a peer mailbox that never answers, a collective with a dead rank) ends after BENCH_WATCHDOG_S seconds
+    # (default 900: half of the driver's own limit) instead of taking the driver's whole time-out with it.  The in-kernel waits are bounded
+    # already (~10 s per hand-off across ranks, then the next transport); this is the last line of defence.
+    import signal
+
+    def _watchdog(signum, frame):
+        sys.stderr.write('bench.py: watchdog - no result after %s s (rank %s of %s); giving up\n' % (
+            os.environ.get('BENCH_WATCHDOG_S', '900'), os.environ.get('RANK', '0'), os.environ.get('WORLD_SIZE', '1')))
+        os._exit(4)
+    signal.signal(signal.SIGALRM, _watchdog)
+    signal.alarm(int(os.environ.get('BENCH_WATCHDOG_S', '900')))
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         respawn(args)
     # stdout carries exactly ONE line (the JSON result): libraries that print to file descriptor 1 (RCCL's start-up
@@ -334,10 +418,12 @@ def main():
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
+        import datetime
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get('BENCH_PG_TIMEOUT_S', '180')))   # (default 10 min: a dead rank should cost minutes, not the run)
         if share:
-            dist.init_process_group(backend='gloo', rank=rank, world_size=world)
+            dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group(backend='nccl', rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         group = dist.group.WORLD
     n_gpus = world
 
@@ -356,8 +442,24 @@ def main():
         out = odeint(f, y0, t, options=opts, **kw)
         return out, dict(odeint.last_stats)
 
-    # engine / handle creation, module load and clock ramp happen here, outside both the warm-up and the timed steps: the
-    # part idles between commands and the first ~20 calls after that run at ramping clocks (reported as `preheat_calls`)
+    # engine / handle creation and module load happen in the first call
+    step()
+    torch.cuda.synchronize()
+    # A full collection of the interpreter's object graph (torch alone keeps ~1e6 objects alive) takes 40-50 ms; when one lands inside
+    # a ten-call timed region it shows up as +4 ms per step on the latency-bound configurations (measured: config 2 at 5.5 instead of
+    # 1.6 ms).  Collect now and keep the collector out of the timed region, as `timeit` does.  NOW means: BEFORE the clock ramp and the
+    # warm-up steps, not between them and the timed steps - round 5 (scripts/power_trace.py, profiles/r05_power_trace_config4.txt): the part
+    # drops its engine clock within milliseconds of going idle and needs tens of milliseconds of work to get it back, and rounds 1-4 put
+    # this 40-50 ms host-side pause right in front of a 13 ms timed region.  The same box then reads 1.70 ms per step in the timed steps
+    # (kernel clock 2167 MHz) and 1.29 ms (2394 MHz) in a 1.5 s loop of the same call seconds later.
+    import gc
+    gc.collect()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
+    hw = Hwmon()
+    smi = {'source': 'amdgpu hwmon files: ' + hw.note, 'before_warmup': hw.read()}
+    # clock ramp (reported as `preheat_calls`), then the W warm-up steps, then - with nothing in between but the barrier and the
+    # synchronisation the contract asks for - the timed steps
     for _ in range(PREHEAT_CALLS):
         step()
     torch.cuda.synchronize()
@@ -365,13 +467,6 @@ def main():
         step()
     if use_dist:
         dist.barrier()
-    # A full collection of the interpreter's object graph (torch alone keeps ~1e6 objects alive) takes 40-50 ms; when one lands inside
-    # a ten-call timed region it shows up as +4 ms per step on the latency-bound configurations (measured: config 2 at 5.5 instead of
-    # 1.6 ms).  Collect now and keep the collector out of the timed region, as `timeit` does.
-    import gc
-    gc.collect()
-    gc_was_enabled = gc.isenabled()
-    gc.disable()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
     prof_last_ms = prof_all_ms = 0.0
@@ -390,11 +485,12 @@ def main():
             clk_n += 1
     torch.cuda.synchronize()
     my_elapsed = time.perf_counter() - t_start                # this rank's own clock, before the closing barrier (config.per_rank)
-    if gc_was_enabled:
-        gc.enable()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
+    smi['after_timed_steps'] = hw.read()                      # (six file reads, ~0.5 ms: after the clock is stopped)
+    if gc_was_enabled:
+        gc.enable()
     per_rank = None
     if use_dist:
         el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
@@ -407,8 +503,24 @@ def main():
                                           'ms_per_step': 1e3 * my_elapsed / args.steps,
                                           'us_per_attempt': 1e6 * my_elapsed / args.steps / att,
                                           'kernel_ms_per_step': prof_last_ms / max(prof_n, 1),
+                                          # time workgroup 0 of this rank's whole-call kernel spent in the grid hand-offs of the last call
+                                          # (the cross-rank exchange included): what the sharding costs per call, seen from inside
+                                          'handoff_us': stats.get('handoff_us'),
                                           # what this rank tried, in order, to carry the per-attempt record, and why each ended as it did
                                           'transport_log': stats.get('cross_rank_log')})
+    # The same call in a loop for 1.5 s with the files sampled every 10 ms, OUTSIDE the timed region (after it): power against its cap,
+    # the clock the driver reports and the temperatures while the kernel of the timed steps is all the part does.
+    if len(hw.dirs) > 0 and os.environ.get('BENCH_NO_SMI_LOOP') != '1':
+        clk2 = []
+
+        def _one():
+            _, st_ = step()
+            if st_.get('clock_mhz', 0) > 0:
+                clk2.append(st_['clock_mhz'])
+        smi['sustained_loop'] = hw.sample_while(_one, 1.5)
+        smi['sustained_loop']['kernel_clock_mhz'] = round(sum(clk2) / len(clk2), 1) if clk2 else None
+        if use_dist:
+            dist.barrier()
     survey = None
     if use_dist and args.config == 4 and args.transport == 'auto' and os.environ.get('BENCH_NO_SURVEY') != '1':
         # First contact with a multi-GPU node should explain itself: OUTSIDE the timed region, every transport in turn (pinned, so
@@ -456,7 +568,12 @@ def main():
         all_ms = prof_all_ms / max(prof_n, 1)
         cfg = {'workload': desc + '; one odeint call per step; rows per GPU %d, global %d' % (int(y0.shape[0]), rows_global),
                'parallelism': 'batch-sharded x%d (%s scaling)' % (n_gpus, args.scaling) if args.config == 4 else 'single GPU',
-               'rccl_ranks': n_gpus if use_dist else 0, 'cross_rank': stats.get('cross_rank', 'single rank'), 'transport_requested': args.transport,
+               # what carried the per-attempt records in the TIMED steps, and how many ranks the RCCL communicator that did it had (0: the
+               # records did not travel through RCCL - peer mailboxes, the host segment or, under BENCH_SHARE_GPU, a gloo group)
+               'records_transport': stats.get('cross_rank', 'single rank'),
+               'rccl_ranks': n_gpus if (use_dist and 'ncclAllGather' in str(stats.get('cross_rank', ''))) else 0,
+               'process_group_backend': (dist.get_backend(group) if group is not None else None),
+               'cross_rank': stats.get('cross_rank', 'single rank'), 'transport_requested': args.transport,
                'preheat_calls': PREHEAT_CALLS, 'attempts_per_step': attempts, 'accepted': int(stats.get('n_accepted', 0)),
                'nfe': int(stats.get('nfe', 0)), 'host_polls': int(stats.get('n_polls', 0)), 'kernel_launches': launches,
                'element_steps_per_s': n_elem_global * max(attempts, 1) * args.steps / elapsed,
@@ -464,7 +581,11 @@ def main():
                # shader clock the whole-call kernel itself observed (its cycle counter against the 100 MHz constant clock), mean
                # over the timed steps: latency-bound configurations move with it (a one-wavefront kernel is granted whatever the
                # governor leaves it at)
-               'clock_mhz': (clk_sum / clk_n) if clk_n else None}
+               'clock_mhz': (clk_sum / clk_n) if clk_n else None,
+               'handoff_us': stats.get('handoff_us'),           # workgroup 0's time in the grid hand-offs of the last timed call
+               # what the driver reports beside it (class Hwmon): a reading right before and right after the timed steps, and the same call
+               # in a 1.5 s loop afterwards with power / sclk / temperatures sampled every 10 ms
+               'smi': smi}
         if per_rank is not None:
             cfg['per_rank'] = per_rank
         if survey is not None:

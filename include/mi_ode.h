@@ -209,6 +209,8 @@ typedef struct mi_ode_stats {
   int64_t n_launches;         /* kernels enqueued */
   double clock_mhz;           /* shader clock the one-launch kernels of the call ran at (their own cycle counter against the
                                  100 MHz constant clock); 0 where not measured */
+  double handoff_us;          /* ABI 13: time workgroup 0 of the whole-call linear tile kernel spent in the call's grid hand-offs (the
+                                 cross-rank exchange of a sharded run included); 0 where not measured */
 } mi_ode_stats;
 
 typedef struct mi_ode_solver* mi_ode_handle;

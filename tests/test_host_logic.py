@@ -278,13 +278,13 @@ def test_adams_scalars_match_the_oracle():
 
 
 def test_time_reversal_uses_the_callables_own_reversal_when_it_has_one():
-    """misc.py:311-321: decreasing t -> t <- -t, func <- -func(-t, y).  A callable with `time_reversed()` (the linear system's augmented
+    """misc.py:311-321: decreasing t -> t <- -t, func <- -func(-t, y).  A callable with `_mi_time_reversed()` (the linear system's augmented
     dynamics: the sign is a scale factor of its kernels) is asked for that function instead of being wrapped in a negation."""
     class Dyn(object):
         def __init__(self, sign=1.0):
             self.sign = sign
 
-        def time_reversed(self):
+        def _mi_time_reversed(self):
             return Dyn(-self.sign)
 
         def __call__(self, t, y):
@@ -300,7 +300,7 @@ def test_time_reversal_uses_the_callables_own_reversal_when_it_has_one():
         assert isinstance(f_wrp, misc._ReverseFunc) == decreasing
         tau = torch.tensor(-1.25 if decreasing else 0.75)
         # the two formulations are the same function of (tau, y) when the dynamics do not depend on t - which is what a callable
-        # promises by offering time_reversed() with a sign alone
+        # promises by offering _mi_time_reversed() with a sign alone
         a = f_nat(torch.tensor(0.0), y0)
         b = tuple(-(v) for v in y0) if decreasing else y0
         for u, v in zip(a, b):
@@ -362,3 +362,69 @@ def test_committed_bench_line_carries_the_contract():
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and d['parity_max_abs_diff'] < 1e-12
+
+
+def test_bench_refuses_more_ranks_than_devices_with_one_line():
+    """`bench.py --gpus N` with fewer than N devices visible ends at once with exit status 3 and ONE line that says why (round-4 review, item 4c:
+    the first 8-GPU contact must not end as eight stack traces or a hang).  No JSON line is printed."""
+    import subprocess
+    import sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip('two or more devices visible')
+    env = dict(os.environ)
+    env.pop('BENCH_SHARE_GPU', None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode == 3
+    assert res.stdout.strip() == ''
+    lines = [ln for ln in res.stderr.strip().split('\n') if ln.startswith('bench.py:')]
+    assert len(lines) == 1 and '--gpus 2' in lines[0] and 'device(s) visible' in lines[0]
+
+
+def test_a_users_own_time_reversed_attribute_is_not_taken_for_the_native_hook():
+    """(advisor, round 4) only the private `_mi_time_reversed` is the hook; a user's callable that happens to have a `time_reversed` attribute is
+    wrapped like any other."""
+    class Dyn(object):
+        def time_reversed(self):
+            raise AssertionError('not ours to call')
+
+        def __call__(self, t, y):
+            return tuple(v + t for v in y)
+    _, f, _, _ = misc._check_inputs(Dyn(), (torch.ones(2),), torch.tensor([1.0, 0.0]))
+    assert isinstance(f, misc._ReverseFunc)
+
+
+def test_trainable_leaves_of_a_plain_callable_come_from_its_autograd_graph():
+    """(advisor, round 4) `odeint(lambda t, y: net(y), ...)`: the tensors the adjoint differentiates with respect to are the grad-requiring
+    LEAVES one evaluation depends on - a module the callable merely could name gets no (zero) gradient, a tensor reached through an attribute
+    chain or a container is found, and the probe is cached per (code, closure) so that a lambda re-created every iteration costs one evaluation
+    in total."""
+    import importlib
+    OD = importlib.import_module('tfdiffeq_amd.odeint')      # (the package exports the FUNCTION under the same name)
+    torch.manual_seed(0)
+    used, unused = torch.nn.Linear(3, 3).double(), torch.nn.Linear(3, 3).double()
+    holder = {'deep': [torch.randn(3, dtype=torch.float64, requires_grad=True)]}
+    frozen = torch.randn(3, dtype=torch.float64)
+    calls = []
+
+    def make():
+        def f(t, y):
+            calls.append(1)
+            _ = unused                                     # named, never evaluated
+            return used(y) + holder['deep'][0] * t + frozen
+        return f
+    y0 = torch.randn(4, 3, dtype=torch.float64)
+    leaves = OD._graph_leaves(make(), y0, torch.tensor([0.0, 1.0]))
+    assert {id(x) for x in leaves} == {id(used.weight), id(used.bias), id(holder['deep'][0])}
+    n = len(calls)
+    assert OD._graph_leaves(make(), y0, torch.tensor([0.0, 1.0])) is leaves and len(calls) == n      # same code, same cells: cached
+    assert OD._wants_grad(make(), y0) is True and OD._wants_grad(lambda t, y: y * 2.0, y0) is False
+    # a tuple state and a callable object
+    class Obj(object):
+        def __init__(self):
+            self.w = torch.ones(3, dtype=torch.float64, requires_grad=True)
+
+        def __call__(self, t, y):
+            return (y[0] * self.w, y[1])
+    o = Obj()
+    lv = OD._graph_leaves(o, (y0, y0.clone()), torch.tensor([0.0, 1.0]))
+    assert len(lv) == 1 and lv[0] is o.w

@@ -27,6 +27,7 @@ SEGMENT_ALIGN = 256
 IPC_HANDLE_BYTES = 64
 RCCL_ID_BYTES = 128
 ST_DT_UNDERFLOW, ST_NONFINITE, ST_MAX_STEPS, ST_BAD_T, ST_SYNC_TIMEOUT = 1, 2, 4, 8, 16
+E_INVALID, E_HIP, E_NODEVICE, E_EXCHANGE = -1, -2, -3, -4          # negative returns: API errors (mi_ode.h)
 
 
 class Tableau(C.Structure):
@@ -101,7 +102,8 @@ class OpqDesc(C.Structure):
 class Stats(C.Structure):
     _fields_ = [('n_attempts', C.c_int64), ('n_accepted', C.c_int64), ('n_rejected', C.c_int64), ('nfe', C.c_int64),
                 ('t', C.c_double), ('dt', C.c_double), ('last_ratio', C.c_double),
-                ('status', C.c_uint32), ('n_polls', C.c_int32), ('n_launches', C.c_int64), ('clock_mhz', C.c_double)]
+                ('status', C.c_uint32), ('n_polls', C.c_int32), ('n_launches', C.c_int64), ('clock_mhz', C.c_double),
+                ('handoff_us', C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -354,7 +354,7 @@ def _linear_dynamics(base, like):
             self.sign = sign
             self.eng_y = self.eng_a = None                   # created on first use: a backward pass only ever runs one direction
 
-        def time_reversed(self):
+        def _mi_time_reversed(self):
             return _Dynamics(-self.sign)
 
         def __call__(self, tt, y_aug):
@@ -487,6 +487,10 @@ class _OdeintAdjointMethod(torch.autograd.Function):
                 vjp_params = torch.zeros((), dtype=like.dtype, device=like.device)
             return (*[f.detach() for f in func_eval], *vjp_y, vjp_t.to(like.dtype), vjp_params.to(like.dtype))
 
+        # torch.autograd.grad cannot run under hipGraph stream capture (the capture aborts inside the autograd engine and takes the
+        # process with it): the device-controlled engine must never record these dynamics - whatever its saved-tensor heuristic sees
+        # (an f whose backward saves nothing, `return -y`, looks capture-safe to it)
+        augmented_dynamics._mi_no_capture = True
         return augmented_dynamics
 
     @staticmethod

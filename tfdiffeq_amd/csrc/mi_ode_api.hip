@@ -274,6 +274,7 @@ static void fill_stats(mi_ode_solver* h, mi_ode_stats* s) {
   s->n_polls = h->n_polls;
   s->n_launches = h->n_launches;
   s->clock_mhz = c->clk_ticks > 0 ? 100.0 * (double)c->clk_cycles / (double)c->clk_ticks : 0.0;
+  s->handoff_us = (h->family == mi::FAM_LINEAR_MFMA && h->persist) ? 0.01 * (double)c->prof[3] : 0.0;
 }
 
 // ------------------------------------------------------------------------------------------------

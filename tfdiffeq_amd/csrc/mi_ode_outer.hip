@@ -28,7 +28,8 @@ __global__ __launch_bounds__(D * 4) void k_outer_partial(const T* __restrict__ y
   using TR = MfmaTraits<T>;
   using acc_t = typename TR::acc_t;
   constexpr int MB = D / 16, NT = D * 4, R = 16, EPT = R * D / NT;   // 16-row tiles (32 KB of LDS at D = 128, fp64; 32 rows: the same 52 us), EPT = 4 elements per thread and plane
-  __shared__ __attribute__((aligned(16))) T sy[R * D], sa[R * D];
+  constexpr int LDP = D + 16;                                  // row stride: the four row groups of an MFMA operand read land in different banks
+  __shared__ __attribute__((aligned(16))) T sy[R * LDP], sa[R * LDP];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, li = lane & 15, lg = lane >> 4;
   acc_t acc[MB];
 #pragma unroll
@@ -78,22 +79,30 @@ __global__ __launch_bounds__(D * 4) void k_outer_partial(const T* __restrict__ y
         CH vy, va;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) { vy.v[v] = py[c * VEC + v]; va.v[v] = pa[c * VEC + v]; }
-        *(CH*)(sy + (c * NT + tid) * VEC) = vy;
-        *(CH*)(sa + (c * NT + tid) * VEC) = va;
+        const int idx = (c * NT + tid) * VEC;
+        *(CH*)(sy + idx / D * LDP + idx % D) = vy;
+        *(CH*)(sa + idx / D * LDP + idx % D) = va;
       }
     } else {
 #pragma unroll
-      for (int e = 0; e < EPT; ++e) { sy[e * NT + tid] = py[e]; sa[e * NT + tid] = pa[e]; }
+      for (int e = 0; e < EPT; ++e) { const int idx = e * NT + tid; sy[idx / D * LDP + idx % D] = py[e]; sa[idx / D * LDP + idx % D] = pa[e]; }
     }
     __syncthreads();
     if (t0 + R < r1) fetch(t0 + R);                            // in flight under this tile's MFMAs
-#pragma unroll
+    T ay[R / 4][MB], bv[R / 4];                                // every operand of the tile out of LDS first, then the chain (round 5: the scheduler put
+#pragma unroll                                                 // an LDS wait in front of every MFMA - 48 -> 3x us per call at 65536 x 128)
     for (int u = 0; u < R / 4; ++u) {
       const int row = 4 * u + lg;
-      const T bv = sa[row * D + ncol];
-      colsum += bv;
+      bv[u] = sa[row * LDP + ncol];
 #pragma unroll
-      for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(sy[row * D + 16 * m + li], bv, acc[m]);   // A operand: A[i = li][k = lg] = y[row][16 m + li]
+      for (int m = 0; m < MB; ++m) ay[u][m] = sy[row * LDP + 16 * m + li];                        // A operand: A[i = li][k = lg] = y[row][16 m + li]
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < R / 4; ++u) {
+      colsum += bv[u];
+#pragma unroll
+      for (int m = 0; m < MB; ++m) acc[m] = TR::mfma(ay[u][m], bv[u], acc[m]);
     }
   }
   // this slab's block: [D x D] (padded) then [D] column sums

@@ -33,6 +33,15 @@ namespace mi {
 #define MI_TOCK(slot, a, b)
 #define MI_SKEW(g, which)
 #endif
+// Always on (product build too), the linear tile kernel only: the time workgroup 0 spends in the grid hand-offs of a call - what a sharded
+// run pays for its records (mi_ode_stats.handoff_us; bench.py prints it per rank).  Two reads of the 100 MHz clock per hand-off by one lane.
+#ifdef MI_PERSIST_PROF
+#define MI_HANDOFF_T0()
+#define MI_HANDOFF_T1()
+#else
+#define MI_HANDOFF_T0() long long ho_t0_ = 0; if (threadIdx.x == 0 && blockIdx.x == 0) ho_t0_ = (long long)wall_clock64()
+#define MI_HANDOFF_T1() do { if (threadIdx.x == 0 && blockIdx.x == 0) s_c.prof[3] += (long long)wall_clock64() - ho_t0_; } while (0)
+#endif
 
 constexpr int kPersistTSmall = 8;      // output times that travel as kernel arguments
 constexpr int kPersistTout = 1024;     // output times cached in LDS
@@ -848,7 +857,9 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     MI_TICK(tf1);
     MI_TOCK(0, tf0, tf1);
     MI_SKEW(gen, 0);
+    MI_HANDOFF_T0();
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    MI_HANDOFF_T1();
     MI_SKEW(gen - 1u, 1);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
     __syncthreads();
@@ -860,7 +871,9 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
     MI_TICK(ti1);
     MI_TOCK(1, ti0, ti1);
     MI_SKEW(gen, 0);
+    MI_HANDOFF_T0();
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
+    MI_HANDOFF_T1();
     MI_SKEW(gen - 1u, 1);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
   }
@@ -911,7 +924,9 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
 #endif
     MI_TICK(ta1);
     MI_SKEW(gen, 0);
+    MI_HANDOFF_T0();
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);                   // (its barriers also fence the reads of sh.pub above)
+    MI_HANDOFF_T1();
     MI_SKEW(gen - 1u, 1);
     MI_TICK(ta2);
     MI_TOCK(2, ta0, ta1); MI_TOCK(3, ta1, ta2);

@@ -284,6 +284,7 @@ class DeviceControlledRK(object):
 
     EAGER_FIRST = 2            # 'auto': eager attempts before a capture is considered (they are the warm-up of the capture)
     MIN_REMAINING = 12         # 'auto': capture only if about this many attempts are still to come
+    _told = False              # the one-time note about what a recorded right-hand side means
     MAX_CHUNK = 64
 
     def __init__(self, solver, graph='auto'):
@@ -300,6 +301,8 @@ class DeviceControlledRK(object):
         self.tableau = solver.tableau
         self.fsal = _is_fsal_shaped(self.tableau)
         self.graph_mode = graph
+        if getattr(self.func, '_mi_no_capture', False) and self.graph_mode != 'host':
+            self.graph_mode = False                         # (adjoint.py: dynamics that call torch.autograd.grad - never recorded)
         y0 = solver.y0
         self.device = y0[0].device
         self.dtype = y0[0].dtype
@@ -380,6 +383,15 @@ class DeviceControlledRK(object):
                 self._keep = self._attempt()
             self.graph = g
             self.captured = True
+            if self.graph_mode == 'auto' and not DeviceControlledRK._told:
+                # (advisor, round 4) a semantic difference from the reference's eager loop, said once: from here on f's PYTHON body does
+                # not run again in this call - only the device work it enqueued when it was recorded is replayed
+                DeviceControlledRK._told = True
+                import warnings
+                warnings.warn("tfdiffeq_amd: the right-hand side was recorded as a hipGraph after %d eager attempts and is replayed from "
+                              "here on: Python-side effects inside f (logging, counters other than an integer `nfe`, hooks) stop, and f "
+                              "received 0-d VIEWS of a device time buffer the controller overwrites (clone t to keep it).  "
+                              "options={'graph': False} keeps one Python evaluation per stage." % self.EAGER_FIRST)
             return True
         except Exception as e:                                   # host synchronisation / data-dependent control flow inside f, ...
             import warnings

@@ -348,6 +348,7 @@ class _TupleFunc(object):
     def __init__(self, base):
         self.base = base
         self.device_rhs = base if getattr(base, 'kind', 0) else None
+        self._mi_no_capture = getattr(base, '_mi_no_capture', False)
 
     def __call__(self, t, y):
         return (self.base(t, y[0]),)
@@ -361,6 +362,7 @@ class _ReverseFunc(object):
         rhs = getattr(base, 'device_rhs', None)
         self.device_rhs = rhs.reversed() if rhs is not None else None
         self.per_component = getattr(base, 'per_component', False)
+        self._mi_no_capture = getattr(base, '_mi_no_capture', False)
 
     def __call__(self, t, y):
         return tuple(-f_ for f_ in self.base(-t, y))
@@ -384,9 +386,9 @@ def _check_inputs(func, y0, t):
     t = _as_time_tensor(t)
     if _decreasing(t):
         t = -t
-        # misc.py:318-321: func <- -func(-t, y).  A callable that can form that itself (`time_reversed()`: e.g. the linear system's
+        # misc.py:318-321: func <- -func(-t, y).  A callable that can form that itself (`_mi_time_reversed()`: e.g. the linear system's
         # augmented dynamics, whose kernels take the sign as a scale factor) spares the wrapper's negation pass over every component
-        native = getattr(func, 'time_reversed', None)
+        native = getattr(func, '_mi_time_reversed', None)     # (a private name: a user's own `time_reversed` attribute means nothing here)
         func = native() if callable(native) else _ReverseFunc(func)
     for y0_ in y0:
         if not torch.is_floating_point(y0_):

@@ -40,6 +40,13 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
 
     Raises ValueError (options without method), KeyError (unknown method), TypeError (non-floating inputs),
     AssertionError (non-monotone t, dt underflow, non-finite state, max_num_steps) - as the reference does.
+
+    One semantic difference from the reference's eager loop (adaptive Runge-Kutta methods, Python callable `func`, default
+    options={'graph': 'auto'}): after two eager attempts, and if about a dozen more are to come, an attempt is RECORDED as a hipGraph and
+    replayed - func's Python body no longer runs (side effects stop; an integer `nfe` attribute is still credited), `t` is a 0-d view
+    of a device buffer the controller overwrites (clone it to keep it), and up to 64 blind replays past the end are no-ops on the
+    device but were recorded with func inside.  A func that synchronises with the host or records autograd is detected and stays eager;
+    options={'graph': False} turns the recording off, 'host' restores the loop with the controller on the host.
     """
     if _wants_grad(func, y0):
         # The reference back-propagates through the solver's eager ops (odeint.py:28-81 under a GradientTape).  The
@@ -51,18 +58,18 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
             return odeint_adjoint(func, y0, t, rtol=rtol, atol=atol, method=method, options=options)
         # A plain callable: the reference differentiates through it all the same (tf.GradientTape sees every op), including
         # through whatever the callable closes over - `odeint(lambda t, y: net(y), enc(x), t)` trains `net`.  The adjoint solve
-        # needs those tensors by name, so look for them: modules and grad-requiring tensors in the callable's closure cells,
-        # bound object, partial arguments, defaults and the globals its code names.  They become the wrapper module's
-        # parameters and receive their gradients like any module's.
+        # needs those tensors by name: they are read off the autograd graph of ONE evaluation f(t[0], y0) (`_graph_leaves`: exactly the
+        # grad-requiring leaves f uses, however it reaches them; cached per callable).  They become the wrapper module's parameters
+        # and receive their gradients like any module's.
         from .adjoint import odeint_adjoint
-        mods, tens = _closure_state(func)
-        if mods or tens:
+        leaves = _graph_leaves(func, y0, t)
+        if leaves:
             _warn_once('odeint: inputs require grad and `func` is a plain callable - gradients are computed with the adjoint method; the '
-                       'modules / tensors it closes over (%d / %d found) are treated as its parameters' % (len(mods), len(tens)))
+                       '%d grad-requiring tensor(s) its evaluation depends on are treated as its parameters' % len(leaves))
         else:
             _warn_once('odeint: y0 requires grad and `func` is a plain callable - gradients w.r.t. y0 and t are computed with the adjoint '
-                       'method (no module or grad-requiring tensor was found in its closure)')
-        return odeint_adjoint(_callable_module(func, mods, tens), y0, t, rtol=rtol, atol=atol, method=method, options=options)
+                       'method (its evaluation depends on no other grad-requiring tensor)')
+        return odeint_adjoint(_callable_module(func, (), leaves), y0, t, rtol=rtol, atol=atol, method=method, options=options)
     tensor_input, func, y0, t = _check_inputs(func, y0, t)
 
     if options is None:
@@ -84,75 +91,79 @@ odeint.last_stats = {}
 _warned = set()
 
 
-def _closure_state(func):
-    """(modules, grad-requiring tensors that belong to none of them) a plain callable can reach: closure cells, the bound object,
-    functools.partial arguments, defaults, and the module-level names its code refers to; containers and nested callables are
-    followed a few levels deep."""
+_LEAF_CACHE = {}
+
+
+def _callable_key(func):
+    """(key, witnesses) identifying a callable for the leaf cache: the code object and what its closure cells / bound object / partial
+    arguments hold (a lambda written inside a training loop is a NEW object every iteration, but the same code over the same cells), else
+    the object itself.  The key is built from ids; `witnesses` are the objects behind those ids - kept by the cache entry as weak
+    references where the type allows it (a module that died and whose id was recycled is then noticed), strongly otherwise."""
     import functools
-    import inspect
-    import torch
-    mods, tens, seen = [], [], set()
-
-    def visit(obj, depth):
-        if id(obj) in seen or depth > 4:
-            return
-        seen.add(id(obj))
-        if isinstance(obj, torch.nn.Module):
-            mods.append(obj)
-        elif isinstance(obj, torch.Tensor):
-            if obj.requires_grad:
-                tens.append(obj)
-        elif isinstance(obj, (list, tuple, set, frozenset)):
-            for o in obj:
-                visit(o, depth + 1)
-        elif isinstance(obj, dict):
-            for o in obj.values():
-                visit(o, depth + 1)
-        elif isinstance(obj, functools.partial):
-            visit(obj.func, depth + 1)
-            visit(obj.args, depth + 1)
-            visit(obj.keywords, depth + 1)
-        elif inspect.isfunction(obj) or inspect.ismethod(obj):
-            walk(obj, depth + 1)
-        elif callable(obj) and hasattr(obj, '__dict__') and not inspect.isclass(obj) and not inspect.ismodule(obj):
-            visit(vars(obj), depth + 1)                  # an object with __call__: what it holds
-            call = getattr(type(obj), '__call__', None)
-            if inspect.isfunction(call):
-                walk(call, depth + 1)
-
-    def walk(f, depth):
+    f = func
+    if isinstance(f, functools.partial):
+        k, w = _callable_key(f.func)
+        held = list(f.args) + [v for _, v in sorted((f.keywords or {}).items())]
+        return ('partial', k, tuple(id(a) for a in held)), w + held
+    fn = getattr(f, '__func__', f)
+    code = getattr(fn, '__code__', None)
+    if code is None:
+        return ('object', id(f)), [f]
+    held = [code]
+    for cell in getattr(fn, '__closure__', None) or ():
         try:
-            f = inspect.unwrap(f)
-        except ValueError:
-            pass
-        owner = getattr(f, '__self__', None)
-        if owner is not None and not inspect.ismodule(owner):
-            visit(owner, depth)
-        fn = getattr(f, '__func__', f)
-        for cell in getattr(fn, '__closure__', None) or ():
-            try:
-                visit(cell.cell_contents, depth)
-            except ValueError:                           # empty cell
-                pass
-        visit(getattr(fn, '__defaults__', None) or (), depth)
-        visit(getattr(fn, '__kwdefaults__', None) or {}, depth)
-        code, glob = getattr(fn, '__code__', None), getattr(fn, '__globals__', None)
-        if code is not None and glob is not None:
-            import dis
-            names, todo = set(), [code]
-            while todo:                                  # LOAD_GLOBAL only (co_names also lists attribute names); nested lambdas /
-                c = todo.pop()                           # comprehensions name globals too
-                names.update(i.argval for i in dis.get_instructions(c) if i.opname in ('LOAD_GLOBAL', 'LOAD_NAME'))
-                todo.extend(k for k in c.co_consts if inspect.iscode(k))
-            for name in names:
-                v = glob.get(name)
-                if isinstance(v, (torch.nn.Module, torch.Tensor, functools.partial)) or inspect.isfunction(v):
-                    visit(v, depth)
+            held.append(cell.cell_contents)
+        except ValueError:                               # empty cell
+            held.append(None)
+    held.append(getattr(f, '__self__', None))
+    return ('code', tuple(id(h) for h in held)), held
 
-    visit(func, 0)
-    owned = {id(p) for m in mods for p in m.parameters()}
-    tens = [x for x in tens if id(x) not in owned]
-    return mods, tens
+
+def _witness(obj):
+    import weakref
+    try:
+        return weakref.ref(obj)
+    except TypeError:
+        return lambda o=obj: o                           # (not weak-referenceable: held, so its id cannot be recycled)
+
+
+def _graph_leaves(func, y0, t):
+    """The grad-requiring LEAF tensors one evaluation f(t[0], y0) depends on, besides y0 and t themselves - read off the autograd
+    graph (AccumulateGrad nodes).  Exactly what the reference's GradientTape would reach: parameters of modules the callable calls,
+    bare tensors it closes over, anything reached through attribute chains or containers - and nothing it merely could name.
+    One extra evaluation of f per distinct callable (cached: see _callable_key; the entry keeps the callable's identity alive only as ids
+    and is dropped when any leaf's storage was freed)."""
+    import torch
+    key, held = _callable_key(func)
+    hit = _LEAF_CACHE.get(key)
+    if hit is not None:
+        if len(hit[0]) == len(held) and all(w() is h for w, h in zip(hit[0], held)):
+            return hit[1]
+        del _LEAF_CACHE[key]                             # an id was recycled by another object
+    ys = y0 if isinstance(y0, (tuple, list)) else (y0,)
+    with torch.enable_grad():
+        probe = tuple(y.detach().requires_grad_(True) for y in ys)
+        t0 = torch.as_tensor(t).reshape(-1)[0].detach().to(device=ys[0].device, dtype=ys[0].dtype).requires_grad_(True)
+        out = func(t0, probe if isinstance(y0, (tuple, list)) else probe[0])
+    outs = out if isinstance(out, (tuple, list)) else (out,)
+    skip = {id(p) for p in probe} | {id(t0)}
+    leaves, seen, todo = [], set(), [o.grad_fn for o in outs if isinstance(o, torch.Tensor) and o.grad_fn is not None]
+    while todo:
+        node = todo.pop()
+        if node is None or node in seen:                 # (the set holds the node objects: an id alone is recycled as soon as a
+            continue                                     # wrapper is dropped, and a recycled id would hide a whole branch of the graph)
+        seen.add(node)
+        var = getattr(node, 'variable', None)            # AccumulateGrad: a leaf
+        if var is not None:
+            if var.requires_grad and id(var) not in skip and all(var is not l_ for l_ in leaves):
+                leaves.append(var)
+            continue
+        todo.extend(fn for fn, _ in node.next_functions)
+    leaves = tuple(leaves)
+    while len(_LEAF_CACHE) >= 16:
+        _LEAF_CACHE.pop(next(iter(_LEAF_CACHE)))
+    _LEAF_CACHE[key] = ([_witness(h) for h in held], leaves)
+    return leaves
 
 
 def _callable_module(func, mods=(), tens=()):
@@ -196,6 +207,22 @@ def _wants_grad(func, y0):
         return any(p.requires_grad for p in func.parameters())
     if getattr(func, 'kind', 0) or not callable(func):     # a DeviceRHS descriptor: weights are plain device tensors
         return False
-    # a plain callable over trainable state (`lambda t, y: net(y)`): the reference's tape would reach net's parameters
-    mods, tens = _closure_state(func)
-    return bool(tens) or any(p.requires_grad for m in mods for p in m.parameters())
+    # a plain callable over trainable state (`lambda t, y: net(y)`): the reference's tape would reach net's parameters.  Whether THIS
+    # callable does is a property of its autograd graph (one cached probe evaluation), not of what its closure could name.
+    return False if _probe_unsafe(y0) else bool(_graph_leaves_or_none(func, y0))
+
+
+def _probe_unsafe(y0):
+    import torch
+    ys = y0 if isinstance(y0, (tuple, list)) else (y0,)
+    return not all(isinstance(y, torch.Tensor) and y.is_floating_point() for y in ys)
+
+
+def _graph_leaves_or_none(func, y0):
+    """_graph_leaves at t = 0 for the routing decision (`odeint` has not validated t yet); a callable that cannot be evaluated like that
+    decides nothing here - the solver will raise the real error."""
+    import torch
+    try:
+        return _graph_leaves(func, y0, torch.zeros(1))
+    except Exception:
+        return ()

@@ -404,15 +404,22 @@ _NO_ENGINE = set()            # keys whose one-launch engine could not be create
 
 
 def _cached_engine_or_none(key, factory):
-    """_cached_engine, but a NativeError at creation is remembered under `key` and answered with None from then on."""
+    """_cached_engine, but "there is no such kernel for this problem" (MI_ODE_E_INVALID: family / shape / co-residency - a property of the
+    key) is remembered under `key` and answered with None from then on.  A HIP failure at creation (out of memory, a busy device) is a
+    property of the MOMENT: it is answered with None once, with a warning, and the next call tries again (advisor, round 4: a transient
+    failure used to pin the shape to the slow per-step loop for the rest of the process, silently)."""
     if key in _NO_ENGINE:
         return None
     try:
         return _cached_engine(key, factory)
-    except N.NativeError:
-        if len(_NO_ENGINE) > 256:
-            _NO_ENGINE.clear()
-        _NO_ENGINE.add(key)
+    except N.NativeError as e:
+        if '(%d)' % N.E_INVALID in str(e):
+            if len(_NO_ENGINE) > 256:
+                _NO_ENGINE.clear()
+            _NO_ENGINE.add(key)
+        else:
+            import warnings
+            warnings.warn('one-launch engine unavailable for this call (%s): taking the per-step loop; the next call tries again' % e)
         return None
 
 
@@ -623,12 +630,14 @@ class FixedGridODESolver(object):
             y = self.y0[0]
             key = ('fixed', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
                    _tableau_key(self._fused_tableau, None), self._fusion)
-            eng = _cached_engine(key, lambda: _FusedEngine(rhs, y, False, self._fused_tableau, fusion=self._fusion))
-            if default_grid and self.eps == 0.0:
+            # (a family that has no kernel for the requested schedule - the MLP with fusion='stage' has none: whole-attempt kernels
+            # only - takes the per-step loop below, as before its fixed-grid kernel existed; advisor, round 4)
+            eng = _cached_engine_or_none(key, lambda: _FusedEngine(rhs, y, False, self._fused_tableau, fusion=self._fusion))
+            if eng is not None and default_grid and self.eps == 0.0:
                 out = eng.integrate(t.to(torch.float64).numpy(), y)
                 self.stats = eng.stats.as_dict()
                 return (out,)
-            if self._fusion not in (1, 'stage'):
+            if eng is not None and self._fusion not in (1, 'stage'):
                 # a grid of its own (step_size / grid_constructor) and / or eps: still one launch - the kernel walks the grid
                 # and interpolates the requested times linearly inside the step that reaches them (solvers.py:86-115)
                 time_grid = self.grid_constructor(self.func, self.y0, t)
