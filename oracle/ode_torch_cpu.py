@@ -130,7 +130,7 @@ def _interp_fit_dopri5(y0, y1, k, dt):
 def _interp_evaluate(coefficients, t0, t1, t):
     """interp.py:39-67."""
     dtype = coefficients[0].dtype
-    t0, t1, t = (torch.tensor(float(v), dtype=dtype) for v in (t0, t1, t))           # :55-57
+    t0, t1, t = (torch.tensor(float(v.detach() if isinstance(v, torch.Tensor) else v), dtype=dtype) for v in (t0, t1, t))   # :55-57 (times: detached, see _scalar)
     assert bool((t0 <= t) & (t <= t1)), 'invalid interpolation, fails `t0 <= t <= t1`: {}, {}, {}'.format(t0, t, t1)
     x = ((t - t0) / (t1 - t0)).to(dtype)                   # :60
     xs = [torch.tensor(1.0, dtype=dtype), x]

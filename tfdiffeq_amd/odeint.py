@@ -141,10 +141,19 @@ def _graph_leaves(func, y0, t):
             return hit[1]
         del _LEAF_CACHE[key]                             # an id was recycled by another object
     ys = y0 if isinstance(y0, (tuple, list)) else (y0,)
+    # the probe is not one of the solver's evaluations: an integer evaluation counter the callable keeps (`nfe`, as the reference's
+    # DETEST harness and ODEFunc do) is put back afterwards
+    counted = [o for o in (func, getattr(func, '__self__', None)) if isinstance(getattr(o, 'nfe', None), int)]
+    before = [o.nfe for o in counted]
     with torch.enable_grad():
         probe = tuple(y.detach().requires_grad_(True) for y in ys)
         t0 = torch.as_tensor(t).reshape(-1)[0].detach().to(device=ys[0].device, dtype=ys[0].dtype).requires_grad_(True)
         out = func(t0, probe if isinstance(y0, (tuple, list)) else probe[0])
+    for o, n in zip(counted, before):
+        try:
+            o.nfe = n
+        except Exception:
+            pass
     outs = out if isinstance(out, (tuple, list)) else (out,)
     skip = {id(p) for p in probe} | {id(t0)}
     leaves, seen, todo = [], set(), [o.grad_fn for o in outs if isinstance(o, torch.Tensor) and o.grad_fn is not None]
