@@ -13,7 +13,7 @@ import torch
 
 from oracle import ode_numpy as O
 from oracle.rhs_numpy import make_rhs
-from tests.bands import assert_f32                  # per-case float32 bands, tests/golden/fp32_bands.json
+from tests.bands import assert_f32, case_ceiling    # per-case float32 bands, tests/golden/fp32_bands.json
 from tests.golden_util import load, mlp_weights, run_cases, traces_touching_the_threshold
 from tests.rhs_util import device_rhs, sine_exact, torch_rhs
 
@@ -275,7 +275,13 @@ def test_fused_engine_reproduces_reference_runs(name, fusion):
     f32 = d['y0'].dtype == np.float32
     assert tuple(sol.shape) == d['y'].shape and sol.dtype == (torch.float32 if f32 else torch.float64)
     if f32:
-        assert_f32(sol.cpu(), d['y'], 'fused/%s/%s' % (name, fusion))
+        # the case's own a-priori ceiling (tests/bands.case_ceiling) from the reference trace's attempt count; Lorenz expands a
+        # perturbation over its horizon (largest Lyapunov exponent 0.9: e^(0.9 t)), the spiral's cubic field about 4x over [0, 25]
+        att = len(d['trace']) if 'trace' in d.files else 300
+        growth = float(np.exp(0.9 * abs(float(d['t'][-1] - d['t'][0])))) if meta['rhs'] == 'lorenz' else (4.0 if meta['rhs'] == 'cubic_linear' else 1.0)
+        assert_f32(sol.cpu(), d['y'], 'fused/%s/%s' % (name, fusion), ceiling=min(1e-3, case_ceiling(att, 7, growth)))
+        if 'trace' in d.files:                              # float32: the step sequence may fork on a last bit of a reduction - but not far
+            assert abs(stats['n_attempts'] - att) <= max(2, att // 20), (stats, att)
     else:
         assert_band(sol.cpu(), d['y'], RTOL, ATOL, name)
     if 'trace' in d.files and not f32:
@@ -300,7 +306,9 @@ def test_plane_kernel_engine_reproduces_reference_runs(name):
     f32 = d['y0'].dtype == np.float32
     assert tuple(sol.shape) == d['y'].shape
     if f32:
-        assert_f32(sol.cpu(), d['y'], 'planes/%s' % name)
+        att = len(d['trace']) if 'trace' in d.files else 300
+        growth = float(np.exp(0.9 * abs(float(d['t'][-1] - d['t'][0])))) if meta['rhs'] == 'lorenz' else (4.0 if meta['rhs'] == 'cubic_linear' else 1.0)
+        assert_f32(sol.cpu(), d['y'], 'planes/%s' % name, ceiling=min(1e-3, case_ceiling(att, 7, growth)))
     elif name == 'run_sine_adams':
         # the reference's own run is 6.7e-5 off the exact solution here (its test bar is 1e-4, odeint_tests.py:86-92):
         # a step sequence that forks on a 1-ulp pow() difference moves the answer by that much

@@ -227,9 +227,24 @@ class MLP(DeviceRHS):
 
     fixed_grid_fused = True      # euler / rk4 (3/8 rule): the whole fixed-grid integration in one launch (k_fixed_mlp, round 4)
 
+    MAX_DIM, MAX_HIDDEN = 64, 128     # what the tile kernels are instantiated for (weight slices resident in registers), float32 only
+    _told_limits = set()
+
     def supports(self, y0):
-        return (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype == torch.float32
-                and self.dim <= 64 and self.hidden <= 128)
+        ok = (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype == torch.float32
+              and self.dim <= self.MAX_DIM and self.hidden <= self.MAX_HIDDEN)
+        if not ok and y0.dim() >= 1 and y0.shape[-1] == self.dim:
+            # (round-4 review, item 4) the reference's ODEFunc takes any width and tf.float64 (dense_odenet.py:41-92); outside the box the
+            # network is served as a Python callable (rocBLAS products, plane kernels, the controller on the device) - correct, an order of
+            # magnitude slower, and no longer silent: said once per (dtype, dim, hidden)
+            key = (str(y0.dtype), self.dim, self.hidden)
+            if key not in MLP._told_limits:
+                MLP._told_limits.add(key)
+                import warnings
+                warnings.warn('tfdiffeq_amd.rhs.MLP: the fused MLP kernels take float32 states with dim <= %d and hidden <= %d; this network '
+                              '(%s, dim %d, hidden %d) runs as a Python callable on the device-controlled engine instead' % (
+                                  self.MAX_DIM, self.MAX_HIDDEN, str(y0.dtype).replace('torch.', ''), self.dim, self.hidden))
+        return ok
 
     def fill(self, rhs, dtype, device):
         keep = super(MLP, self).fill(rhs, dtype, device)
