@@ -100,3 +100,82 @@ def test_plain_callable_gets_gradients_for_exactly_the_leaves_it_uses():
     y.pow(2).sum().backward()
     for p in (used.weight, used.bias, box.inner.scale):
         assert float((p.grad - p.grad_ref).abs().max()) <= 1e-6 * max(1.0, float(p.grad.abs().max()))
+
+
+def test_sixteen_dimensional_user_system_in_one_launch():
+    """(round-4 review, item 5) rhs.CustomRowLocal beyond dim 8: a ring of eight coupled damped oscillators (dim 16) as user device code -
+    the whole adaptive integration in ONE launch, against the numpy oracle on the same function (float64: same attempt counts, 1e-9)."""
+    import numpy as np
+    from oracle import ode_numpy as O
+    from tfdiffeq_amd import odeint, rhs
+    from tfdiffeq_amd import plugin_examples
+    p0, p1, p2 = 1.0, 0.5, 0.05
+    r = plugin_examples.oscillator_ring(8, p0, p1, p2)          # (prebuilt by __graft_entry__.build(): no hipcc run on the GPU box)
+
+    def f_np(t, y):
+        x, v = y[..., :8], y[..., 8:]
+        return np.concatenate([v, -p0 * x + p1 * (np.roll(x, 1, -1) - 2.0 * x + np.roll(x, -1, -1)) - p2 * v], axis=-1)
+    rng = np.random.default_rng(3)
+    y0 = rng.standard_normal((777, 16))
+    t = np.array([0.0, 1.5, 4.0])
+    sol = odeint(r, torch.tensor(y0, device=dev()), torch.tensor(t), rtol=1e-7, atol=1e-9, method='dopri5')
+    st = dict(odeint.last_stats)
+    ref, rs = O.odeint(f_np, y0, t, rtol=1e-7, atol=1e-9, method='dopri5', return_stats=True)
+    assert st['n_launches'] == 1 and st['status'] == 0
+    assert (st['n_attempts'], st['n_accepted']) == (rs.n_attempts, rs.n_accepted)
+    assert np.abs(sol.cpu().numpy() - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    # ... and a float32 system of dim 32 (two such rings): one launch, inside the float32 a-priori ceiling of its attempt count
+    from tests.bands import case_ceiling, observed
+    r32 = plugin_examples.oscillator_ring(16, p0, p1, p2)
+
+    def f32_np(t, y):
+        x, v = y[..., :16], y[..., 16:]
+        return np.concatenate([v, -p0 * x + p1 * (np.roll(x, 1, -1) - 2.0 * x + np.roll(x, -1, -1)) - p2 * v], axis=-1)
+    y32 = rng.standard_normal((300, 32)).astype(np.float32)
+    sol32 = odeint(r32, torch.tensor(y32, device=dev()), torch.tensor([0.0, 2.0]), rtol=1e-4, atol=1e-6, method='dopri5')
+    st32 = dict(odeint.last_stats)
+    ref32 = O.odeint(f32_np, y32.astype(np.float64), np.array([0.0, 2.0]), rtol=1e-4, atol=1e-6, method='dopri5')
+    assert st32['n_launches'] == 1 and st32['status'] == 0
+    assert observed(sol32.cpu().numpy(), ref32) <= max(2e-4, case_ceiling(st32['n_attempts']))     # (the solve's own tolerance is rtol 1e-4)
+
+
+def test_two_layer_relu_network_of_the_user_runs_on_the_fused_mlp_kernels():
+    """(round-4 review, item 5) rhs.from_sequential: nn.Sequential(Linear, ReLU, Linear) as a device descriptor - relu is idempotent, so the
+    two-layer network IS the three-layer kernel with an identity middle layer; one launch per call, against the float64 numpy oracle on the
+    same function inside the float32 ceiling; the three-layer tanh form maps one to one."""
+    import numpy as np
+    from oracle import ode_numpy as O
+    from tests.bands import case_ceiling, observed
+    from tfdiffeq_amd import odeint, rhs
+    torch.manual_seed(4)
+    net = torch.nn.Sequential(torch.nn.Linear(10, 48), torch.nn.ReLU(), torch.nn.Linear(48, 10)).to(dev())
+    with torch.no_grad():
+        for m in net:
+            if isinstance(m, torch.nn.Linear):
+                m.weight.mul_(0.5)
+    r = rhs.from_sequential(net)
+    assert r.activation == 'relu' and r.hidden == 48 and r.dim == 10
+    y0 = torch.randn(999, 10, device=dev())
+    t = torch.tensor([0.0, 0.5, 1.0])
+    sol = odeint(r, y0, t, rtol=1e-5, atol=1e-6, method='dopri5')
+    st = dict(odeint.last_stats)
+    assert st['n_launches'] == 1 and st['status'] == 0
+    W1, b1 = net[0].weight.detach().cpu().double().numpy().T, net[0].bias.detach().cpu().double().numpy()
+    W2, b2 = net[2].weight.detach().cpu().double().numpy().T, net[2].bias.detach().cpu().double().numpy()
+    ref = O.odeint(lambda t_, y: np.maximum(y @ W1 + b1, 0.0) @ W2 + b2, y0.cpu().double().numpy(), t.numpy().astype(np.float64), rtol=1e-5, atol=1e-6,
+                   method='dopri5')
+    assert observed(sol.cpu().numpy(), ref) <= max(5e-5, case_ceiling(st['n_attempts']))          # (rtol 1e-5 of the solve itself)
+    # the Python callable of the same network takes the device-controlled engine: same function
+    with torch.no_grad():
+        sol_py = odeint(lambda t_, y: net(y), y0, t, rtol=1e-5, atol=1e-6, method='dopri5')
+    assert observed(sol.cpu().numpy(), sol_py.cpu().numpy()) <= 5e-5
+    net3 = torch.nn.Sequential(torch.nn.Linear(6, 32), torch.nn.Tanh(), torch.nn.Linear(32, 32), torch.nn.Tanh(), torch.nn.Linear(32, 6)).to(dev())
+    r3 = rhs.from_sequential(net3)
+    y3 = torch.randn(100, 6, device=dev())
+    with torch.no_grad():
+        a = odeint(r3, y3, t, rtol=1e-5, atol=1e-6, method='dopri5')
+        assert dict(odeint.last_stats)['n_launches'] == 1
+        b = odeint(lambda t_, y: net3(y), y3, t, rtol=1e-5, atol=1e-6, method='dopri5')
+    assert observed(a.cpu().numpy(), b.cpu().numpy()) <= 5e-5
+    with pytest.raises(ValueError):
+        rhs.from_sequential(torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Tanh(), torch.nn.Linear(8, 4)))

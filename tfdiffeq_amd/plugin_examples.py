@@ -30,6 +30,19 @@ def van_der_pol(mu=5.0):
                               torch_fn=lambda t, y: torch.stack([y[..., 1], mu * (1 - y[..., 0] ** 2) * y[..., 1] - y[..., 0]], dim=-1))
 
 
+def oscillator_ring(n=8, k0=1.0, coupling=0.5, damping=0.05):
+    """A ring of n coupled damped oscillators, state (x_0 .. x_{n-1}, v_0 .. v_{n-1}) - dim 2 n: user device code beyond the dim-8 limit of
+    rounds 1-4 (n = 8: dim 16 in float64 registers; n = 16: dim 32, float32)."""
+    body = "\n".join(["for (int i = 0; i < %d; ++i) k[i] = y[%d + i];" % (n, n),
+                      "for (int i = 0; i < %d; ++i) k[%d + i] = -p[0] * y[i] + p[1] * (y[(i + %d) %% %d] - (T)2 * y[i] + y[(i + 1) %% %d]) - p[2] * y[%d + i];"
+                      % (n, n, n - 1, n, n, n)])
+
+    def torch_fn(t, y):
+        x, v = y[..., :n], y[..., n:]
+        return torch.cat([v, -k0 * x + coupling * (torch.roll(x, 1, -1) - 2.0 * x + torch.roll(x, -1, -1)) - damping * v], dim=-1)
+    return rhs.CustomRowLocal(2 * n, body, params=[k0, coupling, damping], torch_fn=torch_fn)
+
+
 def prebuild():
     """Compile every example for both state dtypes (cache hits are free) and drop cache entries that belong to older
     kernel headers (the cache key covers the headers, so those can never be hit again)."""
@@ -39,6 +52,8 @@ def prebuild():
     for f in (lorenz(), forced_oscillator(), van_der_pol()):
         for dt in (torch.float64, torch.float32):
             out.append(_plugin_build.build(f.source(dt)))
+    out.append(_plugin_build.build(oscillator_ring(8).source(torch.float64)))
+    out.append(_plugin_build.build(oscillator_ring(16).source(torch.float32)))
     keep = set(os.path.basename(p)[:-3] for p in out)
     d = _plugin_build.plugin_dir()
     for name in os.listdir(d):

@@ -269,6 +269,41 @@ class MLPTanh(MLP):
         super(MLPTanh, self).__init__(W1, b1, W2, b2, W3, b3, activation='tanh')
 
 
+def from_sequential(seq, time_dependent=False):
+    """A torch.nn.Sequential of Linear layers with ONE kind of activation between them, as the device descriptor of the fused MLP kernels
+    (round-4 review, item 5: a user's own dense network should not have to go through the Python-callable engine):
+
+        Linear(d, h), act, Linear(h, h), act, Linear(h, d)     ->  rhs.MLP, as it is (the shape of the reference's ODEFunc, dense_odenet.py:41-92)
+        Linear(d, h), ReLU, Linear(h, d)                       ->  rhs.MLP with an identity middle layer (relu(relu(z)) = relu(z): the same function,
+                                                                   bit for bit - relu is idempotent; tanh / softplus are not, and raise)
+
+    act: nn.Tanh, nn.ReLU or nn.Softplus (default beta / threshold).  The descriptor holds detached float32 COPIES of the weights in
+    [in, out] layout (call again after an optimizer step).  Limits as rhs.MLP: float32, d <= 64, h <= 128; `odeint(from_sequential(net), y0, t)`
+    then runs the whole call in one launch."""
+    nn = torch.nn
+    layers = list(seq)
+    lin = [m for m in layers if isinstance(m, nn.Linear)]
+    acts = [m for m in layers if not isinstance(m, nn.Linear)]
+    if len(layers) != 2 * len(lin) - 1 or any(isinstance(layers[i], nn.Linear) != (i % 2 == 0) for i in range(len(layers))) or len(lin) not in (2, 3):
+        raise ValueError('from_sequential: expected Linear, act, Linear[, act, Linear]')
+    kinds = {nn.Tanh: 'tanh', nn.ReLU: 'relu', nn.Softplus: 'softplus'}
+    names = {kinds.get(type(a)) for a in acts}
+    if len(names) != 1 or None in names:
+        raise ValueError('from_sequential: one kind of activation (Tanh, ReLU or Softplus) between the layers')
+    act = names.pop()
+    if act == 'softplus' and any(a.beta != 1 or a.threshold != 20 for a in acts):
+        raise ValueError('from_sequential: Softplus with its default beta / threshold only')
+    w = [m.weight.detach().t().contiguous().float() for m in lin]
+    b = [None if m.bias is None else m.bias.detach().float() for m in lin]
+    if len(lin) == 2:
+        if act != 'relu':
+            raise ValueError('from_sequential: a two-layer network maps onto the three-layer kernel only for ReLU (idempotent)')
+        h = w[0].shape[1]
+        w = [w[0], torch.eye(h, dtype=torch.float32, device=w[0].device), w[1]]
+        b = [b[0], None, b[1]]
+    return MLP(w[0], b[0], w[1], b[1], w[2], b[2], activation=act, time_dependent=time_dependent)
+
+
 class PerComponent(object):
     """Lift of a row-local DeviceRHS to TUPLE states: func(t, (y_1, .., y_K)) = (f(t, y_1), .., f(t, y_K)) - what the reference's
     own tuple tests do (tests/problems.py `construct_problem(tuple_state=True)`), K <= 8 components of shape [..., dim] each.
@@ -329,14 +364,16 @@ class CustomRowLocal(DeviceRHS):
     `torch_fn(t, y)` is optional: the same function over torch tensors, used where a Python callable is needed (tuple
     states, `odeint_adjoint`, `options={'force_plane_kernels': True}`)."""
     kind = N.RHS_PLUGIN
-    MAX_DIM = 8
-    row_local = True
+    MAX_DIM = 32                  # round 5 (was 8): a thread still owns one trajectory - the state and its S + 1 stage derivatives are
+    row_local = True              # thread-private.  Up to dim 16 (float64) / 32 (float32) the Dopri5 whole-call kernel keeps them in
+                                  # registers (256 VGPRs, <= 160 B of scratch at dim 16 float64); beyond that they spill to scratch
+                                  # memory - still one launch per call, but the per-attempt time grows with the spill traffic
 
     def __init__(self, dim, body, params=(), torch_fn=None):
         super(CustomRowLocal, self).__init__()
         self.dim = int(dim)
         if not 1 <= self.dim <= self.MAX_DIM:
-            raise ValueError('CustomRowLocal supports 1 <= dim <= %d (one trajectory per thread, state in registers)' % self.MAX_DIM)
+            raise ValueError('CustomRowLocal supports 1 <= dim <= %d (one trajectory per thread, state thread-private)' % self.MAX_DIM)
         self.params = [float(v) for v in params]
         if len(self.params) > 8:
             raise ValueError('at most 8 scalar parameters travel by value')
