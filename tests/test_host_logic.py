@@ -186,7 +186,7 @@ def test_rhs_plugin_builds_and_exports_its_table():
     assert tb.launch_init and tb.launch_step and tb.launch_fixed and tb.persist_fn and tb.persist_planes_fn and tb.multistep_fn
     assert not lib.mi_ode_plugin_get(N.dtype_code(torch.float32))                      # built for one dtype only
     with pytest.raises(ValueError):
-        rhs.CustomRowLocal(9, "k[0] = 0;")
+        rhs.CustomRowLocal(rhs.CustomRowLocal.MAX_DIM + 1, "k[0] = 0;")
 
 
 # ---------------------------------------------------------------------------------------------

@@ -31,12 +31,74 @@ struct OpqComp {               // one state component of one attempt
 
 struct OpqErrCoef { double e[MI_ODE_MAX_K]; };
 
+struct OpqCtlArgs {
+  int ncomp, S;
+  int grid[MI_ODE_MAX_SEGMENTS];
+  double n[MI_ODE_MAX_SEGMENTS];
+  double rtol[MI_ODE_MAX_SEGMENTS], atol[MI_ODE_MAX_SEGMENTS];
+  double alpha[MI_ODE_MAX_STAGES];
+  void* ts;                    // [S] stage times of the next attempt, state dtype
+};
+
+// t_sigma = t0 + alpha_sigma * dt in the state dtype (rk_common.py:45-50)
+__device__ __forceinline__ void opq_stage_times(const Ctl* c, const OpqCtlArgs& A, int is_f32) {
+  for (int s = 0; s < A.S; ++s) {
+    if (is_f32) ((float*)A.ts)[s] = (float)c->t1 + (float)A.alpha[s] * (float)c->dt;
+    else ((double*)A.ts)[s] = c->t1 + A.alpha[s] * c->dt;
+  }
+}
+
+// the first wavefront of a workgroup: fold the block records of every component, apply the controller, publish the next attempt's
+// stage times.  SC1: the records were stored write-through by workgroups of the SAME launch (the norms kernel's last workgroup).
+template <bool SC1>
+__device__ __forceinline__ void opq_controller_apply(Ctl* c, const double* part, const OpqCtlArgs& A, const CtrlParams& P, double (*rec)[kRec]) {
+  for (int k = 0; k < A.ncomp; ++k) reduce_block_records<SC1>(part + (long long)k * kMaxBlocks * kRec, A.grid[k], rec[k]);
+  if (threadIdx.x != 0) return;
+  bool nonfinite = false;
+  for (int k = 0; k < A.ncomp; ++k) { rec[k][R_N] = A.n[k]; nonfinite = nonfinite || rec[k][R_FLAG] != 0.0; }
+  if (nonfinite) {                                             // dopri5.py:99-100
+    c->status |= MI_ODE_ST_NONFINITE; c->done = 1; c->accepted = 0;
+    return;
+  }
+  AttemptState a;
+  a.load(*c);
+  attempt_core_seg(a, rec, A.ncomp, P, A.rtol, A.atol);
+  a.store(*c);
+  opq_stage_times(c, A, P.is_f32);
+}
+
+// (the controller as a launch of its own: kept for the function-level surface; mi_ode_opq_finish folds it into the norms kernel)
+__global__ __launch_bounds__(64) void k_opq_controller(Ctl* c, const double* part, OpqCtlArgs A, CtrlParams P) {
+  __shared__ double rec[MI_ODE_MAX_SEGMENTS][kRec];
+  if (c->done) {                                               // a blind replay after the end: nothing to commit any more
+    if (threadIdx.x == 0) c->accepted = 0;
+    return;
+  }
+  opq_controller_apply<false>(c, part, A, P, rec);
+}
+
+
 // block records {max|y0|, max|y1|, sum err^2, -, nonfinite(y0)} with err = add_n((dt * c_error_j) * k_j) formed in registers
 // (NK known at compile time and two grid-stride elements per trip: all 2 (NK + 2) loads of a trip are in flight together - with a
 // run-time stage count and one element per trip a 64 MB component took 165 us, 3.5 TB/s)
-template <typename T, int NK>
-__global__ __launch_bounds__(256) void k_opq_norms(const Ctl* c, OpqComp P, OpqErrCoef E, long long n, double* part) {
-  if (c->done) return;
+// CTRL (round 5: one graph node fewer per attempt): the LAST workgroup to finish - a device-scope ticket, the write-through recipe of
+// finish_attempt (mi_ode_step_fused.h) - folds the records of every component and applies the controller itself; launched so for the last
+// component only (the earlier components' kernels have completed: same stream).  No workgroup reads Ctl after that: each takes its ticket
+// at its very end, Ctl is only read at kernel start.
+struct OpqCtrlTail {
+  Ctl* c;                        // writable
+  const double* part_all;        // records of every component
+  unsigned* ticket;              // device word, zero between launches
+  OpqCtlArgs A;
+  CtrlParams P;
+};
+
+template <typename T, int NK, bool CTRL>
+__global__ __launch_bounds__(256) void k_opq_norms(const Ctl* c, OpqComp P, OpqErrCoef E, long long n, double* part, OpqCtrlTail Z) {
+  if (c->done) {
+    if (CTRL && blockIdx.x == 0 && threadIdx.x == 0) Z.c->accepted = 0;   // a blind replay after the end: nothing to commit any more
+    return;
+  }
   const T hs = (T)c->dt;                                       // rk_common.py:46
   const T* y0 = (const T*)P.y0;
   const T* y1 = (const T*)P.y1;
@@ -70,58 +132,34 @@ __global__ __launch_bounds__(256) void k_opq_norms(const Ctl* c, OpqComp P, OpqE
     fold(y0[i], y1[i], k0);
   }
   __shared__ double red[80];
-  block_reduce_store(acc, red, part + (long long)blockIdx.x * kRec);
+  if constexpr (!CTRL) {
+    block_reduce_store(acc, red, part + (long long)blockIdx.x * kRec);
+  } else {
+    block_reduce_store<true>(acc, red, part + (long long)blockIdx.x * kRec);
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const unsigned t = __hip_atomic_fetch_add(Z.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = (t == gridDim.x - 1);
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __shared__ double rec[MI_ODE_MAX_SEGMENTS][kRec];
+    opq_controller_apply<true>(Z.c, Z.part_all, Z.A, Z.P, rec);
+    if (threadIdx.x == 0) __hip_atomic_store(Z.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
-template <typename T>
-static int opq_norms_t(int nk, dim3 g, hipStream_t st, const Ctl* ctl, const OpqComp& P, const OpqErrCoef& E, long long n, double* part) {
+template <typename T, bool CTRL>
+static int opq_norms_t(int nk, dim3 g, hipStream_t st, const Ctl* ctl, const OpqComp& P, const OpqErrCoef& E, long long n, double* part, const OpqCtrlTail& Z) {
   switch (nk) {
-    case 2: hipLaunchKernelGGL((k_opq_norms<T, 2>), g, dim3(256), 0, st, ctl, P, E, n, part); break;
-    case 4: hipLaunchKernelGGL((k_opq_norms<T, 4>), g, dim3(256), 0, st, ctl, P, E, n, part); break;
-    case 7: hipLaunchKernelGGL((k_opq_norms<T, 7>), g, dim3(256), 0, st, ctl, P, E, n, part); break;
-    case 14: hipLaunchKernelGGL((k_opq_norms<T, 14>), g, dim3(256), 0, st, ctl, P, E, n, part); break;
+    case 2: hipLaunchKernelGGL((k_opq_norms<T, 2, CTRL>), g, dim3(256), 0, st, ctl, P, E, n, part, Z); break;
+    case 4: hipLaunchKernelGGL((k_opq_norms<T, 4, CTRL>), g, dim3(256), 0, st, ctl, P, E, n, part, Z); break;
+    case 7: hipLaunchKernelGGL((k_opq_norms<T, 7, CTRL>), g, dim3(256), 0, st, ctl, P, E, n, part, Z); break;
+    case 14: hipLaunchKernelGGL((k_opq_norms<T, 14, CTRL>), g, dim3(256), 0, st, ctl, P, E, n, part, Z); break;
     default: mi_set_error("opq_finish: unsupported stage count"); return MI_ODE_E_INVALID;
   }
   return 0;
-}
-
-struct OpqCtlArgs {
-  int ncomp, S;
-  int grid[MI_ODE_MAX_SEGMENTS];
-  double n[MI_ODE_MAX_SEGMENTS];
-  double rtol[MI_ODE_MAX_SEGMENTS], atol[MI_ODE_MAX_SEGMENTS];
-  double alpha[MI_ODE_MAX_STAGES];
-  void* ts;                    // [S] stage times of the next attempt, state dtype
-};
-
-// t_sigma = t0 + alpha_sigma * dt in the state dtype (rk_common.py:45-50)
-__device__ __forceinline__ void opq_stage_times(const Ctl* c, const OpqCtlArgs& A, int is_f32) {
-  for (int s = 0; s < A.S; ++s) {
-    if (is_f32) ((float*)A.ts)[s] = (float)c->t1 + (float)A.alpha[s] * (float)c->dt;
-    else ((double*)A.ts)[s] = c->t1 + A.alpha[s] * c->dt;
-  }
-}
-
-// one wavefront: fold the block records of every component, apply the controller, publish the next attempt's stage times
-__global__ __launch_bounds__(64) void k_opq_controller(Ctl* c, const double* part, OpqCtlArgs A, CtrlParams P) {
-  __shared__ double rec[MI_ODE_MAX_SEGMENTS][kRec];
-  if (c->done) {                                               // a blind replay after the end: nothing to commit any more
-    if (threadIdx.x == 0) c->accepted = 0;
-    return;
-  }
-  for (int k = 0; k < A.ncomp; ++k) reduce_block_records(part + (long long)k * kMaxBlocks * kRec, A.grid[k], rec[k]);
-  if (threadIdx.x != 0) return;
-  bool nonfinite = false;
-  for (int k = 0; k < A.ncomp; ++k) { rec[k][R_N] = A.n[k]; nonfinite = nonfinite || rec[k][R_FLAG] != 0.0; }
-  if (nonfinite) {                                             // dopri5.py:99-100
-    c->status |= MI_ODE_ST_NONFINITE; c->done = 1; c->accepted = 0;
-    return;
-  }
-  AttemptState a;
-  a.load(*c);
-  attempt_core_seg(a, rec, A.ncomp, P, A.rtol, A.atol);
-  a.store(*c);
-  opq_stage_times(c, A, P.is_f32);
 }
 
 __global__ void k_opq_times(const Ctl* c, OpqCtlArgs A, int is_f32) {
@@ -187,6 +225,7 @@ struct mi_ode_opq {
   Ctl* ctl;                    // device
   Ctl* ctl_host;               // pinned
   double* partials;            // [n_comp][kMaxBlocks][kRec]
+  unsigned* ticket;            // last-workgroup-done counter of the norms kernel
   double* t_out_dev;
   double* t_out_host;          // pinned
   int t_out_cap;
@@ -205,6 +244,7 @@ extern "C" int mi_ode_opq_destroy(mi_ode_opq_handle h) {
   if (h == nullptr) return 0;
   if (h->ctl) (void)hipFree(h->ctl);
   if (h->partials) (void)hipFree(h->partials);
+  if (h->ticket) (void)hipFree(h->ticket);
   if (h->t_out_dev) (void)hipFree(h->t_out_dev);
   if (h->ctl_host) (void)hipHostFree(h->ctl_host);
   if (h->t_out_host) (void)hipHostFree(h->t_out_host);
@@ -233,6 +273,8 @@ extern "C" int mi_ode_opq_create(const mi_ode_opq_desc* d, mi_ode_opq_handle* ou
   h->S = S; h->nk = nk;
   hipError_t e = hipMalloc((void**)&h->ctl, sizeof(Ctl));
   if (e == hipSuccess) e = hipMalloc((void**)&h->partials, (size_t)d->n_comp * kMaxBlocks * kRec * sizeof(double));
+  if (e == hipSuccess) e = hipMalloc((void**)&h->ticket, sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(h->ticket, 0, sizeof(unsigned));
   if (e == hipSuccess) e = hipHostMalloc((void**)&h->ctl_host, sizeof(Ctl));
   h->t_out_cap = 1024;                           // (allocated up front: a captured graph holds the device address)
   if (e == hipSuccess) e = hipMalloc((void**)&h->t_out_dev, (size_t)h->t_out_cap * sizeof(double));
@@ -330,11 +372,19 @@ extern "C" int mi_ode_opq_finish(mi_ode_opq_handle h, const void* const* y0_dev,
     }
     if (!P.y0 || !P.y1) { mi_set_error("opq_finish: null state"); return MI_ODE_E_INVALID; }
     double* part = h->partials + (long long)c * kMaxBlocks * kRec;
-    const int rcn = h->is_f32 ? opq_norms_t<float>(h->nk, dim3(h->grid[c]), st, h->ctl, P, h->ec, (long long)h->d.n[c], part)
-                              : opq_norms_t<double>(h->nk, dim3(h->grid[c]), st, h->ctl, P, h->ec, (long long)h->d.n[c], part);
+    OpqCtrlTail Z;
+    memset(&Z, 0, sizeof(Z));
+    int rcn;
+    if (c + 1 < h->d.n_comp) {
+      rcn = h->is_f32 ? opq_norms_t<float, false>(h->nk, dim3(h->grid[c]), st, h->ctl, P, h->ec, (long long)h->d.n[c], part, Z)
+                      : opq_norms_t<double, false>(h->nk, dim3(h->grid[c]), st, h->ctl, P, h->ec, (long long)h->d.n[c], part, Z);
+    } else {                                     // the last component's kernel also runs the controller (its last workgroup)
+      Z.c = h->ctl; Z.part_all = h->partials; Z.ticket = h->ticket; Z.A = h->ca; Z.P = h->cp;
+      rcn = h->is_f32 ? opq_norms_t<float, true>(h->nk, dim3(h->grid[c]), st, h->ctl, P, h->ec, (long long)h->d.n[c], part, Z)
+                      : opq_norms_t<double, true>(h->nk, dim3(h->grid[c]), st, h->ctl, P, h->ec, (long long)h->d.n[c], part, Z);
+    }
     if (rcn != 0) return rcn;
   }
-  hipLaunchKernelGGL(k_opq_controller, dim3(1), dim3(64), 0, st, h->ctl, (const double*)h->partials, h->ca, h->cp);
   MI_HIP(hipGetLastError());
   return 0;
 }
