@@ -72,9 +72,10 @@ def assert_f32(got, ref, key, ceiling=CEILING):
         return
     b = _bands().get(key)
     assert b is not None, 'no float32 band for %r in tests/golden/fp32_bands.json (scripts/measure_fp32_bands.sh records them)' % key
-    if b['observed'] == 0.0 and b.get('runs', 1) >= 2:
+    if b['observed'] == 0.0 and b.get('runs', 1) >= 2 and not key.endswith('vs_oracle'):
         # Round 5: a comparison that was bit-exact in every recorded run (plane kernels against the float32 fixtures, fused against plane
-        # kernels on elementwise systems) IS an exactness statement - it is held to equality, not to the 2e-6 floor of a band
+        # kernels on elementwise systems) IS an exactness statement - it is held to equality, not to the 2e-6 floor of a band.  Not for
+        # a comparison against the CPU oracle's own matrix product (`..vs_oracle`): equality there would be a coincidence of two libraries
         assert obs == 0.0, '%s: was bit-exact when recorded (two runs), now max |got - ref| / (1 + |ref|) = %.3e' % (key, obs)
         return
     assert obs <= b['band'], '%s: max |got - ref| / (1 + |ref|) = %.3e outside the band %.1e (observed when recorded: %.3e)' % (
