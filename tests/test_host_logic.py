@@ -343,7 +343,7 @@ def test_committed_bench_line_carries_the_contract():
     """The bench.py line committed under profiles/ (what DESIGN.md section 5 quotes) has every field of the bench contract, the metric
     BASELINE.json names, and figures that are consistent with each other."""
     import json
-    line = open(os.path.join(ROOT, 'profiles', 'r04_bench_config4.json')).read().strip().split('\n')[-1]
+    line = open(os.path.join(ROOT, 'profiles', 'r05_bench_config4.json')).read().strip().split('\n')[-1]
     d = json.loads(line)
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling', 'vs_baseline', 'dtype',
               'data', 'config', 'roofline', 'cpu_baseline'):
@@ -362,6 +362,11 @@ def test_committed_bench_line_carries_the_contract():
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
     assert c['kind'] in ('reference', 'port') and c['cores'] >= 1 and d['parity_max_abs_diff'] < 1e-12
+    # round 5: the transport that actually carried the controller records, the hand-off cost and the board's own telemetry ride along
+    cfg = d['config']
+    assert cfg['records_transport'] == 'single rank' and cfg['rccl_ranks'] == 0 and cfg['handoff_us'] > 0
+    smi = cfg['smi']['sustained_loop']['cards'][0]
+    assert smi['power_w']['max'] < smi['power_cap_w']['min'] and 2000 < smi['sclk_mhz']['max'] <= 2400
 
 
 def test_bench_refuses_more_ranks_than_devices_with_one_line():
