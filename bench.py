@@ -419,7 +419,7 @@ def main():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
         import datetime
-        pg_timeout = datetime.timedelta(seconds=int(os.environ.get('BENCH_PG_TIMEOUT_S', '180')))   # (default 10 min: a dead rank should cost minutes, not the run)
+        pg_timeout = datetime.timedelta(seconds=int(os.environ.get('BENCH_PG_TIMEOUT_S', '180')))   # (default 3 min: a dead rank should cost minutes, not the run)
         if share:
             dist.init_process_group(backend='gloo', rank=rank, world_size=world, timeout=pg_timeout)
         else:

@@ -354,7 +354,8 @@ int mi_ode_outer_reduce(int32_t dtype, int64_t batch, int32_t dim, const void* y
 /* tfdiffeq/adjoint.py:148-160: odeint(augmented_dynamics, (y, adj_y, adj_t, adj_params), [t_i, t_{i-1}]) for f(t, y) = y W + b,
  * dopri5 over the four components with the reference's per-component error ratios, python max() of them, the initial step over all
  * components (misc.py:183-287) and dense output at t_end (interp.py:6-67).  y and adj_y run on config 4's tile kernels (W and W^T
- * resident in registers); adj_params needs ONE product over the batch per accepted step (csrc/mi_ode_linadj.h).  State dtype
+ * resident in registers); adj_params needs ONE product over the batch per INTERVAL - y0^T a0, carried from step to step through the
+ * stage polynomials of the two linear systems (csrc/mi_ode_linadj.h, docs/KERNELS.md 4e).  State dtype
  * float32 or float64, 1 <= dim <= 128.  adj_params is one flat vector: W's gradient [dim, dim] in W's own [in, out] layout, then
  * (with a bias) the dim entries of b's. */
 typedef struct mi_ode_linadj_desc {
