@@ -6,6 +6,7 @@
 //   8. family C (ABI 11): f evaluated by a kernel of THIS program between the library's launches, the controller on the device, one
 //      attempt captured as a hipGraph and replayed in blind chunks
 //   9. (ABI 12) mi_ode_outer_reduce vs a host loop
+//  10. (ABI 13) mi_ode_linadj_segment: a backward interval of the linear system's adjoint in one launch vs a fine RK4 solve written here
 // Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -I include tests/c_abi/c_abi_smoke.cpp -L tfdiffeq_amd -lmi_ode
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -35,6 +36,7 @@ static void lorenz(const double* y, double* f) {
 }
 
 int main() {
+  setvbuf(stdout, nullptr, _IOLBF, 0);                     // (a sanitizer abort at process exit must not swallow the report lines)
   const int B = 1000, D = 3, T = 41;
   const long long n = (long long)B * D;
   std::vector<double> y0(n), t(T);
@@ -477,6 +479,87 @@ int main() {
     if (!(md9 < 1e-13)) { printf("FAIL outer_reduce\n"); return 1; }
     if (mi_ode_outer_reduce(MI_ODE_F64, OB, 200, dy9, da9, -1.0, dw9, db9, ws9, nullptr) >= 0) { printf("FAIL outer_reduce accepted dim 200\n"); return 1; }
     CK(hipFree(dy9)); CK(hipFree(da9)); CK(hipFree(dw9)); CK(hipFree(db9)); CK(hipFree(ws9));
+  }
+  // ---- 10. (ABI 13) mi_ode_linadj_*: one backward interval of odeint_adjoint for f = y W + b in ONE launch, t = 1 -> 0, against a fine RK4
+  //          solve of the augmented system (y' = yW + b, a' = -a W^T, dW' = -y^T a, db' = -sum_rows a) written here ----
+  {
+    const int LB = 70, LD = 8, NP = LD * LD + LD;
+    std::vector<double> W((size_t)LD * LD), bb(LD), y1((size_t)LB * LD), a1((size_t)LB * LD), th(NP, 0.0);
+    for (int i = 0; i < LD; ++i) {
+      bb[i] = 0.05 * cos(1.3 * i);
+      for (int j = 0; j < LD; ++j) W[(size_t)i * LD + j] = (i == j ? -0.4 : 0.0) + 0.3 * sin(0.7 * i - 1.1 * j) / sqrt((double)LD);
+    }
+    for (int r = 0; r < LB; ++r)
+      for (int c = 0; c < LD; ++c) { y1[(size_t)r * LD + c] = sin(0.3 * r + 0.9 * c); a1[(size_t)r * LD + c] = cos(0.17 * r - 0.4 * c) / LB; }
+    // host reference
+    std::vector<double> ry = y1, ra = a1, rth(NP, 0.0);
+    auto F = [&](const std::vector<double>& y, const std::vector<double>& a, std::vector<double>& fy, std::vector<double>& fa, std::vector<double>& fth) {
+      std::fill(fth.begin(), fth.end(), 0.0);
+      for (int r = 0; r < LB; ++r)
+        for (int c = 0; c < LD; ++c) {
+          double sy = bb[c], sa = 0.0;
+          for (int k = 0; k < LD; ++k) { sy += y[(size_t)r * LD + k] * W[(size_t)k * LD + c]; sa -= a[(size_t)r * LD + k] * W[(size_t)c * LD + k]; }
+          fy[(size_t)r * LD + c] = sy; fa[(size_t)r * LD + c] = sa;
+          fth[LD * LD + c] -= a[(size_t)r * LD + c];
+          for (int k = 0; k < LD; ++k) fth[(size_t)k * LD + c] -= y[(size_t)r * LD + k] * a[(size_t)r * LD + c];
+        }
+    };
+    {
+      const int NS = 400;
+      const double dt = -1.0 / NS;
+      const size_t m = (size_t)LB * LD;
+      std::vector<double> ky[4], ka[4], kt[4], ty(m), ta(m);
+      for (int q = 0; q < 4; ++q) { ky[q].resize(m); ka[q].resize(m); kt[q].resize(NP); }
+      for (int sidx = 0; sidx < NS; ++sidx) {
+        F(ry, ra, ky[0], ka[0], kt[0]);
+        for (size_t i = 0; i < m; ++i) { ty[i] = ry[i] + 0.5 * dt * ky[0][i]; ta[i] = ra[i] + 0.5 * dt * ka[0][i]; }
+        F(ty, ta, ky[1], ka[1], kt[1]);
+        for (size_t i = 0; i < m; ++i) { ty[i] = ry[i] + 0.5 * dt * ky[1][i]; ta[i] = ra[i] + 0.5 * dt * ka[1][i]; }
+        F(ty, ta, ky[2], ka[2], kt[2]);
+        for (size_t i = 0; i < m; ++i) { ty[i] = ry[i] + dt * ky[2][i]; ta[i] = ra[i] + dt * ka[2][i]; }
+        F(ty, ta, ky[3], ka[3], kt[3]);
+        for (size_t i = 0; i < m; ++i) {
+          ry[i] += dt / 6 * (ky[0][i] + 2 * ky[1][i] + 2 * ky[2][i] + ky[3][i]);
+          ra[i] += dt / 6 * (ka[0][i] + 2 * ka[1][i] + 2 * ka[2][i] + ka[3][i]);
+        }
+        for (int i = 0; i < NP; ++i) rth[i] += dt / 6 * (kt[0][i] + 2 * kt[1][i] + 2 * kt[2][i] + kt[3][i]);
+      }
+    }
+    mi_ode_linadj_desc ld;
+    memset(&ld, 0, sizeof(ld));
+    if (mi_ode_sizeof(8) != (int64_t)sizeof(ld)) { printf("FAIL sizeof(mi_ode_linadj_desc)\n"); return 1; }
+    ld.batch = LB; ld.dim = LD; ld.dtype = MI_ODE_F64;
+    ld.tableau = d.tableau;                                              // the dopri5 tableau of section 2
+    ld.rtol = 1e-9; ld.atol = 1e-11; ld.safety = 0.9; ld.ifactor = 10.0; ld.dfactor = 0.2; ld.order = 5; ld.init_order = 4;
+    ld.max_num_steps = 1000000;
+    mi_ode_linadj_handle lh = nullptr;
+    MI(mi_ode_linadj_create(&ld, &lh));
+    double *dW = nullptr, *db = nullptr, *dy = nullptr, *da = nullptr, *dat = nullptr, *dth = nullptr, *oa = nullptr, *oat = nullptr, *oth = nullptr;
+    CK(hipMalloc((void**)&dW, W.size() * 8)); CK(hipMalloc((void**)&db, bb.size() * 8)); CK(hipMalloc((void**)&dy, y1.size() * 8));
+    CK(hipMalloc((void**)&da, a1.size() * 8)); CK(hipMalloc((void**)&dat, 8)); CK(hipMalloc((void**)&dth, NP * 8));
+    CK(hipMalloc((void**)&oa, a1.size() * 8)); CK(hipMalloc((void**)&oat, 8)); CK(hipMalloc((void**)&oth, NP * 8));
+    CK(hipMemcpy(dW, W.data(), W.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db, bb.data(), bb.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dy, y1.data(), y1.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(da, a1.data(), a1.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(dat, 0, 8)); CK(hipMemcpy(dth, th.data(), NP * 8, hipMemcpyHostToDevice));
+    mi_ode_stats ls;
+    double hs[2] = {0, 0};
+    const int rcl = mi_ode_linadj_segment(lh, dW, db, dy, da, dat, dth, nullptr, 1.0, 0.0, oa, oat, oth, nullptr, hs, &ls, nullptr);
+    if (rcl != 0) { printf("FAIL linadj segment status %d %s\n", rcl, mi_ode_last_error()); return 1; }
+    std::vector<double> ga(a1.size()), gth(NP);
+    double gat = 1.0;
+    CK(hipMemcpy(ga.data(), oa, ga.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(gth.data(), oth, NP * 8, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(&gat, oat, 8, hipMemcpyDeviceToHost));
+    double mda = 0.0, mdt = 0.0;
+    for (size_t i = 0; i < ga.size(); ++i) mda = fmax(mda, fabs(ga[i] - ra[i]));
+    for (int i = 0; i < NP; ++i) mdt = fmax(mdt, fabs(gth[i] - rth[i]));
+    printf("linadj (70 x 8, fp64, t 1 -> 0): launches %d attempts %lld accepted %lld, max |adj_y - fine rk4| = %.3e, |adj_params - fine rk4| = %.3e, adj_t %.1e\n",
+           (int)ls.n_launches, (long long)ls.n_attempts, (long long)ls.n_accepted, mda, mdt, gat);
+    if (ls.n_launches != 1 || ls.n_accepted < 2 || !(mda < 1e-8) || !(mdt < 1e-8) || gat != 0.0) { printf("FAIL linadj\n"); return 1; }
+    ld.dim = 200;                                                                  // outside the kernel's box: refused, not mis-run
+    mi_ode_linadj_handle bad = nullptr;
+    if (mi_ode_linadj_create(&ld, &bad) >= 0) { printf("FAIL linadj accepted dim 200\n"); return 1; }
+    MI(mi_ode_linadj_destroy(lh));
+    CK(hipFree(dW)); CK(hipFree(db)); CK(hipFree(dy)); CK(hipFree(da)); CK(hipFree(dat)); CK(hipFree(dth)); CK(hipFree(oa)); CK(hipFree(oat)); CK(hipFree(oth));
   }
   printf("C-ABI OK (abi %d)\n", mi_ode_abi_version());
   return 0;
