@@ -55,6 +55,38 @@ struct MlpGeom {
 // fp32 VALU shares its issue slots with the fp32 matrix pipe, scripts/micro/mfma_fill.hip: the activation was ~1/5 of the
 // kernel).  Max relative error 5e-7 (absolute 1.3e-7) over the whole range (the reference's tf.tanh is a rational fp32 approximation of the
 // same class, not a correctly rounded one either).
+// (Round 5 A/B, -DMI_MLP_TANH_RATIONAL: x P(x^2) / Q(x^2) on [-7.9, 7.9], deg P = 5, deg Q = 3 - a least-squares / Lawson fit made for this
+// file, 3.0e-7 relative in fp32 with fused multiply-adds - ONE transcendental instruction and 12 others per value instead of two and
+// 15, all packed (the measured build also started the layers' MFMA chains from the bias instead of adding it behind them).  Measured
+// (profiles/r05_tanh_ab.txt): config 5 0.379 -> 0.374 ms per call, kernel 0.339 -> 0.330 ms; against a float64
+// solve the fused adjoint's gradients are closer with the form below in two cases of three (theta 2.1e-7 vs 1.1e-6, 2.6e-5 vs 3.2e-5,
+// 5.0e-6 vs 4.1e-6).  A third fewer issue slots for 1.3 - 2.6 %: v_exp_f32 / v_rcp_f32 are not quarter rate on this part, and the
+// activation is less of the critical path than its instruction count says.  Not adopted: the bits of every MLP path would change for that.)
+#ifdef MI_MLP_TANH_RATIONAL
+#define MI_TANH_P1 1.298491806e-01f
+#define MI_TANH_P2 2.992105903e-03f
+#define MI_TANH_P3 9.939260963e-06f
+#define MI_TANH_P4 -1.490644053e-08f
+#define MI_TANH_P5 2.410562548e-11f
+#define MI_TANH_Q1 4.631823599e-01f
+#define MI_TANH_Q2 2.405313030e-02f
+#define MI_TANH_Q3 2.380880178e-04f
+#define MI_TANH_XM 7.9f
+__device__ __forceinline__ float mlp_tanh(float x) {
+  const float xc = __builtin_amdgcn_fmed3f(x, -MI_TANH_XM, MI_TANH_XM);
+  const float u = xc * xc;
+  float p = __builtin_fmaf(MI_TANH_P5, u, MI_TANH_P4);
+  p = __builtin_fmaf(p, u, MI_TANH_P3);
+  p = __builtin_fmaf(p, u, MI_TANH_P2);
+  p = __builtin_fmaf(p, u, MI_TANH_P1);
+  p = __builtin_fmaf(p, u, 1.0f);
+  float q = __builtin_fmaf(MI_TANH_Q3, u, MI_TANH_Q2);
+  q = __builtin_fmaf(q, u, MI_TANH_Q1);
+  q = __builtin_fmaf(q, u, 1.0f);
+  const float t = (xc * p) * __builtin_amdgcn_rcpf(q);
+  return __builtin_fmaf(0.0f, x, t);
+}
+#else
 __device__ __forceinline__ float mlp_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(x * 2.8853900817779268f);      // exp(2x); +inf / 0 at the ends give exactly +-1
   const float big = 1.0f - 2.0f * __builtin_amdgcn_rcpf(e + 1.0f);
@@ -62,6 +94,7 @@ __device__ __forceinline__ float mlp_tanh(float x) {
   const float small = x * (1.0f + x2 * (-0.33333334f + x2 * (0.13333334f + x2 * -0.053968254f)));
   return fabsf(x) < 0.25f ? small : big;
 }
+#endif
 
 // The hidden activation: mi_ode_rhs.scalars[0], a TEMPLATE parameter of the kernels (a run-time switch made the compiler evaluate
 // every branch and select: config 5 went from 0.42 to 0.54 ms).  0 = tanh (above); 1 = relu - the DEFAULT of the reference's
@@ -89,6 +122,26 @@ __device__ __forceinline__ float mlp_act(float x) {
 // not overlap with the matrix pipe of their SIMD on this part (profiles/r03_mfma_pair.txt) and tanh is ~3/4 of the vector
 // work of an evaluation, so halving the issue slots of its arithmetic is worth more than anything a schedule can hide.
 typedef float mlp_f2 __attribute__((ext_vector_type(2)));
+#ifdef MI_MLP_TANH_RATIONAL
+__device__ __forceinline__ mlp_f2 mlp_f2_splat(float v) { mlp_f2 r = {v, v}; return r; }
+__device__ __forceinline__ mlp_f2 mlp_tanh2(mlp_f2 x) {                        // mlp_tanh on two values: the same operations, the same bits
+  mlp_f2 xc;
+  xc.x = __builtin_amdgcn_fmed3f(x.x, -MI_TANH_XM, MI_TANH_XM); xc.y = __builtin_amdgcn_fmed3f(x.y, -MI_TANH_XM, MI_TANH_XM);
+  const mlp_f2 u = xc * xc;
+  mlp_f2 p = __builtin_elementwise_fma(mlp_f2_splat(MI_TANH_P5), u, mlp_f2_splat(MI_TANH_P4));
+  p = __builtin_elementwise_fma(p, u, mlp_f2_splat(MI_TANH_P3));
+  p = __builtin_elementwise_fma(p, u, mlp_f2_splat(MI_TANH_P2));
+  p = __builtin_elementwise_fma(p, u, mlp_f2_splat(MI_TANH_P1));
+  p = __builtin_elementwise_fma(p, u, mlp_f2_splat(1.0f));
+  mlp_f2 q = __builtin_elementwise_fma(mlp_f2_splat(MI_TANH_Q3), u, mlp_f2_splat(MI_TANH_Q2));
+  q = __builtin_elementwise_fma(q, u, mlp_f2_splat(MI_TANH_Q1));
+  q = __builtin_elementwise_fma(q, u, mlp_f2_splat(1.0f));
+  mlp_f2 r;
+  r.x = __builtin_amdgcn_rcpf(q.x); r.y = __builtin_amdgcn_rcpf(q.y);
+  const mlp_f2 t = (xc * p) * r;
+  return __builtin_elementwise_fma(mlp_f2_splat(0.0f), x, t);
+}
+#else
 __device__ __forceinline__ mlp_f2 mlp_tanh2(mlp_f2 x) {
   const mlp_f2 t = x * 2.8853900817779268f;
   mlp_f2 e;
@@ -104,6 +157,7 @@ __device__ __forceinline__ mlp_f2 mlp_tanh2(mlp_f2 x) {
   out.y = fabsf(x.y) < 0.25f ? small.y : big.y;
   return out;
 }
+#endif
 template <int ACT>
 __device__ __forceinline__ void mlp_act_pair(float a, float b, float bias, float& oa, float& ob) {
   if constexpr (ACT == MLP_ACT_TANH) {
