@@ -1,6 +1,7 @@
 """GPU tests (-m gpu) added in round 5 outside the linear adjoint (tests/test_gpu_linadj.py): the advisor's round-4 findings."""
 import warnings
 
+import numpy as np
 import pytest
 import torch
 
@@ -179,3 +180,75 @@ def test_two_layer_relu_network_of_the_user_runs_on_the_fused_mlp_kernels():
     assert observed(a.cpu().numpy(), b.cpu().numpy()) <= 5e-5
     with pytest.raises(ValueError):
         rhs.from_sequential(torch.nn.Sequential(torch.nn.Linear(4, 8), torch.nn.Tanh(), torch.nn.Linear(8, 4)))
+
+
+# ---------------------------------------------------------------------------------------------
+# the Adams family for the ODEFunc network in one launch (round-4 review, item 7: "Adams kernels for the MLP family", and float64 /
+# widths beyond the tile kernels' box): a thread per state element, the three layers through LDS (csrc/mi_ode_stage_rowlocal.h: RhsMlpCoop)
+# ---------------------------------------------------------------------------------------------
+def _np_mlp(Ws, bs, act, time_dependent, dtype):
+    acts = {'tanh': np.tanh, 'relu': lambda x: np.maximum(x, dtype(0)), 'softplus': lambda x: np.logaddexp(x, dtype(0)).astype(dtype)}
+    a = acts[act]
+    Ws = [np.asarray(w, dtype=dtype) for w in Ws]
+    bs = [np.asarray(b, dtype=dtype) for b in bs]
+
+    def f(t, y):
+        h = y
+        if time_dependent:
+            h = np.concatenate([np.full(y.shape[:-1] + (1,), dtype(t), dtype=dtype), y], axis=-1)
+        h = a(h @ Ws[0] + bs[0])
+        h = a(h @ Ws[1] + bs[1])
+        return (h @ Ws[2] + bs[2]).astype(dtype)
+    return f
+
+
+@pytest.mark.parametrize('method', ['adams', 'explicit_adams', 'fixed_adams'])
+@pytest.mark.parametrize('dim,hidden,batch,act,td,dtype', [
+    (2, 50, 1, 'tanh', False, np.float64), (8, 16, 300, 'softplus', True, np.float64), (64, 128, 40, 'tanh', False, np.float64),
+    (100, 200, 7, 'relu', False, np.float64), (16, 32, 1000, 'tanh', True, np.float32)])
+def test_adams_family_for_the_mlp_in_one_launch(method, dim, hidden, batch, act, td, dtype):
+    """'adams' / 'explicit_adams' / 'fixed_adams' on rhs.MLP: one launch, float64 and widths the tile kernels do not take included;
+    against the numpy restatement of the reference's solvers over a numpy network (attempt counts exact for 'adams'), and against the
+    host loop of the same solver over the same network as a Python callable."""
+    from oracle import adams_numpy as OA
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(1000 + dim + hidden)
+    sc = 0.7
+    Ws = [sc * rng.standard_normal((dim + (1 if td else 0), hidden)) / np.sqrt(dim), sc * rng.standard_normal((hidden, hidden)) / np.sqrt(hidden),
+          sc * rng.standard_normal((hidden, dim)) / np.sqrt(hidden)]
+    bs = [0.1 * rng.standard_normal(hidden), 0.1 * rng.standard_normal(hidden), 0.1 * rng.standard_normal(dim)]
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    f = rhs.MLP(*[torch.tensor(v, dtype=tdt) for pair in zip(Ws, bs) for v in pair], activation=act, time_dependent=td)
+    fn = _np_mlp(Ws, bs, act, td, dtype)
+    y0 = rng.standard_normal((batch, dim)).astype(dtype)
+    f64 = dtype == np.float64
+    t = np.linspace(0., 1.5, 4) if method == 'adams' else np.linspace(0., 0.5, 26)
+    tol = dict(rtol=1e-6, atol=1e-8) if f64 else dict(rtol=1e-4, atol=1e-6)
+    for tt in (t, -t):
+        got = odeint(f, torch.tensor(y0, device=dev()), torch.tensor(tt), method=method, **tol)
+        st = dict(odeint.last_stats)
+        assert st.get('engine', '').startswith('fused') and st['n_launches'] == 1 and st['status'] == 0, st
+        ref, rst = OA.odeint(fn, y0, tt, method=method, return_stats=True, **tol)
+        scale = max(1.0, np.abs(np.asarray(ref)).max())
+        if method == 'adams' and f64:
+            n_acc = int(sum(1 for r in rst.trace if r[3] > 0))
+            assert (st['n_attempts'], st['n_accepted']) == (len(rst.trace), n_acc), (st, len(rst.trace), n_acc)
+        band = (1e-6 if method == 'adams' else 1e-8) if f64 else 2e-4
+        assert np.abs(got.cpu().numpy().astype(np.float64) - np.asarray(ref, dtype=np.float64)).max() <= band * scale, (method, dim, hidden, batch)
+        loop = odeint(lambda t_, y: f.forward(t_, y), torch.tensor(y0, device=dev()), torch.tensor(tt), method=method, **tol)
+        assert not str(dict(odeint.last_stats).get('engine', '')).startswith('fused')
+        assert float((got - loop).abs().max()) <= band * scale
+
+
+def test_mlp_beyond_the_multistep_kernels_takes_the_host_loop():
+    from tfdiffeq_amd import odeint, rhs
+    g = torch.Generator().manual_seed(3)
+    d, h = 4, 300                                                            # hidden > 256: no one-launch multistep kernel
+    f = rhs.MLP(torch.randn(d, h, generator=g, dtype=torch.float64) / 2, None, torch.randn(h, h, generator=g, dtype=torch.float64) / 17, None,
+                torch.randn(h, d, generator=g, dtype=torch.float64) / 17, None)
+    y0 = torch.randn(5, d, generator=g, dtype=torch.float64).to(dev())
+    t = torch.linspace(0., 0.2, 9)
+    a = odeint(f, y0, t, method='explicit_adams')
+    assert not str(dict(odeint.last_stats).get('engine', '')).startswith('fused')
+    b = odeint(lambda t_, y: f.forward(t_, y), y0, t, method='explicit_adams')
+    assert torch.equal(a, b)

@@ -77,7 +77,7 @@ class VariableCoefficientAdamsBashforth(AdaptiveStepsizeODESolver):
         the base class over plane kernels."""
         from .solvers import _EULER_SHAPE, _FusedEngine, _cached_engine_or_none, _fusable, SyncTimeout
         from .misc import _assert_increasing
-        rhs = _fusable(self.func, self.y0) if not self._force_planes else None
+        rhs = _fusable(self.func, self.y0, multistep=True) if not self._force_planes else None
         if rhs is not None and getattr(rhs, 'multistep_fused', False) and len(self.y0) == 1:
             _assert_increasing(t)
             y = self.y0[0]

@@ -42,7 +42,7 @@ __global__ __launch_bounds__(256) void k_fixed_adams_rowlocal(AdamsArgs A) {
   const T sign = (T)A.f.rhs.sign;
   long long n, off;                                          // elements per solution row; this thread's first element
   bool active;
-  rowmap<RHS>(A.f.batch, A.f.dim, off, active, n);
+  rowmap<RHS>(A.f.batch, A.f.dim, A.f.rhs, off, active, n);
   const T* y0p = (const T*)A.f.y0;
   T* out = (T*)A.f.out;
   const double* AB = A.tab;

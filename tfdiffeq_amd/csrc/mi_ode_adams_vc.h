@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void k_adams_vc_rowlocal(AdamsVcArgs A) {  
   const T sign = (T)A.f.rhs.sign;
   long long n, off;                                          // elements per solution row; this thread's first element
   bool live;
-  rowmap<RHS>(A.f.batch, A.f.dim, off, live, n);
+  rowmap<RHS>(A.f.batch, A.f.dim, A.f.rhs, off, live, n);
   const CtrlParams cp = A.cp;
   const double n_tot = (double)cp.n_local;
   Ctl& c = sh.c;

@@ -321,6 +321,13 @@ static int pick_family(mi_ode_solver* h) {
     }
     case MI_ODE_RHS_MLP_TANH: {
       const int hd = r.hidden;
+      if (h->d.multistep != 0) {                   // the Adams family: a thread per state element, the three layers through LDS (RhsMlpCoop)
+        if (D < 1 || D > 256 || hd < 1 || hd > 256 || !r.w[0] || !r.w[1] || !r.w[2]) {
+          mi_set_error("multistep kernels for the MLP: dim <= 256, hidden <= 256 (got %d, %d)", D, hd);
+          return MI_ODE_E_INVALID;
+        }
+        h->family = FAM_MLP_COOP; return 0;
+      }
       if (!h->is_f32) { mi_set_error("fused MLP kernel is fp32 only"); return MI_ODE_E_INVALID; }
       if (!h->d.adaptive && (h->d.multistep != 0 || (h->d.tableau.n_stages != 0 && h->d.tableau.n_stages != 3))) {
         mi_set_error("fused MLP kernels on a fixed grid: euler or rk4 (3/8 rule) in one launch (k_fixed_mlp); no multistep kernel");
@@ -346,17 +353,22 @@ static bool multistep_family(const mi_ode_solver* h) {
   const bool rowlocal = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
                         h->family == FAM_PLUGIN;
   const bool coop = (h->family == FAM_LINEAR_MFMA || h->family == FAM_LINEAR_VALU) && h->d.dim >= 1 && h->d.dim <= 256;
-  return rowlocal || coop;
+  return rowlocal || coop || h->family == FAM_MLP_COOP;
 }
 static long long multistep_grid(const mi_ode_solver* h) {
   if (h->family == FAM_LINEAR_MFMA || h->family == FAM_LINEAR_VALU) {
     const long long tpw = 256 / h->d.dim;
     return (h->d.batch + tpw - 1) / tpw;
   }
+  if (h->family == FAM_MLP_COOP) {
+    const long long tpw = RhsMlpCoop<float>::tpw(h->rhs, (int)h->d.dim);
+    return (h->d.batch + tpw - 1) / tpw;
+  }
   return (h->d.batch + 255) / 256;
 }
 static void multistep_rhs(const mi_ode_solver* h, RhsParams& r) {
   if (h->family == FAM_LINEAR_MFMA || h->family == FAM_LINEAR_VALU) r.hidden = (int)h->d.dim;   // (RhsLinearCoop reads the row length here)
+  if (h->family == FAM_MLP_COOP) r.cube = (int)h->d.dim;                                         // (RhsMlpCoop: the aux field carries dim)
 }
 
 static void fill_step_args(mi_ode_solver* h, StepArgs& A) {
@@ -1211,7 +1223,7 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
   }
   if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
        h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP || h->family == FAM_PLUGIN ||
-       (h->family == FAM_LINEAR_VALU && h->d.multistep != 0)) && h->d.fusion != 1) {
+       ((h->family == FAM_LINEAR_VALU || h->family == FAM_MLP_COOP) && h->d.multistep != 0)) && h->d.fusion != 1) {
     // trajectories never interact on a fixed grid: the whole integration is ONE launch
     // (k_fixed_rowlocal for the tiny row-local systems, k_fixed_linear_mfma for the linear RHS)
     int rcf = ensure_t_out(h, T + (own_grid ? G : 0));

@@ -20,7 +20,8 @@ enum Family {
   FAM_LINEAR_VALU,   // any dim <= 256, optional cube / bias
   FAM_LINEAR_MFMA,   // dim in {16, 32, 64, 128}
   FAM_MLP,           // fp32 dim<=64, hidden<=128: whole-attempt MFMA kernel only
-  FAM_PLUGIN         // row-local user code behind a mi_ode_rowlocal_plugin table (mi_ode_plugin.h)
+  FAM_PLUGIN,        // row-local user code behind a mi_ode_rowlocal_plugin table (mi_ode_plugin.h)
+  FAM_MLP_COOP       // the ODEFunc network on the one-launch MULTISTEP kernels only: fp32 / fp64, dim, hidden <= 256 (RhsMlpCoop)
 };
 
 struct LaunchInfo {   // filled per (mode) at create time

@@ -52,6 +52,7 @@ struct RhsLinearCoop {
   const T* bias;
   int dim, cube;
   __device__ explicit RhsLinearCoop(const RhsParams& p) : W((const T*)p.w[0]), bias((const T*)p.b[0]), dim(p.hidden), cube(p.cube) {}
+  static __host__ __device__ int tpw(const RhsParams&, int dim) { return 256 / dim; }       // trajectories per 256-thread workgroup
   __device__ __forceinline__ void operator()(T, const T* y, T* f) const {
     __shared__ T s_y[256];
     const int slot = (int)threadIdx.x / dim, col = (int)threadIdx.x - slot * dim;
@@ -67,6 +68,75 @@ struct RhsLinearCoop {
     f[0] = acc;
   }
 };
+// The ODEFunc network dim -> hidden -> hidden -> dim (models/dense_odenet.py:41-92; tanh / relu / softplus, optionally time dependent)
+// for the same one-launch MULTISTEP kernels, in float32 AND float64 and for any dim, hidden <= 256 (round 5; the MFMA tile kernels of
+// mi_ode_mlp.h are float32, dim <= 64, hidden <= 128 and have no multistep schedule).  A thread owns one state element; the dim threads of
+// a trajectory's state element; the hidden units of ALL the workgroup's trajectories are dealt to all its threads (a 2-dimensional state
+// with 50 hidden units would otherwise leave 25 dependent dot products to each of two threads), the state and both hidden activations go
+// through LDS, then every thread forms its own output column.  Weights are read from global
+// memory - consecutive threads read consecutive columns, every trajectory of the workgroup the same addresses (L1 / L2 hits).  Vector
+// ALU work, latency bound: what it replaces is the host loop with ~6 launches per evaluation.  p.cube carries dim here (aux field).
+constexpr int kMlpCoopCap = 2048;        // hidden activations of a workgroup's trajectories per layer: trajectories per workgroup = min(256 / dim, 2048 / hidden)
+template <typename T>
+struct RhsMlpCoop {
+  static constexpr int D = 1;
+  static constexpr bool kCoop = true;
+  const T *W1, *W2, *W3, *B1, *B2, *B3;
+  int dim, hd, act, td, tpw_;
+  __device__ explicit RhsMlpCoop(const RhsParams& p)
+      : W1((const T*)p.w[0]), W2((const T*)p.w[1]), W3((const T*)p.w[2]), B1((const T*)p.b[0]), B2((const T*)p.b[1]), B3((const T*)p.b[2]),
+        dim(p.cube), hd(p.hidden), act((int)p.s[0]), td(p.s[1] != 0.0 ? 1 : 0), tpw_(tpw(p, p.cube)) {}
+  static __host__ __device__ int tpw(const RhsParams& p, int dim) {
+    const int a = 256 / dim, b = kMlpCoopCap / (p.hidden > 0 ? p.hidden : 1);
+    return a < b ? a : b;
+  }
+  static __device__ __forceinline__ T activation(int act, T x) {
+    if constexpr (std::is_same<T, float>::value) {
+      return act == 0 ? tanhf(x) : act == 1 ? (x > 0.f ? x : (x != x ? x : 0.f)) : (x > 20.f ? x : log1pf(expf(x)));
+    } else {
+      return act == 0 ? tanh(x) : act == 1 ? (x > 0.0 ? x : (x != x ? x : 0.0)) : (x > 30.0 ? x : log1p(exp(x)));
+    }
+  }
+  // sum_k x[k] * W[k * ld + j] + acc0: four interleaved partial sums (k = 0, 4, 8 .. | 1, 5, .. | ..) so that the loads of four terms
+  // are in flight together; a fixed order - every launch geometry gives the same bits
+  static __device__ __forceinline__ T dot_col(const T* x, const T* Wc, int n, int ld, T acc0) {
+    T a0 = acc0, a1 = (T)0, a2 = (T)0, a3 = (T)0;
+    int k = 0;
+    for (; k + 4 <= n; k += 4) {
+      a0 = fma(x[k], Wc[(long long)k * ld], a0);
+      a1 = fma(x[k + 1], Wc[(long long)(k + 1) * ld], a1);
+      a2 = fma(x[k + 2], Wc[(long long)(k + 2) * ld], a2);
+      a3 = fma(x[k + 3], Wc[(long long)(k + 3) * ld], a3);
+    }
+    for (; k < n; ++k) a0 = fma(x[k], Wc[(long long)k * ld], a0);
+    return (a0 + a1) + (a2 + a3);
+  }
+  __device__ __forceinline__ void operator()(T t, const T* y, T* f) const {
+    __shared__ T s_y[256];
+    __shared__ T s_h1[kMlpCoopCap];
+    __shared__ T s_h2[kMlpCoopCap];
+    const int slot = (int)threadIdx.x / dim, col = (int)threadIdx.x - slot * dim;
+    const int units = tpw_ * hd;                             // hidden units of the workgroup's trajectories: dealt to ALL its threads
+    __syncthreads();                                         // the previous evaluation's readers are done
+    s_y[threadIdx.x] = y[0];
+    __syncthreads();
+    for (int u = (int)threadIdx.x; u < units; u += (int)blockDim.x) {     // fc1 (+ the time row of concat([t, x]), dense_odenet.py:79-84)
+      const int sl = u / hd, j = u - sl * hd;
+      T acc = B1 != nullptr ? B1[j] : (T)0;
+      if (td) acc = fma(t, W1[j], acc);
+      s_h1[u] = activation(act, dot_col(s_y + sl * dim, W1 + (long long)td * hd + j, dim, hd, acc));
+    }
+    __syncthreads();
+    for (int u = (int)threadIdx.x; u < units; u += (int)blockDim.x) {
+      const int sl = u / hd, j = u - sl * hd;
+      s_h2[u] = activation(act, dot_col(s_h1 + sl * hd, W2 + j, hd, hd, B2 != nullptr ? B2[j] : (T)0));
+    }
+    __syncthreads();
+    T acc = (T)0;
+    if (slot < tpw_) acc = dot_col(s_h2 + slot * hd, W3 + col, hd, dim, B3 != nullptr ? B3[col] : (T)0);
+    f[0] = acc;
+  }
+};
 template <class R, class = void>
 struct rhs_is_coop : std::false_type {};
 template <class R>
@@ -74,9 +144,9 @@ struct rhs_is_coop<R, std::void_t<decltype(R::kCoop)>> : std::true_type {};
 
 // which element(s) of the state this thread owns: offset of its first element, whether it exists, elements per plane
 template <class RHS>
-__device__ __forceinline__ void rowmap(long long batch, int dim, long long& off, bool& live, long long& n_plane) {
+__device__ __forceinline__ void rowmap(long long batch, int dim, const RhsParams& rp, long long& off, bool& live, long long& n_plane) {
   if constexpr (rhs_is_coop<RHS>::value) {
-    const int tpw = (int)blockDim.x / dim;                   // trajectories per workgroup
+    const int tpw = RHS::tpw(rp, dim);                       // trajectories per workgroup
     const int slot = (int)threadIdx.x / dim, col = (int)threadIdx.x - slot * dim;
     const long long traj = (long long)blockIdx.x * tpw + slot;
     live = slot < tpw && traj < batch;

@@ -80,6 +80,10 @@ class DeviceRHS(object):
         """True when the fused kernels can take this state tensor."""
         return y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
 
+    def supports_multistep(self, y0):
+        """True when the one-launch Adams kernels can take this state tensor (a family may take more there than on its Runge-Kutta kernels)."""
+        return self.supports(y0)
+
     def fill(self, rhs, dtype, device):
         """Fill a _native.Rhs struct; returns objects that must stay alive as long as the handle."""
         rhs.kind = self.kind
@@ -245,6 +249,18 @@ class MLP(DeviceRHS):
                               '(%s, dim %d, hidden %d) runs as a Python callable on the device-controlled engine instead' % (
                                   self.MAX_DIM, self.MAX_HIDDEN, str(y0.dtype).replace('torch.', ''), self.dim, self.hidden))
         return ok
+
+    MS_MAX_DIM = MS_MAX_HIDDEN = 256    # the one-launch Adams kernels (csrc/mi_ode_stage_rowlocal.h: RhsMlpCoop): float32 and float64
+
+    @property
+    def multistep_fused(self):
+        """'explicit_adams' / 'fixed_adams' / 'adams' in one launch (round 5): a thread per state element, the threads of a trajectory
+        evaluate the three layers together through LDS - float32 and float64, dim and hidden up to 256."""
+        return self.dim <= self.MS_MAX_DIM and self.hidden <= self.MS_MAX_HIDDEN
+
+    def supports_multistep(self, y0):
+        return (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
+                and self.dim <= self.MS_MAX_DIM and self.hidden <= self.MS_MAX_HIDDEN)
 
     def fill(self, rhs, dtype, device):
         keep = super(MLP, self).fill(rhs, dtype, device)

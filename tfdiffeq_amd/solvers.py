@@ -481,13 +481,15 @@ def _pack_components(y0, dim):
     return packed, rows, offs
 
 
-def _fusable(func, y0):
-    """The DeviceRHS behind `func` if the fused engine can run this problem, else None."""
+def _fusable(func, y0, multistep=False):
+    """The DeviceRHS behind `func` if the fused engine can run this problem, else None.  multistep: for the one-launch Adams kernels
+    (a family may take more there than on its Runge-Kutta kernels: rhs.MLP in float64 / up to 256 wide, round 5)."""
     rhs = getattr(func, 'device_rhs', None)
     if rhs is None or len(y0) != 1:
         return None
     y = y0[0]
-    if not (isinstance(y, torch.Tensor) and y.is_cuda and y.dim() >= 1 and y.numel() > 0 and rhs.supports(y)):
+    ok = rhs.supports_multistep if multistep else rhs.supports
+    if not (isinstance(y, torch.Tensor) and y.is_cuda and y.dim() >= 1 and y.numel() > 0 and ok(y)):
         return None
     return rhs
 
@@ -582,7 +584,8 @@ class FixedGridODESolver(object):
         """solvers.py:82-104."""
         _assert_increasing(t)
         t = t.to(self.y0[0].dtype)                    # :84 time in the STATE dtype here
-        rhs = _fusable(self.func, self.y0)
+        ms = self._fused_multistep()
+        rhs = _fusable(self.func, self.y0) if ms is None else None      # (a multistep solver asks below, with the multistep kernels' own limits)
         default_grid = getattr(self, '_default_grid', False)
         time_grid = None
         if rhs is None and default_grid and self.eps == 0.0 and self._fused_tableau is not None:
@@ -601,8 +604,9 @@ class FixedGridODESolver(object):
                 self.stats['components'] = len(rows)
                 offs = np.concatenate([[0], np.cumsum(rows)])
                 return tuple(out[:, int(o):int(o) + r].reshape((out.shape[0],) + tuple(c.shape)) for c, r, o in zip(self.y0, rows, offs[:-1]))
-        ms = self._fused_multistep() if rhs is not None else None
-        if ms is not None and getattr(rhs, 'multistep_fused', False) and self._fusion not in (1, 'stage') and not self._graph:
+        rhs_ms = _fusable(self.func, self.y0, multistep=True) if ms is not None else None     # (rhs.MLP: float64 / up to 256 wide here)
+        if rhs_ms is not None and getattr(rhs_ms, 'multistep_fused', False) and self._fusion not in (1, 'stage') and not self._graph:
+            rhs = rhs_ms
             # the Adams family on a row-local catalogue system: the whole integration - history, predictor, corrector iterations and
             # their batch-wide convergence test - in ONE launch (csrc/mi_ode_adams.h)
             y = self.y0[0]
@@ -626,6 +630,7 @@ class FixedGridODESolver(object):
                 for _ in range(int(self.stats.get('n_rejected', 0))):                         # fixed_adams.py:197-199
                     print('Warning: Functional iteration did not converge. Solution may be incorrect.', file=sys.stderr)
                 return (out,)
+            rhs = None
         if rhs is not None and rhs.fixed_grid_fused and self._fused_tableau is not None:
             y = self.y0[0]
             key = ('fixed', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
