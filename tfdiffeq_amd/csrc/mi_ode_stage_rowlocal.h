@@ -97,19 +97,21 @@ struct RhsMlpCoop {
       return act == 0 ? tanh(x) : act == 1 ? (x > 0.0 ? x : (x != x ? x : 0.0)) : (x > 30.0 ? x : log1p(exp(x)));
     }
   }
-  // sum_k x[k] * W[k * ld + j] + acc0: four interleaved partial sums (k = 0, 4, 8 .. | 1, 5, .. | ..) so that the loads of four terms
-  // are in flight together; a fixed order - every launch geometry gives the same bits
+  // sum_k x[k] * W[k * ld + j] + acc0: eight interleaved partial sums (k = 0, 8, 16 .. | 1, 9, .. | ..) so that the loads of eight terms
+  // are in flight together (the evaluation is a chain of dependent memory round trips otherwise); a fixed order - every launch
+  // geometry gives the same bits
   static __device__ __forceinline__ T dot_col(const T* x, const T* Wc, int n, int ld, T acc0) {
-    T a0 = acc0, a1 = (T)0, a2 = (T)0, a3 = (T)0;
+    T a[8] = {acc0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
     int k = 0;
-    for (; k + 4 <= n; k += 4) {
-      a0 = fma(x[k], Wc[(long long)k * ld], a0);
-      a1 = fma(x[k + 1], Wc[(long long)(k + 1) * ld], a1);
-      a2 = fma(x[k + 2], Wc[(long long)(k + 2) * ld], a2);
-      a3 = fma(x[k + 3], Wc[(long long)(k + 3) * ld], a3);
+    for (; k + 8 <= n; k += 8) {
+      T w[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) w[i] = Wc[(long long)(k + i) * ld];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) a[i] = fma(x[k + i], w[i], a[i]);
     }
-    for (; k < n; ++k) a0 = fma(x[k], Wc[(long long)k * ld], a0);
-    return (a0 + a1) + (a2 + a3);
+    for (; k < n; ++k) a[0] = fma(x[k], Wc[(long long)k * ld], a[0]);
+    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
   }
   __device__ __forceinline__ void operator()(T t, const T* y, T* f) const {
     __shared__ T s_y[256];
