@@ -38,11 +38,28 @@ struct RhsLinear2 {
   }
 };
 
+// sum_k x[k] * W[k * ld + j] + acc0: eight interleaved partial sums (k = 0, 8, 16 .. | 1, 9, .. | ..) so that the loads of eight terms
+// are in flight together (the evaluation is a chain of dependent memory round trips otherwise); a fixed order - every launch
+// geometry gives the same bits
+template <typename T>
+__device__ __forceinline__ T coop_dot_col(const T* x, const T* Wc, int n, int ld, T acc0) {
+  T a[8] = {acc0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    T w[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) w[i] = Wc[(long long)(k + i) * ld];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = fma(x[k + i], w[i], a[i]);
+  }
+  for (; k < n; ++k) a[0] = fma(x[k], Wc[(long long)k * ld], a[0]);
+  return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 // y @ W (+ b) / (y ** 3) @ W of ANY dim <= 256 for the one-launch MULTISTEP kernels (mi_ode_adams.h, mi_ode_adams_vc.h): those keep a
 // trajectory's state and its history of derivatives in registers, which a dim-51 system (DETEST C4) does not fit into one
 // thread's - so here a thread owns ONE state element (D = 1: its history is 13 registers again) and the threads of a trajectory
-// evaluate f together: the state goes through LDS, every thread forms its column's dot product (the order of the VALU linear
-// kernels: fma over k = 0 .. dim-1).  A 256-thread workgroup holds floor(256 / dim) trajectories; `rowmap` gives a thread its
+// evaluate f together: the state goes through LDS, every thread forms its column's dot product (coop_dot_col above).  A 256-thread workgroup holds floor(256 / dim) trajectories; `rowmap` gives a thread its
 // element.  The kernels call rhs() from uniform control flow (it contains barriers).
 template <typename T>
 struct RhsLinearCoop {
@@ -61,8 +78,7 @@ struct RhsLinearCoop {
     __syncthreads();
     T acc = (T)0;
     if ((slot + 1) * dim <= (int)blockDim.x) {
-      const T* yr = s_y + slot * dim;
-      for (int k = 0; k < dim; ++k) acc = fma(yr[k], W[(long long)k * dim + col], acc);
+      acc = coop_dot_col<T>(s_y + slot * dim, W + col, dim, dim, (T)0);       // (round 5: eight partial sums in flight instead of one chain)
       if (bias != nullptr) acc = acc + bias[col];
     }
     f[0] = acc;
@@ -97,22 +113,6 @@ struct RhsMlpCoop {
       return act == 0 ? tanh(x) : act == 1 ? (x > 0.0 ? x : (x != x ? x : 0.0)) : (x > 30.0 ? x : log1p(exp(x)));
     }
   }
-  // sum_k x[k] * W[k * ld + j] + acc0: eight interleaved partial sums (k = 0, 8, 16 .. | 1, 9, .. | ..) so that the loads of eight terms
-  // are in flight together (the evaluation is a chain of dependent memory round trips otherwise); a fixed order - every launch
-  // geometry gives the same bits
-  static __device__ __forceinline__ T dot_col(const T* x, const T* Wc, int n, int ld, T acc0) {
-    T a[8] = {acc0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0, (T)0};
-    int k = 0;
-    for (; k + 8 <= n; k += 8) {
-      T w[8];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) w[i] = Wc[(long long)(k + i) * ld];
-#pragma unroll
-      for (int i = 0; i < 8; ++i) a[i] = fma(x[k + i], w[i], a[i]);
-    }
-    for (; k < n; ++k) a[0] = fma(x[k], Wc[(long long)k * ld], a[0]);
-    return ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
-  }
   __device__ __forceinline__ void operator()(T t, const T* y, T* f) const {
     __shared__ T s_y[256];
     __shared__ T s_h1[kMlpCoopCap];
@@ -126,16 +126,16 @@ struct RhsMlpCoop {
       const int sl = u / hd, j = u - sl * hd;
       T acc = B1 != nullptr ? B1[j] : (T)0;
       if (td) acc = fma(t, W1[j], acc);
-      s_h1[u] = activation(act, dot_col(s_y + sl * dim, W1 + (long long)td * hd + j, dim, hd, acc));
+      s_h1[u] = activation(act, coop_dot_col<T>(s_y + sl * dim, W1 + (long long)td * hd + j, dim, hd, acc));
     }
     __syncthreads();
     for (int u = (int)threadIdx.x; u < units; u += (int)blockDim.x) {
       const int sl = u / hd, j = u - sl * hd;
-      s_h2[u] = activation(act, dot_col(s_h1 + sl * hd, W2 + j, hd, hd, B2 != nullptr ? B2[j] : (T)0));
+      s_h2[u] = activation(act, coop_dot_col<T>(s_h1 + sl * hd, W2 + j, hd, hd, B2 != nullptr ? B2[j] : (T)0));
     }
     __syncthreads();
     T acc = (T)0;
-    if (slot < tpw_) acc = dot_col(s_h2 + slot * hd, W3 + col, hd, dim, B3 != nullptr ? B3[col] : (T)0);
+    if (slot < tpw_) acc = coop_dot_col<T>(s_h2 + slot * hd, W3 + col, hd, dim, B3 != nullptr ? B3[col] : (T)0);
     f[0] = acc;
   }
 };
