@@ -85,9 +85,11 @@ enum mi_ode_rhs_kind {
   MI_ODE_RHS_MLP_TANH = 5,       /* dim->hidden->hidden->dim MLP of models/dense_odenet.py:41-92; hidden activation =
                                     scalars[0]: 0 tanh, 1 relu (the reference's default, :14), 2 softplus;
                                     scalars[1] != 0: time dependent (:79-84, fc1 sees concat([t, x])): w[0] is
-                                    [dim + 1, hidden] and its row 0 multiplies the stage time.  Runge-Kutta kernels:
-                                    float32, dim <= 64, hidden <= 128 (MFMA tiles); multistep != 0 (the Adams family in one
-                                    launch): float32 and float64, dim, hidden <= 256 (round 5)                    */
+                                    [dim + 1, hidden] and its row 0 multiplies the stage time.  float32, dim <= 64,
+                                    hidden <= 128: MFMA tile kernels (every Runge-Kutta schedule).  Otherwise (float32 /
+                                    float64, dim, hidden <= 256; round 5): a cooperative kernel, a thread per state element -
+                                    adaptive 3- / 6-row tableaus as ONE launch per call (fusion 0 / 4, one rank, co-resident
+                                    grid, T > 1: else MI_ODE_E_INVALID) and multistep != 0 (the Adams family in one launch) */
   MI_ODE_RHS_PLUGIN = 6          /* user device code for a trajectory-local system of small dim: mi_ode_rhs.plugin
                                     (csrc/mi_ode_plugin.h); scalars[0..7] and w[]/b[] are passed through to it  */
 };

@@ -252,3 +252,65 @@ def test_mlp_beyond_the_multistep_kernels_takes_the_host_loop():
     assert not str(dict(odeint.last_stats).get('engine', '')).startswith('fused')
     b = odeint(lambda t_, y: f.forward(t_, y), y0, t, method='explicit_adams')
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# the adaptive Runge-Kutta solvers for the ODEFunc network OUTSIDE the tile kernels' box (float64, dim > 64, hidden > 128) in one launch:
+# the cooperative right-hand side under the whole-call row-local kernel (round-4 review, item 7)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('method', ['dopri5', 'bosh3', 'tsit5'])
+@pytest.mark.parametrize('dim,hidden,batch,act,td,dtype', [
+    (2, 50, 1, 'tanh', False, np.float64), (8, 16, 300, 'softplus', True, np.float64), (64, 128, 40, 'tanh', False, np.float64),
+    (100, 200, 7, 'relu', False, np.float64), (80, 32, 1000, 'tanh', True, np.float32)])
+def test_mlp_outside_the_tile_kernels_runs_in_one_launch(method, dim, hidden, batch, act, td, dtype):
+    from oracle import ode_numpy as O
+    from tfdiffeq_amd import odeint, rhs
+    rng = np.random.default_rng(2000 + dim + hidden)
+    sc = 0.7
+    Ws = [sc * rng.standard_normal((dim + (1 if td else 0), hidden)) / np.sqrt(dim), sc * rng.standard_normal((hidden, hidden)) / np.sqrt(hidden),
+          sc * rng.standard_normal((hidden, dim)) / np.sqrt(hidden)]
+    bs = [0.1 * rng.standard_normal(hidden), 0.1 * rng.standard_normal(hidden), 0.1 * rng.standard_normal(dim)]
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    f = rhs.MLP(*[torch.tensor(v, dtype=tdt) for pair in zip(Ws, bs) for v in pair], activation=act, time_dependent=td)
+    fn = _np_mlp(Ws, bs, act, td, dtype)
+    y0 = rng.standard_normal((batch, dim)).astype(dtype)
+    f64 = dtype == np.float64
+    tol = dict(rtol=1e-6, atol=1e-8) if f64 else dict(rtol=1e-4, atol=1e-6)
+    for tt in (np.array([0., 0.4, 1.5]), np.array([0., -0.4, -1.5])):
+        got = odeint(f, torch.tensor(y0, device=dev()), torch.tensor(tt), method=method, **tol)
+        st = dict(odeint.last_stats)
+        assert st['n_launches'] == 1 and st['status'] == 0 and not str(st.get('engine', '')).startswith('device-controlled'), st
+        # (tsit5: the published tableau on both sides - the reference's own is defective)
+        ref, rst = O.odeint(fn, y0, tt, method=method, return_stats=True, options={'tsit5_fixed': True} if method == 'tsit5' else None, **tol)
+        scale = max(1.0, np.abs(np.asarray(ref)).max())
+        if f64:
+            assert (st['n_attempts'], st['n_accepted']) == (rst.n_attempts, rst.n_accepted), (st, rst.n_attempts, rst.n_accepted)
+        assert np.abs(got.cpu().numpy().astype(np.float64) - np.asarray(ref, dtype=np.float64)).max() <= (1e-9 if f64 else 2e-4) * scale
+        call = odeint(lambda t_, y: f.forward(t_, y), torch.tensor(y0, device=dev()), torch.tensor(tt), method=method, **tol)
+        assert str(dict(odeint.last_stats).get('engine', '')).startswith('device-controlled')
+        assert float((got - call).abs().max()) <= (1e-9 if f64 else 2e-4) * scale
+
+
+def test_mlp_float64_module_trains_and_evaluates_through_the_cooperative_kernel():
+    """models.ODEBlock over a float64 ODEFunc: evaluation in one launch (it used to be a Python callable on the device-controlled engine);
+    a batch too large for a co-resident grid, a single output time and dopri8 fall back to that engine and say so once."""
+    from tfdiffeq_amd import models, odeint
+    torch.manual_seed(5)
+    blk = models.ODEBlock(models.ODEFunc(6, 24, non_linearity='tanh'), tol=1e-6).to(dev()).double()
+    x = torch.randn(50, 6, dtype=torch.float64, device=dev())
+    with torch.no_grad():
+        out = blk(x)
+    st = dict(odeint.last_stats)
+    assert st['n_launches'] == 1 and st['status'] == 0, st
+    ref = odeint(lambda t_, y: blk.odefunc(t_, y), x, torch.tensor([0., 1.]), rtol=1e-6, atol=1e-6, method='dopri5')[1]
+    assert float((out - ref).abs().max()) < 1e-9
+    f = blk.odefunc.device_rhs()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        big = torch.randn(200000, 6, dtype=torch.float64, device=dev())       # 42 trajectories per workgroup: 4762 workgroups, not co-resident
+        o2 = odeint(f, big, torch.tensor([0., 0.1]), rtol=1e-5, atol=1e-7, method='dopri5')
+        assert str(dict(odeint.last_stats).get('engine', '')).startswith('device-controlled') and torch.isfinite(o2).all()
+        o3 = odeint(f, x, torch.tensor([0., 1.]), rtol=1e-6, atol=1e-6, method='dopri8')
+        assert float((o3[1] - out).abs().max()) < 1e-4                        # (another method at the same tolerance)
+    assert sum('runs as a Python callable' in str(m.message) for m in w) == 2, [str(m.message) for m in w]
+    assert torch.equal(odeint(f, x, torch.tensor([0.3]), method='dopri5')[0], x)

@@ -328,6 +328,17 @@ static int pick_family(mi_ode_solver* h) {
         }
         h->family = FAM_MLP_COOP; return 0;
       }
+      const bool tile_box = h->is_f32 && D >= 1 && D <= 64 && hd >= 1 && hd <= 128;
+      if (h->d.adaptive && !tile_box) {
+        // outside the MFMA tile kernels' box (float64, dim > 64, hidden > 128): the cooperative whole-call kernel - a thread per state
+        // element, the three layers through LDS (RhsMlpCoop, round 5) - for batches whose workgroups are co-resident; one rank, one tensor
+        if (D < 1 || D > 256 || hd < 1 || hd > 256 || !r.w[0] || !r.w[1] || !r.w[2] || h->d.world_size > 1 || h->d.allgather != nullptr ||
+            h->d.n_segments > 1 || (h->d.fusion != 0 && h->d.fusion != 4)) {
+          mi_set_error("MLP outside the tile kernels (float32, dim <= 64, hidden <= 128): the cooperative whole-call kernel takes dim, hidden <= 256, one rank, one tensor, fusion auto / whole (got dim %d, hidden %d)", D, hd);
+          return MI_ODE_E_INVALID;
+        }
+        h->family = FAM_MLP_COOP; return 0;
+      }
       if (!h->is_f32) { mi_set_error("fused MLP kernel is fp32 only"); return MI_ODE_E_INVALID; }
       if (!h->d.adaptive && (h->d.multistep != 0 || (h->d.tableau.n_stages != 0 && h->d.tableau.n_stages != 3))) {
         mi_set_error("fused MLP kernels on a fixed grid: euler or rk4 (3/8 rule) in one launch (k_fixed_mlp); no multistep kernel");
@@ -571,8 +582,9 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
                           h->family == FAM_PLUGIN;
     const bool mfma = h->family == FAM_LINEAR_MFMA && h->step_fused;
     const bool mlp = h->family == FAM_MLP;
+    const bool coop = h->family == FAM_MLP_COOP && desc->multistep == 0;
     h->init_tiles16 = mfma ? 1 : 0;
-    long long g = (mfma || mlp) ? (long long)h->step_grid : (desc->batch + 255) / 256;
+    long long g = (mfma || mlp) ? (long long)h->step_grid : coop ? multistep_grid(h) : (desc->batch + 255) / 256;
     const bool single = h->d.world_size <= 1 && desc->allgather == nullptr;
     if (desc->xrank_host != nullptr) {           // cross-rank hand-off segment: make it visible to this GPU
       if (h->d.world_size > kXMaxWorld || desc->xrank_bytes < mi_ode_xrank_bytes(h->d.world_size)) {
@@ -589,7 +601,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       }
       h->xrank_dev = (double*)dptr;
     }
-    bool capable = desc->adaptive && (rowlocal || mfma || mlp) && g <= kPersistMaxGrid;
+    bool capable = desc->adaptive && (rowlocal || mfma || mlp || coop) && g <= kPersistMaxGrid;
     if (capable) {
       const int cap = mlp ? mi_persist_capacity_mlp_f32(h) : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
       capable = cap > 0 && g <= cap;
@@ -633,6 +645,10 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     const bool can = capable && (single || h->xrank_dev != nullptr);
     if (desc->fusion == 4 && !can && single) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local or MFMA-linear RHS, single rank, every workgroup co-resident)"); mi_ode_destroy(h); return MI_ODE_E_INVALID; }
     h->persist = (can && (desc->fusion == 4 || desc->fusion == 0)) ? 1 : 0;
+    if (coop && desc->adaptive && !h->persist) {
+      mi_set_error("cooperative MLP kernel: %lld workgroups cannot be co-resident on this device (the whole-call kernel is its only schedule)", g);
+      mi_ode_destroy(h); return MI_ODE_E_INVALID;
+    }
     if (h->nseg > 1 && !h->persist) {
       mi_set_error("tuple states run on the whole-call kernel only, and its grid (%lld workgroups) is not co-resident on this device", g);
       mi_ode_destroy(h); return MI_ODE_E_INVALID;
@@ -888,6 +904,7 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   PersistArgs A;
   memset(&A, 0, sizeof(A));
   fill_step_args(h, A.s);
+  if (h->family == FAM_MLP_COOP) multistep_rhs(h, A.s.rhs);   // (RhsMlpCoop reads dim from an aux field)
   A.s.ticket = nullptr;
   A.y0 = y0_dev; A.out0 = out_dev; A.n_out = n_out;
   A.ctl_host = h->ctl_host;
@@ -1015,10 +1032,11 @@ extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const doubl
   const bool multi = h->d.world_size > 1 || h->d.allgather != nullptr || h->nccl_comm != nullptr;
   if (h->persist && T > 1 && h->d.adaptive && (!multi || h->xrank_on)) {
     const int prc = integrate_persist(h, y0_dev, t_host, T, out_dev, stats, st);
-    if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4 || multi || h->nseg > 1) return prc;   // (a rank must not change schedule
+    if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4 || multi || h->nseg > 1 || h->family == FAM_MLP_COOP) return prc;   // (a rank must not change schedule
                                                                                                             // alone; tuple states have no other)
     h->persist = 0;        // the grid hand-off timed out (co-residency lost to another persistent kernel?): this
   }                        // handle goes back to one launch per attempt, starting with this call
+  if (h->family == FAM_MLP_COOP) { mi_set_error("the cooperative MLP kernel has the whole-call schedule only (T > 1)"); return MI_ODE_E_INVALID; }
   int rc = begin_impl(h, y0_dev, t_host[0], out_dev, stream);   // before_integrate runs even when T == 1 (solvers.py:31);
   if (rc != 0) return rc;                                        // solution = [y0] is written by the same kernel
   int status = 0;

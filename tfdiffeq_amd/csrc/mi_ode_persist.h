@@ -417,9 +417,12 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
   CtrlParams cp = A.s.cp;
   cp.t_out = persist_stage_tout(A, sh.tout);                  // the output cursor and the dense output read t from LDS
   const double* t_out = cp.t_out;
-  const long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const int nseg = A.nseg;                                    // > 1: tuple state, one component per range of workgroups
-  bool live = row < A.s.batch;
+  // this thread's first element: a trajectory per thread (row * D) - or, for the cooperative right-hand sides (RhsMlpCoop: round 5),
+  // ONE state element per thread, min(256 / dim, ..) trajectories per workgroup, f evaluated by the trajectory's threads together
+  long long e0, n_unused;
+  bool live;
+  rowmap<RHS>(A.s.batch, A.s.dim, A.s.rhs, e0, live, n_unused);
   if (nseg > 1) {
     int sg = 0;
     for (int k = 1; k < nseg; ++k)
@@ -437,8 +440,8 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
 #pragma unroll
   for (int d = 0; d < D; ++d) y.v[d] = (T)0;
   if (live) {
-    y = *(const Row*)((const T*)A.y0 + row * D);
-    *(Row*)((T*)A.out0 + row * D) = y;                        // solution[0] = y0 (solvers.py:30)
+    y = *(const Row*)((const T*)A.y0 + e0);
+    *(Row*)((T*)A.out0 + e0) = y;                             // solution[0] = y0 (solvers.py:30)
   }
   __syncthreads();
   const T t_first = (T)s_c.t1;
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
           for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
           T err_unused, ymid = y.v[d];
           if constexpr (!TS) step_finish<T, S>(y.v[d], kk, hs, A.s, err_unused, ymid, true);
-          step_emit<T, S, TS>(A.s, P, y.v[d], ys[d], kk, ymid, row * D + d, t_out);
+          step_emit<T, S, TS>(A.s, P, y.v[d], ys[d], kk, ymid, e0 + d, t_out);
         }
       }
 #pragma unroll
@@ -586,11 +589,11 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
 
   // ---- hand the final state back: planes idx_y0 / idx_k[0] (mi_ode_get_state; never rotated here), scalars to the host ----
   if (live) {
-    *(Row*)((T*)(A.s.planes + (long long)s_c.idx_y0 * A.s.stride) + row * D) = y;
+    *(Row*)((T*)(A.s.planes + (long long)s_c.idx_y0 * A.s.stride) + e0) = y;
     Row f;
 #pragma unroll
     for (int d = 0; d < D; ++d) f.v[d] = k[0][d];
-    *(Row*)((T*)(A.s.planes + (long long)s_c.idx_k[0] * A.s.stride) + row * D) = f;
+    *(Row*)((T*)(A.s.planes + (long long)s_c.idx_k[0] * A.s.stride) + e0) = f;
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     st.store(s_c);

@@ -138,7 +138,9 @@ class ODEBlock(nn.Module):
             out = odeint_adjoint(self.odefunc, x_aug, integration_time, **kw)
         else:
             fused = None if needs_grad else self.odefunc.device_rhs()
-            func = fused if (fused is not None and fused.supports(x_aug)) else self.odefunc
+            # (the tile kernels, or - float64 / wider networks, round 5 - the cooperative one-launch kernel; if neither takes the problem
+            # the solver runs the descriptor's own forward() as a callable on the device-controlled engine and says so once)
+            func = fused if (fused is not None and (fused.supports(x_aug) or fused.supports_coop(x_aug))) else self.odefunc
             with torch.no_grad():
                 out = odeint(func, x_aug, integration_time, **kw)                           # :184-186
             if func is fused:                                    # f ran inside the kernel: the counter the reference exposes

@@ -235,20 +235,32 @@ class MLP(DeviceRHS):
     _told_limits = set()
 
     def supports(self, y0):
-        ok = (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype == torch.float32
-              and self.dim <= self.MAX_DIM and self.hidden <= self.MAX_HIDDEN)
-        if not ok and y0.dim() >= 1 and y0.shape[-1] == self.dim:
-            # (round-4 review, item 4) the reference's ODEFunc takes any width and tf.float64 (dense_odenet.py:41-92); outside the box the
-            # network is served as a Python callable (rocBLAS products, plane kernels, the controller on the device) - correct, an order of
-            # magnitude slower, and no longer silent: said once per (dtype, dim, hidden)
-            key = (str(y0.dtype), self.dim, self.hidden)
-            if key not in MLP._told_limits:
-                MLP._told_limits.add(key)
-                import warnings
-                warnings.warn('tfdiffeq_amd.rhs.MLP: the fused MLP kernels take float32 states with dim <= %d and hidden <= %d; this network '
-                              '(%s, dim %d, hidden %d) runs as a Python callable on the device-controlled engine instead' % (
-                                  self.MAX_DIM, self.MAX_HIDDEN, str(y0.dtype).replace('torch.', ''), self.dim, self.hidden))
-        return ok
+        """The MFMA tile kernels (Runge-Kutta, adaptive and fixed grid): float32, dim <= 64, hidden <= 128."""
+        return (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype == torch.float32
+                and self.dim <= self.MAX_DIM and self.hidden <= self.MAX_HIDDEN)
+
+    def supports_coop(self, y0):
+        """Outside that box (round 5): the adaptive Runge-Kutta solvers in ONE launch on the cooperative kernel (a thread per state element,
+        the three layers through LDS: csrc/mi_ode_stage_rowlocal.h RhsMlpCoop under k_persist_rowlocal) - float32 / float64, dim and hidden
+        up to 256, as long as the batch's workgroups (min(256 / dim, 2048 / hidden) trajectories each) are co-resident."""
+        return (not self.supports(y0) and y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
+                and self.dim <= self.MS_MAX_DIM and self.hidden <= self.MS_MAX_HIDDEN)
+
+    def warn_limits(self, y0, why=''):
+        """(round-4 review, item 4) the reference's ODEFunc takes any width and tf.float64 (dense_odenet.py:41-92); where no kernel of this
+        family takes a problem the network is served as a Python callable (rocBLAS products, plane kernels, the controller on the device) -
+        correct, slower, and not silent: said once per (dtype, dim, hidden)."""
+        if y0.dim() < 1 or y0.shape[-1] != self.dim:
+            return
+        key = (str(y0.dtype), self.dim, self.hidden, why)
+        if key not in MLP._told_limits:
+            MLP._told_limits.add(key)
+            import warnings
+            warnings.warn('tfdiffeq_amd.rhs.MLP: the MFMA tile kernels take float32 states with dim <= %d and hidden <= %d, the cooperative '
+                          'one-launch kernel float32 / float64 up to %d wide for batches whose workgroups are co-resident; this problem (%s, dim %d, '
+                          'hidden %d%s) runs as a Python callable on the device-controlled engine instead' % (
+                              self.MAX_DIM, self.MAX_HIDDEN, self.MS_MAX_DIM, str(y0.dtype).replace('torch.', ''), self.dim, self.hidden,
+                              (', ' + why) if why else ''))
 
     MS_MAX_DIM = MS_MAX_HIDDEN = 256    # the one-launch Adams kernels (csrc/mi_ode_stage_rowlocal.h: RhsMlpCoop): float32 and float64
 

@@ -756,10 +756,21 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             rhs = _fusable_tuple(self.func, self.y0)            # tuple state of a row-local RHS: one segmented buffer
             if rhs is not None:
                 self._packed = _pack_components(self.y0, rhs.dim)
+        self._coop = False
+        if rhs is None and not self._force_planes and self._pg is None and self._fusion in (0, 'auto', 4, 'whole') and len(self.y0) == 1:
+            # a network outside the tile kernels' box (float64, wide): the cooperative whole-call kernel, if the batch is co-resident there
+            cand = getattr(self.func, 'device_rhs', None)
+            y = self.y0[0]
+            if cand is not None and hasattr(cand, 'supports_coop') and isinstance(y, torch.Tensor) and y.is_cuda and y.numel() > 0 and \
+                    cand.supports_coop(y):
+                rhs, self._coop = cand, True
         if rhs is None:
             return None
         from .rk_common import _is_fsal_shaped
         fsal, rows = _is_fsal_shaped(self.tableau), len(self.tableau.alpha)
+        if self._coop and not (fsal and rows in (3, 6)):
+            rhs.warn_limits(self.y0[0], 'a %d-row tableau' % rows)
+            return None
         if not (fsal and rows in (3, 6)):
             # dopri8 (13 rows) and adaptive_heun (1 row, not FSAL shaped): row-local kernels only, no per-stage schedule
             wide = (fsal and rows == 13) or (not fsal and rows == 1)
@@ -783,6 +794,13 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         key = ('adaptive', rhs.cache_key(y.dtype, y.device), tuple(y.shape), y.dtype, str(y.device),
                _tableau_key(self.tableau, self.c_mid), args, id(self._pg) if self._pg is not None else None,
                self._linear_variant, self._chunk_attempts, bool(self._profile), self._fusion, seg_rows, seg_tols)
+        if self._coop:                                           # (None: the batch's workgroups are not co-resident - remembered under the key)
+            eng = _cached_engine_or_none(key, lambda: _FusedEngine(
+                rhs, y, True, self.tableau, self.c_mid, *args, linear_variant=self._linear_variant, chunk_attempts=self._chunk_attempts,
+                profile=self._profile, fusion=self._fusion))
+            if eng is None:
+                rhs.warn_limits(y, 'batch %d' % int(y.numel() // rhs.dim))
+            return eng
         try:
             return _cached_engine(key, lambda: _FusedEngine(
                 rhs, y, True, self.tableau, self.c_mid, *args, process_group=self._pg, linear_variant=self._linear_variant,
@@ -796,6 +814,21 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
     def integrate(self, t):
         _assert_increasing(t)
         eng = self._make_engine()
+        if eng is not None and self._coop:
+            # the cooperative kernel has the whole-call schedule only: no output beyond t[0], or a hand-off that timed out on a shared
+            # GPU (nothing was committed) -> the device-controlled engine below
+            out = None
+            if len(t) > 1:
+                try:
+                    out = eng.integrate(t.to(torch.float64).numpy(), self.y0[0])
+                except SyncTimeout:
+                    out = None
+            if out is not None:
+                self.stats = eng.stats.as_dict()
+                self.stats['cross_rank'] = eng.transport
+                self.stats['engine'] = 'cooperative whole-call kernel (one launch, a thread per state element)'
+                return (out,)
+            eng = None
         if eng is None:
             out = self._integrate_device_controlled(t)
             if out is not None:
