@@ -314,3 +314,74 @@ def test_mlp_float64_module_trains_and_evaluates_through_the_cooperative_kernel(
         assert float((o3[1] - out).abs().max()) < 1e-4                        # (another method at the same tolerance)
     assert sum('runs as a Python callable' in str(m.message) for m in w) == 2, [str(m.message) for m in w]
     assert torch.equal(odeint(f, x, torch.tensor([0.3]), method='dopri5')[0], x)
+
+
+# ---------------------------------------------------------------------------------------------
+# user device code for ONE state element (rhs.CustomCoop): systems of dimension up to 256 in one launch - a thread per element,
+# the trajectory's state shared through LDS (round-4 review, item 5: "user code beyond dim 8 ... a conv stencil, a user's own dense layer")
+# ---------------------------------------------------------------------------------------------
+def _coop_cases():
+    from tfdiffeq_amd import plugin_examples as PE
+    rng = np.random.default_rng(77)
+    n = 100
+    ring = PE.reaction_diffusion_ring(n, 0.8, 0.05)              # (prebuilt by __graft_entry__.build(): no compilation on the GPU box)
+
+    def ring_np(t, y):
+        return 0.8 * (np.roll(y, -1, axis=-1) - 2 * y + np.roll(y, 1, axis=-1)) - 0.05 * y * y * y
+    d = 48
+    W = (0.5 * rng.standard_normal((d, d)) / np.sqrt(d))
+    b = 0.1 * rng.standard_normal(d)
+    dense = PE.swish_layer(torch.tensor(W), torch.tensor(b), 0.3, 0.2)   # a user's own dense layer, own pointwise function, forcing in t
+
+    def dense_np(t, y):
+        z = y @ W + b
+        return z / (1 + np.exp(-z)) - 0.3 * y + 0.2 * np.sin(t)
+    return [('ring', ring, ring_np, n), ('dense', dense, dense_np, d)]
+
+
+@pytest.mark.parametrize('method', ['dopri5', 'tsit5', 'bosh3', 'dopri8', 'adaptive_heun', 'adams', 'explicit_adams'])
+def test_custom_coop_systems_run_in_one_launch(method):
+    from oracle import adams_numpy as OA
+    from oracle import ode_numpy as O
+    from tfdiffeq_amd import odeint
+    for name, f, fn, dim in _coop_cases():
+        for batch in (1, 37):
+            rng = np.random.default_rng(dim + batch)
+            y0 = rng.standard_normal((batch, dim))
+            if method == 'explicit_adams':
+                t = np.linspace(0., 0.3, 31)
+            elif method in ('adaptive_heun', 'bosh3'):
+                t = np.array([0., 0.05, 0.12])
+            else:
+                t = np.array([0., 0.4, 1.2])
+            tol = dict(rtol=1e-6, atol=1e-8)
+            got = odeint(f, torch.tensor(y0, device=dev()), torch.tensor(t), method=method, **tol)
+            st = dict(odeint.last_stats)
+            assert st['n_launches'] == 1 and st['status'] == 0, (name, method, st)
+            if method in ('adams', 'explicit_adams'):
+                ref, rst = OA.odeint(fn, y0, t, method=method, return_stats=True, **tol)
+                band = 1e-6 if method == 'adams' else 1e-8
+            else:
+                ref, rst = O.odeint(fn, y0, t, method=method, return_stats=True, options={'tsit5_fixed': True} if method == 'tsit5' else None, **tol)
+                assert (st['n_attempts'], st['n_accepted']) == (rst.n_attempts, rst.n_accepted), (name, method, st, rst.n_attempts, rst.n_accepted)
+                band = 1e-9
+            scale = max(1.0, np.abs(np.asarray(ref)).max())
+            assert np.abs(got.cpu().numpy() - np.asarray(ref)).max() <= band * scale, (name, method, batch)
+
+
+def test_custom_coop_limits_are_loud():
+    from tfdiffeq_amd import _native as N
+    from tfdiffeq_amd import odeint, rhs
+    with pytest.raises(ValueError):
+        rhs.CustomCoop(257, "k = y[i];")
+    f = rhs.CustomCoop(128, "k = -y[i];")
+    y0 = torch.randn(4000, 128, dtype=torch.float64, device=dev())           # 2 trajectories per workgroup: 2000 workgroups are not co-resident
+    with pytest.raises(N.NativeError):
+        odeint(f, y0, torch.tensor([0., 1.]), method='dopri5')
+    with pytest.raises(NotImplementedError):                                  # fixed-grid Runge-Kutta: a Python callable is needed
+        odeint(f, y0[:8], torch.tensor([0., 0.5, 1.]), method='rk4')
+    g = rhs.CustomCoop(128, "k = -y[i];", torch_fn=lambda t, y: -y)
+    out = odeint(g, y0[:8], torch.tensor([0., 0.5, 1.]), method='rk4')
+    ref = odeint(g, y0[:8], torch.tensor([0., 0.5, 1.]), method='dopri5', rtol=1e-9, atol=1e-11)
+    assert float((out - ref).abs().max()) < 5e-3                           # (two RK4 steps of 0.5 on y' = -y: 3e-4 |y| each)
+    assert float((ref[-1] - y0[:8] * np.exp(-1.0)).abs().max()) < 1e-8

@@ -317,6 +317,15 @@ static int pick_family(mi_ode_solver* h) {
       }
       if (pl->dtype != h->d.dtype || pl->dim != D) { mi_set_error("RHS plugin is for dtype %d dim %d, the state is dtype %d dim %d", pl->dtype, pl->dim, h->d.dtype, D); return MI_ODE_E_INVALID; }
       h->plugin = pl;
+      if (pl->cooperative) {                       // a thread per state element: whole-call kernel (adaptive) and the multistep kernels only
+        const bool adaptive_ok = h->d.adaptive && h->d.multistep == 0 && (h->d.fusion == 0 || h->d.fusion == 4);
+        if (D < 1 || D > 256 || !(adaptive_ok || h->d.multistep != 0) || h->d.world_size > 1 || h->d.allgather != nullptr || h->d.n_segments > 1 ||
+            pl->persist_fn == nullptr || pl->multistep_fn == nullptr) {
+          mi_set_error("cooperative RHS plugin: dim <= 256, an adaptive solver (fusion auto / whole) or the Adams family, one rank, one tensor");
+          return MI_ODE_E_INVALID;
+        }
+        h->family = FAM_PLUGIN_COOP; return 0;
+      }
       h->family = FAM_PLUGIN; return 0;
     }
     case MI_ODE_RHS_MLP_TANH: {
@@ -364,7 +373,7 @@ static bool multistep_family(const mi_ode_solver* h) {
   const bool rowlocal = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
                         h->family == FAM_PLUGIN;
   const bool coop = (h->family == FAM_LINEAR_MFMA || h->family == FAM_LINEAR_VALU) && h->d.dim >= 1 && h->d.dim <= 256;
-  return rowlocal || coop || h->family == FAM_MLP_COOP;
+  return rowlocal || coop || h->family == FAM_MLP_COOP || h->family == FAM_PLUGIN_COOP;
 }
 static long long multistep_grid(const mi_ode_solver* h) {
   if (h->family == FAM_LINEAR_MFMA || h->family == FAM_LINEAR_VALU) {
@@ -373,6 +382,10 @@ static long long multistep_grid(const mi_ode_solver* h) {
   }
   if (h->family == FAM_MLP_COOP) {
     const long long tpw = RhsMlpCoop<float>::tpw(h->rhs, (int)h->d.dim);
+    return (h->d.batch + tpw - 1) / tpw;
+  }
+  if (h->family == FAM_PLUGIN_COOP) {
+    const long long tpw = 256 / h->d.dim;            // (RhsUserCoop::tpw, rhs.CustomCoop)
     return (h->d.batch + tpw - 1) / tpw;
   }
   return (h->d.batch + 255) / 256;
@@ -480,7 +493,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   if (rc != 0) { mi_ode_destroy(h); return rc; }
   if (desc->adaptive && desc->multistep != 3 && tb.n_stages != 3 && tb.n_stages != 6) {   // (multistep = 3: no tableau at all)
     const bool rowlocal_fam = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
-                              h->family == FAM_PLUGIN;
+                              h->family == FAM_PLUGIN || h->family == FAM_PLUGIN_COOP;
     const bool mfma13 = (h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP) && tb.fsal && tb.n_stages == 13;   // dopri8 on the tile kernels
     if (!(rowlocal_fam || mfma13) || desc->fusion == 1) {
       mi_set_error("%d-row tableaus run on the whole-attempt / whole-call kernels of the row-local families and (13 rows) of the MFMA-linear and MLP families only (no per-stage kernels)", tb.n_stages);
@@ -582,7 +595,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
                           h->family == FAM_PLUGIN;
     const bool mfma = h->family == FAM_LINEAR_MFMA && h->step_fused;
     const bool mlp = h->family == FAM_MLP;
-    const bool coop = h->family == FAM_MLP_COOP && desc->multistep == 0;
+    const bool coop = (h->family == FAM_MLP_COOP || h->family == FAM_PLUGIN_COOP) && desc->multistep == 0;
     h->init_tiles16 = mfma ? 1 : 0;
     long long g = (mfma || mlp) ? (long long)h->step_grid : coop ? multistep_grid(h) : (desc->batch + 255) / 256;
     const bool single = h->d.world_size <= 1 && desc->allgather == nullptr;
@@ -646,7 +659,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     if (desc->fusion == 4 && !can && single) { mi_set_error("fusion=4: no whole-integration kernel for this problem (row-local or MFMA-linear RHS, single rank, every workgroup co-resident)"); mi_ode_destroy(h); return MI_ODE_E_INVALID; }
     h->persist = (can && (desc->fusion == 4 || desc->fusion == 0)) ? 1 : 0;
     if (coop && desc->adaptive && !h->persist) {
-      mi_set_error("cooperative MLP kernel: %lld workgroups cannot be co-resident on this device (the whole-call kernel is its only schedule)", g);
+      mi_set_error("cooperative kernel: %lld workgroups cannot be co-resident on this device (the whole-call kernel is its only schedule)", g);
       mi_ode_destroy(h); return MI_ODE_E_INVALID;
     }
     if (h->nseg > 1 && !h->persist) {
@@ -1032,11 +1045,11 @@ extern "C" int mi_ode_integrate(mi_ode_handle h, const void* y0_dev, const doubl
   const bool multi = h->d.world_size > 1 || h->d.allgather != nullptr || h->nccl_comm != nullptr;
   if (h->persist && T > 1 && h->d.adaptive && (!multi || h->xrank_on)) {
     const int prc = integrate_persist(h, y0_dev, t_host, T, out_dev, stats, st);
-    if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4 || multi || h->nseg > 1 || h->family == FAM_MLP_COOP) return prc;   // (a rank must not change schedule
+    if (prc < 0 || !(prc & MI_ODE_ST_SYNC_TIMEOUT) || h->d.fusion == 4 || multi || h->nseg > 1 || h->family == FAM_MLP_COOP || h->family == FAM_PLUGIN_COOP) return prc;   // (a rank must not change schedule
                                                                                                             // alone; tuple states have no other)
     h->persist = 0;        // the grid hand-off timed out (co-residency lost to another persistent kernel?): this
   }                        // handle goes back to one launch per attempt, starting with this call
-  if (h->family == FAM_MLP_COOP) { mi_set_error("the cooperative MLP kernel has the whole-call schedule only (T > 1)"); return MI_ODE_E_INVALID; }
+  if (h->family == FAM_MLP_COOP || h->family == FAM_PLUGIN_COOP) { mi_set_error("the cooperative kernels have the whole-call schedule only (T > 1)"); return MI_ODE_E_INVALID; }
   int rc = begin_impl(h, y0_dev, t_host[0], out_dev, stream);   // before_integrate runs even when T == 1 (solvers.py:31);
   if (rc != 0) return rc;                                        // solution = [y0] is written by the same kernel
   int status = 0;
@@ -1241,7 +1254,7 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
   }
   if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
        h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP || h->family == FAM_PLUGIN ||
-       ((h->family == FAM_LINEAR_VALU || h->family == FAM_MLP_COOP) && h->d.multistep != 0)) && h->d.fusion != 1) {
+       ((h->family == FAM_LINEAR_VALU || h->family == FAM_MLP_COOP || h->family == FAM_PLUGIN_COOP) && h->d.multistep != 0)) && h->d.fusion != 1) {
     // trajectories never interact on a fixed grid: the whole integration is ONE launch
     // (k_fixed_rowlocal for the tiny row-local systems, k_fixed_linear_mfma for the linear RHS)
     int rcf = ensure_t_out(h, T + (own_grid ? G : 0));

@@ -21,7 +21,9 @@ enum Family {
   FAM_LINEAR_MFMA,   // dim in {16, 32, 64, 128}
   FAM_MLP,           // fp32 dim<=64, hidden<=128: whole-attempt MFMA kernel only
   FAM_PLUGIN,        // row-local user code behind a mi_ode_rowlocal_plugin table (mi_ode_plugin.h)
-  FAM_MLP_COOP       // the ODEFunc network on the one-launch MULTISTEP kernels only: fp32 / fp64, dim, hidden <= 256 (RhsMlpCoop)
+  FAM_MLP_COOP,      // the ODEFunc network outside the tile kernels' box on the cooperative kernels (a thread per state element): the
+                     // whole-call kernel (adaptive 3- / 6-row tableaus) and the one-launch multistep kernels; fp32 / fp64, dim, hidden <= 256
+  FAM_PLUGIN_COOP    // user code on the same cooperative kernels (plugin table with cooperative = 1; rhs.CustomCoop): dim <= 256
 };
 
 struct LaunchInfo {   // filled per (mode) at create time

@@ -31,7 +31,8 @@ struct mi_ode_rowlocal_plugin {
   int abi;                     // MI_ODE_PLUGIN_ABI
   int dtype;                   // MI_ODE_F32 / MI_ODE_F64
   int dim;
-  int reserved;
+  int cooperative;             // 0: a trajectory per thread (RowLocalPlugin); 1: a state ELEMENT per thread, f evaluated by the trajectory's
+                               // threads together (CoopPlugin, round 5): persist_fn and multistep_fn only, dim <= 256
   size_t solver_size;          // sizeof(mi_ode_solver) the plugin was compiled against
   int (*launch_init)(mi_ode_solver* h, int mode, int nk, mi::StageArgs* A, hipStream_t st);   // M_F0 (nk 0), M_INITB (nk 1)
   int (*launch_step)(mi_ode_solver* h, mi::StepArgs* A, hipStream_t st);
@@ -96,6 +97,21 @@ struct RowLocalPlugin {
   }
 };
 
+// Cooperative plugins (round 5): a thread owns ONE state element (RHS::D = 1, RHS::kCoop, RHS::DIM = the system's dimension <= 256,
+// RHS::tpw = trajectories per 256-thread workgroup); the functor receives its element, shares the trajectory's state through LDS
+// and returns the derivative of its element (tfdiffeq_amd.rhs.CustomCoop generates it).  Same kernels: k_persist_rowlocal (the whole
+// adaptive call in one launch - the only Runge-Kutta schedule), k_fixed_adams_rowlocal / k_adams_vc_rowlocal.
+template <typename T, class RHS>
+struct CoopPlugin {
+  static const void* persist_fn(int S, int ts_dense) { return RowLocalPlugin<T, RHS>::persist_fn(S, ts_dense); }
+  static const void* multistep_fn(int kind) { return RowLocalPlugin<T, RHS>::multistep_fn(kind); }
+  static const mi_ode_rowlocal_plugin* table(int dtype) {
+    static const mi_ode_rowlocal_plugin t = {MI_ODE_PLUGIN_ABI, dtype, RHS::DIM, 1, sizeof(mi_ode_solver),
+                                            nullptr, nullptr, nullptr, &persist_fn, nullptr, &multistep_fn};
+    return &t;
+  }
+};
+
 }  // namespace mi
 
 // MI_ODE_PLUGIN_F32 / MI_ODE_PLUGIN_F64 select which state dtypes the plugin is built for (both by default)
@@ -118,5 +134,22 @@ struct RowLocalPlugin {
   extern "C" const mi_ode_rowlocal_plugin* mi_ode_plugin_get(int dtype) {                \
     MI_ODE_PLUGIN_CASE_F64(RHS)                                                          \
     MI_ODE_PLUGIN_CASE_F32(RHS)                                                          \
+    return nullptr;                                                                      \
+  }
+
+#ifdef MI_ODE_PLUGIN_F64
+#define MI_ODE_COOP_CASE_F64(RHS) if (dtype == MI_ODE_F64) return mi::CoopPlugin<double, RHS<double>>::table(MI_ODE_F64);
+#else
+#define MI_ODE_COOP_CASE_F64(RHS)
+#endif
+#ifdef MI_ODE_PLUGIN_F32
+#define MI_ODE_COOP_CASE_F32(RHS) if (dtype == MI_ODE_F32) return mi::CoopPlugin<float, RHS<float>>::table(MI_ODE_F32);
+#else
+#define MI_ODE_COOP_CASE_F32(RHS)
+#endif
+#define MI_ODE_DEFINE_COOP_PLUGIN(RHS)                                                   \
+  extern "C" const mi_ode_rowlocal_plugin* mi_ode_plugin_get(int dtype) {                \
+    MI_ODE_COOP_CASE_F64(RHS)                                                            \
+    MI_ODE_COOP_CASE_F32(RHS)                                                            \
     return nullptr;                                                                      \
   }

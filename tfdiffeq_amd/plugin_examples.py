@@ -43,6 +43,29 @@ def oscillator_ring(n=8, k0=1.0, coupling=0.5, damping=0.05):
     return rhs.CustomRowLocal(2 * n, body, params=[k0, coupling, damping], torch_fn=torch_fn)
 
 
+def reaction_diffusion_ring(n=100, diffusion=0.8, cubic=0.05):
+    """rhs.CustomCoop (round 5): u_t = D (u_{i+1} - 2 u_i + u_{i-1}) - c u^3 on a ring of n cells - a stencil over a state far beyond what
+    one thread keeps; a thread per cell, the trajectory's state shared through LDS."""
+    return rhs.CustomCoop(n, "k = p[0] * (y[(i + 1) % DIM] - 2 * y[i] + y[(i + DIM - 1) % DIM]) - p[1] * y[i] * y[i] * y[i];", params=[diffusion, cubic],
+                          torch_fn=lambda t, y: diffusion * (torch.roll(y, -1, -1) - 2 * y + torch.roll(y, 1, -1)) - cubic * y * y * y)
+
+
+def swish_layer(W, b, decay=0.3, forcing=0.2):
+    """rhs.CustomCoop: a user's own dense layer with their own pointwise function - f = swish(y W + b) - decay y + forcing sin(t);
+    W [d, d] and b [d] travel as device arrays (w0, w1)."""
+    d = int(W.shape[0])
+    body = """
+T z = w1[i];
+for (int j = 0; j < DIM; ++j) z = fma(y[j], w0[j * DIM + i], z);
+k = z / ((T)1 + exp(-z)) - p[0] * y[i] + p[1] * sin(t);
+"""
+
+    def torch_fn(t, y):
+        z = y @ W.to(y) + b.to(y)
+        return z * torch.sigmoid(z) - decay * y + forcing * torch.sin(torch.as_tensor(t, dtype=y.dtype, device=y.device))
+    return rhs.CustomCoop(d, body, params=[decay, forcing], tensors=[W, b], torch_fn=torch_fn)
+
+
 def prebuild():
     """Compile every example for both state dtypes (cache hits are free) and drop cache entries that belong to older
     kernel headers (the cache key covers the headers, so those can never be hit again)."""
@@ -54,6 +77,8 @@ def prebuild():
             out.append(_plugin_build.build(f.source(dt)))
     out.append(_plugin_build.build(oscillator_ring(8).source(torch.float64)))
     out.append(_plugin_build.build(oscillator_ring(16).source(torch.float32)))
+    out.append(_plugin_build.build(reaction_diffusion_ring(100).source(torch.float64)))
+    out.append(_plugin_build.build(swish_layer(torch.zeros(48, 48), torch.zeros(48)).source(torch.float64)))
     keep = set(os.path.basename(p)[:-3] for p in out)
     d = _plugin_build.plugin_dir()
     for name in os.listdir(d):

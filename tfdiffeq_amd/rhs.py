@@ -442,3 +442,105 @@ class CustomRowLocal(DeviceRHS):
 
     def cache_key(self, dtype, device):
         return super(CustomRowLocal, self).cache_key(dtype, device) + (self._plugin(dtype)[1],)
+
+
+_COOP_TEMPLATE = """// generated by tfdiffeq_amd.rhs.CustomCoop - do not edit
+#define {dtype_macro} 1
+#include "mi_ode_plugin.h"
+namespace mi {{
+template <typename T>
+struct RhsUserCoop {{
+  static constexpr int D = 1;                              // a thread owns ONE state element ...
+  static constexpr bool kCoop = true;                      // ... and the threads of a trajectory evaluate f together
+  static constexpr int DIM = {dim};
+  T p[8];                                                  // mi_ode_rhs.scalars in the state dtype
+  const T *w0, *w1, *w2;                                   // mi_ode_rhs.w[0..2]: the caller's device arrays in the state dtype (nullable)
+  __device__ explicit RhsUserCoop(const RhsParams& r) : w0((const T*)r.w[0]), w1((const T*)r.w[1]), w2((const T*)r.w[2]) {{
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p[i] = (T)r.s[i];
+  }}
+  static __host__ __device__ int tpw(const RhsParams&, int) {{ return 256 / DIM; }}     // trajectories per 256-thread workgroup
+  // t: stage time; yv[0]: this thread's element; kv[0]: its derivative.  Called from uniform control flow (barriers inside).
+  __device__ __forceinline__ void operator()(T t, const T* yv, T* kv) const {{
+    __shared__ T s_y[256];
+    const int slot = (int)threadIdx.x / DIM, i = (int)threadIdx.x - slot * DIM;
+    __syncthreads();                                       // the previous evaluation's readers are done
+    s_y[threadIdx.x] = yv[0];
+    __syncthreads();
+    const T* y = s_y + slot * DIM;                         // the trajectory's whole state, read only
+    T k = (T)0;
+    if (slot < 256 / DIM) {{
+      (void)t; (void)y; (void)i;
+{body}
+    }}
+    kv[0] = k;
+  }}
+}};
+}}  // namespace mi
+MI_ODE_DEFINE_COOP_PLUGIN(mi::RhsUserCoop)
+"""
+
+
+class CustomCoop(DeviceRHS):
+    """A system f(t, y) of dimension up to 256 written as device code for ONE state element (round 5; round-4 review, item 5: user code
+    beyond what a thread can keep - coupled oscillator chains, stencils, a dense layer with the user's own pointwise function).
+
+    `body` is HIP C++ that sets `k` - the derivative of element `i` - from `t`, the trajectory's state `y[0..DIM-1]` (read only, shared
+    by the trajectory's threads through LDS), the parameters `p[0..7]` and up to three device arrays `w0`, `w1`, `w2` (`tensors=`, in
+    the state dtype).  A thread owns one element; floor(256 / dim) trajectories share a workgroup:
+
+        ring = rhs.CustomCoop(100, "k = p[0] * (y[(i + 1) % DIM] - 2 * y[i] + y[(i + DIM - 1) % DIM]);", params=[0.3])   # heat equation on a ring
+        sol = odeint(ring, y0, t, method='dopri5')            # y0: [batch, 100] on the GPU; ONE launch per call
+
+    Kernels: every adaptive Runge-Kutta method as one launch per call (csrc/mi_ode_persist.h: k_persist_rowlocal) and the Adams family
+    (one launch) - as long as the batch's workgroups are co-resident (about 1000 workgroups: 2000 trajectories of dim 100); there is no
+    other schedule, a larger batch raises.  The fixed-grid Runge-Kutta methods need `torch_fn` (they run as a Python callable)."""
+    kind = N.RHS_PLUGIN
+    MAX_DIM = 256
+    row_local = False
+    fixed_grid_fused = False
+    multistep_fused = True
+    wide_tableaus = True          # (solvers._make_engine: dopri8 / adaptive_heun exist for this family - the same whole-call kernel)
+
+    def __init__(self, dim, body, params=(), tensors=(), torch_fn=None):
+        super(CustomCoop, self).__init__()
+        self.dim = int(dim)
+        if not 1 <= self.dim <= self.MAX_DIM:
+            raise ValueError('CustomCoop supports 1 <= dim <= %d (a thread per state element, 256-thread workgroups)' % self.MAX_DIM)
+        self.params = [float(v) for v in params]
+        if len(self.params) > 8:
+            raise ValueError('at most 8 scalar parameters travel by value')
+        self.tensors = [torch.as_tensor(v) for v in tensors]
+        if len(self.tensors) > 3:
+            raise ValueError('at most 3 device arrays (w0, w1, w2)')
+        self.body = str(body)
+        self.torch_fn = torch_fn
+        self._plugins = {}
+
+    def forward(self, t, y):
+        if self.torch_fn is None:
+            raise NotImplementedError('this CustomCoop has no torch_fn: only the one-launch kernels (adaptive Runge-Kutta, Adams family) can evaluate it')
+        return self.torch_fn(t, y)
+
+    def source(self, dtype):
+        body = '\n'.join('      ' + ln for ln in self.body.strip().splitlines())
+        return _COOP_TEMPLATE.format(dtype_macro='MI_ODE_PLUGIN_F32' if dtype == torch.float32 else 'MI_ODE_PLUGIN_F64', dim=self.dim, body=body)
+
+    _plugin = CustomRowLocal._plugin
+
+    def fill(self, rhs, dtype, device):
+        keep = super(CustomCoop, self).fill(rhs, dtype, device)
+        lib, table = self._plugin(dtype)
+        rhs.plugin = table
+        for i, v in enumerate(self.params):
+            rhs.scalars[i] = v
+        for i, w in enumerate(self.tensors):
+            wd = self._dev(w, dtype, device)
+            rhs.w[i] = wd.data_ptr()
+            keep.append(wd)
+        keep.append(lib)
+        return keep
+
+    def cache_key(self, dtype, device):
+        return super(CustomCoop, self).cache_key(dtype, device) + (self._plugin(dtype)[1],)
+

@@ -774,7 +774,8 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
         if not (fsal and rows in (3, 6)):
             # dopri8 (13 rows) and adaptive_heun (1 row, not FSAL shaped): row-local kernels only, no per-stage schedule
             wide = (fsal and rows == 13) or (not fsal and rows == 1)
-            ok = getattr(rhs, 'row_local', False) or (fsal and rows == 13 and getattr(rhs, 'tile_dopri8', False))
+            ok = getattr(rhs, 'row_local', False) or getattr(rhs, 'wide_tableaus', False) or \
+                (fsal and rows == 13 and getattr(rhs, 'tile_dopri8', False))
             if not (wide and ok and self._fusion not in (1, 'stage')):
                 return None
         rtol0 = self.rtol if self.pooled_ratio else self.rtol[0]
