@@ -381,6 +381,11 @@ def test_custom_coop_limits_are_loud():
     with pytest.raises(NotImplementedError):                                  # fixed-grid Runge-Kutta: a Python callable is needed
         odeint(f, y0[:8], torch.tensor([0., 0.5, 1.]), method='rk4')
     g = rhs.CustomCoop(128, "k = -y[i];", torch_fn=lambda t, y: -y)
+    with warnings.catch_warnings(record=True) as w:                          # with a torch_fn the oversized batch runs as a callable, said once
+        warnings.simplefilter('always')
+        big = odeint(g, y0, torch.tensor([0., 1.]), method='dopri5', rtol=1e-8, atol=1e-10)
+    assert str(dict(odeint.last_stats).get('engine', '')).startswith('device-controlled') and any('CustomCoop' in str(m.message) for m in w)
+    assert float((big[-1] - y0 * np.exp(-1.0)).abs().max()) < 1e-6
     out = odeint(g, y0[:8], torch.tensor([0., 0.5, 1.]), method='rk4')
     ref = odeint(g, y0[:8], torch.tensor([0., 0.5, 1.]), method='dopri5', rtol=1e-9, atol=1e-11)
     assert float((out - ref).abs().max()) < 5e-3                           # (two RK4 steps of 0.5 on y' = -y: 3e-4 |y| each)

@@ -452,6 +452,18 @@ def _tableau_key(tb, c_mid):
     return hit[2]
 
 
+_COOP_TOLD = set()
+
+
+def _warn_once_coop(rhs, y, err):
+    key = (id(type(rhs)), int(rhs.dim), tuple(y.shape))
+    if key not in _COOP_TOLD:
+        _COOP_TOLD.add(key)
+        import warnings
+        warnings.warn('tfdiffeq_amd: no one-launch kernel for this rhs.CustomCoop problem (%s); its torch_fn runs as a Python callable on the '
+                      'device-controlled engine instead' % (str(err).split(':')[-1].strip(),))
+
+
 def _fusable_tuple(func, y0):
     """The row-local DeviceRHS behind a `rhs.PerComponent` lift if this tuple state can travel as one segmented buffer."""
     rhs = getattr(func, 'device_rhs', None)
@@ -806,8 +818,13 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             return _cached_engine(key, lambda: _FusedEngine(
                 rhs, y, True, self.tableau, self.c_mid, *args, process_group=self._pg, linear_variant=self._linear_variant,
                 chunk_attempts=self._chunk_attempts, profile=self._profile, fusion=self._fusion, seg_rows=seg_rows, seg_tols=seg_tols))
-        except N.NativeError:
+        except N.NativeError as e:
             if seg_rows is None:
+                if '(-1)' in str(e) and getattr(rhs, 'wide_tableaus', False) and getattr(rhs, 'torch_fn', None) is not None:
+                    # rhs.CustomCoop whose batch is not co-resident on the cooperative kernel (its only schedule), with a torch_fn:
+                    # the same function as a Python callable on the device-controlled engine - said once
+                    _warn_once_coop(rhs, y, e)
+                    return None
                 raise
             self._packed = None                                  # e.g. more workgroups than are co-resident: the generic path
             return None
