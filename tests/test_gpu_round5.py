@@ -378,8 +378,8 @@ def test_custom_coop_limits_are_loud():
     y0 = torch.randn(4000, 128, dtype=torch.float64, device=dev())           # 2 trajectories per workgroup: 2000 workgroups are not co-resident
     with pytest.raises(N.NativeError):
         odeint(f, y0, torch.tensor([0., 1.]), method='dopri5')
-    with pytest.raises(NotImplementedError):                                  # fixed-grid Runge-Kutta: a Python callable is needed
-        odeint(f, y0[:8], torch.tensor([0., 0.5, 1.]), method='rk4')
+    with pytest.raises(NotImplementedError):                                  # midpoint / heun: no kernel, a Python callable is needed
+        odeint(f, y0[:8], torch.tensor([0., 0.5, 1.]), method='midpoint')
     g = rhs.CustomCoop(128, "k = -y[i];", torch_fn=lambda t, y: -y)
     with warnings.catch_warnings(record=True) as w:                          # with a torch_fn the oversized batch runs as a callable, said once
         warnings.simplefilter('always')
@@ -390,3 +390,26 @@ def test_custom_coop_limits_are_loud():
     ref = odeint(g, y0[:8], torch.tensor([0., 0.5, 1.]), method='dopri5', rtol=1e-9, atol=1e-11)
     assert float((out - ref).abs().max()) < 5e-3                           # (two RK4 steps of 0.5 on y' = -y: 3e-4 |y| each)
     assert float((ref[-1] - y0[:8] * np.exp(-1.0)).abs().max()) < 1e-8
+
+
+@pytest.mark.parametrize('method', ['euler', 'rk4'])
+def test_fixed_grid_methods_on_the_cooperative_kernels(method):
+    """euler / rk4 (3/8 rule) in one launch for rhs.CustomCoop and for a float64 network outside the tile kernels' box - any batch size
+    (trajectories never interact on a fixed grid) - against the numpy restatement of fixed_grid.py / rk_common.py:73-81."""
+    from oracle import ode_numpy as O
+    from tfdiffeq_amd import odeint, rhs
+    cases = [(f, fn, dim) for _, f, fn, dim in _coop_cases()]
+    rng = np.random.default_rng(11)
+    d, hd = 6, 40
+    Ws = [0.7 * rng.standard_normal((d, hd)) / np.sqrt(d), 0.7 * rng.standard_normal((hd, hd)) / np.sqrt(hd), 0.7 * rng.standard_normal((hd, d)) / np.sqrt(hd)]
+    bs = [0.1 * rng.standard_normal(hd), 0.1 * rng.standard_normal(hd), 0.1 * rng.standard_normal(d)]
+    cases.append((rhs.MLP(*[torch.tensor(v) for pair in zip(Ws, bs) for v in pair], activation='tanh'), _np_mlp(Ws, bs, 'tanh', False, np.float64), d))
+    for f, fn, dim in cases:
+        for batch in (3, 5000):                                               # 5000 x dim 100: 2500 workgroups - fine on a fixed grid
+            y0 = rng.standard_normal((batch, dim))
+            for t in (np.linspace(0., 0.5, 11), -np.linspace(0., 0.05, 11)):      # (backwards the diffusion ring is anti-diffusion: a short horizon)
+                got = odeint(f, torch.tensor(y0, device=dev()), torch.tensor(t), method=method)
+                st = dict(odeint.last_stats)
+                assert st['n_launches'] == 1 and st['status'] == 0, st
+                ref = np.asarray(O.odeint(fn, y0, t, method=method))
+                assert np.isfinite(ref).all() and np.abs(got.cpu().numpy() - ref).max() <= 1e-12 * max(1.0, np.abs(ref).max())

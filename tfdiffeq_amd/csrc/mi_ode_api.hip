@@ -319,9 +319,10 @@ static int pick_family(mi_ode_solver* h) {
       h->plugin = pl;
       if (pl->cooperative) {                       // a thread per state element: whole-call kernel (adaptive) and the multistep kernels only
         const bool adaptive_ok = h->d.adaptive && h->d.multistep == 0 && (h->d.fusion == 0 || h->d.fusion == 4);
-        if (D < 1 || D > 256 || !(adaptive_ok || h->d.multistep != 0) || h->d.world_size > 1 || h->d.allgather != nullptr || h->d.n_segments > 1 ||
+        const bool fixed_ok = !h->d.adaptive && h->d.multistep == 0 && h->d.fusion != 1 && (h->d.tableau.n_stages == 0 || h->d.tableau.n_stages == 3);
+        if (D < 1 || D > 256 || !(adaptive_ok || fixed_ok || h->d.multistep != 0) || h->d.world_size > 1 || h->d.allgather != nullptr || h->d.n_segments > 1 ||
             pl->persist_fn == nullptr || pl->multistep_fn == nullptr) {
-          mi_set_error("cooperative RHS plugin: dim <= 256, an adaptive solver (fusion auto / whole) or the Adams family, one rank, one tensor");
+          mi_set_error("cooperative RHS plugin: dim <= 256; an adaptive solver (fusion auto / whole), euler / rk4 on a fixed grid or the Adams family; one rank, one tensor");
           return MI_ODE_E_INVALID;
         }
         h->family = FAM_PLUGIN_COOP; return 0;
@@ -338,11 +339,12 @@ static int pick_family(mi_ode_solver* h) {
         h->family = FAM_MLP_COOP; return 0;
       }
       const bool tile_box = h->is_f32 && D >= 1 && D <= 64 && hd >= 1 && hd <= 128;
-      if (h->d.adaptive && !tile_box) {
+      const bool fixed_rk = !h->d.adaptive && h->d.multistep == 0 && (h->d.tableau.n_stages == 0 || h->d.tableau.n_stages == 3);
+      if ((h->d.adaptive || fixed_rk) && !tile_box) {
         // outside the MFMA tile kernels' box (float64, dim > 64, hidden > 128): the cooperative whole-call kernel - a thread per state
         // element, the three layers through LDS (RhsMlpCoop, round 5) - for batches whose workgroups are co-resident; one rank, one tensor
         if (D < 1 || D > 256 || hd < 1 || hd > 256 || !r.w[0] || !r.w[1] || !r.w[2] || h->d.world_size > 1 || h->d.allgather != nullptr ||
-            h->d.n_segments > 1 || (h->d.fusion != 0 && h->d.fusion != 4)) {
+            h->d.n_segments > 1 || (h->d.adaptive && h->d.fusion != 0 && h->d.fusion != 4) || (fixed_rk && h->d.fusion == 1)) {
           mi_set_error("MLP outside the tile kernels (float32, dim <= 64, hidden <= 128): the cooperative whole-call kernel takes dim, hidden <= 256, one rank, one tensor, fusion auto / whole (got dim %d, hidden %d)", D, hd);
           return MI_ODE_E_INVALID;
         }
@@ -1254,7 +1256,7 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
   }
   if ((h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
        h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP || h->family == FAM_PLUGIN ||
-       ((h->family == FAM_LINEAR_VALU || h->family == FAM_MLP_COOP || h->family == FAM_PLUGIN_COOP) && h->d.multistep != 0)) && h->d.fusion != 1) {
+       h->family == FAM_MLP_COOP || h->family == FAM_PLUGIN_COOP || (h->family == FAM_LINEAR_VALU && h->d.multistep != 0)) && h->d.fusion != 1) {
     // trajectories never interact on a fixed grid: the whole integration is ONE launch
     // (k_fixed_rowlocal for the tiny row-local systems, k_fixed_linear_mfma for the linear RHS)
     int rcf = ensure_t_out(h, T + (own_grid ? G : 0));
@@ -1302,7 +1304,8 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
       }
       return (int)h->adams_res[1];
     }
-    if (h->family == FAM_PLUGIN) {
+    if (h->family == FAM_MLP_COOP) multistep_rhs(h, F.rhs);                 // (RhsMlpCoop reads dim from an aux field)
+    if (h->family == FAM_PLUGIN || h->family == FAM_PLUGIN_COOP) {
       rcf = h->plugin->launch_fixed(h, &F, st);
       if (rcf != 0) { mi_set_error("plugin fixed-grid kernel launch failed"); return rcf; }
       h->n_launches += 1;

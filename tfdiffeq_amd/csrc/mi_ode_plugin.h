@@ -32,7 +32,7 @@ struct mi_ode_rowlocal_plugin {
   int dtype;                   // MI_ODE_F32 / MI_ODE_F64
   int dim;
   int cooperative;             // 0: a trajectory per thread (RowLocalPlugin); 1: a state ELEMENT per thread, f evaluated by the trajectory's
-                               // threads together (CoopPlugin, round 5): persist_fn and multistep_fn only, dim <= 256
+                               // threads together (CoopPlugin, round 5): persist_fn, multistep_fn and launch_fixed only, dim <= 256
   size_t solver_size;          // sizeof(mi_ode_solver) the plugin was compiled against
   int (*launch_init)(mi_ode_solver* h, int mode, int nk, mi::StageArgs* A, hipStream_t st);   // M_F0 (nk 0), M_INITB (nk 1)
   int (*launch_step)(mi_ode_solver* h, mi::StepArgs* A, hipStream_t st);
@@ -100,14 +100,23 @@ struct RowLocalPlugin {
 // Cooperative plugins (round 5): a thread owns ONE state element (RHS::D = 1, RHS::kCoop, RHS::DIM = the system's dimension <= 256,
 // RHS::tpw = trajectories per 256-thread workgroup); the functor receives its element, shares the trajectory's state through LDS
 // and returns the derivative of its element (tfdiffeq_amd.rhs.CustomCoop generates it).  Same kernels: k_persist_rowlocal (the whole
-// adaptive call in one launch - the only Runge-Kutta schedule), k_fixed_adams_rowlocal / k_adams_vc_rowlocal.
+// adaptive call in one launch - the only adaptive schedule), k_fixed_rowlocal (Euler / RK4 on a fixed grid), k_fixed_adams_rowlocal /
+// k_adams_vc_rowlocal.
 template <typename T, class RHS>
 struct CoopPlugin {
   static const void* persist_fn(int S, int ts_dense) { return RowLocalPlugin<T, RHS>::persist_fn(S, ts_dense); }
   static const void* multistep_fn(int kind) { return RowLocalPlugin<T, RHS>::multistep_fn(kind); }
+  static int launch_fixed(mi_ode_solver*, FixedArgs* A, hipStream_t st) {       // Euler / RK4 on a fixed grid: trajectories never interact, any batch
+    const long long tpw = RHS::tpw(A->rhs, A->dim);
+    long long g = (A->batch + tpw - 1) / tpw;
+    if (g < 1) g = 1;
+    if (g > kMaxBlocks) g = kMaxBlocks;
+    hipLaunchKernelGGL((k_fixed_rowlocal<T, RHS>), dim3((unsigned)g), dim3(256), 0, st, *A);
+    return hipGetLastError() == hipSuccess ? 0 : MI_ODE_E_HIP;
+  }
   static const mi_ode_rowlocal_plugin* table(int dtype) {
     static const mi_ode_rowlocal_plugin t = {MI_ODE_PLUGIN_ABI, dtype, RHS::DIM, 1, sizeof(mi_ode_solver),
-                                            nullptr, nullptr, nullptr, &persist_fn, nullptr, &multistep_fn};
+                                            nullptr, nullptr, &launch_fixed, &persist_fn, nullptr, &multistep_fn};
     return &t;
   }
 };

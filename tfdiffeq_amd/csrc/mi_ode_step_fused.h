@@ -271,15 +271,21 @@ __global__ __launch_bounds__(256) void k_fixed_rowlocal(FixedArgs A) {
   using Row = RowVec<T, D>;
   const RHS rhs(A.rhs);
   const T sign = (T)A.rhs.sign;
-  const long long n = A.batch * D;
+  const long long n = rhs_is_coop<RHS>::value ? A.batch * A.dim : A.batch * D;      // elements per solution row
   const T* y0p = (const T*)A.y0;
   T* out = (T*)A.out;
   FixedClk clk;
   clk.begin();
-  for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < A.batch;
-       row += (long long)gridDim.x * blockDim.x) {
-    Row y = *(const Row*)(y0p + row * D);
-    *(Row*)(out + row * D) = y;                              // solution = [y0]
+  // e0: this thread's first element; live: it exists (cooperative right-hand sides call rhs() from every thread of the workgroup - it
+  // contains barriers - so a thread without a trajectory runs the loop too and only skips its loads and stores)
+  auto run = [&](long long e0, bool live) {
+    Row y;
+#pragma unroll
+    for (int d = 0; d < D; ++d) y.v[d] = (T)0;
+    if (live) {
+      y = *(const Row*)(y0p + e0);
+      *(Row*)(out + e0) = y;                                   // solution = [y0]
+    }
     int j = 1;
     const T eps = (T)A.eps;
     for (int i = 0; i < A.M; ++i) {
@@ -318,11 +324,21 @@ __global__ __launch_bounds__(256) void k_fixed_rowlocal(FixedArgs A) {
 #pragma unroll
         for (int d = 0; d < D; ++d)
           o.v[d] = (tj == t0) ? y.v[d] : ((tj == t1) ? yn.v[d] : y.v[d] + ((yn.v[d] - y.v[d]) / (t1 - t0)) * (tj - t0));
-        *(Row*)(out + (long long)j * n + row * D) = o;
+        if (live) *(Row*)(out + (long long)j * n + e0) = o;
         ++j;
       }
       y = yn;
     }
+  };
+  if constexpr (rhs_is_coop<RHS>::value) {                   // a thread per state element, tpw trajectories per workgroup (uniform trip count)
+    const int tpw = RHS::tpw(A.rhs, A.dim);
+    const int slot = (int)threadIdx.x / A.dim, col = (int)threadIdx.x - slot * A.dim;
+    for (long long tr0 = (long long)blockIdx.x * tpw; tr0 < A.batch; tr0 += (long long)gridDim.x * tpw) {
+      const long long traj = tr0 + slot;
+      run(traj * A.dim + col, slot < tpw && traj < A.batch);
+    }
+  } else {
+    for (long long row = (long long)blockIdx.x * blockDim.x + threadIdx.x; row < A.batch; row += (long long)gridDim.x * blockDim.x) run(row * D, true);
   }
   clk.end(A.clk);
 }

@@ -494,11 +494,12 @@ class CustomCoop(DeviceRHS):
 
     Kernels: every adaptive Runge-Kutta method as one launch per call (csrc/mi_ode_persist.h: k_persist_rowlocal) and the Adams family
     (one launch) - as long as the batch's workgroups are co-resident (about 1000 workgroups: 2000 trajectories of dim 100); there is no
-    other schedule, a larger batch raises.  The fixed-grid Runge-Kutta methods need `torch_fn` (they run as a Python callable)."""
+    other adaptive schedule: a larger batch raises, or - with a `torch_fn` - runs that as a Python callable.  euler / rk4 run in one launch
+    for any batch size; midpoint / heun need `torch_fn`."""
     kind = N.RHS_PLUGIN
     MAX_DIM = 256
     row_local = False
-    fixed_grid_fused = False
+    fixed_grid_fused = True       # euler / rk4 (3/8 rule) in one launch, any batch size (trajectories never interact on a fixed grid)
     multistep_fused = True
     wide_tableaus = True          # (solvers._make_engine: dopri8 / adaptive_heun exist for this family - the same whole-call kernel)
 

@@ -598,6 +598,13 @@ class FixedGridODESolver(object):
         t = t.to(self.y0[0].dtype)                    # :84 time in the STATE dtype here
         ms = self._fused_multistep()
         rhs = _fusable(self.func, self.y0) if ms is None else None      # (a multistep solver asks below, with the multistep kernels' own limits)
+        if rhs is None and ms is None and len(self.y0) == 1 and self._fused_tableau is not None:
+            # a network outside the tile kernels' box (float64, wide): euler / rk4 on the cooperative one-launch kernel (round 5)
+            cand = getattr(self.func, 'device_rhs', None)
+            y_ = self.y0[0]
+            if cand is not None and hasattr(cand, 'supports_coop') and isinstance(y_, torch.Tensor) and y_.is_cuda and y_.numel() > 0 and \
+                    cand.supports_coop(y_):
+                rhs = cand
         default_grid = getattr(self, '_default_grid', False)
         time_grid = None
         if rhs is None and default_grid and self.eps == 0.0 and self._fused_tableau is not None:
