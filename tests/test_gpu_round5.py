@@ -292,8 +292,9 @@ def test_mlp_outside_the_tile_kernels_runs_in_one_launch(method, dim, hidden, ba
 
 
 def test_mlp_float64_module_trains_and_evaluates_through_the_cooperative_kernel():
-    """models.ODEBlock over a float64 ODEFunc: evaluation in one launch (it used to be a Python callable on the device-controlled engine);
-    a batch too large for a co-resident grid, a single output time and dopri8 fall back to that engine and say so once."""
+    """models.ODEBlock over a float64 ODEFunc: evaluation in one launch (it used to be a Python callable on the device-controlled engine) -
+    also for a batch far beyond a co-resident grid (the plane-streaming whole-call kernel); dopri8 falls back to the callable engine and says
+    so once; a single output time is served without a solve."""
     from tfdiffeq_amd import models, odeint
     torch.manual_seed(5)
     blk = models.ODEBlock(models.ODEFunc(6, 24, non_linearity='tanh'), tol=1e-6).to(dev()).double()
@@ -307,12 +308,16 @@ def test_mlp_float64_module_trains_and_evaluates_through_the_cooperative_kernel(
     f = blk.odefunc.device_rhs()
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter('always')
-        big = torch.randn(200000, 6, dtype=torch.float64, device=dev())       # 42 trajectories per workgroup: 4762 workgroups, not co-resident
+        big = torch.randn(200000, 6, dtype=torch.float64, device=dev())       # 42 trajectories per workgroup: 4762 workgroups - the state streams through planes
         o2 = odeint(f, big, torch.tensor([0., 0.1]), rtol=1e-5, atol=1e-7, method='dopri5')
-        assert str(dict(odeint.last_stats).get('engine', '')).startswith('device-controlled') and torch.isfinite(o2).all()
+        st2 = dict(odeint.last_stats)
+        assert st2['n_launches'] == 1 and st2['status'] == 0, st2
+        o2c = odeint(lambda t_, y: f.forward(t_, y), big, torch.tensor([0., 0.1]), rtol=1e-5, atol=1e-7, method='dopri5')
+        assert (st2['n_attempts'], st2['n_accepted']) == (odeint.last_stats['n_attempts'], odeint.last_stats['n_accepted'])
+        assert float((o2 - o2c).abs().max()) < 1e-10
         o3 = odeint(f, x, torch.tensor([0., 1.]), rtol=1e-6, atol=1e-6, method='dopri8')
         assert float((o3[1] - out).abs().max()) < 1e-4                        # (another method at the same tolerance)
-    assert sum('runs as a Python callable' in str(m.message) for m in w) == 2, [str(m.message) for m in w]
+    assert sum('runs as a Python callable' in str(m.message) for m in w) == 1, [str(m.message) for m in w]
     assert torch.equal(odeint(f, x, torch.tensor([0.3]), method='dopri5')[0], x)
 
 
@@ -370,22 +375,16 @@ def test_custom_coop_systems_run_in_one_launch(method):
 
 
 def test_custom_coop_limits_are_loud():
-    from tfdiffeq_amd import _native as N
     from tfdiffeq_amd import odeint, rhs
     with pytest.raises(ValueError):
         rhs.CustomCoop(257, "k = y[i];")
     f = rhs.CustomCoop(128, "k = -y[i];")
-    y0 = torch.randn(4000, 128, dtype=torch.float64, device=dev())           # 2 trajectories per workgroup: 2000 workgroups are not co-resident
-    with pytest.raises(N.NativeError):
-        odeint(f, y0, torch.tensor([0., 1.]), method='dopri5')
+    y0 = torch.randn(4000, 128, dtype=torch.float64, device=dev())           # 2 trajectories per workgroup: 2000 workgroups are not co-resident -
+    big = odeint(f, y0, torch.tensor([0., 1.]), method='dopri5', rtol=1e-8, atol=1e-10)      # the plane-streaming whole-call kernel, still one launch
+    assert dict(odeint.last_stats)['n_launches'] == 1 and float((big[-1] - y0 * np.exp(-1.0)).abs().max()) < 1e-6
     with pytest.raises(NotImplementedError):                                  # midpoint / heun: no kernel, a Python callable is needed
         odeint(f, y0[:8], torch.tensor([0., 0.5, 1.]), method='midpoint')
     g = rhs.CustomCoop(128, "k = -y[i];", torch_fn=lambda t, y: -y)
-    with warnings.catch_warnings(record=True) as w:                          # with a torch_fn the oversized batch runs as a callable, said once
-        warnings.simplefilter('always')
-        big = odeint(g, y0, torch.tensor([0., 1.]), method='dopri5', rtol=1e-8, atol=1e-10)
-    assert str(dict(odeint.last_stats).get('engine', '')).startswith('device-controlled') and any('CustomCoop' in str(m.message) for m in w)
-    assert float((big[-1] - y0 * np.exp(-1.0)).abs().max()) < 1e-6
     out = odeint(g, y0[:8], torch.tensor([0., 0.5, 1.]), method='rk4')
     ref = odeint(g, y0[:8], torch.tensor([0., 0.5, 1.]), method='dopri5', rtol=1e-9, atol=1e-11)
     assert float((out - ref).abs().max()) < 5e-3                           # (two RK4 steps of 0.5 on y' = -y: 3e-4 |y| each)

@@ -621,17 +621,18 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       const int cap = mlp ? mi_persist_capacity_mlp_f32(h) : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
       capable = cap > 0 && g <= cap;
     }
-    if (!capable && desc->adaptive && rowlocal) {
+    if (!capable && desc->adaptive && (rowlocal || coop)) {
       // more trajectories than one-per-thread keeps co-resident: the same loop with the state in HBM planes, a co-resident
       // grid walking the batch (k_persist_rowlocal_planes)
       h->persist_planes = 1;
       h->persist_planes_block = 256;                 // (512 measured: +3 % at 1M Lorenz rows, -50 % at 4M)
-      if (const char* eb = getenv("MI_ODE_PERSIST_PLANES_BLOCK")) { const int v = atoi(eb); if (v == 256 || v == 512) h->persist_planes_block = v; }
+      if (const char* eb = getenv("MI_ODE_PERSIST_PLANES_BLOCK")) { const int v = atoi(eb); if ((v == 256 || v == 512) && !coop) h->persist_planes_block = v; }
       const int cap = h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h);
       long long gp = cap < kPersistMaxGrid ? cap : kPersistMaxGrid;
       if (gp > h->num_cus) gp = h->num_cus;                  // the hand-off is all-to-all: one (large) workgroup per CU
       if (const char* eg = getenv("MI_ODE_PERSIST_PLANES_GRID")) { const long long v = atoll(eg); if (v >= 1 && v <= gp) gp = v; }
-      if (gp > (desc->batch + h->persist_planes_block - 1) / h->persist_planes_block) gp = (desc->batch + h->persist_planes_block - 1) / h->persist_planes_block;
+      const long long gneed = coop ? multistep_grid(h) : (desc->batch + h->persist_planes_block - 1) / h->persist_planes_block;   // (cooperative: tpw trajectories per workgroup)
+      if (gp > gneed) gp = gneed;
       if (h->nseg > 1 && gp < h->nseg) gp = 0;               // tuple state: every component needs a workgroup of its own
       if (cap > 0 && gp >= 1) { capable = true; g = gp; }
       else h->persist_planes = 0;

@@ -628,9 +628,26 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
   // this thread's rows: first, first + pitch, ... < batch.  Tuple state (nseg > 1): the workgroup belongs to ONE component - rows
   // seg_off .. seg_off + seg_rows of the packed buffer (components padded to MI_ODE_SEGMENT_ALIGN rows), walked by that
   // component's workgroups only, so a workgroup's record is a record of its component (grid_reduce folds per seg_blk range)
+  // Cooperative right-hand sides (a thread per state ELEMENT, round 5): the loop variable is the first trajectory of the workgroup's
+  // current group of tpw - the same for every thread of the workgroup, since rhs() contains barriers - and `locate` gives a thread its
+  // element of that group (or none: it then runs the loop without loads and stores).
+  constexpr bool COOP = rhs_is_coop<RHS>::value;
   const int nseg = A.nseg;
-  long long first = (long long)blockIdx.x * blockDim.x + threadIdx.x, pitch = (long long)gridDim.x * blockDim.x;
+  const int tpw = coop_tpw<RHS>(A.s.rhs, A.s.dim);
+  const int c_slot = COOP ? (int)threadIdx.x / A.s.dim : 0, c_col = COOP ? (int)threadIdx.x - c_slot * A.s.dim : 0;
+  long long first = COOP ? (long long)blockIdx.x * tpw : (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  long long pitch = COOP ? (long long)gridDim.x * tpw : (long long)gridDim.x * blockDim.x;
   long long batch = A.s.batch;
+  auto locate = [&](long long it, long long& e0) -> bool {    // e0: this thread's first element for loop position `it`; returns "it exists"
+    if constexpr (COOP) {
+      const long long traj = it + c_slot;
+      e0 = traj * A.s.dim + c_col;
+      return c_slot < tpw && traj < batch;
+    } else {
+      e0 = it * D;
+      return true;
+    }
+  };
   if (nseg > 1) {
     int sg = 0;
     long long off = 0;
@@ -652,10 +669,16 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
   T* const fa = (T*)(A.s.planes + 2 * A.s.stride);
   T* const fb = (T*)(A.s.planes + (long long)(2 + S) * A.s.stride);
   const T* const y_user = (const T*)A.y0;
-  auto load_row = [](const T* plane, long long row) {        // planes rewritten inside this launch: skip this CU's L1 (sc0)
+  auto load_row = [](const T* plane, long long e0) {         // planes rewritten inside this launch: skip this CU's L1 (sc0)
     Row v;
 #pragma unroll
-    for (int d = 0; d < D; ++d) v.v[d] = __hip_atomic_load(plane + row * D + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    for (int d = 0; d < D; ++d) v.v[d] = __hip_atomic_load(plane + e0 + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return v;
+  };
+  auto zero_row = []() {
+    Row v;
+#pragma unroll
+    for (int d = 0; d < D; ++d) v.v[d] = (T)0;
     return v;
   };
 
@@ -664,8 +687,13 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
   {                                                           // before_integrate, first half (misc.py:225-233)
     Acc acc;
     for (long long row = first; row < batch; row += pitch) {
-      const Row y = *(const Row*)(y_user + row * D);
-      *(Row*)((T*)A.out0 + row * D) = y;                      // solution[0] = y0 (solvers.py:30)
+      long long e0;
+      const bool live = locate(row, e0);
+      Row y = zero_row();
+      if (live) {
+        y = *(const Row*)(y_user + e0);
+        *(Row*)((T*)A.out0 + e0) = y;                         // solution[0] = y0 (solvers.py:30)
+      }
       T ys[D], f0[D];
 #pragma unroll
       for (int d = 0; d < D; ++d) ys[d] = y.v[d];
@@ -673,7 +701,8 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
       Row f;
 #pragma unroll
       for (int d = 0; d < D; ++d) f.v[d] = sign * f0[d];
-      *(Row*)(fa + row * D) = f;
+      if (!live) continue;                                    // (after rhs(): its barriers are behind every thread)
+      *(Row*)(fa + e0) = f;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const T sc = (T)cp.atol + fabs(y.v[d]) * (T)cp.rtol;  // misc.py:225
@@ -699,12 +728,15 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
     Acc acc;
     const T h0 = (T)uniform_d(s_c.h0);
     for (long long row = first; row < batch; row += pitch) {
-      const Row y = *(const Row*)(y_user + row * D);
-      const Row f0 = load_row(fa, row);
+      long long e0;
+      const bool live = locate(row, e0);
+      const Row y = live ? *(const Row*)(y_user + e0) : zero_row();
+      const Row f0 = live ? load_row(fa, e0) : zero_row();
       T ys[D], f1[D];
 #pragma unroll
       for (int d = 0; d < D; ++d) ys[d] = y.v[d] + h0 * f0.v[d];
       rhs(sign * (t_first + (T)1.0 * h0), ys, f1);
+      if (!live) continue;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const T kn = sign * f1[d];
@@ -751,10 +783,15 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
     Acc acc;
     Row y0n, f0n;                                             // the next row of this thread, loaded one iteration ahead
     auto fetch = [&](long long row) {
-      if (row < batch) { y0n = (cur_y == y_user) ? *(const Row*)(y_user + row * D) : load_row(P.y0, row); f0n = load_row(P.f0, row); }
+      long long en;
+      const bool have = row < batch && locate(row, en);
+      if (have) { y0n = (cur_y == y_user) ? *(const Row*)(y_user + en) : load_row(P.y0, en); f0n = load_row(P.f0, en); }
+      else if constexpr (COOP) { y0n = zero_row(); f0n = zero_row(); }
     };
     fetch(first);
     for (long long row = first; row < batch; row += pitch) {
+      long long e0;
+      const bool live = locate(row, e0);
       const Row y0 = y0n;
       T hs = P.hs;
       asm volatile("" : "+v"(hs));                            // dt * coefficient products are formed per row, not kept (and spilled) across rows
@@ -778,6 +815,7 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
         for (int d = 0; d < D; ++d) k[SG][d] = sign * kn[d];
       };
       for_stages<1, S>(stage);
+      if (!live) continue;
       Row y1, f1;
 #pragma unroll
       for (int d = 0; d < D; ++d) {
@@ -792,10 +830,10 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
         acc.maxa = fmax(acc.maxa, (double)fabs(y0.v[d]));
         acc.maxb = fmax(acc.maxb, (double)fabs(ys[d]));
         acc.suma += (double)err * (double)err;
-        step_emit<T, S, TS>(A.s, P, y0.v[d], ys[d], kk, ymid, row * D + d, t_out);
+        step_emit<T, S, TS>(A.s, P, y0.v[d], ys[d], kk, ymid, e0 + d, t_out);
       }
-      *(Row*)(P.y1 + row * D) = y1;
-      *(Row*)(P.f1 + row * D) = f1;
+      *(Row*)(P.y1 + e0) = y1;
+      *(Row*)(P.f1 + e0) = f1;
     }
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);            // (its barriers also fence the reads of sh.pub above)
     if (threadIdx.x == 0) {
@@ -812,8 +850,10 @@ __global__ __launch_bounds__(512) void k_persist_rowlocal_planes(PersistArgs A) 
 
   // final state for mi_ode_get_state: plane indices as controller_apply's rotation would have left them
   if (cur_y == y_user) {                                      // no accepted step (error exit): seed plane 0 with y0
-    for (long long row = first; row < batch; row += pitch)
-      *(Row*)(ya + row * D) = *(const Row*)(y_user + row * D);
+    for (long long row = first; row < batch; row += pitch) {
+      long long e0;
+      if (locate(row, e0)) *(Row*)(ya + e0) = *(const Row*)(y_user + e0);
+    }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     sh.st.store(s_c);

@@ -32,7 +32,7 @@ struct mi_ode_rowlocal_plugin {
   int dtype;                   // MI_ODE_F32 / MI_ODE_F64
   int dim;
   int cooperative;             // 0: a trajectory per thread (RowLocalPlugin); 1: a state ELEMENT per thread, f evaluated by the trajectory's
-                               // threads together (CoopPlugin, round 5): persist_fn, multistep_fn and launch_fixed only, dim <= 256
+                               // threads together (CoopPlugin, round 5): persist_fn, persist_planes_fn, multistep_fn and launch_fixed only, dim <= 256
   size_t solver_size;          // sizeof(mi_ode_solver) the plugin was compiled against
   int (*launch_init)(mi_ode_solver* h, int mode, int nk, mi::StageArgs* A, hipStream_t st);   // M_F0 (nk 0), M_INITB (nk 1)
   int (*launch_step)(mi_ode_solver* h, mi::StepArgs* A, hipStream_t st);
@@ -105,6 +105,7 @@ struct RowLocalPlugin {
 template <typename T, class RHS>
 struct CoopPlugin {
   static const void* persist_fn(int S, int ts_dense) { return RowLocalPlugin<T, RHS>::persist_fn(S, ts_dense); }
+  static const void* persist_planes_fn(int S, int ts_dense) { return RowLocalPlugin<T, RHS>::persist_planes_fn(S, ts_dense); }   // any batch size
   static const void* multistep_fn(int kind) { return RowLocalPlugin<T, RHS>::multistep_fn(kind); }
   static int launch_fixed(mi_ode_solver*, FixedArgs* A, hipStream_t st) {       // Euler / RK4 on a fixed grid: trajectories never interact, any batch
     const long long tpw = RHS::tpw(A->rhs, A->dim);
@@ -116,7 +117,7 @@ struct CoopPlugin {
   }
   static const mi_ode_rowlocal_plugin* table(int dtype) {
     static const mi_ode_rowlocal_plugin t = {MI_ODE_PLUGIN_ABI, dtype, RHS::DIM, 1, sizeof(mi_ode_solver),
-                                            nullptr, nullptr, &launch_fixed, &persist_fn, nullptr, &multistep_fn};
+                                            nullptr, nullptr, &launch_fixed, &persist_fn, &persist_planes_fn, &multistep_fn};
     return &t;
   }
 };

@@ -144,6 +144,13 @@ struct rhs_is_coop : std::false_type {};
 template <class R>
 struct rhs_is_coop<R, std::void_t<decltype(R::kCoop)>> : std::true_type {};
 
+// trajectories per 256-thread workgroup of a cooperative right-hand side (1 for the thread-per-trajectory ones: unused there)
+template <class RHS>
+__device__ __forceinline__ int coop_tpw(const RhsParams& rp, int dim) {
+  if constexpr (rhs_is_coop<RHS>::value) return RHS::tpw(rp, dim);
+  else return 1;
+}
+
 // which element(s) of the state this thread owns: offset of its first element, whether it exists, elements per plane
 template <class RHS>
 __device__ __forceinline__ void rowmap(long long batch, int dim, const RhsParams& rp, long long& off, bool& live, long long& n_plane) {
