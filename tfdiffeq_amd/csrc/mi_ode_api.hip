@@ -629,7 +629,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       if (const char* eb = getenv("MI_ODE_PERSIST_PLANES_BLOCK")) { const int v = atoi(eb); if ((v == 256 || v == 512) && !coop) h->persist_planes_block = v; }
       const int cap = h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h);
       long long gp = cap < kPersistMaxGrid ? cap : kPersistMaxGrid;
-      if (gp > h->num_cus) gp = h->num_cus;                  // the hand-off is all-to-all: one (large) workgroup per CU
+      if (gp > h->num_cus && !coop) gp = h->num_cus;         // the hand-off is all-to-all: one (large) workgroup per CU; the cooperative
+                                                             // right-hand sides (barriers inside every evaluation) want every co-resident workgroup
       if (const char* eg = getenv("MI_ODE_PERSIST_PLANES_GRID")) { const long long v = atoll(eg); if (v >= 1 && v <= gp) gp = v; }
       const long long gneed = coop ? multistep_grid(h) : (desc->batch + h->persist_planes_block - 1) / h->persist_planes_block;   // (cooperative: tpw trajectories per workgroup)
       if (gp > gneed) gp = gneed;

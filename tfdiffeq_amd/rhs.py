@@ -242,7 +242,8 @@ class MLP(DeviceRHS):
     def supports_coop(self, y0):
         """Outside that box (round 5): the adaptive Runge-Kutta solvers in ONE launch on the cooperative kernel (a thread per state element,
         the three layers through LDS: csrc/mi_ode_stage_rowlocal.h RhsMlpCoop under k_persist_rowlocal) - float32 / float64, dim and hidden
-        up to 256, as long as the batch's workgroups (min(256 / dim, 2048 / hidden) trajectories each) are co-resident."""
+        up to 256; state in registers while the batch's workgroups (min(256 / dim, 2048 / hidden) trajectories each) are co-resident, streamed
+        through HBM planes beyond (csrc/mi_ode_persist.h: k_persist_rowlocal_planes)."""
         return (not self.supports(y0) and y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
                 and self.dim <= self.MS_MAX_DIM and self.hidden <= self.MS_MAX_HIDDEN)
 
@@ -257,7 +258,7 @@ class MLP(DeviceRHS):
             MLP._told_limits.add(key)
             import warnings
             warnings.warn('tfdiffeq_amd.rhs.MLP: the MFMA tile kernels take float32 states with dim <= %d and hidden <= %d, the cooperative '
-                          'one-launch kernel float32 / float64 up to %d wide for batches whose workgroups are co-resident; this problem (%s, dim %d, '
+                          'one-launch kernel float32 / float64 up to %d wide (dopri5 / tsit5 / bosh3, euler / rk4, the Adams family); this problem (%s, dim %d, '
                           'hidden %d%s) runs as a Python callable on the device-controlled engine instead' % (
                               self.MAX_DIM, self.MAX_HIDDEN, self.MS_MAX_DIM, str(y0.dtype).replace('torch.', ''), self.dim, self.hidden,
                               (', ' + why) if why else ''))
@@ -492,10 +493,10 @@ class CustomCoop(DeviceRHS):
         ring = rhs.CustomCoop(100, "k = p[0] * (y[(i + 1) % DIM] - 2 * y[i] + y[(i + DIM - 1) % DIM]);", params=[0.3])   # heat equation on a ring
         sol = odeint(ring, y0, t, method='dopri5')            # y0: [batch, 100] on the GPU; ONE launch per call
 
-    Kernels: every adaptive Runge-Kutta method as one launch per call (csrc/mi_ode_persist.h: k_persist_rowlocal) and the Adams family
-    (one launch) - as long as the batch's workgroups are co-resident (about 1000 workgroups: 2000 trajectories of dim 100); there is no
-    other adaptive schedule: a larger batch raises, or - with a `torch_fn` - runs that as a Python callable.  euler / rk4 run in one launch
-    for any batch size; midpoint / heun need `torch_fn`."""
+    Kernels: every adaptive Runge-Kutta method as one launch per call at any batch size (csrc/mi_ode_persist.h: k_persist_rowlocal with
+    the state in registers while the batch's workgroups are co-resident - about 1000 workgroups: 2000 trajectories of dim 100 -,
+    k_persist_rowlocal_planes with the state streamed through HBM planes beyond), euler / rk4 (one launch, any batch) and the Adams
+    family (one launch, co-resident grid).  midpoint / heun, tuple states and `odeint_adjoint` need `torch_fn`."""
     kind = N.RHS_PLUGIN
     MAX_DIM = 256
     row_local = False
