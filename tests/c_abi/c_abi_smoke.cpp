@@ -7,6 +7,7 @@
 //      attempt captured as a hipGraph and replayed in blind chunks
 //   9. (ABI 12) mi_ode_outer_reduce vs a host loop
 //  10. (ABI 13) mi_ode_linadj_segment: a backward interval of the linear system's adjoint in one launch vs a fine RK4 solve written here
+//  11. (round 5) a float64 MLP on the cooperative kernels (registers / planes / fixed grid) vs a fine RK4 solve of the network written here
 // Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -I include tests/c_abi/c_abi_smoke.cpp -L tfdiffeq_amd -lmi_ode
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -560,6 +561,84 @@ int main() {
     if (mi_ode_linadj_create(&ld, &bad) >= 0) { printf("FAIL linadj accepted dim 200\n"); return 1; }
     MI(mi_ode_linadj_destroy(lh));
     CK(hipFree(dW)); CK(hipFree(db)); CK(hipFree(dy)); CK(hipFree(da)); CK(hipFree(dat)); CK(hipFree(dth)); CK(hipFree(oa)); CK(hipFree(oat)); CK(hipFree(oth));
+  }
+  // ---- 11. (round 5) MI_ODE_RHS_MLP_TANH outside the tile kernels' box - float64, 6 -> 24 -> 24 -> 6, tanh - through the plain engine entry
+  //          points: the cooperative kernel (a thread per state element), one launch per call, at two batch sizes (state in registers /
+  //          streamed through HBM planes) and on a fixed grid (rk4), against a fine RK4 solve of the same network written here ----
+  {
+    const int MD = 6, MH = 24;
+    std::vector<double> W1((size_t)MD * MH), W2((size_t)MH * MH), W3((size_t)MH * MD), b1(MH), b2(MH), b3(MD);
+    for (int i = 0; i < MD; ++i) for (int j = 0; j < MH; ++j) W1[(size_t)i * MH + j] = 0.6 * sin(1.3 * i + 0.7 * j) / sqrt((double)MD);
+    for (int i = 0; i < MH; ++i) for (int j = 0; j < MH; ++j) W2[(size_t)i * MH + j] = 0.6 * cos(0.9 * i - 1.1 * j) / sqrt((double)MH);
+    for (int i = 0; i < MH; ++i) for (int j = 0; j < MD; ++j) W3[(size_t)i * MD + j] = 0.6 * sin(0.5 * i + 1.9 * j + 0.3) / sqrt((double)MH);
+    for (int j = 0; j < MH; ++j) { b1[j] = 0.1 * cos(j); b2[j] = 0.1 * sin(2.0 * j); }
+    for (int j = 0; j < MD; ++j) b3[j] = 0.05 * cos(3.0 * j);
+    auto net = [&](const double* y, double* f) {
+      double h1[24], h2[24];
+      for (int j = 0; j < MH; ++j) { double a = b1[j]; for (int k = 0; k < MD; ++k) a += y[k] * W1[(size_t)k * MH + j]; h1[j] = tanh(a); }
+      for (int j = 0; j < MH; ++j) { double a = b2[j]; for (int k = 0; k < MH; ++k) a += h1[k] * W2[(size_t)k * MH + j]; h2[j] = tanh(a); }
+      for (int j = 0; j < MD; ++j) { double a = b3[j]; for (int k = 0; k < MH; ++k) a += h2[k] * W3[(size_t)k * MD + j]; f[j] = a; }
+    };
+    double *dW1, *dW2, *dW3, *db1, *db2, *db3;
+    CK(hipMalloc((void**)&dW1, W1.size() * 8)); CK(hipMalloc((void**)&dW2, W2.size() * 8)); CK(hipMalloc((void**)&dW3, W3.size() * 8));
+    CK(hipMalloc((void**)&db1, b1.size() * 8)); CK(hipMalloc((void**)&db2, b2.size() * 8)); CK(hipMalloc((void**)&db3, b3.size() * 8));
+    CK(hipMemcpy(dW1, W1.data(), W1.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dW2, W2.data(), W2.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dW3, W3.data(), W3.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db1, b1.data(), b1.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db2, b2.data(), b2.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(db3, b3.data(), b3.size() * 8, hipMemcpyHostToDevice));
+    const long long batches[2] = {50, 120000};                  // 42 trajectories per workgroup: 2 / 2858 workgroups (the latter not co-resident)
+    for (int bi = 0; bi < 2; ++bi) {
+      const long long MB = batches[bi];
+      std::vector<double> my0((size_t)MB * MD), mout((size_t)3 * MB * MD);
+      for (long long r = 0; r < MB; ++r) for (int c = 0; c < MD; ++c) my0[(size_t)r * MD + c] = sin(0.37 * (double)(r % 977) + 1.1 * c);
+      double *dmy = nullptr, *dmo = nullptr;
+      CK(hipMalloc((void**)&dmy, my0.size() * 8)); CK(hipMalloc((void**)&dmo, mout.size() * 8));
+      CK(hipMemcpy(dmy, my0.data(), my0.size() * 8, hipMemcpyHostToDevice));
+      for (int fixed = 0; fixed < 2; ++fixed) {
+        mi_ode_desc md = d;                                      // dopri5, rtol 1e-9 / atol 1e-11 (section 2)
+        md.batch = MB; md.dim = MD; md.dtype = MI_ODE_F64;
+        memset(&md.rhs, 0, sizeof(md.rhs));
+        md.rhs.kind = MI_ODE_RHS_MLP_TANH; md.rhs.sign = 1.0; md.rhs.hidden = MH;
+        md.rhs.w[0] = dW1; md.rhs.w[1] = dW2; md.rhs.w[2] = dW3; md.rhs.b[0] = db1; md.rhs.b[1] = db2; md.rhs.b[2] = db3;
+        if (fixed) { md.adaptive = 0; md.tableau.n_stages = 3; md.first_step = NAN; }
+        mi_ode_handle mh = nullptr;
+        MI(mi_ode_create(&md, &mh));
+        mi_ode_stats ms;
+        double tm[3] = {0.0, 0.5, 1.0};
+        std::vector<double> tg(41);
+        for (int i = 0; i < 41; ++i) tg[i] = 0.025 * i;
+        int mb;
+        if (fixed) mb = mi_ode_fixed_grid_integrate_on(mh, dmy, tg.data(), 41, tm, 3, 0.0, dmo, &ms, nullptr);
+        else mb = mi_ode_integrate(mh, dmy, tm, 3, dmo, &ms, nullptr);
+        if (mb != 0) { printf("FAIL cooperative MLP (batch %lld, fixed %d): %d %s\n", MB, fixed, mb, mi_ode_last_error()); return 1; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(mout.data(), dmo, mout.size() * 8, hipMemcpyDeviceToHost));
+        double mdm = 0.0;
+        for (long long r = 0; r < MB; r += (MB > 1000 ? 997 : 1)) {              // (a sample of the large batch)
+          double y[6], k1[6], k2[6], k3[6], k4[6], ys[6];
+          for (int c = 0; c < MD; ++c) y[c] = my0[(size_t)r * MD + c];
+          const int NS = 400;
+          for (int sidx = 0; sidx < NS; ++sidx) {
+            const double dt = 1.0 / NS;
+            net(y, k1);
+            for (int c = 0; c < MD; ++c) ys[c] = y[c] + 0.5 * dt * k1[c];
+            net(ys, k2);
+            for (int c = 0; c < MD; ++c) ys[c] = y[c] + 0.5 * dt * k2[c];
+            net(ys, k3);
+            for (int c = 0; c < MD; ++c) ys[c] = y[c] + dt * k3[c];
+            net(ys, k4);
+            for (int c = 0; c < MD; ++c) y[c] += dt / 6 * (k1[c] + 2 * k2[c] + 2 * k3[c] + k4[c]);
+            if (sidx + 1 == NS / 2) for (int c = 0; c < MD; ++c) mdm = fmax(mdm, fabs(mout[(size_t)MB * MD + (size_t)r * MD + c] - y[c]));
+          }
+          for (int c = 0; c < MD; ++c) mdm = fmax(mdm, fabs(mout[(size_t)2 * MB * MD + (size_t)r * MD + c] - y[c]));
+        }
+        printf("cooperative MLP 6-24-24-6 fp64, batch %lld, %s: launches %d attempts %lld, max |gpu - fine rk4| = %.3e\n", MB,
+               fixed ? "rk4 on a 40-step grid" : "dopri5", (int)ms.n_launches, (long long)ms.n_attempts, mdm);
+        if (ms.n_launches != 1 || !(mdm < (fixed ? 1e-6 : 1e-8))) { printf("FAIL cooperative MLP\n"); return 1; }
+        MI(mi_ode_destroy(mh));
+      }
+      CK(hipFree(dmy)); CK(hipFree(dmo));
+    }
+    CK(hipFree(dW1)); CK(hipFree(dW2)); CK(hipFree(dW3)); CK(hipFree(db1)); CK(hipFree(db2)); CK(hipFree(db3));
   }
   printf("C-ABI OK (abi %d)\n", mi_ode_abi_version());
   return 0;
