@@ -495,7 +495,7 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   if (rc != 0) { mi_ode_destroy(h); return rc; }
   if (desc->adaptive && desc->multistep != 3 && tb.n_stages != 3 && tb.n_stages != 6) {   // (multistep = 3: no tableau at all)
     const bool rowlocal_fam = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
-                              h->family == FAM_PLUGIN || h->family == FAM_PLUGIN_COOP;
+                              h->family == FAM_PLUGIN || h->family == FAM_PLUGIN_COOP || h->family == FAM_MLP_COOP;
     const bool mfma13 = (h->family == FAM_LINEAR_MFMA || h->family == FAM_MLP) && tb.fsal && tb.n_stages == 13;   // dopri8 on the tile kernels
     if (!(rowlocal_fam || mfma13) || desc->fusion == 1) {
       mi_set_error("%d-row tableaus run on the whole-attempt / whole-call kernels of the row-local families and (13 rows) of the MFMA-linear and MLP families only (no per-stage kernels)", tb.n_stages);

@@ -258,7 +258,7 @@ class MLP(DeviceRHS):
             MLP._told_limits.add(key)
             import warnings
             warnings.warn('tfdiffeq_amd.rhs.MLP: the MFMA tile kernels take float32 states with dim <= %d and hidden <= %d, the cooperative '
-                          'one-launch kernel float32 / float64 up to %d wide (dopri5 / tsit5 / bosh3, euler / rk4, the Adams family); this problem (%s, dim %d, '
+                          'one-launch kernel float32 / float64 up to %d wide (every adaptive method, euler / rk4, the Adams family); this problem (%s, dim %d, '
                           'hidden %d%s) runs as a Python callable on the device-controlled engine instead' % (
                               self.MAX_DIM, self.MAX_HIDDEN, self.MS_MAX_DIM, str(y0.dtype).replace('torch.', ''), self.dim, self.hidden,
                               (', ' + why) if why else ''))

@@ -783,14 +783,13 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             if cand is not None and hasattr(cand, 'supports_coop') and isinstance(y, torch.Tensor) and y.is_cuda and y.numel() > 0 and \
                     cand.supports_coop(y):
                 rhs, self._coop = cand, True
+            elif cand is not None and hasattr(cand, 'warn_limits') and isinstance(y, torch.Tensor) and y.is_cuda:
+                cand.warn_limits(y)                                  # (e.g. hidden > 256: no kernel of the family takes it - said once)
         if rhs is None:
             return None
         from .rk_common import _is_fsal_shaped
         fsal, rows = _is_fsal_shaped(self.tableau), len(self.tableau.alpha)
-        if self._coop and not (fsal and rows in (3, 6)):
-            rhs.warn_limits(self.y0[0], 'a %d-row tableau' % rows)
-            return None
-        if not (fsal and rows in (3, 6)):
+        if not (fsal and rows in (3, 6)) and not self._coop:           # (the cooperative kernel exists for every adaptive tableau)
             # dopri8 (13 rows) and adaptive_heun (1 row, not FSAL shaped): row-local kernels only, no per-stage schedule
             wide = (fsal and rows == 13) or (not fsal and rows == 1)
             ok = getattr(rhs, 'row_local', False) or getattr(rhs, 'wide_tableaus', False) or \
