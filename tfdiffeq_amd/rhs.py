@@ -244,6 +244,19 @@ class MLP(DeviceRHS):
         the three layers through LDS: csrc/mi_ode_stage_rowlocal.h RhsMlpCoop under k_persist_rowlocal) - float32 / float64, dim and hidden
         up to 256; state in registers while the batch's workgroups (min(256 / dim, 2048 / hidden) trajectories each) are co-resident, streamed
         through HBM planes beyond (csrc/mi_ode_persist.h: k_persist_rowlocal_planes)."""
+        if not self.coop_in_box(y0):
+            return False
+        # The cooperative evaluation is vector-ALU work fed from L2 (~0.9e12 fma/s measured): it beats the callable engine (three rocBLAS
+        # products per evaluation, but 130 - 550 us of launches per attempt) while an evaluation stays under ~50 M multiply-adds -
+        # 1500 trajectories of a 64-128-128-64 network, 24 000 of 16-32-32-16; beyond that the callable engine is the faster route
+        # (profiles/r05_mlp_coop_kernel_stats.csv: 3.1 ms against 1.7 ms per call at 4096 x 64-128-128-64).
+        rows = y0.numel() // max(self.dim, 1)
+        return rows * (self.dim * self.hidden + self.hidden * self.hidden + self.hidden * self.dim) <= self.COOP_MAX_FMA
+
+    COOP_MAX_FMA = 5e7
+
+    def coop_in_box(self, y0):
+        """What the cooperative kernels can take at all (dtype, widths) - whether they are the faster route is supports_coop's business."""
         return (not self.supports(y0) and y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
                 and self.dim <= self.MS_MAX_DIM and self.hidden <= self.MS_MAX_HIDDEN)
 

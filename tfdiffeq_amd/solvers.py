@@ -783,7 +783,7 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             if cand is not None and hasattr(cand, 'supports_coop') and isinstance(y, torch.Tensor) and y.is_cuda and y.numel() > 0 and \
                     cand.supports_coop(y):
                 rhs, self._coop = cand, True
-            elif cand is not None and hasattr(cand, 'warn_limits') and isinstance(y, torch.Tensor) and y.is_cuda:
+            elif cand is not None and hasattr(cand, 'warn_limits') and isinstance(y, torch.Tensor) and y.is_cuda and not cand.coop_in_box(y):
                 cand.warn_limits(y)                                  # (e.g. hidden > 256: no kernel of the family takes it - said once)
         if rhs is None:
             return None
