@@ -433,3 +433,32 @@ def test_trainable_leaves_of_a_plain_callable_come_from_its_autograd_graph():
     o = Obj()
     lv = OD._graph_leaves(o, (y0, y0.clone()), torch.tensor([0.0, 1.0]))
     assert len(lv) == 1 and lv[0] is o.w
+
+
+def test_cooperative_right_hand_sides_host_logic():
+    """Round 5, no GPU needed: which kernel family an ODEFunc-shaped network is offered (tile kernels / cooperative kernel / callable), and
+    the translation unit rhs.CustomCoop generates (a cooperative plugin: one state element per thread)."""
+    from tfdiffeq_amd import rhs
+    mk = lambda d, h, dt: rhs.MLP(torch.zeros(d, h, dtype=dt), None, torch.zeros(h, h, dtype=dt), None, torch.zeros(h, d, dtype=dt), None)   # noqa: E731
+    small32 = mk(64, 128, torch.float32)
+    y = torch.zeros(10, 64)
+    assert small32.supports(y) and not small32.supports_coop(y) and small32.supports_multistep(y)         # the MFMA tile kernels' box
+    f64 = mk(64, 128, torch.float64)
+    y64 = torch.zeros(1000, 64, dtype=torch.float64)
+    assert not f64.supports(y64) and f64.coop_in_box(y64) and f64.supports_coop(y64) and f64.multistep_fused
+    big = torch.zeros(4096, 64, dtype=torch.float64)                                                     # 1.3e8 multiply-adds per evaluation
+    assert f64.coop_in_box(big) and not f64.supports_coop(big)
+    wide = mk(100, 300, torch.float32)
+    assert not wide.supports(torch.zeros(5, 100)) and not wide.coop_in_box(torch.zeros(5, 100)) and not wide.multistep_fused
+    with pytest.raises(ValueError):
+        rhs.CustomCoop(300, 'k = y[i];')
+    with pytest.raises(ValueError):
+        rhs.CustomCoop(8, 'k = y[i];', tensors=[torch.zeros(1)] * 4)
+    c = rhs.CustomCoop(100, 'k = p[0] * (y[(i + 1) % DIM] - y[i]);', params=[0.5])
+    src = c.source(torch.float64)
+    for needle in ('static constexpr int DIM = 100;', 'static constexpr bool kCoop = true;', 'MI_ODE_DEFINE_COOP_PLUGIN(mi::RhsUserCoop)',
+                   'MI_ODE_PLUGIN_F64', 'k = p[0] * (y[(i + 1) % DIM] - y[i]);', 'return 256 / DIM;'):
+        assert needle in src, needle
+    assert c.supports(torch.zeros(3, 100, dtype=torch.float64)) and c.multistep_fused and c.fixed_grid_fused and not c.row_local
+    with pytest.raises(NotImplementedError):
+        c(torch.tensor(0.0), torch.zeros(3, 100))                        # no torch_fn: only the kernels can evaluate it
