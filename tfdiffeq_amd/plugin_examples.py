@@ -71,14 +71,12 @@ def prebuild():
     kernel headers (the cache key covers the headers, so those can never be hit again)."""
     import os
     from . import _plugin_build
-    out = []
-    for f in (lorenz(), forced_oscillator(), van_der_pol()):
-        for dt in (torch.float64, torch.float32):
-            out.append(_plugin_build.build(f.source(dt)))
-    out.append(_plugin_build.build(oscillator_ring(8).source(torch.float64)))
-    out.append(_plugin_build.build(oscillator_ring(16).source(torch.float32)))
-    out.append(_plugin_build.build(reaction_diffusion_ring(100).source(torch.float64)))
-    out.append(_plugin_build.build(swish_layer(torch.zeros(48, 48), torch.zeros(48)).source(torch.float64)))
+    sources = [f.source(dt) for f in (lorenz(), forced_oscillator(), van_der_pol()) for dt in (torch.float64, torch.float32)]
+    sources += [oscillator_ring(8).source(torch.float64), oscillator_ring(16).source(torch.float32),
+                reaction_diffusion_ring(100).source(torch.float64), swish_layer(torch.zeros(48, 48), torch.zeros(48)).source(torch.float64)]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:      # (hipcc runs in subprocesses: ten plugins in the time of the slowest)
+        out = list(pool.map(_plugin_build.build, sources))
     keep = set(os.path.basename(p)[:-3] for p in out)
     d = _plugin_build.plugin_dir()
     for name in os.listdir(d):
