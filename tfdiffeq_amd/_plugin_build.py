@@ -56,7 +56,9 @@ def _headers_digest():
 
 def build(source, verbose=False):
     """Path of the compiled plugin for `source` (compiles on a cache miss; the key covers the kernel headers too)."""
-    key = hashlib.sha256((source + _headers_digest() + ' '.join(FLAGS)).encode()).hexdigest()[:24]
+    # (the include directories are NOT part of the key - their content is, through _headers_digest: a checkout that was moved, or copied to
+    # another machine with its in-tree plugin cache, keeps hitting it)
+    key = hashlib.sha256((source + _headers_digest() + ' '.join(f for f in FLAGS if not os.path.isabs(f))).encode()).hexdigest()[:24]
     out = os.path.join(plugin_dir(), 'rhs_%s.so' % key)
     if os.path.exists(out):
         if not _owned_private(out):
