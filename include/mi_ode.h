@@ -90,8 +90,10 @@ enum mi_ode_rhs_kind {
                                     float64, dim, hidden <= 256; round 5): a cooperative kernel, a thread per state element -
                                     adaptive 3- / 6-row tableaus as ONE launch per call (fusion 0 / 4, one rank, co-resident
                                     grid, T > 1: else MI_ODE_E_INVALID) and multistep != 0 (the Adams family in one launch) */
-  MI_ODE_RHS_PLUGIN = 6          /* user device code for a trajectory-local system of small dim: mi_ode_rhs.plugin
-                                    (csrc/mi_ode_plugin.h); scalars[0..7] and w[]/b[] are passed through to it  */
+  MI_ODE_RHS_PLUGIN = 6          /* user device code for a trajectory-local system: mi_ode_rhs.plugin (csrc/mi_ode_plugin.h) -
+                                    a trajectory per thread (dim <= 32) or, with mi_ode_rowlocal_plugin.cooperative = 1, a
+                                    state element per thread (dim <= 256; adaptive methods as one launch per call, euler /
+                                    rk4, the Adams family); scalars[0..7] and w[]/b[] are passed through to it          */
 };
 
 enum mi_ode_controller {
