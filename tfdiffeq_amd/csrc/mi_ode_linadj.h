@@ -499,13 +499,20 @@ __global__ __launch_bounds__(D * 4) void k_linadj(LinAdjArgs A) {
       la_tile_job_split<D, KSPLIT>(A.pw + (long long)p * D * D, g0c, A.lmat + (long long)p * D * D, D, t / (D / 16), t % (D / 16),
                                    A.has_bias ? A.cvec + p * D : nullptr, g0c + D * D, active, slot, kpart, (double*)smem_raw);
     }
-    for (int j = gg; j < kLaP * D; j += ngg) {                 // row D of M_0q: g0 P_q
+    // row D of M_0q: g0 P_q - small vector jobs, dealt from the LAST lane groups of the grid (the first workgroups carry the split tile
+    // jobs above and two M jobs per wavefront: with these on top they were the last to reach every hand-off by 10 - 12 us), two partial
+    // sums per lane (a chain of 16 dependent loads otherwise)
+    for (int j = ngg - 1 - gg; j < kLaP * D; j += ngg) {
       const int q = j / D, c = j % D;
       const double* P = A.pw + (long long)q * D * D;
-      double s_ = 0.0;
-#pragma unroll
-      for (int k = part8; k < D; k += 8) s_ = fma(g0c[D * D + k], P[(long long)k * D + c], s_);
-      s_ = group8_sum(s_);
+      double s0 = 0.0, s1 = 0.0;
+      int k = part8;
+      for (; k + 8 < D; k += 16) {
+        s0 = fma(g0c[D * D + k], P[(long long)k * D + c], s0);
+        s1 = fma(g0c[D * D + k + 8], P[(long long)(k + 8) * D + c], s1);
+      }
+      for (; k < D; k += 8) s0 = fma(g0c[D * D + k], P[(long long)k * D + c], s0);
+      const double s_ = group8_sum(s0 + s1);
       if (part8 == 0) st_wt(A.mmat + (long long)q * E + D * D + c, s_);
     }
   };
