@@ -70,6 +70,24 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
             _warn_once('odeint: y0 requires grad and `func` is a plain callable - gradients w.r.t. y0 and t are computed with the adjoint '
                        'method (its evaluation depends on no other grad-requiring tensor)')
         return odeint_adjoint(_callable_module(func, (), leaves), y0, t, rtol=rtol, atol=atol, method=method, options=options)
+    lowered = _try_lower(func, y0, method, options)
+    if lowered is not None:
+        low, why = lowered
+        if low is not None:
+            return _run_lowered(low, func, y0, t, rtol, atol, method, options)
+        options = dict(options or {})
+        impure = 'changed its own Python state' in why
+        if impure and 'graph' not in options and method is not None:
+            # a callable with observable Python state of its own (a step counter in a list, a log): recording an attempt as a hipGraph would
+            # stop those side effects after two attempts - eager evaluation unless the caller asks for the recording (round-5 review, item 8)
+            options['graph'] = False
+        options.pop('lower', None)
+        options = options or None
+        _note = {'lowered': False, 'why': why}
+    else:
+        _note = None
+        if options is not None and 'lower' in options:
+            options = {k: v for k, v in options.items() if k != 'lower'} or (None if method is None else {})
     tensor_input, func, y0, t = _check_inputs(func, y0, t)
 
     if options is None:
@@ -82,9 +100,70 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     solver = SOLVERS[method](func, y0, rtol=rtol, atol=atol, **options)
     solution = solver.integrate(t)
     odeint.last_stats = getattr(solver, 'stats', {})
+    if _note is not None and isinstance(odeint.last_stats, dict):
+        odeint.last_stats['lower'] = _note
     if tensor_input:
         solution = solution[0]
     return solution
+
+
+_LOWER_METHODS = ('dopri5', 'tsit5', 'bosh3', 'dopri8', 'adaptive_heun', 'euler', 'rk4', 'midpoint', 'heun', 'huen', 'explicit_adams',
+                  'fixed_adams', 'adams')
+
+
+def _try_lower(func, y0, method, options):
+    """(Lowered, None) / (None, reason) when this call is one the tracer is asked to look at, None when it is not (a DeviceRHS, a CPU
+    state - the solver raises its own error -, a tuple of several components, an explicit request for one of the callable engines).
+    options['lower']: 'auto' (default) - lower when possible, say once why not otherwise; True - raise if the callable cannot be lowered;
+    False - never trace."""
+    import torch
+    opts = options or {}
+    mode = opts.get('lower', 'auto')
+    if mode is False or mode == 'off' or not callable(func) or getattr(func, 'kind', 0) or getattr(func, 'per_component', False):
+        return None
+    if method is not None and method not in _LOWER_METHODS:
+        return None
+    if any(k in opts for k in ('process_group', 'force_plane_kernels', 'grid_constructor')) or (opts.get('graph', 'auto') != 'auto' and mode is not True):
+        return None
+    y = y0[0] if isinstance(y0, (tuple, list)) and len(y0) == 1 else y0
+    if not isinstance(y, torch.Tensor) or not y.is_cuda or y.dtype not in (torch.float32, torch.float64) or y.numel() == 0:
+        return None
+    from . import lower as _lower
+    wrapped = func
+    if y is not y0:                                       # a one-component tuple (the adjoint's forward pass): the tensor form of the same system
+        def wrapped(t_, y_, _f=func):
+            return _f(t_, (y_,))[0]
+    try:
+        return _lower.lower(wrapped, y), None
+    except _lower.TraceError as e:
+        why = str(e)
+    except Exception as e:                                # the callable itself failed on the proxies (an operation torch refuses for them)
+        why = 'tracing failed: %s: %s' % (type(e).__name__, e)
+    if mode is True:
+        raise ValueError('odeint(options={\'lower\': True}): this callable cannot be lowered onto the fused kernels: ' + why)
+    _warn_once('odeint: `func` runs as a Python callable between library kernels (not lowered onto the fused kernels: %s)' % why)
+    return None, why
+
+
+def _run_lowered(low, func, y0, t, rtol, atol, method, options):
+    """The call with the traced callable's device right-hand side in its place: state reshaped to [*batch, dim] and back."""
+    import torch
+    from .graph_step import _credit_nfe
+    tuple_in = isinstance(y0, (tuple, list))
+    y = y0[0] if tuple_in else y0
+    opts = {k: v for k, v in (options or {}).items() if k != 'lower'}
+    state = y.detach().reshape(low.state_shape).contiguous()
+    sol = odeint(low.rhs, state, t, rtol=rtol, atol=atol, method=method, options=None if options is None else opts)
+    stats = odeint.last_stats if isinstance(odeint.last_stats, dict) else {}
+    info = low.describe()
+    info['lowered'] = True
+    stats['lower'] = info
+    odeint.last_stats = stats
+    # f ran inside the kernels: an integer `nfe` counter of the callable stays meaningful (evaluations that DID run the Python body - a
+    # method or a batch no one-launch kernel takes - have counted themselves)
+    _credit_nfe(func, int(stats.get('nfe', 0)) - low.py_calls)
+    sol = sol.reshape((sol.shape[0],) + tuple(y.shape))
+    return (sol,) if tuple_in else sol
 
 
 odeint.last_stats = {}
