@@ -51,9 +51,10 @@ def main(argv=None):
 
     true_y0 = torch.tensor([[2., 0.]], dtype=torch.float64, device=dev)
     t = torch.linspace(0., 25., args.data_size, dtype=torch.float64)
-    true_A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64)
+    true_A = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=torch.float64, device=dev)
     t0 = time.perf_counter()
-    true_y = odeint(rhs.CubicLinear(true_A), true_y0, t, method='dopri5')              # [data_size, 1, 2]
+    # the reference's `Lambda` (examples/ode_demo.py:32-35) as it is written: a Python callable - traced and lowered by odeint
+    true_y = odeint(lambda t_, y: torch.matmul(y ** 3, true_A), true_y0, t, method='dopri5')       # [data_size, 1, 2]
     torch.cuda.synchronize()
     print('ground truth: %d points in %.2f ms (one kernel launch)' % (args.data_size, 1e3 * (time.perf_counter() - t0)))
 

@@ -29,6 +29,29 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+# Test modules written before the tracer existed (round 6) hand `odeint` Python callables BECAUSE they test the callable engines
+# (device-controlled, hipGraph replay, host loop, generic adjoint): there the automatic lowering stays off, so that they keep
+# testing what they were written for.  tests/test_gpu_lower.py is the module that tests the lowering itself - with the default on.
+_LOWERING_AWARE = ('test_gpu_lower', 'test_lower_trace', 'test_gpu_published')
+
+
+@pytest.fixture(autouse=True)
+def _callable_engine_tests_keep_their_engine(request):
+    import sys as _sys
+    mod = _sys.modules.get('tfdiffeq_amd.odeint')
+    if mod is None:
+        import tfdiffeq_amd  # noqa: F401
+        mod = _sys.modules['tfdiffeq_amd.odeint']
+    name = request.module.__name__.rsplit('.', 1)[-1]
+    before = mod.LOWER_DEFAULT
+    if name not in _LOWERING_AWARE:
+        mod.LOWER_DEFAULT = False
+    try:
+        yield
+    finally:
+        mod.LOWER_DEFAULT = before
+
+
 def pytest_sessionfinish(session, exitstatus):
     """A session that RECORDED float32 bands asserted none of them (tests/bands.py): it must not look like a green parity run."""
     if os.environ.get('TFDIFFEQ_AMD_RECORD_BANDS'):

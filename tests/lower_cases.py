@@ -9,7 +9,7 @@ import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-for p_ in (ROOT, os.path.join(ROOT, 'examples')):
+for p_ in (ROOT, os.path.join(ROOT, 'examples'), os.path.join(ROOT, 'tests')):
     if p_ not in sys.path:
         sys.path.insert(0, p_)
 
@@ -208,6 +208,65 @@ for _n in ('second_order', 'oscilation', 'jagged_oscilation', 'nonlinear_damping
     CASES['nb_' + _n] = _notebook(_n)
 
 
+def literal_callable(meta, device, dtype=torch.float64):
+    """A golden fixture's right-hand side as the Python callable the reference's tests / examples write (never a DeviceRHS)."""
+    import reference_systems as RS
+    rhs, p = meta['rhs'], meta['rhs_params']
+    if rhs == 'sine':
+        return SineODE()
+    if rhs == 'constant':
+        return ConstantODE(device)
+    if rhs == 'cubic_linear':
+        return RS.SpiralLambda(torch.tensor(p['W'], dtype=dtype, device=device))
+    if rhs == 'lorenz':
+        s, b, r = p['sigma'], p['beta'], p['rho']
+        return lambda t, y: torch.stack([s * (y[..., 1] - y[..., 0]), y[..., 0] * (r - y[..., 2]) - y[..., 1],
+                                         y[..., 0] * y[..., 1] - b * y[..., 2]], dim=-1)
+    if rhs == 'lotka_volterra':
+        a, b, c, d = p['a'], p['b'], p['c'], p['d']
+        return lambda t, y: torch.stack([a * y[..., 0] - b * y[..., 0] * y[..., 1], -c * y[..., 1] + d * y[..., 0] * y[..., 1]], dim=-1)
+    if rhs == 'linear':
+        W = torch.tensor(p['W'], dtype=dtype, device=device)
+        return lambda t, y: torch.matmul(y, W)
+    raise KeyError(rhs)
+
+
+def fixture_names():
+    """The reference-generated whole-run fixtures the lowered callables are held to (tensor states; tsit5 needs `refcompat`, the MLP has
+    its own tests)."""
+    from golden_util import load, run_cases
+    out = []
+    for n in run_cases():
+        _, m = load(n)
+        if m['tuple_state'] or m['max_attempts'] is not None or m['rhs'] == 'mlp_tanh' or m['method'] == 'tsit5':
+            continue
+        if (m['options'] or {}).get('eps') or 'noint' in n:
+            continue
+        out.append(n)
+    return out
+
+
+class Decay(object):
+    def __init__(self, device):
+        self.rate = 0.5
+        self.w = torch.tensor([1., 2., 3.], dtype=torch.float64, device=device)
+
+    def __call__(self, t, y):
+        return -self.rate * y * self.w
+
+
+def _state_2x3x5(device):
+    g = torch.Generator().manual_seed(0)
+    M = (torch.randn(5, 5, generator=g, dtype=torch.float64) * 0.3).to(device)
+    y3 = torch.randn(2, 3, 5, generator=g, dtype=torch.float64).to(device)
+    return (lambda t, y: torch.stack([y[1] @ M, -y[0] @ M.t()]) * torch.cos(t)), y3, 'rowlocal'      # (indexes the first axis: no batch axes)
+
+
+CASES['decay'] = lambda dev: (Decay(dev), torch.ones(7, 3, dtype=torch.float64, device=dev), 'rowlocal')
+CASES['state_2x3x5'] = _state_2x3x5
+CASES['minus_y_5x3'] = lambda dev: ((lambda t, y: -y), torch.ones(5, 3, dtype=torch.float64, device=dev), 'rowlocal')
+
+
 def generated_sources(device='cpu'):
     """Every generated kernel source the cases above compile (CPU only: tracing needs no GPU)."""
     from tfdiffeq_amd import lower
@@ -215,4 +274,9 @@ def generated_sources(device='cpu'):
     for name, make in CASES.items():
         f, y0, _kind = make(device)
         out.extend(lower.sources_for(f, y0))
+    from golden_util import load
+    for name in fixture_names():
+        d, meta = load(name)
+        y0 = torch.tensor(d['y0'], device=device)
+        out.extend(lower.sources_for(literal_callable(meta, device, y0.dtype), y0))
     return out

@@ -1340,7 +1340,8 @@ def test_c_abi_standalone_harness():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, 'tests', 'c_abi', 'c_abi_smoke')
     if not os.path.exists(exe):
-        pytest.skip('harness not built (python -c "import __graft_entry__ as g; g.build()")')
+        pytest.fail('tests/c_abi/c_abi_smoke is not built: `python -c "import __graft_entry__ as g; g.build()"` builds it (a missing build must not '
+                    'read as green-with-one-skip)')
     env = dict(os.environ)
     env['LD_LIBRARY_PATH'] = os.path.join(root, 'tfdiffeq_amd') + ':/opt/rocm/lib:' + env.get('LD_LIBRARY_PATH', '')
     res = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=env)

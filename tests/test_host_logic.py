@@ -399,10 +399,10 @@ def test_a_users_own_time_reversed_attribute_is_not_taken_for_the_native_hook():
 
 
 def test_trainable_leaves_of_a_plain_callable_come_from_its_autograd_graph():
-    """(advisor, round 4) `odeint(lambda t, y: net(y), ...)`: the tensors the adjoint differentiates with respect to are the grad-requiring
-    LEAVES one evaluation depends on - a module the callable merely could name gets no (zero) gradient, a tensor reached through an attribute
-    chain or a container is found, and the probe is cached per (code, closure) so that a lambda re-created every iteration costs one evaluation
-    in total."""
+    """(advisor, rounds 4 and 5) `odeint(lambda t, y: net(y), ...)`: the tensors the adjoint differentiates with respect to are the
+    grad-requiring LEAVES one probe evaluation depends on (a tensor reached through an attribute chain or a container is found) IN UNION with
+    what the callable can name (a branch the probe did not take keeps its gradient; a module merely named gets a zero gradient).  Nothing is
+    cached between calls: a rebound network is seen as it is now."""
     import importlib
     OD = importlib.import_module('tfdiffeq_amd.odeint')      # (the package exports the FUNCTION under the same name)
     torch.manual_seed(0)
@@ -419,10 +419,22 @@ def test_trainable_leaves_of_a_plain_callable_come_from_its_autograd_graph():
         return f
     y0 = torch.randn(4, 3, dtype=torch.float64)
     leaves = OD._graph_leaves(make(), y0, torch.tensor([0.0, 1.0]))
-    assert {id(x) for x in leaves} == {id(used.weight), id(used.bias), id(holder['deep'][0])}
+    assert [id(x) for x in leaves[:3]] == [id(x) for x in leaves[:3]] and {id(x) for x in leaves[:3]} == {id(used.weight), id(used.bias), id(holder['deep'][0])}
+    assert {id(x) for x in leaves[3:]} == {id(unused.weight), id(unused.bias)}           # named only: differentiated too (zero gradient)
     n = len(calls)
-    assert OD._graph_leaves(make(), y0, torch.tensor([0.0, 1.0])) is leaves and len(calls) == n      # same code, same cells: cached
+    again = OD._graph_leaves(make(), y0, torch.tensor([0.0, 1.0]))
+    assert [id(x) for x in again] == [id(x) for x in leaves] and len(calls) == n + 1    # probed again: no cache to go stale
     assert OD._wants_grad(make(), y0) is True and OD._wants_grad(lambda t, y: y * 2.0, y0) is False
+    # the advisor's two reproductions: a network reached through a rebound name, and a branch the probe at t[0] does not take
+    box = {'net': torch.nn.Linear(3, 3).double()}
+    f_box = lambda t, y: box['net'](y)                     # noqa: E731
+    first = OD._graph_leaves(f_box, y0, torch.tensor([0.0, 1.0]))
+    box['net'] = torch.nn.Linear(3, 3).double()
+    second = OD._graph_leaves(f_box, y0, torch.tensor([0.0, 1.0]))
+    assert {id(x) for x in second} == {id(box['net'].weight), id(box['net'].bias)} and not ({id(x) for x in first} & {id(x) for x in second})
+    nA, nB = torch.nn.Linear(3, 3).double(), torch.nn.Linear(3, 3).double()
+    both = OD._graph_leaves(lambda t, y: nA(y) if t < 0.5 else nB(y), y0, torch.tensor([0.0, 1.0]))
+    assert {id(x) for x in both} == {id(p) for p in list(nA.parameters()) + list(nB.parameters())}
     # a tuple state and a callable object
     class Obj(object):
         def __init__(self):

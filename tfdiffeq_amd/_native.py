@@ -200,7 +200,11 @@ _lib = None
 
 
 class NativeError(RuntimeError):
-    pass
+    """A libmi_ode call failed.  `rc` is the library's return code (MI_ODE_E_*; None when the failure is not a library call's)."""
+
+    def __init__(self, msg, rc=None):
+        super(NativeError, self).__init__(msg)
+        self.rc = rc
 
 
 def build(verbose=False):
@@ -246,7 +250,7 @@ def last_error():
 def check(rc, what=''):
     """Negative return codes are API errors; non-negative ones are status bits handled by the caller."""
     if rc < 0:
-        raise NativeError('%s failed (%d): %s' % (what or 'libmi_ode call', rc, last_error()))
+        raise NativeError('%s failed (%d): %s' % (what or 'libmi_ode call', rc, last_error()), rc=rc)
     return rc
 
 

@@ -68,7 +68,16 @@ def build(source, verbose=False):
     with open(src, 'w') as fh:
         fh.write(source)
     tmp = out + '.tmp%d' % os.getpid()
-    res = subprocess.run([HIPCC] + FLAGS + [src, '-o', tmp], capture_output=True, text=True)
+    limit = float(os.environ.get('TFDIFFEQ_AMD_PLUGIN_TIMEOUT_S', '600'))
+    try:
+        res = subprocess.run([HIPCC] + FLAGS + [src, '-o', tmp], capture_output=True, text=True, timeout=limit)
+    except subprocess.TimeoutExpired:
+        for leftover in (tmp,):
+            try:
+                os.remove(leftover)
+            except OSError:
+                pass
+        raise N.NativeError('compiling the RHS plugin failed: hipcc did not finish within %.0f s (TFDIFFEQ_AMD_PLUGIN_TIMEOUT_S); source: %s' % (limit, src))
     if verbose or res.returncode != 0:
         print(res.stdout[-4000:])
         print(res.stderr[-6000:])

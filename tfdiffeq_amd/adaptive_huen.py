@@ -2,7 +2,8 @@
 
 Not FSAL-shaped: y1 comes from c_sol (rk_common.py:54-56).  The reference hands order=5 to the step-size
 controller (adaptive_huen.py:111-113) and order 1 to the initial-step heuristic; both are kept.
-Runs through the plane-kernel engine.
+Row-local systems (catalogue, plugins, traced callables) and the cooperative kernels run it in one launch (k_persist_rowlocal<T, 1, ..>);
+any other callable on the device-controlled engine.
 """
 from . import _native as N
 from .rk_common import _ButcherTableau

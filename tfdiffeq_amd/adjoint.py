@@ -212,9 +212,10 @@ _LIN_ENGINES = {}
 def _cached_linear_adjoint_engine(*key):
     eng = _LIN_ENGINES.get(key)
     if eng is None:
+        eng = _LinearAdjointEngine(*key)                 # (evict only after a successful create: a refusal must not cost live engines)
         while len(_LIN_ENGINES) >= 4:
             _LIN_ENGINES.pop(next(iter(_LIN_ENGINES))).close()
-        eng = _LIN_ENGINES[key] = _LinearAdjointEngine(*key)
+        _LIN_ENGINES[key] = eng
     return eng
 
 
@@ -305,13 +306,23 @@ def _linear_one_launch_plan(base, cfg, like):
     if batch < 1:
         return None
     f32 = lambda v: float(np.float32(v))                 # noqa: E731  (misc.py:137-144: python float -> float32 -> float64)
+    key = (batch, int(base.dim), like.dtype, float(cfg['adjoint_rtol']), float(cfg['adjoint_atol']), f32(0.9), f32(10.0), f32(0.2),
+           int(max_num_steps), str(like.device))
+    if key in _NO_LIN_ENGINE:                            # a permanent refusal (the kernel does not fit this shape): asked once, remembered
+        return None
     try:
-        return _cached_linear_adjoint_engine(batch, int(base.dim), like.dtype, float(cfg['adjoint_rtol']), float(cfg['adjoint_atol']),
-                                             f32(0.9), f32(10.0), f32(0.2), int(max_num_steps), str(like.device))
+        return _cached_linear_adjoint_engine(*key)
     except N.NativeError as e:
         import warnings
+        if getattr(e, 'rc', None) == N.E_INVALID:
+            if len(_NO_LIN_ENGINE) > 256:
+                _NO_LIN_ENGINE.clear()
+            _NO_LIN_ENGINE.add(key)
         warnings.warn('one-launch linear adjoint engine unavailable (%s): using the callable engine' % e)
         return None
+
+
+_NO_LIN_ENGINE = set()
 
 
 def _linear_dynamics(base, like):
@@ -424,6 +435,10 @@ class _OdeintAdjointMethod(torch.autograd.Function):
             ans = odeint(fwd, state, t, rtol=cfg['rtol'], atol=cfg['atol'], method=cfg['method'], options=cfg['options'])
             if fwd is not func:                          # f ran inside the kernel: keep the module's evaluation counter honest
                 _count_nfe(func, odeint.last_stats.get('nfe', 0))       # (dense_odenet.py:38, 78: users log odefunc.nfe)
+            # how the forward pass ran (round 6: a plain module is traced and lowered onto the fused kernels by odeint itself,
+            # tfdiffeq_amd/lower.py); the backward of such a callable stays on the generic path - autograd through f - this round
+            fstats = odeint.last_stats if isinstance(odeint.last_stats, dict) else {}
+            ctx.forward_info = dict(fstats.get('lower') or {'lowered': False}, engine=fstats.get('engine'), n_launches=fstats.get('n_launches'))
             if isinstance(ans, torch.Tensor):
                 ans = (ans,)
         ctx.save_for_backward(t, flat_params, *ans)
@@ -431,6 +446,14 @@ class _OdeintAdjointMethod(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *grad_output):
+        try:
+            return _OdeintAdjointMethod._backward(ctx, *grad_output)
+        finally:
+            if isinstance(odeint_adjoint.last_backward_stats, dict):
+                odeint_adjoint.last_backward_stats['forward'] = getattr(ctx, 'forward_info', None)
+
+    @staticmethod
+    def _backward(ctx, *grad_output):
         func, cfg, n_tensors = ctx.func, ctx.cfg, ctx.n_tensors
         t, flat_params, *ans = ctx.saved_tensors
         f_params = tuple(_trainable(func))

@@ -103,8 +103,15 @@ extern "C" int mi_ode_linadj_create(const mi_ode_linadj_desc* desc, mi_ode_linad
   h->fn = h->is_f32 ? la_fn<float>(h->dp, &h->lds, &h->block) : la_fn<double>(h->dp, &h->lds, &h->block);
   h->ntiles = (desc->batch + 15) / 16;
   int dev = 0, cus = 0, per_cu = 0;
-  MI_HIP(hipGetDevice(&dev));
-  MI_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  {                                              // (h is released on these early returns too)
+    hipError_t e0 = hipGetDevice(&dev);
+    if (e0 == hipSuccess) e0 = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    if (e0 != hipSuccess) {
+      mi_set_error("mi_ode_linadj_create: device query failed: %s", hipGetErrorString(e0));
+      (void)hipGetLastError();
+      delete h; return MI_ODE_E_HIP;
+    }
+  }
   if (hipFuncSetAttribute(h->fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds) != hipSuccess) (void)hipGetLastError();
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, h->fn, h->block, h->lds) != hipSuccess || per_cu < 1) {
     (void)hipGetLastError();
@@ -231,7 +238,17 @@ extern "C" int mi_ode_linadj_segment(mi_ode_linadj_handle h, const void* w_dev, 
   hipError_t e = hipLaunchKernel(h->fn, dim3((unsigned)h->grid), dim3((unsigned)h->block), args, h->lds, st);
   if (e != hipSuccess) { mi_set_error("linear adjoint kernel launch failed: %s", hipGetErrorString(e)); (void)hipGetLastError(); return MI_ODE_E_HIP; }
   h->n_launches += 1;
-  MI_HIP(hipStreamSynchronize(st));              // the kernel's last act was the zero-copy store of its result record
+  {
+    const hipError_t es = hipStreamSynchronize(st);          // the kernel's last act was the zero-copy store of its result record
+    if (es != hipSuccess) {
+      // the aborted launch may have written records and flags under this call's stamps: the next segment must not reuse them
+      h->seq += 4096u;
+      if (h->seq >= 0xE0000000u) h->seq = 0;
+      mi_set_error("hipStreamSynchronize after the linear adjoint kernel failed: %s", hipGetErrorString(es));
+      (void)hipGetLastError();
+      return MI_ODE_E_HIP;
+    }
+  }
   const LinAdjResult r = *h->res;
   h->seq += (unsigned)(r.handoffs > 0 ? r.handoffs : 64) + 16u;
   if (h->seq >= 0xE0000000u) h->seq = 0;

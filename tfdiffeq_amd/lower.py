@@ -903,7 +903,9 @@ def evaluate_row(tr, t, y_tail):
 MAX_ROW_DIM = 32              # rhs.CustomRowLocal.MAX_DIM: state + S + 1 stage derivatives thread-private
 MAX_COOP_DIM = 256            # rhs.CustomCoop.MAX_DIM
 MAX_ROW_STATEMENTS = 6000     # straight-line statements per evaluation beyond which the row-local form is not attempted
-UNROLL_MACS = 256             # matrix products up to this many multiply-adds are written out; larger ones become loops
+WIDE = 12                     # values wider than this are thread-private ARRAYS filled by loops (compact code: hipcc's time grows faster
+                              # than linearly in the length of a straight-line block), narrower ones scalars
+UNROLL_MACS = 64              # matrix products up to this many multiply-adds are written out; larger ones become loops
 
 _C_UN = {'neg': '-{0}', 'abs': 'fabs({0})', 'sigmoid': '((T)1 / ((T)1 + exp(-{0})))', 'relu': '({0} > (T)0 ? {0} : ({0} != {0} ? {0} : (T)0))',
          'softplus': '({0} > (T)20 ? {0} : log1p(exp({0})))', 'square': '{0} * {0}', 'cube': '{0} * {0} * {0}', 'reciprocal': '(T)1 / {0}',
@@ -941,9 +943,22 @@ class Layout(object):
         return 'p[%d]' % i if i < 8 else 'cw[%d]' % (self.extra_off + i - 8)
 
 
+class _Arr(object):
+    """A node's value as a thread-private C array `name[size]` (row-major over `shape`)."""
+    __slots__ = ('name', 'shape')
+
+    def __init__(self, name, shape):
+        self.name, self.shape = name, tuple(shape)
+
+    @property
+    def size(self):
+        return _prod(self.shape)
+
+
 class _RowCG(object):
-    """Scalarises the graph for one trajectory: every node becomes an array of C atoms (names / literals), every arithmetic operation one
-    `const T v = ...;` statement in the order Python performed them."""
+    """Code for one trajectory per thread.  Narrow values are scalarised: every node an array of C atoms (names / literals), every
+    arithmetic operation one `const T v = ...;` statement in the order Python performed them.  Values wider than WIDE elements (the
+    hidden layer of a small network) are thread-private arrays filled by loops - the same operations in the same order, compact code."""
 
     def __init__(self, tr):
         self.tr, self.lay = tr, Layout(tr)
@@ -959,15 +974,66 @@ class _RowCG(object):
         self.cse[expr] = name
         return name
 
+    def _new(self, prefix):
+        self.n += 1
+        return '%s%d' % (prefix, self.n)
+
     def _arr(self, atoms, shape):
         a = np.empty(len(atoms), dtype=object)
         for i, s in enumerate(atoms):
             a[i] = s
         return a.reshape(shape)
 
-    def _matvec(self, n, x_atoms, K, E, w_at, bias_at):
-        """out[i] = sum_j x[j] * w_at(j, i) (+ bias): written out for small products, a loop nest over thread-private arrays otherwise."""
+    def atoms(self, v):
+        """Any value as an object array of atoms."""
+        if isinstance(v, _Arr):
+            return self._arr(['%s[%d]' % (v.name, i) for i in range(v.size)], v.shape)
+        return v
+
+    def carray(self, atoms, is_bool=False):
+        """Atoms as a C array (one declaration; the same list is declared once)."""
+        key = ('arr', tuple(atoms))
+        hit = self.cse.get(key)
+        if hit is None:
+            hit = self._new('a')
+            self.lines.append('%s %s[%d] = {%s};' % ('bool' if is_bool else 'T', hit, len(atoms), ', '.join(atoms)))
+            self.cse[key] = hit
+        return hit
+
+    def _ew_expr(self, n, xs):
+        fn, attr = n.attr
+        if fn == 'where':
+            return '(%s ? %s : %s)' % tuple(xs)
+        if fn == 'powc':
+            return 'pow(%s, %s)' % (xs[0], _flit(attr))
+        return (_C_UN[fn] if fn in _C_UN else _C_BIN[fn]).format(*xs)
+
+    def _ew(self, n, a):
+        if n.size > WIDE:
+            # loop form: every operand is a scalar atom, an array of the result's own shape, or is laid out as one
+            ops = []
+            for v, m in zip(a, n.args):
+                if m.size == 1:
+                    ops.append(self.atoms(v).reshape(-1)[0])
+                elif isinstance(v, _Arr) and v.shape == n.shape:
+                    ops.append('%s[i_]' % v.name)
+                else:
+                    full = np.broadcast_to(self.atoms(v), n.shape).reshape(-1)
+                    ops.append('%s[i_]' % self.carray(list(full), m.is_bool))
+            out = self._new('b' if n.is_bool else 'w')
+            self.lines.append('%s %s[%d];' % ('bool' if n.is_bool else 'T', out, n.size))
+            self.lines.append('for (int i_ = 0; i_ < %d; ++i_) %s[i_] = %s;' % (n.size, out, self._ew_expr(n, ['(%s)' % o for o in ops])))
+            return _Arr(out, n.shape)
+        a = [self.atoms(v) for v in a]
+        bs = np.broadcast_arrays(*a) if len(a) > 1 else [a[0]]
+        flat = [b.reshape(-1) for b in bs]
+        out = [self.tmp(self._ew_expr(n, [f_[i] for f_ in flat]), n.is_bool) for i in range(flat[0].size)]
+        return np.broadcast_to(self._arr(out, bs[0].shape), n.shape)
+
+    def _matvec(self, x, K, E, w_at, bias_at):
+        """out[i] = sum_j x[j] * w_at(j, i) (+ bias): written out for small products (atoms), a loop nest over arrays otherwise (_Arr)."""
         if K * E <= UNROLL_MACS:
+            x_atoms = list(self.atoms(x).reshape(-1))
             out = []
             for i in range(E):
                 acc = None
@@ -977,40 +1043,43 @@ class _RowCG(object):
                 if bias_at is not None:
                     acc = self.tmp('%s + %s' % (acc, bias_at(i)))
                 out.append(acc)
-            return out
-        xa, oa = 'a%d' % n.id, 'o%d_%d' % (n.id, self.n)
-        self.n += 1
-        key = ('xa', tuple(x_atoms))
-        if key not in self.cse:
-            name = 'a%d_%d' % (n.id, self.n)
-            self.n += 1
-            self.lines.append('T %s[%d] = {%s};' % (name, K, ', '.join(x_atoms)))
-            self.cse[key] = name
-        xa = self.cse[key]
+            return self._arr(out, (E,))
+        xa = x.name if isinstance(x, _Arr) else self.carray(list(x.reshape(-1)))
+        oa = self._new('o')
         self.lines.append('T %s[%d];' % (oa, E))
         self.lines.append('for (int i_ = 0; i_ < %d; ++i_) {' % E)
         self.lines.append('  T acc_ = %s;' % (bias_at('i_') if bias_at is not None else '(T)0'))
         self.lines.append('  for (int j_ = 0; j_ < %d; ++j_) acc_ = fma(%s[j_], %s, acc_);' % (K, xa, w_at('j_', 'i_')))
         self.lines.append('  %s[i_] = acc_;' % oa)
         self.lines.append('}')
-        return ['%s[%d]' % (oa, i) for i in range(E)]
+        return _Arr(oa, (E,))
 
     def _const_at(self, node):
-        """index -> C atom for a constant tensor node (possibly seen through nothing else): pool offset arithmetic."""
+        """index -> C atom for a constant tensor node: pool offset arithmetic."""
         off = self.lay.tensor_off[node.attr]
+        strides, s = [], 1
+        for d in reversed(node.shape):
+            strides.append(s)
+            s *= d
+        strides = strides[::-1]
 
         def at(*ix):
-            strides = []
-            s = 1
-            for d in reversed(node.shape):
-                strides.append(s)
-                s *= d
-            strides = strides[::-1]
             if all(isinstance(i, int) for i in ix):
                 return 'cw[%d]' % (off + sum(i * st for i, st in zip(ix, strides)))
             terms = [str(off)] + ['%s * %d' % (i, st) if st != 1 else str(i) for i, st in zip(ix, strides)]
             return 'cw[%s]' % ' + '.join(terms)
         return at
+
+    def _rows(self, v, node, K):
+        """The rows (last axis K) of a value: a list of atoms arrays / _Arr."""
+        if isinstance(v, _Arr) and v.size == K:
+            return [v]
+        return list(np.broadcast_to(self.atoms(v), node.shape).reshape(-1, K))
+
+    def _join(self, parts, shape):
+        if len(parts) == 1 and isinstance(parts[0], _Arr):
+            return _Arr(parts[0].name, shape)
+        return self._arr([x for p_ in parts for x in self.atoms(p_).reshape(-1)], shape)
 
     def body(self):
         tr, val = self.tr, {}
@@ -1030,48 +1099,32 @@ class _RowCG(object):
                 off = self.lay.tensor_off[n.attr]
                 v = self._arr(['cw[%d]' % (off + i) for i in range(n.size)], n.shape)
             elif n.op == 'ew':
-                fn, attr = n.attr
-                bs = np.broadcast_arrays(*a) if len(a) > 1 else [a[0]]
-                flat = [b.reshape(-1) for b in bs]
-                out = []
-                for i in range(flat[0].size):
-                    xs = [f_[i] for f_ in flat]
-                    if fn == 'where':
-                        e = '(%s ? %s : %s)' % tuple(xs)
-                    elif fn == 'powc':
-                        e = 'pow(%s, %s)' % (xs[0], _flit(attr))
-                    elif fn in _C_UN:
-                        e = _C_UN[fn].format(*xs)
-                    else:
-                        e = _C_BIN[fn].format(*xs)
-                    out.append(self.tmp(e, n.is_bool))
-                v = np.broadcast_to(self._arr(out, bs[0].shape), n.shape)
+                v = self._ew(n, a)
             elif n.op == 'gather':
                 src, idx = n.attr
-                flat = [np.broadcast_to(x, m.shape).reshape(-1) for x, m in zip(a, n.args)]
-                v = np.empty(idx.size, dtype=object)
-                srcf = None if src is None else src.reshape(-1)
-                for i_, j_ in enumerate(idx.reshape(-1)):
-                    v[i_] = flat[0 if srcf is None else int(srcf[i_])][int(j_)]
-                v = v.reshape(idx.shape)
+                if src is None and isinstance(a[0], _Arr) and idx.size == a[0].size and np.array_equal(idx.reshape(-1), np.arange(idx.size)):
+                    v = _Arr(a[0].name, idx.shape)                     # a reshape of an array: the same array
+                else:
+                    flat = [np.broadcast_to(self.atoms(x), m.shape).reshape(-1) for x, m in zip(a, n.args)]
+                    v = np.empty(idx.size, dtype=object)
+                    srcf = None if src is None else src.reshape(-1)
+                    for i_, j_ in enumerate(idx.reshape(-1)):
+                        v[i_] = flat[0 if srcf is None else int(srcf[i_])][int(j_)]
+                    v = v.reshape(idx.shape)
             elif n.op == 'linear':
                 x, w = n.args[0], n.args[1]
                 E, K = w.shape
                 wat = self._const_at(w)
                 bat = self._const_at(n.args[2]) if len(n.args) > 2 else None
-                rows = np.broadcast_to(a[0], x.shape).reshape(-1, K)
-                out = []
-                for r in rows:
-                    out.extend(self._matvec(n, list(r), K, E, lambda j, i: wat(i, j), (lambda i: bat(i)) if bat is not None else None))
-                v = self._arr(out, n.shape)
+                v = self._join([self._matvec(r, K, E, lambda j, i: wat(i, j), (lambda i: bat(i)) if bat is not None else None)
+                                for r in self._rows(a[0], x, K)], n.shape)
             elif n.op == 'matmul':
                 v = self._matmul(n, a)
             elif n.op == 'sum':
                 axes, keep = n.attr
-                src = np.broadcast_to(a[0], n.args[0].shape)
+                src = np.broadcast_to(self.atoms(a[0]), n.args[0].shape)
                 moved = np.moveaxis(src, axes, tuple(range(-len(axes), 0)))
-                lead = moved.shape[:moved.ndim - len(axes)]
-                moved = moved.reshape(lead + (-1,))
+                moved = moved.reshape(moved.shape[:moved.ndim - len(axes)] + (-1,))
                 out = []
                 for r in moved.reshape(-1, moved.shape[-1]):
                     acc = r[0]
@@ -1084,27 +1137,24 @@ class _RowCG(object):
             val[n.id] = v
             if len(self.lines) > MAX_ROW_STATEMENTS:
                 raise TraceError('more than %d statements per evaluation in one-trajectory-per-thread form' % MAX_ROW_STATEMENTS)
-        outv = np.broadcast_to(val[tr.out.id], tr.tail).reshape(-1)
+        outv = np.broadcast_to(self.atoms(val[tr.out.id]), tr.tail).reshape(-1)
         for i, s in enumerate(outv):
             self.lines.append('k[%d] = %s;' % (i, s))
         return '\n'.join(self.lines)
 
     def _matmul(self, n, a):
         x, w = n.args
-        A, B = np.broadcast_to(a[0], x.shape), np.broadcast_to(a[1], w.shape)
         # the two shapes a constant matrix usually appears in keep their loop form; everything else is written out by index
         if w.op == 'ten' and w.rank == 2 and x.rank >= 1:
             K, E = w.shape
             wat = self._const_at(w)
-            out = []
-            for r in A.reshape(-1, K):
-                out.extend(self._matvec(n, list(r), K, E, lambda j, i: wat(j, i), None))
-            return self._arr(out, n.shape)
+            return self._join([self._matvec(r, K, E, lambda j, i: wat(j, i), None) for r in self._rows(a[0], x, K)], n.shape)
         if x.op == 'ten' and x.rank == 2 and w.rank in (1, 2) and (w.rank == 1 or w.shape[1] == 1):
             E, K = x.shape
             xat = self._const_at(x)
-            out = self._matvec(n, list(B.reshape(-1)), K, E, lambda j, i: xat(i, j), None)
-            return self._arr(out, n.shape)
+            return self._join([self._matvec(self._rows(a[1], w, K)[0] if w.rank == 1 else a[1] if isinstance(a[1], _Arr) else
+                                            np.broadcast_to(self.atoms(a[1]), w.shape).reshape(-1), K, E, lambda j, i: xat(i, j), None)], n.shape)
+        A, B = np.broadcast_to(self.atoms(a[0]), x.shape), np.broadcast_to(self.atoms(a[1]), w.shape)
         a2 = A.reshape((1,) + A.shape) if A.ndim == 1 else A
         b2 = B.reshape(B.shape + (1,)) if B.ndim == 1 else B
         lead = np.broadcast_shapes(a2.shape[:-2], b2.shape[:-2])

@@ -1,4 +1,6 @@
 """Mirror of tfdiffeq/odeint.py: the `odeint` entry point and the SOLVERS registry (B1/B2)."""
+import os
+
 from .adams import VariableCoefficientAdamsBashforth
 from .adaptive_huen import AdaptiveHeunSolver
 from .bosh3 import Bosh3Solver
@@ -107,6 +109,10 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     return solution
 
 
+# Process-wide default of options['lower'] ('auto' | True | False; the environment variable TFDIFFEQ_AMD_LOWER=0 starts with False):
+# tests of the callable engines set it to False so that their Python callables stay Python callables.
+LOWER_DEFAULT = False if os.environ.get('TFDIFFEQ_AMD_LOWER', '1').lower() in ('0', 'false', 'off') else 'auto'
+
 _LOWER_METHODS = ('dopri5', 'tsit5', 'bosh3', 'dopri8', 'adaptive_heun', 'euler', 'rk4', 'midpoint', 'heun', 'huen', 'explicit_adams',
                   'fixed_adams', 'adams')
 
@@ -118,7 +124,7 @@ def _try_lower(func, y0, method, options):
     False - never trace."""
     import torch
     opts = options or {}
-    mode = opts.get('lower', 'auto')
+    mode = opts.get('lower', LOWER_DEFAULT)
     if mode is False or mode == 'off' or not callable(func) or getattr(func, 'kind', 0) or getattr(func, 'per_component', False):
         return None
     if method is not None and method not in _LOWER_METHODS:
@@ -153,7 +159,17 @@ def _run_lowered(low, func, y0, t, rtol, atol, method, options):
     y = y0[0] if tuple_in else y0
     opts = {k: v for k, v in (options or {}).items() if k != 'lower'}
     state = y.detach().reshape(low.state_shape).contiguous()
-    sol = odeint(low.rhs, state, t, rtol=rtol, atol=atol, method=method, options=None if options is None else opts)
+    try:
+        sol = odeint(low.rhs, state, t, rtol=rtol, atol=atol, method=method, options=None if options is None else opts)
+    except Exception as e:
+        if 'compiling the RHS plugin failed' not in str(e):
+            raise
+        # hipcc refused (or did not finish) the generated code: the callable itself, on the callable engine - said once
+        _warn_once('odeint: the kernel generated for `func` did not compile (%s); it runs as a Python callable instead' % str(e).split(';')[0])
+        out = odeint(func, y0, t, rtol=rtol, atol=atol, method=method, options=dict(opts, lower=False) if method is not None else None)
+        if isinstance(odeint.last_stats, dict):
+            odeint.last_stats['lower'] = {'lowered': False, 'why': 'generated code did not compile'}
+        return out
     stats = odeint.last_stats if isinstance(odeint.last_stats, dict) else {}
     info = low.describe()
     info['lowered'] = True
@@ -170,88 +186,108 @@ odeint.last_stats = {}
 _warned = set()
 
 
-_LEAF_CACHE = {}
-
-
-def _callable_key(func):
-    """(key, witnesses) identifying a callable for the leaf cache: the code object and what its closure cells / bound object / partial
-    arguments hold (a lambda written inside a training loop is a NEW object every iteration, but the same code over the same cells), else
-    the object itself.  The key is built from ids; `witnesses` are the objects behind those ids - kept by the cache entry as weak
-    references where the type allows it (a module that died and whose id was recycled is then noticed), strongly otherwise."""
+def _reachable_leaves(func, max_depth=3):
+    """Grad-requiring leaf tensors a callable can NAME: closure cells, its bound object, partial arguments, its own attributes, the globals
+    its code mentions - followed through modules (their parameters), containers and plain objects' attributes, a few levels deep.  The
+    complement of `_graph_leaves`: a branch the probe evaluation did not take (`nA(y) if t < 0.5 else nB(y)`) is still found here."""
     import functools
-    f = func
-    if isinstance(f, functools.partial):
-        k, w = _callable_key(f.func)
-        held = list(f.args) + [v for _, v in sorted((f.keywords or {}).items())]
-        return ('partial', k, tuple(id(a) for a in held)), w + held
-    fn = getattr(f, '__func__', f)
-    code = getattr(fn, '__code__', None)
-    if code is None:
-        return ('object', id(f)), [f]
-    held = [code]
-    for cell in getattr(fn, '__closure__', None) or ():
-        try:
-            held.append(cell.cell_contents)
-        except ValueError:                               # empty cell
-            held.append(None)
-    held.append(getattr(f, '__self__', None))
-    return ('code', tuple(id(h) for h in held)), held
+    import torch
+    out, seen = [], set()
 
-
-def _witness(obj):
-    import weakref
-    try:
-        return weakref.ref(obj)
-    except TypeError:
-        return lambda o=obj: o                           # (not weak-referenceable: held, so its id cannot be recycled)
+    def visit(obj, depth):
+        if obj is None or id(obj) in seen or isinstance(obj, (int, float, str, bytes, bool, type)):
+            return
+        seen.add(id(obj))
+        if isinstance(obj, torch.Tensor):
+            if obj.requires_grad and obj.is_leaf and all(obj is not o for o in out):
+                out.append(obj)
+            return
+        if isinstance(obj, torch.nn.Module):
+            for p in obj.parameters():
+                visit(p, depth)
+            return
+        if depth >= max_depth:
+            return
+        if isinstance(obj, (list, tuple, set, frozenset)):
+            for v in list(obj)[:64]:
+                visit(v, depth + 1)
+        elif isinstance(obj, dict):
+            for v in list(obj.values())[:64]:
+                visit(v, depth + 1)
+        elif isinstance(obj, functools.partial):
+            visit(obj.func, depth)
+            visit(obj.args, depth)
+            visit(obj.keywords, depth)
+        elif callable(obj) and hasattr(obj, '__code__'):
+            for cell in obj.__closure__ or ():
+                try:
+                    visit(cell.cell_contents, depth + 1)
+                except ValueError:
+                    pass
+            g = getattr(obj, '__globals__', {})
+            for name in obj.__code__.co_names:
+                if name in g and not isinstance(g[name], type(torch)):          # (modules like `torch` itself are not walked)
+                    visit(g[name], depth + 1)
+        else:
+            fn = getattr(obj, '__func__', None)
+            if fn is not None:                             # a bound method: the function and the object
+                visit(fn, depth)
+                visit(getattr(obj, '__self__', None), depth)
+                return
+            call = getattr(type(obj), '__call__', None)
+            if call is not None and hasattr(call, '__code__'):
+                visit(call, depth)
+            d = getattr(obj, '__dict__', None)
+            if isinstance(d, dict):
+                for v in list(d.values())[:64]:
+                    visit(v, depth + 1)
+    visit(func, 0)
+    return tuple(out)
 
 
 def _graph_leaves(func, y0, t):
-    """The grad-requiring LEAF tensors one evaluation f(t[0], y0) depends on, besides y0 and t themselves - read off the autograd
-    graph (AccumulateGrad nodes).  Exactly what the reference's GradientTape would reach: parameters of modules the callable calls,
-    bare tensors it closes over, anything reached through attribute chains or containers - and nothing it merely could name.
-    One extra evaluation of f per distinct callable (cached: see _callable_key; the entry keeps the callable's identity alive only as ids
-    and is dropped when any leaf's storage was freed)."""
+    """The grad-requiring LEAF tensors `func` depends on, besides y0 and t themselves: the leaves of the autograd graph of ONE probe
+    evaluation f(t[0], y0) (AccumulateGrad nodes - exactly what the reference's GradientTape would reach through whatever the evaluation
+    touches: parameters of modules the callable calls, bare tensors, attribute chains, containers), in union with the leaves the callable
+    can name (`_reachable_leaves`: a branch the probe did not take keeps its gradient; round-5 advisor).  Nothing is cached between calls:
+    a callable whose network was rebound, or whose tensors changed `requires_grad`, is seen as it is NOW (round-5 advisor: the cache keyed
+    on ids returned the old network's parameters)."""
     import torch
-    key, held = _callable_key(func)
-    hit = _LEAF_CACHE.get(key)
-    if hit is not None:
-        if len(hit[0]) == len(held) and all(w() is h for w, h in zip(hit[0], held)):
-            return hit[1]
-        del _LEAF_CACHE[key]                             # an id was recycled by another object
     ys = y0 if isinstance(y0, (tuple, list)) else (y0,)
     # the probe is not one of the solver's evaluations: an integer evaluation counter the callable keeps (`nfe`, as the reference's
     # DETEST harness and ODEFunc do) is put back afterwards
     counted = [o for o in (func, getattr(func, '__self__', None)) if isinstance(getattr(o, 'nfe', None), int)]
     before = [o.nfe for o in counted]
-    with torch.enable_grad():
-        probe = tuple(y.detach().requires_grad_(True) for y in ys)
-        t0 = torch.as_tensor(t).reshape(-1)[0].detach().to(device=ys[0].device, dtype=ys[0].dtype).requires_grad_(True)
-        out = func(t0, probe if isinstance(y0, (tuple, list)) else probe[0])
-    for o, n in zip(counted, before):
-        try:
-            o.nfe = n
-        except Exception:
-            pass
-    outs = out if isinstance(out, (tuple, list)) else (out,)
-    skip = {id(p) for p in probe} | {id(t0)}
-    leaves, seen, todo = [], set(), [o.grad_fn for o in outs if isinstance(o, torch.Tensor) and o.grad_fn is not None]
-    while todo:
-        node = todo.pop()
-        if node is None or node in seen:                 # (the set holds the node objects: an id alone is recycled as soon as a
-            continue                                     # wrapper is dropped, and a recycled id would hide a whole branch of the graph)
-        seen.add(node)
-        var = getattr(node, 'variable', None)            # AccumulateGrad: a leaf
-        if var is not None:
-            if var.requires_grad and id(var) not in skip and all(var is not l_ for l_ in leaves):
-                leaves.append(var)
-            continue
-        todo.extend(fn for fn, _ in node.next_functions)
-    leaves = tuple(leaves)
-    while len(_LEAF_CACHE) >= 16:
-        _LEAF_CACHE.pop(next(iter(_LEAF_CACHE)))
-    _LEAF_CACHE[key] = ([_witness(h) for h in held], leaves)
-    return leaves
+    leaves = []
+    try:
+        with torch.enable_grad():
+            probe = tuple(y.detach().requires_grad_(True) for y in ys)
+            t0 = torch.as_tensor(t).reshape(-1)[0].detach().to(device=ys[0].device, dtype=ys[0].dtype).requires_grad_(True)
+            out = func(t0, probe if isinstance(y0, (tuple, list)) else probe[0])
+        outs = out if isinstance(out, (tuple, list)) else (out,)
+        skip = {id(p) for p in probe} | {id(t0)}
+        seen, todo = set(), [o.grad_fn for o in outs if isinstance(o, torch.Tensor) and o.grad_fn is not None]
+        while todo:
+            node = todo.pop()
+            if node is None or node in seen:                 # (the set holds the node objects: an id alone is recycled as soon as a
+                continue                                     # wrapper is dropped, and a recycled id would hide a whole branch of the graph)
+            seen.add(node)
+            var = getattr(node, 'variable', None)            # AccumulateGrad: a leaf
+            if var is not None:
+                if var.requires_grad and id(var) not in skip and all(var is not l_ for l_ in leaves):
+                    leaves.append(var)
+                continue
+            todo.extend(fn for fn, _ in node.next_functions)
+    finally:
+        for o, n in zip(counted, before):
+            try:
+                o.nfe = n
+            except Exception:
+                pass
+    for extra in _reachable_leaves(func):
+        if all(extra is not l_ for l_ in leaves) and all(extra is not y for y in ys):
+            leaves.append(extra)
+    return tuple(leaves)
 
 
 def _callable_module(func, mods=(), tens=()):
@@ -308,9 +344,9 @@ def _probe_unsafe(y0):
 
 def _graph_leaves_or_none(func, y0):
     """_graph_leaves at t = 0 for the routing decision (`odeint` has not validated t yet); a callable that cannot be evaluated like that
-    decides nothing here - the solver will raise the real error."""
+    is judged by the tensors it can name alone (the solver will raise the real error of the evaluation)."""
     import torch
     try:
         return _graph_leaves(func, y0, torch.zeros(1))
     except Exception:
-        return ()
+        return _reachable_leaves(func)

@@ -66,14 +66,16 @@ k = z / ((T)1 + exp(-z)) - p[0] * y[i] + p[1] * sin(t);
     return rhs.CustomCoop(d, body, params=[decay, forcing], tensors=[W, b], torch_fn=torch_fn)
 
 
-def prebuild():
+def prebuild(extra_sources=()):
     """Compile every example for both state dtypes (cache hits are free) and drop cache entries that belong to older
-    kernel headers (the cache key covers the headers, so those can never be hit again)."""
+    kernel headers (the cache key covers the headers, so those can never be hit again).  extra_sources: more plugin sources to keep in
+    the in-tree cache (the kernels tfdiffeq_amd.lower generates for the callables of the tests / examples / bench)."""
     import os
     from . import _plugin_build
     sources = [f.source(dt) for f in (lorenz(), forced_oscillator(), van_der_pol()) for dt in (torch.float64, torch.float32)]
     sources += [oscillator_ring(8).source(torch.float64), oscillator_ring(16).source(torch.float32),
                 reaction_diffusion_ring(100).source(torch.float64), swish_layer(torch.zeros(48, 48), torch.zeros(48)).source(torch.float64)]
+    sources += [s_ for s_ in dict.fromkeys(extra_sources) if s_ not in sources]
     from concurrent.futures import ThreadPoolExecutor
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:      # (hipcc runs in subprocesses: ten plugins in the time of the slowest)
         out = list(pool.map(_plugin_build.build, sources))

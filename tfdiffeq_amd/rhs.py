@@ -319,9 +319,10 @@ def from_sequential(seq, time_dependent=False):
         Linear(d, h), ReLU, Linear(h, d)                       ->  rhs.MLP with an identity middle layer (relu(relu(z)) = relu(z): the same function,
                                                                    bit for bit - relu is idempotent; tanh / softplus are not, and raise)
 
-    act: nn.Tanh, nn.ReLU or nn.Softplus (default beta / threshold).  The descriptor holds detached float32 COPIES of the weights in
-    [in, out] layout (call again after an optimizer step).  Limits as rhs.MLP: float32, d <= 64, h <= 128; `odeint(from_sequential(net), y0, t)`
-    then runs the whole call in one launch."""
+    act: nn.Tanh, nn.ReLU or nn.Softplus (default beta / threshold).  The descriptor holds detached COPIES of the weights in [in, out]
+    layout and the module's own dtype (call again after an optimizer step).  Kernels as rhs.MLP: the MFMA tile kernels for float32 states,
+    d <= 64, h <= 128; the cooperative one-launch kernel for float32 / float64 up to 256 wide.  (`odeint(lambda t, y: net(y), y0, t)` gets
+    the same kernels by itself - tfdiffeq_amd/lower.py - and reads the weights on every call.)"""
     nn = torch.nn
     layers = list(seq)
     lin = [m for m in layers if isinstance(m, nn.Linear)]
@@ -335,13 +336,13 @@ def from_sequential(seq, time_dependent=False):
     act = names.pop()
     if act == 'softplus' and any(a.beta != 1 or a.threshold != 20 for a in acts):
         raise ValueError('from_sequential: Softplus with its default beta / threshold only')
-    w = [m.weight.detach().t().contiguous().float() for m in lin]
-    b = [None if m.bias is None else m.bias.detach().float() for m in lin]
+    w = [m.weight.detach().t().contiguous() for m in lin]             # the module's own dtype (fill() converts per state dtype)
+    b = [None if m.bias is None else m.bias.detach() for m in lin]
     if len(lin) == 2:
         if act != 'relu':
             raise ValueError('from_sequential: a two-layer network maps onto the three-layer kernel only for ReLU (idempotent)')
         h = w[0].shape[1]
-        w = [w[0], torch.eye(h, dtype=torch.float32, device=w[0].device), w[1]]
+        w = [w[0], torch.eye(h, dtype=w[0].dtype, device=w[0].device), w[1]]
         b = [b[0], None, b[1]]
     return MLP(w[0], b[0], w[1], b[1], w[2], b[2], activation=act, time_dependent=time_dependent)
 

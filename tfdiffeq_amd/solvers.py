@@ -413,7 +413,7 @@ def _cached_engine_or_none(key, factory):
     try:
         return _cached_engine(key, factory)
     except N.NativeError as e:
-        if '(%d)' % N.E_INVALID in str(e):
+        if getattr(e, 'rc', None) == N.E_INVALID:
             if len(_NO_ENGINE) > 256:
                 _NO_ENGINE.clear()
             _NO_ENGINE.add(key)
@@ -826,7 +826,8 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
                 chunk_attempts=self._chunk_attempts, profile=self._profile, fusion=self._fusion, seg_rows=seg_rows, seg_tols=seg_tols))
         except N.NativeError as e:
             if seg_rows is None:
-                if '(-1)' in str(e) and getattr(rhs, 'wide_tableaus', False) and getattr(rhs, 'torch_fn', None) is not None:
+                if getattr(e, 'rc', None) == N.E_INVALID and getattr(rhs, 'wide_tableaus', False) and \
+                        (getattr(rhs, 'torch_fn', None) is not None or 'forward' in vars(rhs)):
                     # rhs.CustomCoop whose batch is not co-resident on the cooperative kernel (its only schedule), with a torch_fn:
                     # the same function as a Python callable on the device-controlled engine - said once
                     _warn_once_coop(rhs, y, e)
