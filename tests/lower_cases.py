@@ -278,5 +278,5 @@ def generated_sources(device='cpu'):
     for name in fixture_names():
         d, meta = load(name)
         y0 = torch.tensor(d['y0'], device=device)
-        out.extend(lower.sources_for(literal_callable(meta, device, y0.dtype), y0))
+        out.extend(lower.sources_for(literal_callable(meta, device, y0.dtype), y0, method=meta['method']))
     return out

@@ -1486,11 +1486,12 @@ def _activation(n):
     return None
 
 
-def classify(tr):
-    """('linear' | 'cubic' | 'mlp' | 'rowlocal' | 'coop', details)."""
+def classify(tr, generic=False):
+    """('linear' | 'cubic' | 'mlp' | 'rowlocal' | 'coop', details).  generic: generated code only (a method the catalogue families have
+    no kernel for - adaptive_heun exists on the row-local / cooperative kernels alone)."""
     dim = _prod(tr.tail)
     ynode = next((n for n in tr.nodes if n.op == 'y'), None)
-    aff = _affine(tr.out)
+    aff = None if generic else _affine(tr.out)
     if aff is not None and dim >= 5 and aff[3] == aff[4] == dim:
         src = aff[0]
         if src is ynode:
@@ -1576,9 +1577,9 @@ class _GeneratedRHS(R.DeviceRHS):
 class Program(object):
     """What a structure key maps to: the classification, the DeviceRHS that carries it and its persistent device buffers."""
 
-    def __init__(self, tr):
-        self.key = tr.key()
-        self.kind, self.info = classify(tr)
+    def __init__(self, tr, generic=False):
+        self.key = tr.key() + ('g' if generic else '')
+        self.kind, self.info = classify(tr, generic)
         self.dim = _prod(tr.tail)
         self.dtype = tr.dtype
         self.layout = Layout(tr)
@@ -1671,11 +1672,11 @@ _PROGRAMS = {}
 _PROGRAMS_MAX = 64
 
 
-def program_for(tr):
-    key = tr.key()
+def program_for(tr, generic=False):
+    key = tr.key() + ('g' if generic else '')
     prog = _PROGRAMS.get(key)
     if prog is None:
-        prog = Program(tr)
+        prog = Program(tr, generic)
         while len(_PROGRAMS) >= _PROGRAMS_MAX:
             _PROGRAMS.pop(next(iter(_PROGRAMS)))
         _PROGRAMS[key] = prog
@@ -1765,7 +1766,10 @@ class Lowered(object):
                 'scalars': len(self.trace.scalars), 'tensors': len(self.trace.tensors), 'program': self.program.key}
 
 
-def lower(func, y0, nb=None):
+GENERIC_ONLY_METHODS = ('adaptive_heun',)       # tableaus only the row-local / cooperative kernels are instantiated for
+
+
+def lower(func, y0, nb=None, method=None):
     """Trace `func` for a state like y0 and bind this call's constants; raises TraceError with the reason when it cannot be lowered."""
     before = fingerprint(func)
     try:
@@ -1776,15 +1780,15 @@ def lower(func, y0, nb=None):
     if not pure:
         changed = sorted(str(k[-1]) for k in set(before) | set(after) if before.get(k) != after.get(k))
         raise TraceError('the callable changed its own Python state while it was traced (%s): not a pure function of (t, y)' % ', '.join(changed))
-    prog = program_for(tr)
+    prog = program_for(tr, generic=method in GENERIC_ONLY_METHODS)
     rhs = prog.bind(tr, y0.device)
     low = Lowered(prog, rhs, tr, func)
     rhs.forward = low.torch_fn                  # (instance attribute: THIS call's callable, whatever the catalogue class computes itself)
     return low
 
 
-def sources_for(func, y0, nb=None):
+def sources_for(func, y0, nb=None, method=None):
     """The generated source(s) a call with this callable and state would compile (build-time prebuilding; [] for catalogue routes)."""
     tr = trace(func, y0, nb=nb)
-    prog = program_for(tr)
+    prog = program_for(tr, generic=method in GENERIC_ONLY_METHODS)
     return [prog.source] if prog.source is not None else []

@@ -79,7 +79,9 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
             return _run_lowered(low, func, y0, t, rtol, atol, method, options)
         options = dict(options or {})
         impure = 'changed its own Python state' in why
-        if impure and 'graph' not in options and method is not None:
+        if impure and method is None:
+            method = 'dopri5'                              # (odeint.py:75-76: the default method, named so that it can carry an option)
+        if impure and 'graph' not in options:
             # a callable with observable Python state of its own (a step counter in a list, a log): recording an attempt as a hipGraph would
             # stop those side effects after two attempts - eager evaluation unless the caller asks for the recording (round-5 review, item 8)
             options['graph'] = False
@@ -140,7 +142,7 @@ def _try_lower(func, y0, method, options):
         def wrapped(t_, y_, _f=func):
             return _f(t_, (y_,))[0]
     try:
-        return _lower.lower(wrapped, y), None
+        return _lower.lower(wrapped, y, method=method), None
     except _lower.TraceError as e:
         why = str(e)
     except Exception as e:                                # the callable itself failed on the proxies (an operation torch refuses for them)
