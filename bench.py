@@ -5,6 +5,7 @@ A "step" is one whole `odeint` call.  Default = config 4: li
 float64, rtol 1e-6, atol 1e-9, t = [0, 1]; inputs resident in HBM before the timed region.  ONE JSON line on stdout.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--scaling weak|strong] [--config 1..5]
+    python bench.py --config published [--published-all]     # the reference's own published workloads, one line each
 
 N > 1: one process per GPU over RCCL.  Launched by the driver as `python -m torch.distributed.run ... bench.py --gpus N`
 (RANK / WORLD_SIZE in the environment); a bare `python bench.py --gpus N` re-executes itself under
@@ -343,6 +344,72 @@ def workload(cfg, args, rank, world, dev):
     raise SystemExit('unknown --config %r' % cfg)
 
 
+def published(args):
+    """The reference's own published workloads (`%%time` outputs of examples/ode_usage.ipynb, the Lorenz script) - single
+    trajectories with 1000 - 10 000 output times, thousands of dependent attempts on one lane.  Every system is handed to `odeint` as the
+    PYTHON CALLABLE the notebook writes (examples/reference_systems.py); one JSON line per system:
+      gpu_lowered_s    the call as a user makes it: traced, lowered onto the fused kernels, ONE launch (median of --steps calls)
+      gpu_callable_s   options={'lower': False}: the same callable evaluated by torch between library kernels (device-controlled engine)
+      gpu_catalogue_s  the hand-written device right-hand side where the catalogue has one (rhs.Lorenz, rhs.LotkaVolterra), else null
+      cpu_restatement_s  the op-for-op torch-CPU eager restatement of the reference's Dopri5 path (the oracle) on this host, same callable
+      published_s      the wall time the reference's notebook records (Colab CPU, TensorFlow eager) - another machine, quoted not measured
+    attempts / accepted are the GPU run's, oracle_attempts / oracle_accepted the restatement's (must be equal)."""
+    import statistics
+    sys.path.insert(0, os.path.join(ROOT, 'examples'))
+    import reference_systems as RS
+    from oracle import ode_torch_cpu as TC                 # the checker / CPU baseline leg only
+    from tfdiffeq_amd import odeint, rhs
+    if not torch.cuda.is_available():
+        sys.stderr.write('bench.py: no GPU visible (there is no CPU path)\n')
+        sys.exit(3)
+    dev = torch.device('cuda:0')
+    gpu, cpu = RS.systems(dev), RS.systems('cpu')
+    names = list(gpu) if args.published_all else list(RS.PUBLISHED)
+    catalogue = {'lorenz': lambda: rhs.Lorenz(10., 8. / 3., 28.), 'predator_prey': lambda: rhs.LotkaVolterra(1.5, 1., 3., 1.)}
+
+    def timed(fn, reps):
+        out = []
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            out.append(time.perf_counter() - t0)
+        return out
+    for name in names:
+        s = gpu[name]
+        f, y0, t = s['func'], s['y0'], s['t']
+        first = timed(lambda: odeint(f, y0, t), 1)[0]                       # includes tracing + loading the prebuilt kernel
+        sol = odeint(f, y0, t)
+        st = dict(odeint.last_stats)
+        low = timed(lambda: odeint(f, y0, t), max(args.steps, 3))
+        call = timed(lambda: odeint(f, y0, t, method='dopri5', options={'lower': False}), 2)
+        cst = dict(odeint.last_stats)
+        cat = None
+        if name in catalogue:
+            r = catalogue[name]()
+            odeint(r, y0.reshape(1, -1), t)
+            cat = statistics.median(timed(lambda: odeint(r, y0.reshape(1, -1), t), max(args.steps, 3)))
+        c = cpu[name]
+        t0 = time.perf_counter()
+        ref, rst = TC.odeint_dopri5(c['func'], c['y0'], c['t'])
+        cpu_s = time.perf_counter() - t0
+        err = float((sol.cpu() - ref).abs().max())
+        line = {'metric': 'wall seconds per odeint call (reference-published workload)', 'workload': name, 'source': s['source'],
+                'outputs': int(t.shape[0]), 'state_elements': int(y0.numel()), 'dtype': 'f64', 'method': 'dopri5', 'rtol': 1e-7, 'atol': 1e-9,
+                'published_s': s['published_s'], 'published_on': 'Colab CPU, TensorFlow eager (examples/ode_usage.ipynb %%time output; not this host)',
+                'gpu_lowered_s': statistics.median(low), 'gpu_lowered_first_call_s': first, 'gpu_callable_s': min(call), 'gpu_catalogue_s': cat,
+                'cpu_restatement_s': cpu_s, 'cpu': cpu_model(), 'lower': st.get('lower'), 'engine': st.get('engine'),
+                'n_launches': int(st.get('n_launches', -1)), 'attempts': int(st['n_attempts']), 'accepted': int(st['n_accepted']), 'nfe': int(st.get('nfe', -1)),
+                'oracle_attempts': rst.n_attempts, 'oracle_accepted': rst.n_accepted, 'oracle_nfe': rst.nfe,
+                'us_per_attempt_lowered': 1e6 * statistics.median(low) / max(int(st['n_attempts']), 1),
+                'us_per_attempt_callable': 1e6 * min(call) / max(int(cst.get('n_attempts', st['n_attempts'])), 1),
+                'callable_engine': cst.get('engine'), 'max_abs_diff_vs_oracle': err,
+                'speedup_vs_published': s['published_s'] / statistics.median(low) if s['published_s'] else None,
+                'speedup_vs_cpu_restatement': cpu_s / statistics.median(low), 'data': 'the notebook\'s own initial state and output grid'}
+        print(json.dumps(line), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -350,7 +417,10 @@ def main():
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=BATCH, help='config 4: rows per GPU (weak) / global rows (strong)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
-    ap.add_argument('--config', type=int, default=4, choices=[1, 2, 3, 4, 5], help='BASELINE.json configuration (default: the headline, 4)')
+    ap.add_argument('--config', default='4', choices=['1', '2', '3', '4', '5', 'published'],
+                    help="BASELINE.json configuration (default: the headline, 4); 'published': the workloads the reference publishes wall times "
+                         "for (examples/ode_usage.ipynb, lorenz_attractor.py), as the Python callables it writes them")
+    ap.add_argument('--published-all', action='store_true', help='--config published: every system of the notebook, not only the ones BASELINE.md lists')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-worker', type=int, default=0, help='internal: run the pinned torch-CPU leg with this many threads and exit')
     ap.add_argument('--cpu-runs', type=int, default=3)
@@ -363,6 +433,10 @@ def main():
                     help="'stage': one kernel per RK stage (34 planes/attempt, HBM-bound); 'step': whole attempt in one kernel; "
                          "'whole'/'auto': the whole call in one launch")
     args = ap.parse_args()
+    if args.config == 'published':
+        published(args)
+        return
+    args.config = int(args.config)
     if args.cpu_worker > 0:
         cpu_worker(args.cpu_worker, args.cpu_runs)
         return

@@ -474,3 +474,49 @@ def test_cooperative_right_hand_sides_host_logic():
     assert c.supports(torch.zeros(3, 100, dtype=torch.float64)) and c.multistep_fused and c.fixed_grid_fused and not c.row_local
     with pytest.raises(NotImplementedError):
         c(torch.tensor(0.0), torch.zeros(3, 100))                        # no torch_fn: only the kernels can evaluate it
+
+
+def test_plan_names_the_engine_of_the_five_baseline_configurations():
+    """odeint.plan (round-5 review, item 9): the engine a call WILL take and the predicate that chose it, without a GPU - pinned for the
+    five BASELINE.json configurations, as device right-hand sides and as the Python callables the reference's users write."""
+    import numpy as np
+    f64, f32 = torch.float64, torch.float32
+    AUTO = {'lower': 'auto'}          # (this module's other tests keep Python callables on the callable engines: tests/conftest.py)
+    # 1: Lotka-Volterra 2-D, fixed-step RK4, 1000 steps
+    p = odeint.plan(rhs.LotkaVolterra(), torch.ones(1, 2, dtype=f64), method='rk4')
+    assert p['engine'] == 'fused' and p['kernel'].startswith('k_fixed_rowlocal<double') and p['launches'] == 'one per call'
+    # 2: spiral, batch 4096 x 2, Dopri5 float64
+    W = torch.tensor([[-0.1, 2.0], [-2.0, -0.1]], dtype=f64)
+    p = odeint.plan(rhs.CubicLinear(W), torch.ones(4096, 2, dtype=f64), method='dopri5')
+    assert p['engine'] == 'fused' and p['kernel'].startswith('k_persist_rowlocal<double, 6') and 'row_local' in p['why']
+    p2 = odeint.plan(lambda t, y: torch.matmul(y ** 3, W), torch.ones(4096, 2, dtype=f64), method='dopri5', options=AUTO)
+    assert p2['lower'] == {'lowered': True, 'kind': 'rowlocal', 'dim': 2, 'batch_axes': 1} and p2['kernel'] == p['kernel']
+    # 3: Lorenz 65536 x 3, Tsit5
+    p = odeint.plan(rhs.Lorenz(), torch.ones(65536, 3, dtype=f64), method='tsit5')
+    assert p['kernel'].startswith('k_persist_rowlocal<double, 6') and p['state'] == '65536 x 3 float64'
+    # 4: linear 65536 x 128, Dopri5 float64 (the headline)
+    A = torch.tensor(np.random.RandomState(0).randn(128, 128))
+    p = odeint.plan(rhs.Linear(A), torch.ones(65536, 128, dtype=f64), method='dopri5')
+    assert p['engine'] == 'fused' and p['kernel'].startswith('k_persist_linear_mfma<double, 128, 6>') and 'MFMA' in p['why']
+    p2 = odeint.plan(lambda t, y: y @ A, torch.ones(65536, 128, dtype=f64), method='dopri5', options=AUTO)
+    assert p2['lower']['kind'] == 'linear' and p2['kernel'] == p['kernel']
+    assert odeint.plan(rhs.Linear(A), torch.ones(65536, 128, dtype=f64), method='dopri5', options={'fusion': 'stage'})['kernel'].startswith('k_stage_linear_mfma')
+    # 5: ODENet MLP 64-128-128-64 tanh, 32768 x 64 float32
+    net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Tanh(), torch.nn.Linear(128, 128), torch.nn.Tanh(), torch.nn.Linear(128, 64))
+    p = odeint.plan(rhs.from_sequential(net), torch.ones(32768, 64, dtype=f32), method='dopri5')
+    assert p['engine'] == 'fused' and p['kernel'].startswith('k_persist_mlp<DP, HP, 0, 6>')
+    p2 = odeint.plan(lambda t, y: net(y), torch.ones(32768, 64, dtype=f32), method='dopri5', options=AUTO)
+    assert p2['lower']['kind'] == 'mlp' and p2['kernel'] == p['kernel']
+    # ... and the ways OUT of the fused engine say why
+    p = odeint.plan(rhs.from_sequential(net.double()), torch.ones(32768, 64, dtype=f64), method='dopri5')
+    assert p['engine'] == 'callable' and 'supports(y0) is False' in p['why']
+    p = odeint.plan(lambda t, y: torch.cumsum(y, -1), torch.ones(8, 3, dtype=f64), method='dopri5', options=AUTO)
+    assert p['engine'] == 'callable' and p['lower'] == {'lowered': False, 'why': 'operation `cumsum` is outside the op set'}
+    p = odeint.plan(rhs.Lorenz(), torch.ones(8, 3, dtype=f64), method='midpoint')
+    assert p['engine'] == 'plane kernels' and 'midpoint has no fused kernel' in p['why']
+    p = odeint.plan(rhs.Linear(A), torch.ones(64, 128, dtype=f64), method='adaptive_heun')
+    assert p['engine'] == 'callable' and '1-row tableau' in p['why']
+    p = odeint.plan(lambda t, y: y @ A, torch.ones(64, 128, dtype=f64), method='adaptive_heun', options=AUTO)       # lowered: generated cooperative code
+    assert p['engine'] == 'fused' and p['lower']['kind'] == 'coop'
+    p = odeint.plan(rhs.Lorenz(), torch.ones(8, 3, dtype=f64), method='adams')
+    assert p['kernel'].startswith('k_adams_vc_rowlocal<double')

@@ -264,3 +264,28 @@ def test_generated_sources_are_stable_text():
         f, y0, _ = LC.CASES[name]('cpu')
         assert a == L.sources_for(f, y0) and len(a) == 1
         assert 'MI_ODE_DEFINE_' in a[0]
+
+
+def test_compiled_callables_trace_once_and_still_read_tensors_fresh():
+    class F(object):
+        def __init__(self):
+            self.a = 2.0
+            self.w = torch.tensor([1., 2.], dtype=torch.float64)
+            self.calls = []
+
+        def __call__(self, t, y):
+            return self.a * y * self.w
+    f = F()
+    y0 = torch.zeros(4, 2, dtype=torch.float64)
+    c = L.compile(f, y0)
+    n_nodes = len(c._traces[next(iter(c._traces))].nodes)
+    low = L.lower(c, y0)
+    assert low.kind == 'rowlocal' and low.rhs.params == [2.0]
+    f.w.mul_(3.0)                                           # tensors: by reference
+    f.a = 5.0                                               # Python numbers: frozen at compile time (the documented promise)
+    low = L.lower(c, y0)
+    assert low.rhs.params == [2.0] and torch.equal(low.rhs.pool[:2], torch.tensor([3., 6.], dtype=torch.float64))
+    assert len(c._traces) == 1 and len(c._traces[next(iter(c._traces))].nodes) == n_nodes
+    L.lower(c, torch.zeros(4, 2, dtype=torch.float32))      # another dtype: traced afresh (and then sees a = 5)
+    assert len(c._traces) == 2
+    np.testing.assert_allclose(c(0.0, torch.ones(1, 2, dtype=torch.float64)).numpy(), [[15., 30.]])

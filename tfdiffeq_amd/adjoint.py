@@ -35,6 +35,31 @@ def _flatten(seq):
     return torch.cat(flat) if len(flat) > 0 else torch.tensor([])
 
 
+class _FlatParams(torch.autograd.Function):
+    """torch.cat of the trainable tensors, whose backward hands a slice back only to the tensors the backward solve actually differentiated
+    through.  The differentiation set is the UNION of what one probe evaluation depends on and what the callable can name (odeint.
+    _graph_leaves: a branch the probe did not take must not lose its gradient); a tensor of that set that NO evaluation of the augmented
+    dynamics reached gets None, not zeros (an optimizer with weight decay would move it) - `usage['used']`, filled by the generic backward."""
+
+    @staticmethod
+    def forward(ctx, usage, *params):
+        ctx.usage = usage
+        ctx.shapes = [tuple(p.shape) for p in params]
+        return torch.cat([p.reshape(-1) for p in params])
+
+    @staticmethod
+    def backward(ctx, g):
+        used = ctx.usage.get('used')
+        out, off = [], 0
+        for i, shp in enumerate(ctx.shapes):
+            n = 1
+            for d in shp:
+                n *= d
+            out.append(None if (g is None or (used is not None and i < len(used) and not used[i])) else g[off:off + n].reshape(shp))
+            off += n
+        return (None,) + tuple(out)
+
+
 class _FusedAdjointEngine(object):
     """Owns one mi_ode_adjoint handle: the augmented system (y, adj_y, adj_t, adj_params) of adjoint.py:57-178 for a
     [batch, dim] float32 state and the dim -> hidden -> hidden -> dim MLP (rhs.MLP: relu, softplus or tanh; time_dependent:
@@ -487,6 +512,8 @@ class _OdeintAdjointMethod(torch.autograd.Function):
 
     @staticmethod
     def _augmented_dynamics(func, n_tensors, f_params, like):
+        used = [False] * len(f_params)
+
         def augmented_dynamics(tt, y_aug):
             # dynamics of the original system augmented with the adjoint wrt y, t and the parameters (adjoint.py:69-105)
             y, adj_y = y_aug[:n_tensors], y_aug[n_tensors:2 * n_tensors]
@@ -503,6 +530,9 @@ class _OdeintAdjointMethod(torch.autograd.Function):
                 else:
                     vjp = (None,) * (1 + n_tensors + len(f_params))
             vjp_t, vjp_y, vjp_params = vjp[0], vjp[1:1 + n_tensors], vjp[1 + n_tensors:]
+            for i_, g_ in enumerate(vjp_params):           # which parameters an evaluation reached at all (_FlatParams)
+                if g_ is not None:
+                    used[i_] = True
             vjp_t = torch.zeros_like(tt) if vjp_t is None else vjp_t
             vjp_y = tuple(torch.zeros_like(v) if g is None else g for g, v in zip(vjp_y, y))
             vjp_params = _flatten([torch.zeros_like(p) if g is None else g for g, p in zip(vjp_params, f_params)])
@@ -514,6 +544,7 @@ class _OdeintAdjointMethod(torch.autograd.Function):
         # process with it): the device-controlled engine must never record these dynamics - whatever its saved-tensor heuristic sees
         # (an f whose backward saves nothing, `return -y`, looks capture-safe to it)
         augmented_dynamics._mi_no_capture = True
+        augmented_dynamics.used = used
         return augmented_dynamics
 
     @staticmethod
@@ -609,6 +640,8 @@ class _OdeintAdjointMethod(torch.autograd.Function):
             time_vjps.append(adj_time.reshape(1))
             time_vjps = torch.cat(time_vjps[::-1]).to(dtype=t.dtype, device=t.device)
             grad_params = adj_params.to(flat_params.dtype) if flat_params.numel() > 0 else None
+            if isinstance(cfg.get('_usage'), dict) and hasattr(augmented_dynamics, 'used'):
+                cfg['_usage']['used'] = list(augmented_dynamics.used)
         return (None, None, None, time_vjps, grad_params, *adj_y)
 
 
@@ -637,9 +670,10 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
         y0 = (y0,)
         func = _TupleModule(func)
     params = _trainable(func)
-    flat_params = _flatten(params) if params else torch.zeros(0, device=y0[0].device, dtype=y0[0].dtype)
+    usage = {}
+    flat_params = _FlatParams.apply(usage, *params) if params else torch.zeros(0, device=y0[0].device, dtype=y0[0].dtype)
     cfg = dict(rtol=rtol, atol=atol, method=method, options=options, adjoint_method=adjoint_method,
-               adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol, adjoint_options=adjoint_options)
+               adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol, adjoint_options=adjoint_options, _usage=usage)
     t = torch.as_tensor(t)
     ys = _OdeintAdjointMethod.apply(func, len(y0), cfg, t, flat_params, *y0)
     if tensor_input:

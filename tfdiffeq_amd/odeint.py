@@ -185,6 +185,15 @@ def _run_lowered(low, func, y0, t, rtol, atol, method, options):
 
 
 odeint.last_stats = {}
+
+
+def _plan(*args, **kwargs):
+    from .plan import plan
+    return plan(*args, **kwargs)
+
+
+_plan.__doc__ = 'odeint.plan(func, y0, t=None, rtol=.., atol=.., method=None, options=None): the engine this call will take and why (tfdiffeq_amd/plan.py).'
+odeint.plan = _plan
 _warned = set()
 
 
