@@ -457,9 +457,9 @@ def test_cooperative_right_hand_sides_host_logic():
     assert small32.supports(y) and not small32.supports_coop(y) and small32.supports_multistep(y)         # the MFMA tile kernels' box
     f64 = mk(64, 128, torch.float64)
     y64 = torch.zeros(1000, 64, dtype=torch.float64)
-    assert not f64.supports(y64) and f64.coop_in_box(y64) and f64.supports_coop(y64) and f64.multistep_fused
+    assert f64.supports(y64) and not f64.coop_in_box(y64) and f64.multistep_fused          # (round 6: float64 tile kernels)
     big = torch.zeros(4096, 64, dtype=torch.float64)                                                     # 1.3e8 multiply-adds per evaluation
-    assert f64.coop_in_box(big) and not f64.supports_coop(big)
+    assert f64.supports(big)
     wide = mk(100, 300, torch.float32)
     assert not wide.supports(torch.zeros(5, 100)) and not wide.coop_in_box(torch.zeros(5, 100)) and not wide.multistep_fused
     with pytest.raises(ValueError):
@@ -509,6 +509,9 @@ def test_plan_names_the_engine_of_the_five_baseline_configurations():
     assert p2['lower']['kind'] == 'mlp' and p2['kernel'] == p['kernel']
     # ... and the ways OUT of the fused engine say why
     p = odeint.plan(rhs.from_sequential(net.double()), torch.ones(32768, 64, dtype=f64), method='dopri5')
+    assert p['engine'] == 'fused' and p['kernel'].startswith('k_persist_mlp64<DP, HP, 0, 6>')      # (round 6: the float64 tile kernels)
+    wide = torch.nn.Sequential(torch.nn.Linear(64, 300), torch.nn.Tanh(), torch.nn.Linear(300, 300), torch.nn.Tanh(), torch.nn.Linear(300, 64))
+    p = odeint.plan(rhs.from_sequential(wide), torch.ones(32768, 64, dtype=f32), method='dopri5')
     assert p['engine'] == 'callable' and 'supports(y0) is False' in p['why']
     p = odeint.plan(lambda t, y: torch.cumsum(y, -1), torch.ones(8, 3, dtype=f64), method='dopri5', options=AUTO)
     assert p['engine'] == 'callable' and p['lower'] == {'lowered': False, 'why': 'operation `cumsum` is outside the op set'}

@@ -45,12 +45,29 @@ def plugin_dir():
     return d
 
 
+def _plugin_headers():
+    """The headers a plugin translation unit actually sees: the #include closure of mi_ode_plugin.h inside csrc/ and include/ (a change to
+    the MLP / adjoint / linear-adjoint kernels does not invalidate the cache of compiled right-hand sides)."""
+    import re
+    inc = os.path.join(os.path.dirname(N.CSRC.rstrip(os.sep).rsplit(os.sep, 1)[0]), 'include')
+    seen, todo = [], ['mi_ode_plugin.h']
+    while todo:
+        name = todo.pop()
+        for d in (N.CSRC, inc):
+            path = os.path.join(d, os.path.basename(name))
+            if os.path.exists(path) and path not in seen:
+                seen.append(path)
+                with open(path, 'r') as fh:
+                    todo.extend(re.findall(r'^\s*#\s*include\s*"([^"]+)"', fh.read(), flags=re.M))
+                break
+    return sorted(seen)
+
+
 def _headers_digest():
     h = hashlib.sha256()
-    for name in sorted(os.listdir(N.CSRC)):
-        if name.endswith('.h'):
-            with open(os.path.join(N.CSRC, name), 'rb') as fh:
-                h.update(fh.read())
+    for path in _plugin_headers():
+        with open(path, 'rb') as fh:
+            h.update(fh.read())
     return h.hexdigest()
 
 

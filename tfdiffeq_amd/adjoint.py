@@ -37,9 +37,11 @@ def _flatten(seq):
 
 class _FlatParams(torch.autograd.Function):
     """torch.cat of the trainable tensors, whose backward hands a slice back only to the tensors the backward solve actually differentiated
-    through.  The differentiation set is the UNION of what one probe evaluation depends on and what the callable can name (odeint.
-    _graph_leaves: a branch the probe did not take must not lose its gradient); a tensor of that set that NO evaluation of the augmented
-    dynamics reached gets None, not zeros (an optimizer with weight decay would move it) - `usage['used']`, filled by the generic backward."""
+    through.  For a PLAIN CALLABLE the differentiation set is the union of what one probe evaluation depends on and what the callable can
+    name (odeint._graph_leaves: a branch the probe did not take must not lose its gradient); a merely-named tensor (`usage['optional']`)
+    that NO evaluation of the augmented dynamics reached gets None, not zeros (an optimizer with weight decay would move it) -
+    `usage['used']`, filled by the generic backward.  A module's own parameters always get their gradient, zeros if f does not depend on
+    them (the reference asks for UnconnectedGradients.ZERO, adjoint.py:83-95)."""
 
     @staticmethod
     def forward(ctx, usage, *params):
@@ -55,7 +57,8 @@ class _FlatParams(torch.autograd.Function):
             n = 1
             for d in shp:
                 n *= d
-            out.append(None if (g is None or (used is not None and i < len(used) and not used[i])) else g[off:off + n].reshape(shp))
+            skip = used is not None and i < len(used) and not used[i] and i in ctx.usage.get('optional', ())
+            out.append(None if (g is None or skip) else g[off:off + n].reshape(shp))
             off += n
         return (None,) + tuple(out)
 
@@ -670,7 +673,9 @@ def odeint_adjoint(func, y0, t, rtol=1e-6, atol=1e-12, method=None, options=None
         y0 = (y0,)
         func = _TupleModule(func)
     params = _trainable(func)
-    usage = {}
+    base = getattr(func, 'base_func', func)
+    optional = getattr(base, '_mi_optional_params', ())
+    usage = {'optional': frozenset(i for i, p in enumerate(params) if any(p is o for o in optional))}
     flat_params = _FlatParams.apply(usage, *params) if params else torch.zeros(0, device=y0[0].device, dtype=y0[0].dtype)
     cfg = dict(rtol=rtol, atol=atol, method=method, options=options, adjoint_method=adjoint_method,
                adjoint_rtol=adjoint_rtol, adjoint_atol=adjoint_atol, adjoint_options=adjoint_options, _usage=usage)

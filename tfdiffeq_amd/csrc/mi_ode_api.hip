@@ -157,7 +157,7 @@ static int enqueue_attempt_kernels(mi_ode_solver* h, hipStream_t st, hipEvent_t 
     MlpArgs M;
     fill_mlp_args(h, M);
     if (ev_last) (void)hipEventRecord(ev_last, st);
-    return mi_launch_mlp_f32(h, MLP_STEP, M, st);
+    return h->is_f32 ? mi_launch_mlp_f32(h, MLP_STEP, M, st) : mi_launch_mlp_f64(h, MLP_STEP, M, st);
   }
   if (h->step_fused) {
     StepArgs A;
@@ -338,7 +338,9 @@ static int pick_family(mi_ode_solver* h) {
         }
         h->family = FAM_MLP_COOP; return 0;
       }
-      const bool tile_box = h->is_f32 && D >= 1 && D <= 64 && hd >= 1 && hd <= 128;
+      // the MFMA tile kernels: float32 (weights resident in registers, mi_ode_mlp.h) and - round 6 - float64 (weights streamed from a
+      // packed copy, mi_ode_mlp64.h: instantiated for the padded geometries 16 x 16 and 64 x 128)
+      const bool tile_box = D >= 1 && D <= 64 && hd >= 1 && hd <= 128;
       const bool fixed_rk = !h->d.adaptive && h->d.multistep == 0 && (h->d.tableau.n_stages == 0 || h->d.tableau.n_stages == 3);
       if ((h->d.adaptive || fixed_rk) && !tile_box) {
         // outside the MFMA tile kernels' box (float64, dim > 64, hidden > 128): the cooperative whole-call kernel - a thread per state
@@ -350,7 +352,6 @@ static int pick_family(mi_ode_solver* h) {
         }
         h->family = FAM_MLP_COOP; return 0;
       }
-      if (!h->is_f32) { mi_set_error("fused MLP kernel is fp32 only"); return MI_ODE_E_INVALID; }
       if (!h->d.adaptive && (h->d.multistep != 0 || (h->d.tableau.n_stages != 0 && h->d.tableau.n_stages != 3))) {
         mi_set_error("fused MLP kernels on a fixed grid: euler or rk4 (3/8 rule) in one launch (k_fixed_mlp); no multistep kernel");
         return MI_ODE_E_INVALID;
@@ -361,6 +362,7 @@ static int pick_family(mi_ode_solver* h) {
       }
       h->mlp_dp = D <= 16 ? 16 : 64;
       h->mlp_hp = hd <= 16 ? 16 : 128;
+      if (!h->is_f32 && h->mlp_dp != (h->mlp_hp == 16 ? 16 : 64)) { h->mlp_dp = 64; h->mlp_hp = 128; }   // float64: two geometries (16 x 16, 64 x 128)
       h->family = FAM_MLP; return 0;
     }
     default:
@@ -438,6 +440,7 @@ extern "C" int mi_ode_destroy(mi_ode_handle h) {
   if (h->planes) (void)hipFree(h->planes);
   if (h->partials) (void)hipFree(h->partials);
   if (h->adams_tab) (void)hipFree(h->adams_tab);
+  if (h->mlp_pack) (void)hipFree(h->mlp_pack);
   if (h->adams_res) (void)hipHostFree(h->adams_res);
   if (h->rank_rec && h->own_exchange) (void)hipFree(h->rank_rec);
   if (h->gathered && h->own_exchange) (void)hipFree(h->gathered);
@@ -493,6 +496,14 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   h->rhs.hidden = desc->rhs.hidden;
   int rc = pick_family(h);
   if (rc != 0) { mi_ode_destroy(h); return rc; }
+  if (h->family == FAM_MLP && !h->is_f32) {          // float64 tile kernels: the packed copy of the weights (refreshed before every launch)
+    const int nd = mi_mlp64_pack_doubles(h->mlp_dp, h->mlp_hp);
+    if (nd <= 0 || hipMalloc((void**)&h->mlp_pack, (size_t)nd * sizeof(double)) != hipSuccess) {
+      (void)hipGetLastError();
+      mi_set_error("float64 MLP kernels: cannot allocate the weight pack (%d doubles)", nd);
+      mi_ode_destroy(h); return nd <= 0 ? MI_ODE_E_INVALID : MI_ODE_E_HIP;
+    }
+  }
   if (desc->adaptive && desc->multistep != 3 && tb.n_stages != 3 && tb.n_stages != 6) {   // (multistep = 3: no tableau at all)
     const bool rowlocal_fam = h->family == FAM_CUBIC2 || h->family == FAM_LINEAR2 || h->family == FAM_LV || h->family == FAM_LORENZ ||
                               h->family == FAM_PLUGIN || h->family == FAM_PLUGIN_COOP || h->family == FAM_MLP_COOP;
@@ -618,7 +629,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     }
     bool capable = desc->adaptive && (rowlocal || mfma || mlp || coop) && g <= kPersistMaxGrid;
     if (capable) {
-      const int cap = mlp ? mi_persist_capacity_mlp_f32(h) : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
+      const int cap = mlp ? (h->is_f32 ? mi_persist_capacity_mlp_f32(h) : mi_persist_capacity_mlp_f64(h))
+                          : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
       capable = cap > 0 && g <= cap;
     }
     if (!capable && desc->adaptive && (rowlocal || coop)) {
@@ -786,13 +798,13 @@ static int begin_impl(mi_ode_handle h, const void* y0_dev, double t0, void* firs
     MlpArgs M;
     fill_mlp_args(h, M);
     M.x_y0 = y0_dev; M.copy_a = h->planes; M.copy_b = first_out_dev;
-    int rcm = mi_launch_mlp_f32(h, MLP_F0, M, st);
+    int rcm = h->is_f32 ? mi_launch_mlp_f32(h, MLP_F0, M, st) : mi_launch_mlp_f64(h, MLP_F0, M, st);
     if (rcm != 0) return rcm;
     rcm = enqueue_controller(h, PH_F0, st);
     if (rcm != 0) return rcm;
     if (h->cp.auto_first_step) {
       fill_mlp_args(h, M);
-      rcm = mi_launch_mlp_f32(h, MLP_INITB, M, st);
+      rcm = h->is_f32 ? mi_launch_mlp_f32(h, MLP_INITB, M, st) : mi_launch_mlp_f64(h, MLP_INITB, M, st);
       if (rcm != 0) return rcm;
       rcm = enqueue_controller(h, PH_INITB, st);
       if (rcm != 0) return rcm;
@@ -945,7 +957,7 @@ static int integrate_persist(mi_ode_solver* h, const void* y0_dev, const double*
   A.sleep_first = h->persist_sleep_first; A.sleep_poll = h->persist_sleep_poll;
   const bool prof = h->d.profile && h->ev_ready;
   if (prof) (void)hipEventRecord(h->ev_a[0], st);
-  if (h->family == FAM_MLP) rc = mi_launch_persist_mlp_f32(h, A, h->persist_grid, st);
+  if (h->family == FAM_MLP) rc = h->is_f32 ? mi_launch_persist_mlp_f32(h, A, h->persist_grid, st) : mi_launch_persist_mlp_f64(h, A, h->persist_grid, st);
   else rc = h->is_f32 ? mi_launch_persist_f32(h, A, h->persist_grid, st) : mi_launch_persist_f64(h, A, h->persist_grid, st);
   if (rc != 0) return rc;
   if (prof) (void)hipEventRecord(h->ev_c[0], st);
@@ -1312,7 +1324,7 @@ static int fixed_impl(mi_ode_handle h, const void* y0_dev, const double* grid_ho
       if (rcf != 0) { mi_set_error("plugin fixed-grid kernel launch failed"); return rcf; }
       h->n_launches += 1;
     } else if (h->family == FAM_MLP) {
-      rcf = mi_launch_fixed_mlp_f32(h, F, st);
+      rcf = h->is_f32 ? mi_launch_fixed_mlp_f32(h, F, st) : mi_launch_fixed_mlp_f64(h, F, st);
     } else {
       rcf = h->is_f32 ? mi_launch_fixed_f32(h, F, st) : mi_launch_fixed_f64(h, F, st);
     }

@@ -71,7 +71,9 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
         else:
             _warn_once('odeint: y0 requires grad and `func` is a plain callable - gradients w.r.t. y0 and t are computed with the adjoint '
                        'method (its evaluation depends on no other grad-requiring tensor)')
-        return odeint_adjoint(_callable_module(func, (), leaves), y0, t, rtol=rtol, atol=atol, method=method, options=options)
+        mod = _callable_module(func, (), leaves)
+        mod._mi_optional_params = tuple(getattr(_graph_leaves, 'named_only', ()))
+        return odeint_adjoint(mod, y0, t, rtol=rtol, atol=atol, method=method, options=options)
     lowered = _try_lower(func, y0, method, options)
     if lowered is not None:
         low, why = lowered
@@ -295,9 +297,11 @@ def _graph_leaves(func, y0, t):
                 o.nfe = n
             except Exception:
                 pass
+    n_probe = len(leaves)
     for extra in _reachable_leaves(func):
         if all(extra is not l_ for l_ in leaves) and all(extra is not y for y in ys):
             leaves.append(extra)
+    _graph_leaves.named_only = tuple(leaves[n_probe:])      # (of the LAST call: odeint marks them "None if no evaluation reaches them")
     return tuple(leaves)
 
 

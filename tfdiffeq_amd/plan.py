@@ -67,7 +67,7 @@ def plan_rhs(rhs, y, method, options=None):
         if not rhs.supports(y):
             if coop_ok and 'process_group' not in opts and fusion in (0, 'auto', 4, 'whole'):
                 return out({'engine': 'fused', 'kernel': 'k_persist_rowlocal<%s, %d, .., RhsMlpCoop> (planes variant beyond a co-resident batch)' % (T, S),
-                            'launches': 'one per call', 'why': 'rhs.MLP.supports_coop: outside the tile kernels\' box (float32, dim <= 64, hidden <= 128), '
+                            'launches': 'one per call', 'why': 'rhs.MLP.supports_coop: outside the tile kernels\' box (dim <= 64, hidden <= 128), '
                             'inside the cooperative kernel\'s (<= 256 wide) and under COOP_MAX_FMA multiply-adds per evaluation'})
             return out(_callable_engine(method, opts, '%s.supports(y0) is False (dim %s, dtype %s)' % (type(rhs).__name__, rhs.dim, y.dtype)))
         wide = (fsal and S == 13) or (not fsal and S == 1)
@@ -83,9 +83,11 @@ def plan_rhs(rhs, y, method, options=None):
             return out({'engine': 'fused', 'kernel': 'k_persist_rowlocal<%s, %d, .., RhsUserCoop> (planes variant beyond a co-resident batch)' % (T, S),
                         'launches': 'one per call', 'why': 'cooperative plugin: a thread per state element, dim <= 256'})
         if fam == 'mlp':
-            return out({'engine': 'fused', 'kernel': 'k_persist_mlp<DP, HP, %d, %d> (dim / hidden padded; k_mlp per attempt when the tile grid is not co-resident)'
-                        % (R.MLP.ACTIVATIONS[rhs.activation], S), 'launches': 'one per call',
-                        'why': 'rhs.MLP.supports: float32, dim <= 64, hidden <= 128 - the MFMA tile kernels'})
+            kern = 'k_persist_mlp' if y.dtype == torch.float32 else 'k_persist_mlp64'
+            return out({'engine': 'fused', 'kernel': '%s<DP, HP, %d, %d> (dim / hidden padded; k_mlp per attempt when the tile grid is not co-resident)'
+                        % (kern, R.MLP.ACTIVATIONS[rhs.activation], S), 'launches': 'one per call',
+                        'why': 'rhs.MLP.supports: dim <= 64, hidden <= 128 - the MFMA tile kernels (float32: weights resident in registers; '
+                               'float64: weights streamed from a packed copy)'})
         if fam in ('linear', 'cubic_linear'):
             if 3 <= rhs.dim <= 128 and fam == 'linear' or (fam == 'cubic_linear' and 3 <= rhs.dim <= 128):
                 sched = {1: 'k_stage_linear_mfma (one kernel per stage)', 'stage': 'k_stage_linear_mfma (one kernel per stage)',

@@ -231,12 +231,13 @@ class MLP(DeviceRHS):
 
     fixed_grid_fused = True      # euler / rk4 (3/8 rule): the whole fixed-grid integration in one launch (k_fixed_mlp, round 4)
 
-    MAX_DIM, MAX_HIDDEN = 64, 128     # what the tile kernels are instantiated for (weight slices resident in registers), float32 only
+    MAX_DIM, MAX_HIDDEN = 64, 128     # what the tile kernels are instantiated for: float32 (weight slices resident in registers,
+                                      # csrc/mi_ode_mlp.h) and - round 6 - float64 (weights streamed from a packed copy, csrc/mi_ode_mlp64.h)
     _told_limits = set()
 
     def supports(self, y0):
-        """The MFMA tile kernels (Runge-Kutta, adaptive and fixed grid): float32, dim <= 64, hidden <= 128."""
-        return (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype == torch.float32
+        """The MFMA tile kernels (Runge-Kutta, adaptive and fixed grid): float32 or float64, dim <= 64, hidden <= 128."""
+        return (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
                 and self.dim <= self.MAX_DIM and self.hidden <= self.MAX_HIDDEN)
 
     def supports_coop(self, y0):
@@ -270,7 +271,7 @@ class MLP(DeviceRHS):
         if key not in MLP._told_limits:
             MLP._told_limits.add(key)
             import warnings
-            warnings.warn('tfdiffeq_amd.rhs.MLP: the MFMA tile kernels take float32 states with dim <= %d and hidden <= %d, the cooperative '
+            warnings.warn('tfdiffeq_amd.rhs.MLP: the MFMA tile kernels take float32 / float64 states with dim <= %d and hidden <= %d, the cooperative '
                           'one-launch kernel float32 / float64 up to %d wide (every adaptive method, euler / rk4, the Adams family); this problem (%s, dim %d, '
                           'hidden %d%s) runs as a Python callable on the device-controlled engine instead' % (
                               self.MAX_DIM, self.MAX_HIDDEN, self.MS_MAX_DIM, str(y0.dtype).replace('torch.', ''), self.dim, self.hidden,
