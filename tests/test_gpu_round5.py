@@ -321,9 +321,16 @@ def test_mlp_float64_module_trains_and_evaluates_through_the_cooperative_kernel(
         assert float((o3[1] - out).abs().max()) < 1e-4                        # (another method at the same tolerance)
     assert sum('runs as a Python callable' in str(m.message) for m in w) == 0, [str(m.message) for m in w]
     assert torch.equal(odeint(f, x, torch.tensor([0.3]), method='dopri5')[0], x)
-    # beyond ~50 M multiply-adds per evaluation the callable engine (rocBLAS products) is the faster route: chosen silently
+    # (round 6: a float64 network of this size is on the MFMA tile kernels - csrc/mi_ode_mlp64.h - at any batch size)
     huge = torch.randn(100000, 6, dtype=torch.float64, device=dev())
     odeint(f, huge, torch.tensor([0., 0.1]), rtol=1e-5, atol=1e-7, method='dopri5')
+    assert dict(odeint.last_stats)['n_launches'] == 1
+    # a network OUTSIDE the tile kernels' box (hidden 200) is on the cooperative kernel while an evaluation stays under ~50 M
+    # multiply-adds; beyond that the callable engine (rocBLAS products) is the faster route: chosen silently
+    wide = models.ODEFunc(6, 200, non_linearity='tanh').to(dev()).double().device_rhs()
+    odeint(wide, x, torch.tensor([0., 0.1]), rtol=1e-5, atol=1e-7, method='dopri5')
+    assert 'cooperative' in str(dict(odeint.last_stats).get('engine', ''))
+    odeint(wide, huge, torch.tensor([0., 0.1]), rtol=1e-5, atol=1e-7, method='dopri5')
     assert str(dict(odeint.last_stats).get('engine', '')).startswith('device-controlled')
 
 

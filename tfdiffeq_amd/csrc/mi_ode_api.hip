@@ -340,7 +340,8 @@ static int pick_family(mi_ode_solver* h) {
       }
       // the MFMA tile kernels: float32 (weights resident in registers, mi_ode_mlp.h) and - round 6 - float64 (weights streamed from a
       // packed copy, mi_ode_mlp64.h: instantiated for the padded geometries 16 x 16 and 64 x 128)
-      const bool tile_box = D >= 1 && D <= 64 && hd >= 1 && hd <= 128;
+      const bool one_row = h->d.adaptive && h->d.tableau.n_stages == 1;      // adaptive_heun: no tile kernel - the cooperative one
+      const bool tile_box = D >= 1 && D <= 64 && hd >= 1 && hd <= 128 && !one_row;
       const bool fixed_rk = !h->d.adaptive && h->d.multistep == 0 && (h->d.tableau.n_stages == 0 || h->d.tableau.n_stages == 3);
       if ((h->d.adaptive || fixed_rk) && !tile_box) {
         // outside the MFMA tile kernels' box (float64, dim > 64, hidden > 128): the cooperative whole-call kernel - a thread per state

@@ -135,22 +135,36 @@ struct MlpCtx64 {
   using G = MlpGeom64<DP, HP>;
   static constexpr int V = G::V, NW = G::NW;
   static constexpr int P1 = G::KS1 / 2, P2 = G::KS2 / 2;     // k-pairs of a layer-1 / layer-2, 3 slice
-  static constexpr int CH = P2 >= 16 ? 8 : P2;               // chunk: k-pairs per double-buffer half (layer 1's slice is one chunk: P1 <= CH)
+  static constexpr int CH = P2 >= 16 ? 8 : P2;               // chunk: k-pairs per buffer (layer 1's slice is one chunk: P1 <= CH)
   static constexpr int NC2 = P2 / CH;                        // chunks per slice in layers 2, 3
   static_assert(P1 <= CH && P2 % CH == 0, "chunking");
+  // The weights of one evaluation as a STREAM of chunks: V of layer 1 (one per virtual wavefront), V * NC2 of layer 2, V * NC2 of
+  // layer 3; chunk c + PD is requested while chunk c is consumed (PD = 2: two 8-KB requests per wavefront in flight - with one, the
+  // kernel ran at 6 TB/s of L2 traffic over 256 workgroups, every chain waiting out most of a round trip), across column blocks,
+  // layers, barriers and evaluations (the stream wraps: the first PD chunks of the next evaluation are carried in `wn`).
+  static constexpr int NCH = V + 2 * V * NC2;
+  static constexpr int PD = 2, NB = PD + 1;
   double *s_x, *s_h1, *s_h2;
   const double* pack;
   double sign;
-  mlp_d2 wn[CH];                                             // first chunk of the next evaluation (layer 1, v = 0)
+  mlp_d2 wn[PD][CH];
   int lane, wave, li, lg, d;
 
   __device__ __forceinline__ int vw(int v) const { return wave + v * NW; }
   __device__ __forceinline__ int col(int v) const { return 16 * (vw(v) % G::CB3) + li; }
   __device__ __forceinline__ int row_of(int v, int i) const { return 16 * (vw(v) / G::CB3) + lg + 4 * i; }
   __device__ __forceinline__ bool owner(int v) const { return vw(v) < G::NW3 && col(v) < d; }
-  __device__ __forceinline__ const mlp_d2* w1p(int v) const { return (const mlp_d2*)(pack + G::OFF_W1) + (vw(v) * P1) * 64 + lane; }
-  __device__ __forceinline__ const mlp_d2* w2p(int v) const { return (const mlp_d2*)(pack + G::OFF_W2) + (vw(v) * P2) * 64 + lane; }
-  __device__ __forceinline__ const mlp_d2* w3p(int v) const { return (const mlp_d2*)(pack + G::OFF_W3) + ((vw(v) % G::CB3) * P2) * 64 + lane; }
+  // chunk c of the stream (c taken modulo NCH): layer, virtual wavefront, part of the slice
+  static __device__ __forceinline__ constexpr int c_layer(int c) { return c < V ? 1 : (c < V + V * NC2 ? 2 : 3); }
+  static __device__ __forceinline__ constexpr int c_v(int c) { return c < V ? c : ((c - V) % (V * NC2)) / NC2; }
+  static __device__ __forceinline__ constexpr int c_h(int c) { return c < V ? 0 : ((c - V) % (V * NC2)) % NC2; }
+  __device__ __forceinline__ void request(int c, mlp_d2* w) const {       // (guarded by the chunk's consumer: a wavefront idles where it owns nothing)
+    c = c % NCH;
+    const int L = c_layer(c), v = c_v(c), h = c_h(c);
+    if (L == 1) { if (vw(v) < G::NW12) mlp64_load<P1>((const mlp_d2*)(pack + G::OFF_W1) + (vw(v) * P1) * 64 + lane, w); }
+    else if (L == 2) { if (vw(v) < G::NW12) mlp64_load<CH>((const mlp_d2*)(pack + G::OFF_W2) + (vw(v) * P2 + h * CH) * 64 + lane, w); }
+    else { if (vw(v) < G::NW3) mlp64_load<CH>((const mlp_d2*)(pack + G::OFF_W3) + ((vw(v) % G::CB3) * P2 + h * CH) * 64 + lane, w); }
+  }
 
   __device__ __forceinline__ void init(const RhsParams& rhs, int dim, char* smem) {
     s_x = (double*)smem;
@@ -160,7 +174,8 @@ struct MlpCtx64 {
     d = dim;
     pack = (const double*)rhs.w[0];                          // (the launcher put the pack here)
     sign = rhs.sign;
-    if (vw(0) < G::NW12) mlp64_load<P1>(w1p(0), wn);
+#pragma unroll
+    for (int c = 0; c < PD; ++c) request(c, wn[c]);
   }
   __device__ __forceinline__ void put_x(const double (*v4)[4]) {
 #pragma unroll
@@ -173,80 +188,64 @@ struct MlpCtx64 {
   }
   // ts: the time the network sees (already multiplied by the direction sign); it only shifts the first layer's bias
   __device__ __forceinline__ void eval(double (*out)[4], double ts) {
-    mlp_d2 wb[2][CH];                                        // the double buffer; wb[0] starts as wn
+    mlp_d2 wb[NB][CH];
 #pragma unroll
-    for (int s = 0; s < CH; ++s) wb[0][s] = wn[s];
-    int q = 0;                                               // chunks consumed so far (compile-time after unrolling)
+    for (int c = 0; c < PD; ++c) {
+#pragma unroll
+      for (int s = 0; s < CH; ++s) wb[c][s] = wn[c][s];
+    }
+    mlp_d4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
     __syncthreads();                                         // s_x is complete
-    // ---- layer 1: [32 x DP] @ [DP x 16] per virtual wavefront -------------------------------------------------
 #pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const bool on = vw(v) < G::NW12;
-      // (a prefetch is guarded by ITS consumer: the chunk after this one may belong to a virtual wavefront / layer this one idles in)
-      if (v + 1 < V) { if (vw(v + 1) < G::NW12) mlp64_load<P1>(w1p(v + 1), wb[(q + 1) & 1]); }
-      else if (vw(0) < G::NW12) mlp64_load<CH>(w2p(0), wb[(q + 1) & 1]);
-      if (on) {
-        mlp_d4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-        mlp64_chain<P1, true>(s_x + li * G::LDX + lg * G::KS1, s_x + (16 + li) * G::LDX + lg * G::KS1, wb[q & 1], c0, c1);
-        const int c = 16 * vw(v) + li;
-        const double b = pack[G::OFF_B1 + c] + ts * pack[G::OFF_WT + c];
+    for (int c = 0; c < NCH; ++c) {
+      const int L = c_layer(c), v = c_v(c), h = c_h(c);
+      if (c == V || c == V + V * NC2) __syncthreads();       // layer 2 reads s_h1, layer 3 reads s_h2
+      request(c + PD, wb[(c + PD) % NB]);
+      const mlp_d2* w = wb[c % NB];
+      if (L == 1) {                                          // [32 x DP] @ [DP x 16] per virtual wavefront
+        if (vw(v) < G::NW12) {
+          c0 = mlp_d4{0, 0, 0, 0}; c1 = mlp_d4{0, 0, 0, 0};
+          mlp64_chain<P1, true>(s_x + li * G::LDX + lg * G::KS1, s_x + (16 + li) * G::LDX + lg * G::KS1, w, c0, c1);
+          const int cc = 16 * vw(v) + li;
+          const double b = pack[G::OFF_B1 + cc] + ts * pack[G::OFF_WT + cc];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          s_h1[(lg + 4 * i) * G::LDH + c] = mlp64_act<ACT>(c0[i] + b);
-          s_h1[(16 + lg + 4 * i) * G::LDH + c] = mlp64_act<ACT>(c1[i] + b);
+          for (int i = 0; i < 4; ++i) {
+            s_h1[(lg + 4 * i) * G::LDH + cc] = mlp64_act<ACT>(c0[i] + b);
+            s_h1[(16 + lg + 4 * i) * G::LDH + cc] = mlp64_act<ACT>(c1[i] + b);
+          }
+        }
+      } else if (L == 2) {                                   // [32 x HP] @ [HP x 16]
+        if (vw(v) < G::NW12) {
+          if (h == 0) { c0 = mlp_d4{0, 0, 0, 0}; c1 = mlp_d4{0, 0, 0, 0}; }
+          mlp64_chain<CH, true>(s_h1 + li * G::LDH + lg * G::KS2 + 2 * CH * h, s_h1 + (16 + li) * G::LDH + lg * G::KS2 + 2 * CH * h, w, c0, c1);
+          if (h == NC2 - 1) {
+            const int cc = 16 * vw(v) + li;
+            const double b = pack[G::OFF_B2 + cc];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              s_h2[(lg + 4 * i) * G::LDH + cc] = mlp64_act<ACT>(c0[i] + b);
+              s_h2[(16 + lg + 4 * i) * G::LDH + cc] = mlp64_act<ACT>(c1[i] + b);
+            }
+          }
+        }
+      } else {                                               // one 16-row block x 16 output columns per virtual wavefront
+        if (vw(v) < G::NW3) {
+          if (h == 0) c0 = mlp_d4{0, 0, 0, 0};
+          const double* ap = s_h2 + (16 * (vw(v) / G::CB3) + li) * G::LDH + lg * G::KS2 + 2 * CH * h;
+          mlp64_chain<CH, false>(ap, ap, w, c0, c1);
+          if (h == NC2 - 1) {
+            const double b = pack[G::OFF_B3 + col(v)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) out[v][i] = c0[i] + b;
+          }
         }
       }
-      ++q;
-    }
-    __syncthreads();
-    // ---- layer 2: [32 x HP] @ [HP x 16] ----------------------------------------------------------------------
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const bool on = vw(v) < G::NW12;
-      mlp_d4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-      const double* a0p = s_h1 + li * G::LDH + lg * G::KS2;
-      const double* a1p = s_h1 + (16 + li) * G::LDH + lg * G::KS2;
-#pragma unroll
-      for (int h = 0; h < NC2; ++h) {
-        if (h + 1 < NC2) { if (on) mlp64_load<CH>(w2p(v) + (h + 1) * CH * 64, wb[(q + 1) & 1]); }
-        else if (v + 1 < V) { if (vw(v + 1) < G::NW12) mlp64_load<CH>(w2p(v + 1), wb[(q + 1) & 1]); }
-        else if (vw(0) < G::NW3) mlp64_load<CH>(w3p(0), wb[(q + 1) & 1]);
-        if (on) mlp64_chain<CH, true>(a0p + 2 * CH * h, a1p + 2 * CH * h, wb[q & 1], c0, c1);
-        ++q;
-      }
-      if (on) {
-        const int c = 16 * vw(v) + li;
-        const double b = pack[G::OFF_B2 + c];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          s_h2[(lg + 4 * i) * G::LDH + c] = mlp64_act<ACT>(c0[i] + b);
-          s_h2[(16 + lg + 4 * i) * G::LDH + c] = mlp64_act<ACT>(c1[i] + b);
-        }
-      }
-    }
-    __syncthreads();
-    // ---- layer 3: one 16-row block x 16 output columns per virtual wavefront ----------------------------------------
-#pragma unroll
-    for (int v = 0; v < V; ++v) {
-      const bool on = vw(v) < G::NW3;
-      mlp_d4 c = {0, 0, 0, 0}, unused = {0, 0, 0, 0};
-      const double* ap = s_h2 + (16 * (vw(v) / G::CB3) + li) * G::LDH + lg * G::KS2;
-#pragma unroll
-      for (int h = 0; h < NC2; ++h) {
-        if (h + 1 < NC2) { if (on) mlp64_load<CH>(w3p(v) + (h + 1) * CH * 64, wb[(q + 1) & 1]); }
-        else if (v + 1 < V) { if (vw(v + 1) < G::NW3) mlp64_load<CH>(w3p(v + 1), wb[(q + 1) & 1]); }
-        else if (vw(0) < G::NW12) mlp64_load<P1>(w1p(0), wb[(q + 1) & 1]);     // the NEXT evaluation's first chunk
-        if (on) mlp64_chain<CH, false>(ap + 2 * CH * h, ap, wb[q & 1], c, unused);
-        ++q;
-      }
-      if (on) {
-        const double b = pack[G::OFF_B3 + col(v)];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) out[v][i] = c[i] + b;
-      }
     }
 #pragma unroll
-    for (int s = 0; s < CH; ++s) wn[s] = wb[q & 1][s];
+    for (int c = 0; c < PD; ++c) {                           // the next evaluation's first chunks, requested under layer 3
+#pragma unroll
+      for (int s = 0; s < CH; ++s) wn[c][s] = wb[(NCH + c) % NB][s];
+    }
   }
 };
 

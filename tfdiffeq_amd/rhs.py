@@ -240,12 +240,15 @@ class MLP(DeviceRHS):
         return (y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
                 and self.dim <= self.MAX_DIM and self.hidden <= self.MAX_HIDDEN)
 
-    def supports_coop(self, y0):
+    def supports_coop(self, y0, any_box=False):
         """Outside that box (round 5): the adaptive Runge-Kutta solvers in ONE launch on the cooperative kernel (a thread per state element,
         the three layers through LDS: csrc/mi_ode_stage_rowlocal.h RhsMlpCoop under k_persist_rowlocal) - float32 / float64, dim and hidden
         up to 256; state in registers while the batch's workgroups (min(256 / dim, 2048 / hidden) trajectories each) are co-resident, streamed
         through HBM planes beyond (csrc/mi_ode_persist.h: k_persist_rowlocal_planes)."""
-        if not self.coop_in_box(y0):
+        # (any_box: a tableau the tile kernels are not instantiated for - adaptive_heun - takes the cooperative kernel inside their box too)
+        in_box = self.coop_in_box(y0) or (any_box and y0.dim() >= 1 and y0.shape[-1] == self.dim and y0.dtype in (torch.float32, torch.float64)
+                                          and self.dim <= self.MS_MAX_DIM and self.hidden <= self.MS_MAX_HIDDEN)
+        if not in_box:
             return False
         # The cooperative evaluation is vector-ALU work fed from L2 (~0.9e12 fma/s measured): it beats the callable engine (three rocBLAS
         # products per evaluation, but 130 - 550 us of launches per attempt) while an evaluation stays under ~50 M multiply-adds -

@@ -770,6 +770,10 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
     # -- fused engine ----------------------------------------------------------------------------
     def _make_engine(self):
         rhs = None if self._force_planes else _fusable(self.func, self.y0)
+        from .rk_common import _is_fsal_shaped
+        one_row = len(self.tableau.alpha) == 1 and not _is_fsal_shaped(self.tableau)
+        if rhs is not None and one_row and hasattr(rhs, 'supports_coop'):
+            rhs = None                                       # adaptive_heun: the MLP tile kernels have no 1-row tableau - the cooperative kernel does
         self._packed = None
         if rhs is None and not self._force_planes and self._pg is None and self._fusion in (0, 'auto', 4, 'whole'):
             rhs = _fusable_tuple(self.func, self.y0)            # tuple state of a row-local RHS: one segmented buffer
@@ -781,7 +785,7 @@ class _AdaptiveRKSolver(AdaptiveStepsizeODESolver):
             cand = getattr(self.func, 'device_rhs', None)
             y = self.y0[0]
             if cand is not None and hasattr(cand, 'supports_coop') and isinstance(y, torch.Tensor) and y.is_cuda and y.numel() > 0 and \
-                    cand.supports_coop(y):
+                    cand.supports_coop(y, any_box=one_row):
                 rhs, self._coop = cand, True
             elif cand is not None and hasattr(cand, 'warn_limits') and isinstance(y, torch.Tensor) and y.is_cuda and not cand.coop_in_box(y):
                 cand.warn_limits(y)                                  # (e.g. hidden > 256: no kernel of the family takes it - said once)
