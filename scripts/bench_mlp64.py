@@ -21,24 +21,28 @@ for d, h in ((64, 128), (16, 16)):
             for _ in range(5):
                 blk(x)
             st = dict(odeint.last_stats)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            n = 50
-            for _ in range(n):
+            ts = []
+            for _ in range(50):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 blk(x)
-            torch.cuda.synchronize()
-            ms = (time.perf_counter() - t0) / n * 1e3
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+            ts.sort()
+            ms, ms_min, ms_max = ts[len(ts) // 2], ts[0], ts[-1]
             f = lambda t, y: blk.odefunc(t, y)   # noqa: E731
             opts = {'lower': False, 'max_num_steps': 1000}
             for _ in range(3):
                 odeint(f, x, torch.tensor([0., 1.]), rtol=1e-3, atol=1e-3, method='dopri5', options=opts)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            tc = []
             for _ in range(10):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
                 odeint(f, x, torch.tensor([0., 1.]), rtol=1e-3, atol=1e-3, method='dopri5', options=opts)
-            torch.cuda.synchronize()
-            ms_c = (time.perf_counter() - t0) / 10 * 1e3
+                torch.cuda.synchronize()
+                tc.append((time.perf_counter() - t0) * 1e3)
+            ms_c = sorted(tc)[len(tc) // 2]
         nfe = int(st.get('nfe', 0))
         flops = nfe * batch * 2.0 * (d * h + h * h + h * d)
-        print('float64 %d-%d-%d-%d tanh batch %6d: ODEBlock call %.3f ms on the tile kernels (attempts %d, NFE %d, launches %d, %.1f TF = %.2f of the fp64 MFMA peak) | '
-              'as a Python callable %.3f ms' % (d, h, h, d, batch, ms, st['n_attempts'], nfe, st['n_launches'], flops / ms / 1e9, flops / ms / 1e9 / 78.6, ms_c), flush=True)
+        print('float64 %d-%d-%d-%d tanh batch %6d: ODEBlock call %.3f ms median of 50 (min %.3f, max %.3f) on the tile kernels (attempts %d, NFE %d, launches %d, %.1f TF = %.2f of the fp64 MFMA peak) | '
+              'as a Python callable %.3f ms' % (d, h, h, d, batch, ms, ms_min, ms_max, st['n_attempts'], nfe, st['n_launches'], flops / ms / 1e9, flops / ms / 1e9 / 78.6, ms_c), flush=True)

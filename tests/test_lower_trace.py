@@ -289,3 +289,14 @@ def test_compiled_callables_trace_once_and_still_read_tensors_fresh():
     L.lower(c, torch.zeros(4, 2, dtype=torch.float32))      # another dtype: traced afresh (and then sees a = 5)
     assert len(c._traces) == 2
     np.testing.assert_allclose(c(0.0, torch.ones(1, 2, dtype=torch.float64)).numpy(), [[15., 30.]])
+
+
+def test_generated_cooperative_code_is_refused_where_rocblas_is_faster():
+    """A network with an elementwise pre-op is not the catalogue's MLP shape: small batches get generated cooperative code, a batch whose
+    evaluation exceeds ~5e7 multiply-adds stays on the callable engine (and says why)."""
+    net = torch.nn.Sequential(torch.nn.Linear(64, 128), torch.nn.Tanh(), torch.nn.Linear(128, 128), torch.nn.Tanh(), torch.nn.Linear(128, 64)).double()
+    f = lambda t, y: net(y ** 3)                            # noqa: E731
+    small = L.lower(f, torch.zeros(100, 64, dtype=torch.float64))
+    assert small.kind == 'coop' and small.program.macs == 64 * 128 + 128 * 128 + 128 * 64
+    with pytest.raises(L.TraceError, match='rocBLAS'):
+        L.lower(f, torch.zeros(32768, 64, dtype=torch.float64))

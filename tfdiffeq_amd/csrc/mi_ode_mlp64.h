@@ -113,19 +113,26 @@ __device__ __forceinline__ void mlp64_load(const mlp_d2* wp, mlp_d2* w) {     //
 #pragma unroll
   for (int s = 0; s < N; ++s) w[s] = wp[s * 64];
 }
+// N k-pairs of a chain.  The activation operands of the WHOLE chunk are read from LDS first (one wavefront per SIMD: nobody else covers
+// an LDS round trip in front of an MFMA), then the MFMAs run back to back on two independent accumulators.
 template <int N, bool TWO>
 __device__ __forceinline__ void mlp64_chain(const double* a0p, const double* a1p, const mlp_d2* w, mlp_d4& c0, mlp_d4& c1) {
+  mlp_d2 a0[N], a1[TWO ? N : 1];
 #pragma unroll
   for (int m = 0; m < N; ++m) {
-    const mlp_d2 a0 = *(const mlp_d2*)(a0p + 2 * m);
-    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[0], w[m][0], c0, 0, 0, 0);
+    a0[m] = *(const mlp_d2*)(a0p + 2 * m);
+    if constexpr (TWO) a1[m] = *(const mlp_d2*)(a1p + 2 * m);
+  }
+  __builtin_amdgcn_sched_barrier(0);                         // (the scheduler otherwise sinks every read back in front of its MFMA)
+#pragma unroll
+  for (int m = 0; m < N; ++m) {
+    c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[m][0], w[m][0], c0, 0, 0, 0);
     if constexpr (TWO) {
-      const mlp_d2 a1 = *(const mlp_d2*)(a1p + 2 * m);
-      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[0], w[m][0], c1, 0, 0, 0);
-      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], w[m][1], c0, 0, 0, 0);
-      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[1], w[m][1], c1, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[m][0], w[m][0], c1, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[m][1], w[m][1], c0, 0, 0, 0);
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[m][1], w[m][1], c1, 0, 0, 0);
     } else {
-      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[1], w[m][1], c0, 0, 0, 0);
+      c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[m][1], w[m][1], c0, 0, 0, 0);
     }
   }
 }

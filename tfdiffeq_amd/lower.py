@@ -1490,9 +1490,28 @@ def _activation(n):
     return None
 
 
-def classify(tr, generic=False):
+def graph_macs(tr):
+    """Multiply-adds of the matrix products of ONE evaluation of one trajectory."""
+    macs = 0
+    for n in tr.live():
+        if n.op == 'linear':
+            macs += (n.args[0].size // max(n.args[1].shape[1], 1)) * n.args[1].shape[0] * n.args[1].shape[1]
+        elif n.op == 'matmul':
+            a, b = n.args
+            k = a.shape[-1]
+            macs += n.size * k
+    return macs
+
+
+COOP_MAX_FMA = 5e7            # generated cooperative code is vector-ALU work fed from L2 (~1e12 fma/s, rhs.MLP.COOP_MAX_FMA): beyond this many
+                              # multiply-adds per evaluation of the whole batch the callable engine's rocBLAS products are the faster route
+ROW_MAX_MACS = 8192           # ... and a thread that owns a trajectory does its products alone
+
+
+def classify(tr, generic=False, rows=1):
     """('linear' | 'cubic' | 'mlp' | 'rowlocal' | 'coop', details).  generic: generated code only (a method the catalogue families have
-    no kernel for - adaptive_heun exists on the row-local / cooperative kernels alone)."""
+    no kernel for - adaptive_heun exists on the row-local / cooperative kernels alone).  rows: trajectories of this call (the cost guard
+    of the generated kinds)."""
     dim = _prod(tr.tail)
     ynode = next((n for n in tr.nodes if n.op == 'y'), None)
     aff = None if generic else _affine(tr.out)
@@ -1522,9 +1541,13 @@ def classify(tr, generic=False):
             ok2 = len(layers) == 2 and layers[1][3] == hid and acts[0] == 'relu'
             if (ok3 or ok2) and (dim > 4 or hid > 16):
                 return 'mlp', {'layers': [(l_[1], l_[2]) for l_ in layers], 'act': acts[0], 'hidden': hid}
-    if dim <= MAX_ROW_DIM:
+    macs = graph_macs(tr)
+    if dim <= MAX_ROW_DIM and macs <= ROW_MAX_MACS:
         return 'rowlocal', {}
     if dim <= MAX_COOP_DIM:
+        if macs * rows > COOP_MAX_FMA:
+            raise TraceError('%d multiply-adds per trajectory x %d trajectories per evaluation: generated cooperative code (vector ALU, weights from L2) '
+                             'would be slower than the callable engine\'s rocBLAS products' % (macs, rows))
         return 'coop', {}
     raise TraceError('a system of %d elements per trajectory with no matrix structure the catalogue knows' % dim)
 
@@ -1584,6 +1607,7 @@ class Program(object):
     def __init__(self, tr, generic=False):
         self.key = tr.key() + ('g' if generic else '')
         self.kind, self.info = classify(tr, generic)
+        self.macs = graph_macs(tr)
         self.dim = _prod(tr.tail)
         self.dtype = tr.dtype
         self.layout = Layout(tr)
@@ -1786,6 +1810,8 @@ def lower(func, y0, nb=None, method=None):
     if not pure:
         changed = sorted(str(k[-1]) for k in set(before) | set(after) if before.get(k) != after.get(k))
         raise TraceError('the callable changed its own Python state while it was traced (%s): not a pure function of (t, y)' % ', '.join(changed))
+    rows = _prod(tr.batch_shape)
+    classify(tr, generic=method in GENERIC_ONLY_METHODS, rows=rows)        # (the cost guard of generated cooperative code: raises)
     prog = program_for(tr, generic=method in GENERIC_ONLY_METHODS)
     rhs = prog.bind(tr, y0.device)
     low = Lowered(prog, rhs, tr, func)
@@ -1823,6 +1849,7 @@ class CompiledCallable(object):
         tr = self._trace_for(y0, method)
         if tr.device != y0.device:
             tr.device = y0.device
+        classify(tr, generic=method in GENERIC_ONLY_METHODS, rows=_prod(tr.batch_shape))
         prog = program_for(tr, generic=method in GENERIC_ONLY_METHODS)
         rhs = prog.bind(tr, y0.device)
         low = Lowered(prog, rhs, tr, self.func)
