@@ -264,3 +264,35 @@ def test_ode_demo_trains_with_its_forward_on_a_generated_kernel():
     pred.abs().mean().backward()
     assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in f.parameters())
     assert 'forward' in odeint_adjoint.last_backward_stats and odeint_adjoint.last_backward_stats['forward']['lowered']
+
+
+def test_plain_callable_over_trainable_tensors_is_differentiated_without_a_probe():
+    """`odeint(lambda t, y: net(y ** 3) * scale, y0, t)` under grad mode, y0 not requiring grad: the tensors the callable closes over are
+    read off its trace (no probe evaluation with autograd per call); the ones that require grad make the call an adjoint solve - forward
+    on the generated kernel - and receive their gradients; with none of them requiring grad the call is the plain one-launch solve."""
+    from tfdiffeq_amd import odeint, odeint_adjoint
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(3, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3)).double().to(dev())
+    scale = torch.tensor(0.7, dtype=torch.float64, device=dev(), requires_grad=True)
+    f = lambda t, y: net(y ** 3) * scale                    # noqa: E731
+    y0 = torch.randn(12, 3, dtype=torch.float64, device=dev())
+    t = torch.tensor([0., 0.5])
+    out = odeint(f, y0, t, rtol=1e-8, atol=1e-10)
+    assert out.requires_grad
+    out[-1].pow(2).sum().backward()
+    assert odeint_adjoint.last_backward_stats['forward']['lowered']
+    got = [p.grad.clone() for p in list(net.parameters()) + [scale]]
+    for p in list(net.parameters()) + [scale]:
+        p.grad = None
+    y = y0.clone()
+    h = 0.5 / 200
+    for _ in range(200):                                    # autograd through a fine RK4 integration of the same callable
+        k1 = f(0, y); k2 = f(0, y + 0.5 * h * k1); k3 = f(0, y + 0.5 * h * k2); k4 = f(0, y + h * k3)
+        y = y + (h / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
+    y.pow(2).sum().backward()
+    for g, p in zip(got, list(net.parameters()) + [scale]):
+        assert float((g - p.grad).abs().max()) <= 1e-6 * max(1.0, float(p.grad.abs().max()))
+    for p in list(net.parameters()) + [scale]:
+        p.requires_grad_(False)
+    out = odeint(f, y0, t, rtol=1e-8, atol=1e-10)
+    assert not out.requires_grad and odeint.last_stats['lower']['lowered'] and odeint.last_stats['n_launches'] == 1

@@ -300,3 +300,59 @@ def test_generated_cooperative_code_is_refused_where_rocblas_is_faster():
     assert small.kind == 'coop' and small.program.macs == 64 * 128 + 128 * 128 + 128 * 64
     with pytest.raises(L.TraceError, match='rocBLAS'):
         L.lower(f, torch.zeros(32768, 64, dtype=torch.float64))
+
+
+def test_trace_cache_is_reused_only_while_nothing_the_callable_names_has_changed():
+    """lower() re-traces a callable only when something it can NAME changed (numbers by value, tensors by identity); a constant the walk
+    cannot explain (a float computed inside the callable) makes the callable uncacheable - it is then simply traced on every call."""
+    class F(object):
+        def __init__(self):
+            self.rate = 0.5
+            self.w = torch.tensor([1., 2., 3.], dtype=torch.float64)
+            self.net = torch.nn.Linear(3, 3).double()
+
+        def __call__(self, t, y):
+            return self.rate * y * self.w + self.net(y)
+    f = F()
+    y0 = torch.zeros(4, 3, dtype=torch.float64)
+    L._TRACES.clear()
+    st = L.trace_cache_stats
+
+    def delta(fn):
+        before = dict(st)
+        out = fn()
+        return out, {k: st[k] - before[k] for k in st}
+    low, d = delta(lambda: L.lower(f, y0))
+    assert d == {'hits': 0, 'misses': 1, 'uncacheable': 0} and low.rhs.params == [0.5]
+    low, d = delta(lambda: L.lower(f, y0))
+    assert d['hits'] == 1
+    f.rate = 0.75                                           # a number changed: by VALUE
+    low, d = delta(lambda: L.lower(f, y0))
+    assert d['misses'] == 1 and low.rhs.params == [0.75]
+    f.w.mul_(2.0)                                           # a tensor updated in place: no re-trace needed - tensors are re-read on every call
+    with torch.no_grad():
+        f.net.weight.add_(1.0)
+    low, d = delta(lambda: L.lower(f, y0))
+    assert d['hits'] == 1
+    np.testing.assert_allclose(L.evaluate_row(low.trace, 0.0, np.ones(3)), f(0.0, torch.ones(1, 3, dtype=torch.float64)).detach().numpy()[0], rtol=1e-14)
+    f.w = torch.tensor([5., 5., 5.], dtype=torch.float64)   # a tensor REBOUND: identity changed
+    low, d = delta(lambda: L.lower(f, y0))
+    assert d['misses'] == 1 and float(low.rhs.pool[low.program.layout.tensor_off[0]]) == 5.0
+    f.net = torch.nn.Linear(3, 3).double()                  # a module replaced
+    _, d = delta(lambda: L.lower(f, y0))
+    assert d['misses'] == 1
+    _, d = delta(lambda: L.lower(f, torch.zeros(9, 3, dtype=torch.float64)))       # another batch shape: its own entry
+    assert d['misses'] == 1
+    # a lambda re-created on every call: the same code over the same cells
+    a = 2.0
+    mk = lambda: (lambda t, y: a * y)                       # noqa: E731
+    L.lower(mk(), y0)
+    _, d = delta(lambda: L.lower(mk(), y0))
+    assert d['hits'] == 1
+    # a float computed inside the callable is not something the walk can see: never cached
+    g = lambda t, y: (-f.rate) * y                          # noqa: E731
+    L.lower(g, y0)
+    _, d = delta(lambda: L.lower(g, y0))
+    assert d == {'hits': 0, 'misses': 0, 'uncacheable': 1}
+    f.rate = 0.1
+    assert L.lower(g, y0).rhs.params == [-0.1]

@@ -1794,22 +1794,170 @@ class Lowered(object):
                 'scalars': len(self.trace.scalars), 'tensors': len(self.trace.tensors), 'program': self.program.key}
 
 
+TRACE_CACHE = True            # reuse a trace while nothing the callable can name has changed (see _cached_trace)
 GENERIC_ONLY_METHODS = ('adaptive_heun',)       # tableaus only the row-local / cooperative kernels are instantiated for
+
+
+# ---------------------------------------------------------------------------------------------
+# trace cache: a callable is traced again only when something it can NAME has changed
+# ---------------------------------------------------------------------------------------------
+# Tracing costs 0.3 - 0.5 ms of Python per call - more than the kernel of a short integration.  A trace may be reused when a repeat of the
+# evaluation would record the same graph with the same constants.  That is decided without running the callable: `_snapshot` walks what
+# the callable can name (closure cells, its bound object, its own attributes, the globals and constants its code mentions, defaults;
+# through containers, plain objects and nn.Modules, a few levels deep) and records every number BY VALUE and every tensor / array BY
+# IDENTITY.  A trace is cacheable only if EVERY constant it used is one of those named objects (a float computed inside the callable -
+# `2 * self.a` - is not, and such a callable is simply traced on every call); a later call reuses it when the snapshot is equal.
+_SNAP_MAX = 512
+
+
+def _snapshot(func):
+    """(entries, objects): entries - a tuple of (path, kind, value | id) for every number / tensor the callable can name, or None if
+    there are too many; objects - the ids of those objects (to decide whether a trace is explained by them)."""
+    import functools
+    entries, ids, seen = [], set(), set()
+
+    def leaf(path, obj):
+        if isinstance(obj, (bool, int, float)) or obj is None:
+            entries.append((path, 'n', obj if obj is None else (type(obj).__name__, obj)))
+            ids.add(id(obj))
+            return True
+        if isinstance(obj, (np.floating, np.integer, np.bool_)):
+            entries.append((path, 'n', (type(obj).__name__, obj.item())))
+            ids.add(id(obj))
+            return True
+        if isinstance(obj, (torch.Tensor, np.ndarray)):
+            entries.append((path, 't', id(obj)))
+            ids.add(id(obj))
+            return True
+        return False
+
+    def visit(path, obj, depth):
+        if len(entries) > _SNAP_MAX:
+            return
+        if leaf(path, obj):
+            return
+        if isinstance(obj, (str, bytes, type)) or id(obj) in seen or depth > 3:
+            return
+        seen.add(id(obj))
+        if isinstance(obj, torch.nn.Module):
+            entries.append((path, 'm', (id(obj), obj.training)))
+            for k, v in obj._parameters.items():
+                visit(path + ('p', k), v, depth)
+            for k, v in obj._buffers.items():
+                visit(path + ('b', k), v, depth)
+            for k, v in obj._modules.items():
+                visit(path + ('m', k), v, depth)
+            for k, v in obj.__dict__.items():
+                if k[:1] != '_' or k in ('_mi_extra_params',):
+                    visit(path + ('a', k), v, depth + 1)
+            return
+        if isinstance(obj, (list, tuple)):
+            entries.append((path, 'l', len(obj)))
+            for i, v in enumerate(obj[:64]):
+                visit(path + (i,), v, depth + 1)
+            return
+        if isinstance(obj, dict):
+            entries.append((path, 'l', len(obj)))
+            for k, v in list(obj.items())[:64]:
+                if isinstance(k, (str, int, float, bool)):
+                    visit(path + ('k', k), v, depth + 1)
+            return
+        if isinstance(obj, functools.partial):
+            visit(path + ('pf',), obj.func, depth)
+            visit(path + ('pa',), obj.args, depth)
+            visit(path + ('pk',), obj.keywords, depth)
+            return
+        fn = getattr(obj, '__func__', None)
+        if fn is not None:                                   # bound method
+            visit(path + ('f',), fn, depth)
+            visit(path + ('s',), getattr(obj, '__self__', None), depth)
+            return
+        code = getattr(obj, '__code__', None)
+        if code is not None:                                 # a function: closure, defaults, the globals and constants its code mentions
+            entries.append((path, 'c', id(code)))
+            for c in code.co_consts:
+                if isinstance(c, (int, float, bool)):
+                    ids.add(id(c))
+            for i, cell in enumerate(obj.__closure__ or ()):
+                try:
+                    visit(path + ('c', i), cell.cell_contents, depth + 1)
+                except ValueError:
+                    pass
+            for i, v in enumerate(obj.__defaults__ or ()):
+                visit(path + ('d', i), v, depth + 1)
+            for k, v in (obj.__kwdefaults__ or {}).items():
+                visit(path + ('kd', k), v, depth + 1)
+            g = getattr(obj, '__globals__', {})
+            for name in code.co_names:
+                if name in g and not isinstance(g[name], type(torch)):
+                    visit(path + ('g', name), g[name], depth + 1)
+            return
+        call = getattr(type(obj), '__call__', None)
+        if call is not None and hasattr(call, '__code__'):
+            visit(path + ('call',), call, depth)
+        d = getattr(obj, '__dict__', None)
+        if isinstance(d, dict):
+            entries.append((path, 'o', id(type(obj))))
+            for k, v in list(d.items())[:64]:
+                visit(path + ('a', k), v, depth + 1)
+    visit((), func, 0)
+    if len(entries) > _SNAP_MAX:
+        return None, ids
+    return tuple(entries), ids
+
+
+_TRACES = {}
+_TRACES_MAX = 64
+trace_cache_stats = {'hits': 0, 'misses': 0, 'uncacheable': 0}
+
+
+def _cached_trace(func, y0, nb):
+    """(trace, hit) - see the comment above.  The entry keeps the trace (and through it the tensors it refers to) alive."""
+    fn = getattr(func, '__func__', func)
+    code = getattr(fn, '__code__', None) or getattr(getattr(type(func), '__call__', None), '__code__', None)
+    if code is None:
+        return None, False
+    key = (id(code), tuple(y0.shape), y0.dtype, str(y0.device), nb)
+    snap, ids = _snapshot(func)
+    ent = _TRACES.get(key)
+    if ent is not None and snap is not None and ent[0] is code and ent[1] == snap:
+        trace_cache_stats['hits'] += 1
+        return ent[2], True
+    before = fingerprint(func)
+    tr = trace(func, y0, nb=nb)
+    pure = _restore_nfe(func, before, fingerprint(func))
+    if not pure:
+        raise TraceError('the callable changed its own Python state while it was traced: not a pure function of (t, y)')
+    explained = snap is not None and all(id(o) in ids for o in tr._keep)
+    if explained:
+        snap2, _ = _snapshot(func)                           # (taken again: the evaluation itself must not have changed what it names)
+        explained = snap2 == snap
+    if explained:
+        trace_cache_stats['misses'] += 1
+        while len(_TRACES) >= _TRACES_MAX:
+            _TRACES.pop(next(iter(_TRACES)))
+        _TRACES[key] = (code, snap, tr)
+    else:
+        trace_cache_stats['uncacheable'] += 1
+        _TRACES.pop(key, None)
+    return tr, False
 
 
 def lower(func, y0, nb=None, method=None):
     """Trace `func` for a state like y0 and bind this call's constants; raises TraceError with the reason when it cannot be lowered."""
     if isinstance(func, CompiledCallable):
         return func.lowered(y0, method)
-    before = fingerprint(func)
-    try:
-        tr = trace(func, y0, nb=nb)
-    finally:
-        after = fingerprint(func)
-        pure = _restore_nfe(func, before, after)
-    if not pure:
-        changed = sorted(str(k[-1]) for k in set(before) | set(after) if before.get(k) != after.get(k))
-        raise TraceError('the callable changed its own Python state while it was traced (%s): not a pure function of (t, y)' % ', '.join(changed))
+    tr, _hit = _cached_trace(func, y0, nb) if TRACE_CACHE else (None, False)
+    if tr is None:
+        before = fingerprint(func)
+        try:
+            tr = trace(func, y0, nb=nb)
+        finally:
+            after = fingerprint(func)
+            pure = _restore_nfe(func, before, after)
+        if not pure:
+            changed = sorted(str(k[-1]) for k in set(before) | set(after) if before.get(k) != after.get(k))
+            raise TraceError('the callable changed its own Python state while it was traced (%s): not a pure function of (t, y)' % ', '.join(changed))
     rows = _prod(tr.batch_shape)
     classify(tr, generic=method in GENERIC_ONLY_METHODS, rows=rows)        # (the cost guard of generated cooperative code: raises)
     prog = program_for(tr, generic=method in GENERIC_ONLY_METHODS)

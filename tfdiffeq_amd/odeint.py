@@ -50,6 +50,19 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
     device but were recorded with func inside.  A func that synchronises with the host or records autograd is detected and stays eager;
     options={'graph': False} turns the recording off, 'host' restores the loop with the controller on the host.
     """
+    pre = None
+    if _plain_callable_no_grad_state(func, y0):
+        # A plain callable over a state that does not require grad: whether it has TRAINABLE inputs of its own is read off its trace - the
+        # tensors it closes over are exactly the trace's tensor constants - instead of a probe evaluation with autograd on every call.
+        pre = _try_lower(func, y0, method, options)
+        if pre is not None and pre[0] is not None:
+            leaves = tuple(e['t'] for e in pre[0].trace.tensors if isinstance(e['t'], __import__('torch').Tensor) and e['t'].requires_grad)
+            if not leaves:
+                return _run_lowered(pre[0], func, y0, t, rtol, atol, method, options)
+            from .adjoint import odeint_adjoint
+            _warn_once('odeint: `func` is a plain callable over %d grad-requiring tensor(s) - gradients are computed with the adjoint method; '
+                       'they are treated as its parameters' % len(leaves))
+            return odeint_adjoint(_callable_module(func, (), leaves), y0, t, rtol=rtol, atol=atol, method=method, options=options)
     if _wants_grad(func, y0):
         # The reference back-propagates through the solver's eager ops (odeint.py:28-81 under a GradientTape).  The
         # kernels here are not taped: gradients come from the adjoint solve, which integrates the same system.
@@ -74,7 +87,7 @@ def odeint(func, y0, t, rtol=1e-7, atol=1e-9, method=None, options=None):
         mod = _callable_module(func, (), leaves)
         mod._mi_optional_params = tuple(getattr(_graph_leaves, 'named_only', ()))
         return odeint_adjoint(mod, y0, t, rtol=rtol, atol=atol, method=method, options=options)
-    lowered = _try_lower(func, y0, method, options)
+    lowered = pre if pre is not None else _try_lower(func, y0, method, options)
     if lowered is not None:
         low, why = lowered
         if low is not None:
@@ -349,6 +362,14 @@ def _wants_grad(func, y0):
     # a plain callable over trainable state (`lambda t, y: net(y)`): the reference's tape would reach net's parameters.  Whether THIS
     # callable does is a property of its autograd graph (one cached probe evaluation), not of what its closure could name.
     return False if _probe_unsafe(y0) else bool(_graph_leaves_or_none(func, y0))
+
+
+def _plain_callable_no_grad_state(func, y0):
+    import torch
+    if not torch.is_grad_enabled() or not callable(func) or getattr(func, 'kind', 0) or isinstance(func, torch.nn.Module):
+        return False
+    ys = y0 if isinstance(y0, (tuple, list)) else (y0,)
+    return all(isinstance(y, torch.Tensor) and not y.requires_grad for y in ys)
 
 
 def _probe_unsafe(y0):
