@@ -45,6 +45,7 @@ namespace mi {
 
 constexpr int kPersistTSmall = 8;      // output times that travel as kernel arguments
 constexpr int kPersistTout = 1024;     // output times cached in LDS
+constexpr int kEmitShareRows = 8;      // up to this many trajectories: the lanes of wavefront 0 share the dense output of a step
 
 struct PersistArgs {
   StepArgs s;                  // tableau, RHS, controller parameters; out = solution[1:], t_out = t[1:] (device);
@@ -566,7 +567,39 @@ __global__ __launch_bounds__(256) void k_persist_rowlocal(PersistArgs A) {
     MI_TOCK(0, tk0, tk1); MI_TOCK(1, tk1, tk2); MI_TOCK(2, tk2, tk3);
     __syncthreads();
     if (sh.pub.accepted) {
-      if (live && sh.pub.emit_hi > sh.pub.emit_lo) {
+      // A handful of trajectories with MANY output times per step (the reference's published workloads: one trajectory, 1000 - 10 000
+      // outputs): the owner lane would evaluate the interpolant once per output, one after the other (~0.4 us each: a dependent chain of
+      // fp64 instructions on one lane).  Here the quartic's coefficients are formed by the owner lane as always and BROADCAST; the 64
+      // lanes of wavefront 0 then take one output time each.  Same operations per output, same bits.  (round 6)
+      bool emitted = false;
+      if constexpr (!TS && !rhs_is_coop<RHS>::value) {
+        if (nseg <= 1 && A.s.batch <= kEmitShareRows && sh.pub.emit_hi - sh.pub.emit_lo >= 4) {
+          emitted = true;
+          if (blockIdx.x == 0 && threadIdx.x < 64) {
+            const int j_lo = sh.pub.emit_lo, j_hi = sh.pub.emit_hi;
+            const double e_t0 = sh.pub.emit_t0, e_t1 = sh.pub.emit_t1;
+            T* const out = (T*)A.s.out;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+              T kk[S + 1];
+#pragma unroll
+              for (int j = 0; j <= S; ++j) kk[j] = k[j][d];
+              T err_unused, ymid = y.v[d];
+              step_finish<T, S>(y.v[d], kk, hs, A.s, err_unused, ymid, true);
+              T co[5];
+              quartic_from_mid<T>(y.v[d], ys[d], ymid, kk[0], kk[S], (T)sh.pub.emit_dt, co);
+              for (int r_ = 0; r_ < (int)A.s.batch; ++r_) {   // rows 0 .. batch - 1 are lanes 0 .. batch - 1 of this wavefront
+                T cb[5];
+#pragma unroll
+                for (int i = 0; i < 5; ++i) cb[i] = __shfl(co[i], r_);
+                for (int j = j_lo + (int)threadIdx.x; j < j_hi; j += 64)
+                  out[(long long)j * A.s.n_plane + (long long)r_ * D + d] = quartic_eval<T>(cb, interp_x<T>(e_t0, e_t1, t_out[j]));
+              }
+            }
+          }
+        }
+      }
+      if (!emitted && live && sh.pub.emit_hi > sh.pub.emit_lo) {
         StepPlanes<T, S> P;
         P.j_lo = sh.pub.emit_lo; P.j_hi = sh.pub.emit_hi;
         P.t_start = sh.pub.emit_t0; P.t_new = sh.pub.emit_t1; P.dt64 = sh.pub.emit_dt;
