@@ -7,7 +7,8 @@
 //      attempt captured as a hipGraph and replayed in blind chunks
 //   9. (ABI 12) mi_ode_outer_reduce vs a host loop
 //  10. (ABI 13) mi_ode_linadj_segment: a backward interval of the linear system's adjoint in one launch vs a fine RK4 solve written here
-//  11. (round 5) a float64 MLP on the cooperative kernels (registers / planes / fixed grid) vs a fine RK4 solve of the network written here
+//  11. (round 5) a float64 MLP through the plain engine entry points vs a fine RK4 solve of the network written here (round 5: the cooperative
+//      kernels; since round 6 a network of this size runs on the float64 MFMA tile kernels, csrc/mi_ode_mlp64.h - same calls, same bars)
 // Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -I include tests/c_abi/c_abi_smoke.cpp -L tfdiffeq_amd -lmi_ode
 #include <hip/hip_runtime.h>
 #include <math.h>
@@ -562,9 +563,9 @@ int main() {
     MI(mi_ode_linadj_destroy(lh));
     CK(hipFree(dW)); CK(hipFree(db)); CK(hipFree(dy)); CK(hipFree(da)); CK(hipFree(dat)); CK(hipFree(dth)); CK(hipFree(oa)); CK(hipFree(oat)); CK(hipFree(oth));
   }
-  // ---- 11. (round 5) MI_ODE_RHS_MLP_TANH outside the tile kernels' box - float64, 6 -> 24 -> 24 -> 6, tanh - through the plain engine entry
-  //          points: the cooperative kernel (a thread per state element), one launch per call, at two batch sizes (state in registers /
-  //          streamed through HBM planes) and on a fixed grid (rk4), against a fine RK4 solve of the same network written here ----
+  // ---- 11. MI_ODE_RHS_MLP_TANH in float64, 6 -> 24 -> 24 -> 6, tanh, through the plain engine entry points: one launch per call at two
+  //          batch sizes and on a fixed grid (rk4), against a fine RK4 solve of the same network written here.  (Round 5: the cooperative
+  //          kernel, a thread per state element; round 6: the float64 MFMA tile kernels k_persist_mlp64 / k_fixed_mlp64 take this size.) ----
   {
     const int MD = 6, MH = 24;
     std::vector<double> W1((size_t)MD * MH), W2((size_t)MH * MH), W3((size_t)MH * MD), b1(MH), b2(MH), b3(MD);
@@ -609,7 +610,7 @@ int main() {
         int mb;
         if (fixed) mb = mi_ode_fixed_grid_integrate_on(mh, dmy, tg.data(), 41, tm, 3, 0.0, dmo, &ms, nullptr);
         else mb = mi_ode_integrate(mh, dmy, tm, 3, dmo, &ms, nullptr);
-        if (mb != 0) { printf("FAIL cooperative MLP (batch %lld, fixed %d): %d %s\n", MB, fixed, mb, mi_ode_last_error()); return 1; }
+        if (mb != 0) { printf("FAIL float64 MLP (batch %lld, fixed %d): %d %s\n", MB, fixed, mb, mi_ode_last_error()); return 1; }
         CK(hipDeviceSynchronize());
         CK(hipMemcpy(mout.data(), dmo, mout.size() * 8, hipMemcpyDeviceToHost));
         double mdm = 0.0;
@@ -631,9 +632,9 @@ int main() {
           }
           for (int c = 0; c < MD; ++c) mdm = fmax(mdm, fabs(mout[(size_t)2 * MB * MD + (size_t)r * MD + c] - y[c]));
         }
-        printf("cooperative MLP 6-24-24-6 fp64, batch %lld, %s: launches %d attempts %lld, max |gpu - fine rk4| = %.3e\n", MB,
+        printf("float64 MLP 6-24-24-6 (MFMA tile kernels), batch %lld, %s: launches %d attempts %lld, max |gpu - fine rk4| = %.3e\n", MB,
                fixed ? "rk4 on a 40-step grid" : "dopri5", (int)ms.n_launches, (long long)ms.n_attempts, mdm);
-        if (ms.n_launches != 1 || !(mdm < (fixed ? 1e-6 : 1e-8))) { printf("FAIL cooperative MLP\n"); return 1; }
+        if (ms.n_launches != 1 || !(mdm < (fixed ? 1e-6 : 1e-8))) { printf("FAIL float64 MLP\n"); return 1; }
         MI(mi_ode_destroy(mh));
       }
       CK(hipFree(dmy)); CK(hipFree(dmo));

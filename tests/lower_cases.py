@@ -274,6 +274,10 @@ def generated_sources(device='cpu'):
     for name, make in CASES.items():
         f, y0, _kind = make(device)
         out.extend(lower.sources_for(f, y0))
+    g = lambda t, y: (torch.cos(t) * y[0] - y[0] ** 3, torch.cos(t) * y[1] - y[1] ** 3)     # noqa: E731  (tests/test_gpu_lower.py: tuple states)
+    out.extend(lower.sources_for(g, (torch.zeros(40, 2, dtype=torch.float64, device=device), torch.zeros(7, 2, dtype=torch.float64, device=device))))
+    c = ConstantODE(device)
+    out.extend(lower.sources_for(lambda t, y: (c(t, y[0]), c(t, y[1])), (torch.tensor(3.2, dtype=torch.float64, device=device),) * 2))
     from golden_util import load
     for name in fixture_names():
         d, meta = load(name)

@@ -296,3 +296,37 @@ def test_plain_callable_over_trainable_tensors_is_differentiated_without_a_probe
         p.requires_grad_(False)
     out = odeint(f, y0, t, rtol=1e-8, atol=1e-10)
     assert not out.requires_grad and odeint.last_stats['lower']['lowered'] and odeint.last_stats['n_launches'] == 1
+
+
+def test_tuple_states_of_the_reference_api_tests():
+    """tests/api_tests.py:26-34: `tuple_f = lambda t, y: (f(t, y[0]), f(t, y[1]))`, `tuple_y0 = (y0, y0)` - a tuple state whose components
+    follow the same function is traced per component and integrated in ONE launch with one error ratio per component (rhs.PerComponent);
+    the reference-generated tuple fixture: its attempt / accept counts exactly.  Components that interact keep their Python loop."""
+    from tfdiffeq_amd import odeint
+    d, meta = load('run_constant_dopri5_tuple')
+    f = LC.ConstantODE(dev())
+    tuple_f = lambda t, y: (f(t, y[0]), f(t, y[1]))         # noqa: E731
+    y0 = (torch.tensor(d['y0_0'], device=dev()), torch.tensor(d['y0_1'], device=dev()))
+    sol = odeint(tuple_f, y0, torch.as_tensor(d['t']), method='dopri5')
+    st = dict(odeint.last_stats)
+    assert isinstance(sol, tuple) and len(sol) == 2 and st['lower']['lowered'] and st['lower']['components'] == 2 and st['n_launches'] == 1, st
+    assert (st['n_attempts'], st['n_accepted']) == (len(d['trace']), int(d['trace'][:, 2].sum()))
+    for k in range(2):
+        ref = torch.tensor(d['y_%d' % k])
+        assert tuple(sol[k].shape) == tuple(ref.shape) and bool(((sol[k].cpu() - ref).abs() <= ATOL + RTOL * ref.abs()).all())
+    # components of different batch shapes, a time-dependent factor shared by both
+    g = lambda t, y: (torch.cos(t) * y[0] - y[0] ** 3, torch.cos(t) * y[1] - y[1] ** 3)     # noqa: E731
+    ya = torch.randn(40, 2, dtype=torch.float64, device=dev(), generator=None)
+    yb = torch.randn(7, 2, dtype=torch.float64, device=dev())
+    tt = torch.tensor([0., 0.5, 1.5])
+    sol = odeint(g, (ya, yb), tt, method='dopri5')
+    st = dict(odeint.last_stats)
+    ref = odeint(g, (ya, yb), tt, method='dopri5', options={'lower': False})
+    rst = dict(odeint.last_stats)
+    assert st['lower']['lowered'] and st['n_launches'] == 1 and (st['n_attempts'], st['n_accepted']) == (rst['n_attempts'], rst['n_accepted'])
+    assert all(float((a - b).abs().max()) < 1e-10 for a, b in zip(sol, ref))
+    # interacting components: not one function per component - the callable engine, and the stats say why
+    h = lambda t, y: (y[1], -y[0])                          # noqa: E731
+    sol = odeint(h, (ya, ya.clone()), tt, method='dopri5')
+    assert 'interact' in odeint.last_stats['lower']['why']
+    np.testing.assert_allclose(sol[0][-1].cpu().numpy(), (ya * np.cos(1.5) + ya * np.sin(1.5)).cpu().numpy(), rtol=1e-5, atol=1e-6)

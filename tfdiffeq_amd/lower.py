@@ -75,7 +75,10 @@ class Trace(object):
         self.tensors = []             # dicts: t (the tensor), lead (leading axes dropped at index 0), shape (what the graph sees)
         self._ids = {}
         self._keep = []               # every constant object seen (ids must not be recycled while the trace lives)
+        self._par_obj = []            # the object behind scalar i
         self.out = None
+        self.time_trace = None        # tuple states: the trace that holds expressions of t alone (imported on use)
+        self._imported = {}
 
     def node(self, op, args, attr, shape, batched, is_bool=False, akey=None):
         akey = attr if akey is None else akey
@@ -104,8 +107,32 @@ class Trace(object):
         v = float(obj)
         n = self.node('par', (), len(self.scalars), (), False)
         self.scalars.append(v)
+        self._par_obj.append(obj)
         self._ids[('s', id(obj))] = n
         return n
+
+    def import_node(self, n, src):
+        """A node of the time trace `src` (expressions of t and constants only) re-created here."""
+        hit = self._imported.get(n.id)
+        if hit is not None:
+            return hit
+        if n.op == 't':
+            out = self.node('t', (), None, (), False)
+        elif n.op == 'lit':
+            out = self.lit(n.attr)
+        elif n.op == 'litf':
+            out = self.litf(n.attr)
+        elif n.op == 'par':
+            out = self.par(src._par_obj[n.attr])
+        elif n.op == 'ten':
+            e = src.tensors[n.attr]
+            out = self._tensor_entry(e['t'], e['lead'], e['shape'], n.batched)
+        elif n.op == 'y':
+            raise TraceError('a value of another component of the state')
+        else:
+            out = self.node(n.op, [self.import_node(a, src) for a in n.args], n.attr, n.shape, n.batched, n.is_bool, n.akey)
+        self._imported[n.id] = out
+        return out
 
     def tensor(self, x, mode='ew'):
         """A real tensor the callable closed over.  mode 'ew': operand of an elementwise operation (leading axes that ARE the batch axes
@@ -143,7 +170,9 @@ class Trace(object):
     def lift(self, x, mode='ew'):
         if isinstance(x, Sym):
             if x.tr is not self:
-                raise TraceError('a value of another trace')
+                if x.tr is self.time_trace and self.time_trace is not None:
+                    return self.import_node(x.node, x.tr)
+                raise TraceError('the components of a tuple state interact (a value of another component)')
             return x.node
         if isinstance(x, (bool, np.bool_)):
             return self.lit(int(x))
@@ -349,13 +378,19 @@ _install_operators()
 
 def _trace_of(args):
     todo = list(args)
+    found = None
     while todo:
         a = todo.pop()
         if isinstance(a, Sym):
-            return a.tr
-        if isinstance(a, (list, tuple)):
+            if a.tr.time_trace is not None or found is None:     # (a component's trace wins over the time trace of a tuple state)
+                found = a.tr
+                if a.tr.time_trace is not None:
+                    return found
+        elif isinstance(a, (list, tuple)):
             todo.extend(a)
-    raise TraceError('no traced operand')
+    if found is None:
+        raise TraceError('no traced operand')
+    return found
 
 
 def _ew(tr, fn, vals, attr=None, out_bool=False):
@@ -777,6 +812,36 @@ def _dispatch(name, args, kw):
 # ---------------------------------------------------------------------------------------------
 # tracing a callable
 # ---------------------------------------------------------------------------------------------
+def _finish(tr, out, shape):
+    """The callable's result for one state tensor -> tr.out (expanded to the state's shape where it is f(t) only or broadcastable)."""
+    if not isinstance(out, Sym):
+        if isinstance(out, torch.Tensor):
+            raise TraceError('the result does not depend on t or y through traced operations')
+        raise TraceError('the callable returned %s' % type(out).__name__)
+    node = tr.lift(out)                                      # (tuple states: an expression of t alone lives in the time trace)
+    if node.is_bool:
+        raise TraceError('boolean result')
+    if not node.batched or node.shape != tr.tail:             # f(t) only, or a broadcastable result: expand to the state's shape
+        if node.batched and node.rank != len(tr.tail):
+            raise TraceError('result of shape %s for a state of shape %s' % (list(out.shape), list(shape)))
+        tail = tr.tail
+
+        def fit(a):
+            while a.ndim > len(tail) and a.shape[0] == 1:
+                a = a[0]
+            return np.broadcast_to(a, tail)
+        try:
+            fitted = _move(tr, node, fit)
+        except TraceError:
+            raise TraceError('result of shape %s for a state of shape %s' % (list(out.shape), list(shape)))
+        node = fitted
+        if not node.batched:
+            node = tr.node('gather', (node,), (None, np.arange(node.size, dtype=np.int64).reshape(node.shape)), node.shape, True,
+                           akey=('gb', node.shape))
+    tr.out = node
+    return tr
+
+
 def trace(func, y0, nb=None, t_dtype=None):
     """Evaluate `func(t, y)` on proxies.  y0: the state tensor (only shape, dtype and device are used).  nb: number of leading batch axes
     (default: all but the last; on "indexes / operates on a batch axis" fewer are tried, down to none - the whole tensor as ONE system -
@@ -794,38 +859,60 @@ def trace(func, y0, nb=None, t_dtype=None):
             out = func(t, y)
             if isinstance(out, (tuple, list)) and len(out) == 1:
                 out = out[0]
-            if not isinstance(out, Sym):
-                if isinstance(out, torch.Tensor):
-                    raise TraceError('the result does not depend on t or y through traced operations')
-                raise TraceError('the callable returned %s' % type(out).__name__)
-            node = out.node
-            if node.is_bool:
-                raise TraceError('boolean result')
-            if not node.batched or node.shape != tr.tail:             # f(t) only, or a broadcastable result: expand to the state's shape
-                if node.batched and node.rank != len(tr.tail):
-                    raise TraceError('result of shape %s for a state of shape %s' % (list(out.shape), list(shape)))
-                tail = tr.tail
-
-                def fit(a):
-                    while a.ndim > len(tail) and a.shape[0] == 1:
-                        a = a[0]
-                    return np.broadcast_to(a, tail)
-                try:
-                    fitted = _move(tr, node, fit)
-                except TraceError:
-                    raise TraceError('result of shape %s for a state of shape %s' % (list(out.shape), list(shape)))
-                node = fitted
-                if not node.batched:
-                    node = tr.node('gather', (node,), (None, np.arange(node.size, dtype=np.int64).reshape(node.shape)), node.shape, True,
-                                   akey=('gb', node.shape))
-            tr.out = node
-            return tr
+            return _finish(tr, out, shape)
         except TraceError as e:
             last = e
             if 'batch axis' not in str(e) and 'batch axes' not in str(e):
                 raise
     if last is None:
         raise TraceError('state of %d elements per trajectory (the generated kernels take up to %d)' % (_prod(shape[-1:]), MAX_COOP_DIM))
+    raise last
+
+
+def trace_tuple(func, y0s):
+    """A TUPLE state (the reference's tests/api_tests.py:29-34: `tuple_f = lambda t, y: (f(t, y[0]), f(t, y[1]))`): every component gets
+    a trace of its own, expressions of t alone live in a shared time trace and are imported on use; components must not interact.  Returns
+    the list of traces if they are the SAME function of their component (equal structure, equal constants) - what rhs.PerComponent
+    integrates in one launch with one error ratio per component - and raises TraceError otherwise."""
+    K = len(y0s)
+    shapes = [tuple(int(s) for s in y.shape) for y in y0s]
+    ranks = {len(s) for s in shapes}
+    if len(ranks) != 1 or len({y.dtype for y in y0s}) != 1:
+        raise TraceError('tuple components of different rank / dtype')
+    rank = ranks.pop()
+    last = None
+    for nb in range(max(rank - 1, 0), -1, -1):
+        if any(_prod(s[nb:]) > MAX_ROW_DIM for s in shapes):
+            break
+        tt = Trace((), 0, y0s[0].dtype, y0s[0].device)
+        t = Sym(tt, tt.node('t', (), None, (), False))
+        trs = []
+        for s in shapes:
+            tr = Trace(s, nb, y0s[0].dtype, y0s[0].device)
+            tr.time_trace = tt
+            trs.append(tr)
+        ys = tuple(Sym(tr, tr.node('y', (), 0, tr.tail, True)) for tr in trs)
+        try:
+            out = func(t, ys)
+            if not isinstance(out, (tuple, list)) or len(out) != K:
+                raise TraceError('the callable returned %s for a state of %d components' % (type(out).__name__, K))
+            for tr, o, s in zip(trs, out, shapes):
+                if isinstance(o, Sym) and o.tr is not tr and o.tr is not tt:
+                    raise TraceError('the components of a tuple state interact (component result computed from another component)')
+                _finish(tr, o, s)
+            k0 = trs[0].key()
+            for tr in trs[1:]:
+                same = tr.key() == k0 and tr.scalars == trs[0].scalars and len(tr.tensors) == len(trs[0].tensors) and \
+                    all(a['t'] is b['t'] and a['lead'] == b['lead'] for a, b in zip(tr.tensors, trs[0].tensors))
+                if not same:
+                    raise TraceError('the components of the tuple state follow different functions (one kernel integrates ONE function per component)')
+            return trs
+        except TraceError as e:
+            last = e
+            if 'batch axis' not in str(e) and 'batch axes' not in str(e):
+                raise
+    if last is None:
+        raise TraceError('tuple components of more than %d elements per trajectory' % MAX_ROW_DIM)
     raise last
 
 
@@ -1781,6 +1868,7 @@ class Lowered(object):
         self.state_shape = tr.batch_shape + (prog.dim,)
         self.full_shape = tr.full_shape
         self.py_calls = 0
+        self.per_component = False
         full, state = tr.full_shape, self.state_shape
 
         def torch_fn(t, y, _f=func):
@@ -2010,8 +2098,41 @@ def compile(func, y0, nb=None):                  # noqa: A001  (the name users e
     return CompiledCallable(func, y0, nb=nb)
 
 
+def lower_tuple(func, y0s, method=None):
+    """`lower` for a tuple state of K >= 2 components that all follow the same trajectory-local function: a `Lowered` whose `rhs` is the
+    generated right-hand side of ONE component (to be lifted with rhs.PerComponent) and whose `state_shapes` reshape every component."""
+    before = fingerprint(func)
+    try:
+        trs = trace_tuple(func, list(y0s))
+    finally:
+        pure = _restore_nfe(func, before, fingerprint(func))
+    if not pure:
+        raise TraceError('the callable changed its own Python state while it was traced: not a pure function of (t, y)')
+    tr = trs[0]
+    generic = True                                           # (PerComponent integrates row-local right-hand sides: generated code only)
+    classify(tr, generic=generic, rows=max(_prod(t_.batch_shape) for t_ in trs))
+    prog = program_for(tr, generic=generic)
+    if prog.kind != 'rowlocal':
+        raise TraceError('tuple states run in one launch for trajectory-local systems of up to %d elements per component' % MAX_ROW_DIM)
+    rhs = prog.bind(tr, y0s[0].device)
+    K = len(trs)
+
+    def one_component(t_, yk, _f=func):                      # the same function of ONE component (verified above), for the callable paths
+        return _f(t_, (yk,) * K)[0]
+    low = Lowered(prog, rhs, tr, one_component)
+    low.per_component = True
+    low.state_shapes = [t_.batch_shape + (prog.dim,) for t_ in trs]
+    low.full_shapes = [t_.full_shape for t_ in trs]
+    rhs.forward = low.torch_fn
+    return low
+
+
 def sources_for(func, y0, nb=None, method=None):
     """The generated source(s) a call with this callable and state would compile (build-time prebuilding; [] for catalogue routes)."""
-    tr = trace(func, y0, nb=nb)
-    prog = program_for(tr, generic=method in GENERIC_ONLY_METHODS)
+    if isinstance(y0, (tuple, list)):
+        tr = trace_tuple(func, list(y0))[0]
+        prog = program_for(tr, generic=True)
+    else:
+        tr = trace(func, y0, nb=nb)
+        prog = program_for(tr, generic=method in GENERIC_ONLY_METHODS)
     return [prog.source] if prog.source is not None else []
