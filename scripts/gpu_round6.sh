@@ -6,7 +6,7 @@ O=$R/gpurun_out/r06
 mkdir -p $O
 cd $R
 want() { [[ " $ARGS " == *" $1 "* ]]; }
-ARGS="${*:-tests bench published mlp64 prof}"
+ARGS="${*:-tests bench published mlp64 prof adjoint}"
 if want tests; then
   timeout 1500 python -m pytest tests -q -m gpu -rfs 2>&1 | tail -25 > $O/r06_pytest_gpu_summary.txt
   timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | grep -v Warn | tail -2 >> $O/r06_pytest_gpu_summary.txt
@@ -50,4 +50,20 @@ for k, d in acc.items():
 PY
   cat $O/r06_mlp_f64_sq_pmc.txt 2>/dev/null
   rm -rf $O/prof_mlp64 $O/pmc_mlp64
+fi
+if want adjoint; then
+  # the fused MLP adjoint (k_adjoint_mlp) and config 5's forward kernel again (the review of round 5: no profile of the adjoint kernel since round 4)
+  for td in 0; do
+    D=$O/prof_adj$td; rm -rf $D
+    (cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R && ADJ_TD=$td timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $D -o r -- python $R/scripts/adjoint_train_step.py fused 10 > $O/r06_adjoint_td${td}_train_step.txt 2>&1)
+    f=$(find $D -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f" > $O/r06_adjoint_td${td}_kernel_stats.csv
+    grep ms_per $O/r06_adjoint_td${td}_train_step.txt | cut -c1-250
+    rm -rf $D
+  done
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c5 -o r -- python $R/bench.py --config 5 --steps 200 --warmup 5 --no-cpu-baseline > $O/prof_c5.log 2>&1)
+  f=$(find $O/prof_c5 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -6 "$f" > $O/r06_c5_kernel_stats.csv && head -3 $O/r06_c5_kernel_stats.csv | cut -c1-200
+  rm -rf $O/prof_c5
+  (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -o r -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline > $O/prof_c4.log 2>&1)
+  f=$(find $O/prof_c4 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -6 "$f" > $O/r06_whole_kernel_stats.csv && head -3 $O/r06_whole_kernel_stats.csv | cut -c1-200
+  rm -rf $O/prof_c4
 fi
