@@ -517,6 +517,13 @@ def test_plan_names_the_engine_of_the_five_baseline_configurations():
     assert p['engine'] == 'callable' and p['lower'] == {'lowered': False, 'why': 'operation `cumsum` is outside the op set'}
     p = odeint.plan(rhs.Lorenz(), torch.ones(8, 3, dtype=f64), method='midpoint')
     assert p['engine'] == 'plane kernels' and 'midpoint has no fused kernel' in p['why']
+    A256 = torch.eye(256, dtype=f64)
+    p = odeint.plan(rhs.Linear(A256), torch.ones(65536, 256, dtype=f64), method='dopri5')              # round 6: W streamed, 256-wide tiles
+    assert p['kernel'].startswith('k_persist_linear_mfma<double, 256, 6>') and 'streamed' in p['why']
+    p = odeint.plan(rhs.Linear(A256[:200, :200].contiguous()), torch.ones(8, 200, dtype=f32), method='bosh3')
+    assert p['kernel'].startswith('k_persist_linear_mfma<float, 256, 3>')
+    assert odeint.plan(rhs.Linear(A256), torch.ones(8, 256, dtype=f64), method='dopri5', options={'fusion': 'stage'})['kernel'] == 'k_stage_linear_valu'
+    assert odeint.plan(rhs.Linear(A256), torch.ones(8, 256, dtype=f64), method='rk4')['kernel'].startswith('k_fixed_linear_mfma')
     p = odeint.plan(rhs.Linear(A), torch.ones(64, 128, dtype=f64), method='adaptive_heun')
     assert p['engine'] == 'callable' and '1-row tableau' in p['why']
     p = odeint.plan(lambda t, y: y @ A, torch.ones(64, 128, dtype=f64), method='adaptive_heun', options=AUTO)       # lowered: generated cooperative code

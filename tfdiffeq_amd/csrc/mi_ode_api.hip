@@ -283,8 +283,14 @@ static void fill_stats(mi_ode_solver* h, mi_ode_stats* s) {
 static int pick_family(mi_ode_solver* h) {
   const mi_ode_rhs& r = h->d.rhs;
   const int D = (int)h->d.dim;
-  const bool mfma_dim = D >= 3 && D <= 128;                // any dim up to 128: zero padded to the next tile width (16, 32, 64, 128)
-  h->lin_dp = D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : 128));
+  // any dim up to 128: zero padded to the next tile width (16, 32, 64, 128), W resident in registers.  129 .. 256 (round 6): the
+  // 256-wide tile kernels with W streamed from L2 - the whole-attempt / whole-call kernels of the three- and six-row FSAL tableaus
+  // and the fixed-grid kernel (their per-stage schedule and every other tableau stay with the vector-ALU family).
+  const mi_ode_tableau& tbp = h->d.tableau;
+  const bool wide_ok = D > 128 && D <= 256 && h->d.multistep == 0 && h->d.fusion != 1 &&
+                       (h->d.adaptive ? (tbp.fsal && (tbp.n_stages == 3 || tbp.n_stages == 6)) : (tbp.n_stages == 0 || tbp.n_stages == 3));
+  const bool mfma_dim = (D >= 3 && D <= 128) || wide_ok;
+  h->lin_dp = D <= 16 ? 16 : (D <= 32 ? 32 : (D <= 64 ? 64 : (D <= 128 ? 128 : 256)));
   h->rhs.cube = 0;
   switch (r.kind) {
     case MI_ODE_RHS_LOTKA_VOLTERRA:
@@ -303,7 +309,7 @@ static int pick_family(mi_ode_solver* h) {
       }
       h->rhs.cube = cube ? 1 : 0;
       if (!cube && mfma_dim && h->d.linear_variant != 1) { h->family = FAM_LINEAR_MFMA; return 0; }
-      if (h->d.linear_variant == 2) { mi_set_error("MFMA linear kernel needs 3 <= dim <= 128 and no cube"); return MI_ODE_E_INVALID; }
+      if (h->d.linear_variant == 2) { mi_set_error("MFMA linear kernel needs 3 <= dim <= 128 (<= 256 for dopri5 / tsit5 / bosh3 / the fixed grid) and no cube"); return MI_ODE_E_INVALID; }
       if (D > 256) { mi_set_error("fused linear RHS supports dim <= 256 (got %d)", D); return MI_ODE_E_INVALID; }
       h->family = FAM_LINEAR_VALU; return 0;
     }
@@ -442,6 +448,7 @@ extern "C" int mi_ode_destroy(mi_ode_handle h) {
   if (h->partials) (void)hipFree(h->partials);
   if (h->adams_tab) (void)hipFree(h->adams_tab);
   if (h->mlp_pack) (void)hipFree(h->mlp_pack);
+  if (h->lin_pack) (void)hipFree(h->lin_pack);
   if (h->adams_res) (void)hipHostFree(h->adams_res);
   if (h->rank_rec && h->own_exchange) (void)hipFree(h->rank_rec);
   if (h->gathered && h->own_exchange) (void)hipFree(h->gathered);
@@ -497,6 +504,13 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
   h->rhs.hidden = desc->rhs.hidden;
   int rc = pick_family(h);
   if (rc != 0) { mi_ode_destroy(h); return rc; }
+  if (h->family == FAM_LINEAR_MFMA && h->lin_dp == 256) {   // streamed W: the copy in consumption order (256 x 256 elements, refreshed before every launch)
+    if (hipMalloc(&h->lin_pack, (size_t)256 * 256 * (size_t)h->elt) != hipSuccess) {
+      (void)hipGetLastError();
+      mi_set_error("linear tile kernels (dim > 128): cannot allocate the copy of W");
+      mi_ode_destroy(h); return MI_ODE_E_HIP;
+    }
+  }
   if (h->family == FAM_MLP && !h->is_f32) {          // float64 tile kernels: the packed copy of the weights (refreshed before every launch)
     const int nd = mi_mlp64_pack_doubles(h->mlp_dp, h->mlp_hp);
     if (nd <= 0 || hipMalloc((void**)&h->mlp_pack, (size_t)nd * sizeof(double)) != hipSuccess) {

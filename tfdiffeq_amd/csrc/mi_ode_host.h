@@ -18,7 +18,7 @@ enum Family {
   FAM_LV,            // rowlocal, dim 2
   FAM_LORENZ,        // rowlocal, dim 3
   FAM_LINEAR_VALU,   // any dim <= 256, optional cube / bias
-  FAM_LINEAR_MFMA,   // dim in {16, 32, 64, 128}
+  FAM_LINEAR_MFMA,   // 3 <= dim <= 256 (tile widths 16, 32, 64, 128 with W resident in registers; 256 with W streamed from L2)
   FAM_MLP,           // fp32 dim<=64, hidden<=128: whole-attempt MFMA kernel only
   FAM_PLUGIN,        // row-local user code behind a mi_ode_rowlocal_plugin table (mi_ode_plugin.h)
   FAM_MLP_COOP,      // the ODEFunc network outside the tile kernels' box on the cooperative kernels (a thread per state element): the
@@ -95,7 +95,8 @@ struct mi_ode_solver {
   double* adams_tab;          // device: the multistep coefficient tables of the descriptor (mi_ode_adams.h), or null
   long long* adams_res;       // pinned host: {steps whose corrector did not converge, status}; multistep = 3: {attempts, accepted, nfe, status}
   double adams_gamma_star[13]; // multistep = 3 (adams.py:15-18)
-  int lin_dp;                 // FAM_LINEAR_MFMA: tile width the kernels are instantiated for (16 / 32 / 64 / 128 >= dim, zero padded)
+  int lin_dp;                 // FAM_LINEAR_MFMA: tile width the kernels are instantiated for (16 / 32 / 64 / 128 / 256 >= dim, zero padded)
+  void* lin_pack;             // lin_dp = 256 (W streamed, mi_ode_step_fused.h LinCtx::STREAM): the copy of W in consumption order, refreshed before every launch
   // bookkeeping
   long long n_launches;
   int n_polls;

@@ -359,6 +359,19 @@ __device__ __forceinline__ void lds_barrier() {
 }
 
 // Per-thread context of the 16-row-tile linear kernels: the wavefront's W slice (resident in VGPRs), bias, LDS tile.
+//
+// D = 256 (round 6, dims 129 .. 256): sixteen wavefronts, four per SIMD, 128 registers each - a wavefront's slice of W (64 values
+// per lane, 128 registers in float64) cannot stay resident next to the stage derivatives of the tile.  STREAM: the slice is read
+// again for every evaluation, from a copy of W in the order the lanes consume it (k_lin_pack below: chunk m of wavefront w is 64
+// consecutive 16-byte pieces, one per lane - every wave instruction reads 1 KB of consecutive addresses), two chunks ahead of the
+// MFMAs that consume them; the last group of an evaluation loads the FIRST two chunks again - W does not depend on the tile, so the
+// next evaluation's chain starts on operands that arrived long ago.  The register budget (128) has no room for the resident
+// kernels' prefetch of the next tile's y0 / f0 nor for the pre-read combination coefficients: both are read where they are used
+// (PF below).  The copy is dim-independent
+// (zero padded to 256 x 256: 512 KB in float64) and stays in every XCD's L2; what the schedule needs from L2 is one 16-byte piece per
+// lane for every two float64 (four float32) MFMAs: 32 B per clock and CU with the matrix pipe saturated.  Everything else - the
+// accumulator-layout ownership of the stage derivatives, the two alternating LDS tiles, one barrier per evaluation, the k-permutation
+// (lane group g covers k in [g KS, (g + 1) KS)) and hence the summation order of every product - is the resident kernels'.
 template <typename T, int D>
 struct LinCtx {
   using TR = MfmaTraits<T>;
@@ -369,11 +382,16 @@ struct LinCtx {
   static constexpr int KS = D / 4;
   static constexpr int TILE = R_ * LD;                       // one stage tile; the kernels allocate kBufs of them
   static constexpr int kBufs = 2;
+  static constexpr bool STREAM = D > 128;                    // W slice streamed per evaluation instead of resident
+  static constexpr int NCH = KS / VEC;                       // 16-byte chunks of the slice per lane
+  static constexpr bool PF = !STREAM;                        // the passes prefetch the next tile / the next combination's coefficients
   using CH = Chunk<T, VEC>;
   int lane, wave, li, lg, col;
   int d;                                                     // the state's true row length, d <= D: the tile kernels are instantiated
   bool colok;                                                // for D in {16, 32, 64, 128} and run any smaller dim zero padded (columns >= d
-  T bf[KS];                                                  // are never loaded or stored; W rows / columns >= d are zero, so the padding
+  T bf[STREAM ? 1 : KS];                                     // are never loaded or stored; W rows / columns >= d are zero, so the padding
+  const CH* wp;                                              // STREAM: this lane's first chunk of the packed copy (chunk m at wp[64 m])
+  CH r0, r1;                                                 // STREAM: the two chunks the next MFMA group consumes (in flight or landed)
   T bias_v, sign;                                            // contributes exact zeros to every product, sum and norm)
   bool has_bias;
   bool plain;                                                // no bias, forward time: k is the accumulator as it is (the bias add and
@@ -390,11 +408,28 @@ struct LinCtx {
 #endif
 
   __device__ __forceinline__ void init(const RhsParams& rhs, T* lds, int dim) {
-    init_matrix((const T*)rhs.w[0], (const T*)rhs.b[0], rhs.sign, false, lds, dim);
+    if constexpr (STREAM) {                                  // (the launcher put the packed copy into rhs.w[0]: mi_lin_pack)
+      const int tid = threadIdx.x;
+      lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
+      col = 16 * wave + li;
+      d = dim; colok = col < dim;
+      wp = (const CH*)rhs.w[0] + (long long)wave * NCH * 64 + lane;
+      r0 = wp[0]; r1 = wp[64];
+      bf[0] = (T)0;
+      const T* bias = (const T*)rhs.b[0];
+      has_bias = bias != nullptr;
+      bias_v = (has_bias && colok) ? bias[col] : (T)0;
+      sign = (T)rhs.sign;
+      plain = bias == nullptr && rhs.sign == 1.0;
+      s_ys = lds;
+    } else {
+      init_matrix((const T*)rhs.w[0], (const T*)rhs.b[0], rhs.sign, false, lds, dim);
+    }
   }
   // f(y) = sgn (y M + bias) with M = W, or M = W^T when `transposed` (the adjoint system a' = -s a W^T of the linear right-hand side,
   // csrc/mi_ode_linadj.h: the same resident-slice tile kernel with the other operand order of W)
   __device__ __forceinline__ void init_matrix(const T* W, const T* bias, double sgn, bool transposed, T* lds, int dim) {
+    static_assert(!STREAM, "streamed W: init() takes the packed copy");
     const int tid = threadIdx.x;
     lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
     col = 16 * wave + li;
@@ -416,6 +451,7 @@ struct LinCtx {
   }
   // ... from a matrix already zero padded to [D, D] (row stride D): no bounds, every load coalesced over the sixteen lanes of a group
   __device__ __forceinline__ void init_padded(const T* Mpad, const T* bias, double sgn, T* lds, int dim) {
+    static_assert(!STREAM, "streamed W: init() takes the packed copy");
     const int tid = threadIdx.x;
     lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
     col = 16 * wave + li;
@@ -458,13 +494,29 @@ struct LinCtx {
     acc_t c0 = {0, 0, 0, 0};
     const T* ap = tile + li * LD + lg * KS;
 #if (MI_ABL & 1)
-    c0[0] = ap[0] * bf[0]; c0[1] = ap[1] * bf[1]; c0[2] = ap[2] * bf[2]; c0[3] = ap[3] * bf[3];
+    c0[0] = ap[0] * bf[0]; c0[1] = ap[1] * bf[0]; c0[2] = ap[2] * bf[0]; c0[3] = ap[3] * bf[0];
 #else
+    if constexpr (STREAM) {
+      static_assert(NCH % 2 == 0, "chunk pairs");
+#pragma unroll 1
+      for (int g = 0; g < NCH / 2; ++g) {
+        const CH a0 = *(const CH*)(ap + (2 * g) * VEC);
+        const CH a1 = *(const CH*)(ap + (2 * g + 1) * VEC);
+        const CH b0 = r0, b1 = r1;
+        const CH* wn = wp + 64 * ((g + 1 == NCH / 2) ? 0 : 2 * g + 2);     // (the last group: chunks 0, 1 for the NEXT evaluation)
+        r0 = wn[0]; r1 = wn[64];
 #pragma unroll
-    for (int m = 0; m < KS / VEC; ++m) {
-      const CH a0 = *(const CH*)(ap + m * VEC);
+        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], b0.v[v], c0);
 #pragma unroll
-      for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], bf[m * VEC + v], c0);
+        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a1.v[v], b1.v[v], c0);
+      }
+    } else {
+#pragma unroll
+      for (int m = 0; m < KS / VEC; ++m) {
+        const CH a0 = *(const CH*)(ap + m * VEC);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], bf[m * VEC + v], c0);
+      }
     }
 #endif
     stamp();
@@ -482,6 +534,19 @@ struct LinCtx {
     stamp();
   }
 };
+
+// W [dim, dim] (row major) -> the copy the STREAM kernels read (LinCtx<T, D>::wp): piece (w, m, lane) holds
+// W[k = (lane >> 4) KS + m VEC + v][16 w + (lane & 15)], v < VEC, zero beyond dim.  Launched on the stream in front of every
+// kernel of the streamed family (the caller may have updated W in place since the last call).
+template <typename T, int D>
+__global__ __launch_bounds__(256) void k_lin_pack(const T* W, int dim, T* pack) {
+  constexpr int VEC = MfmaTraits<T>::VEC, KS = D / 4, NCH = KS / VEC;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < D * D; e += gridDim.x * blockDim.x) {
+    const int v = e % VEC, lane = (e / VEC) % 64, m = (e / (VEC * 64)) % NCH, w = e / (VEC * 64 * NCH);
+    const int k = (lane >> 4) * KS + m * VEC + v, c = 16 * w + (lane & 15);
+    pack[e] = (k < dim && c < dim) ? W[(long long)k * dim + c] : (T)0;
+  }
+}
 
 // dt * coefficient products of an attempt, staged in LDS once per pass: (T)dt * (T)c, the very products step_combine /
 // step_finish form.  Rows of beta back to back (row s at s(s-1)/2, s = 1..S), then c_error, then c_mid.  Reading one back is
@@ -532,6 +597,7 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
   const long long ntiles = (A.batch + R_ - 1) / R_;
   lin_fill_coef<T, S>(A, P.hs, coef);
   lds_barrier();
+  constexpr bool PF = LinCtx<T, D>::PF;                      // (streamed W: no registers for the prefetches - read at the point of use)
   T y0n[4], f0n[4];                                          // prefetched next tile (accumulator layout)
   auto fetch = [&](long long t_i) {
     const T* ty = P.y0 + t_i * R_ * cx.d;
@@ -544,22 +610,23 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
       f0n[i] = ok ? stream_load<SC0>(tf + cx.off_of(i)) : (T)0;
     }
   };
-  if ((long long)blk < ntiles) fetch(blk);
+  if (PF && (long long)blk < ntiles) fetch(blk);
   const T c_first = coef[CF::row(1)];                        // dt * beta_{1,0}: the same for every tile
-  T cnx[S + 1];                                              // the coefficients of the NEXT combination (read under the MFMA chain)
+  T cnx[PF ? S + 1 : 1];                                     // the coefficients of the NEXT combination (read under the MFMA chain)
 
   for (long long tile_i = blk; tile_i < ntiles; tile_i += nblk) {
     const long long row0 = tile_i * R_;
     T y0e[4], k[S + 1][4], ys[4];
+    if constexpr (!PF) fetch(tile_i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { y0e[i] = y0n[i]; k[0][i] = f0n[i]; }
-    if (tile_i + nblk < ntiles) fetch(tile_i + nblk);
+    if (PF && tile_i + nblk < ntiles) fetch(tile_i + nblk);
 
     auto stage = [&](auto sg_c) {
       constexpr int SG = decltype(sg_c)::value;
       T cb[SG];                                              // dt * beta_{SG, j}: step_combine's products, from the table
 #pragma unroll
-      for (int j = 0; j < SG; ++j) cb[j] = (SG == 1) ? c_first : cnx[j];
+      for (int j = 0; j < SG; ++j) cb[j] = (SG == 1) ? c_first : (PF ? cnx[PF ? j : 0] : coef[CF::row(SG) + j]);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         T a_ = cb[0] * k[0][i];                              // misc._scaled_dot_product order (rk_common.py:51)
@@ -568,8 +635,10 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
         ys[i] = y0e[i] + a_;
       }
       cx.rhs_eval(ys, k[SG], [&] {                           // next: row SG + 1 of beta, after the last stage c_error
+        if constexpr (PF) {
 #pragma unroll
-        for (int j = 0; j <= SG; ++j) cnx[j] = coef[(SG < S ? CF::row(SG + 1) : CF::kErr) + j];
+          for (int j = 0; j <= SG; ++j) cnx[j] = coef[(SG < S ? CF::row(SG + 1) : CF::kErr) + j];
+        }
       });
     };
     for_stages<1, S>(stage);
@@ -577,7 +646,7 @@ __device__ __forceinline__ void lin_attempt_pass(const StepArgs& A, const StepPl
     T err4[4], ym4[4];                                       // rk_common.py:60 / dopri5.py:42: step_finish's operations, one table
 #pragma unroll                                               // entry at a time (the coefficients are vector registers now)
     for (int j = 0; j <= S; ++j) {
-      const T ce = cnx[j];
+      const T ce = PF ? cnx[PF ? j : 0] : coef[CF::kErr + j];
 #pragma unroll
       for (int i = 0; i < 4; ++i) err4[i] = (j == 0) ? ce * k[0][i] : lin_madd(ce, k[j][i], err4[i]);
     }
@@ -635,12 +704,14 @@ __device__ __forceinline__ void lin_f0_pass(const StepArgs& A, const T* y0, T* f
       if constexpr (DOT) gn[i] = ok ? (gdot + t_i * R_ * cx.d)[cx.off_of(i)] : (T)0;
     }
   };
-  if ((long long)blk < ntiles) fetch(blk);
+  constexpr bool PF = LinCtx<T, D>::PF;
+  if (PF && (long long)blk < ntiles) fetch(blk);
   for (long long tile_i = blk; tile_i < ntiles; tile_i += nblk) {
     T y0e[4], kn[4], ge[DOT ? 4 : 1];
+    if constexpr (!PF) fetch(tile_i);
 #pragma unroll
     for (int i = 0; i < 4; ++i) { y0e[i] = y0n[i]; if constexpr (DOT) ge[i] = gn[i]; }
-    if (tile_i + nblk < ntiles) fetch(tile_i + nblk);
+    if (PF && tile_i + nblk < ntiles) fetch(tile_i + nblk);
     cx.rhs_eval(y0e, kn);
     const int nr = cx.rows_here(tile_i, A.batch);
     const long long tb = tile_i * R_ * cx.d;

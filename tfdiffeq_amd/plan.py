@@ -96,13 +96,19 @@ def plan_rhs(rhs, y, method, options=None):
                              % (T, max(16, 1 << (int(rhs.dim) - 1).bit_length()), S))
                 return out({'engine': 'fused', 'kernel': sched, 'launches': 'one per call' if fusion in (0, 'auto', 4, 'whole') else 'per stage / attempt',
                             'why': '3 <= dim <= 128: the MFMA tile kernels (W slice resident in registers)'})
+            if fam == 'linear' and 128 < rhs.dim <= 256 and S in (3, 6) and fusion not in (1, 'stage'):
+                sched = 'k_step_linear_mfma<%s, 256, %d> (one kernel per attempt)' % (T, S) if fusion in (2, 'step') else \
+                    'k_persist_linear_mfma<%s, 256, %d> (co-resident batch; k_step_linear_mfma per attempt otherwise)' % (T, S)
+                return out({'engine': 'fused', 'kernel': sched, 'launches': 'one per call' if fusion in (0, 'auto', 4, 'whole') else 'per attempt',
+                            'why': '128 < dim <= 256, three- or six-row tableau: the 256-wide MFMA tile kernels (W streamed from a copy in '
+                                   'consumption order, csrc/mi_ode_step_fused.h LinCtx::STREAM)'})
             return out({'engine': 'fused', 'kernel': 'k_stage_linear_valu', 'launches': 'one per stage',
-                        'why': 'dim %d outside 3 .. 128: the vector-ALU fallback (dim <= 256)' % rhs.dim})
+                        'why': 'dim %d outside 3 .. 128 (and not a dopri5 / tsit5 / bosh3 call at dim <= 256): the vector-ALU fallback (dim <= 256)' % rhs.dim})
         return out({'engine': 'fused', 'kernel': 'catalogue kernels of %s' % type(rhs).__name__, 'launches': 'one per call', 'why': 'supports(y0)'})
     if method in FIXED_RK:
         if FIXED_RK[method] and rhs.fixed_grid_fused and (rhs.supports(y) or coop_ok):
             k = 'k_fixed_rowlocal' if (getattr(rhs, 'row_local', False) or getattr(rhs, 'coop', False) or isinstance(rhs, R.CustomCoop) or coop_ok) else \
-                ('k_fixed_mlp' if fam == 'mlp' else 'k_fixed_linear_mfma' if 3 <= rhs.dim <= 128 else 'FX_* stage kernels (vector ALU)')
+                ('k_fixed_mlp' if fam == 'mlp' else 'k_fixed_linear_mfma' if (3 <= rhs.dim <= 128 or (fam == 'linear' and rhs.dim <= 256)) else 'FX_* stage kernels (vector ALU)')
             return out({'engine': 'fused', 'kernel': '%s<%s, ..>' % (k, T), 'launches': 'one per call',
                         'why': 'euler / rk4 have one-launch fixed-grid kernels for every fused family'})
         return out({'engine': 'plane kernels', 'kernel': 'step_func over mi_ode_lincomb, one evaluation of forward() per stage',
