@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-6 GPU session (one gpurun call): scripts/gpu_round6.sh [tests] [bench] [published] [mlp64] [prof]
+# Round-6 GPU session (one gpurun call): scripts/gpu_round6.sh [tests] [bench] [published] [mlp64] [prof] [adjoint] [wide]
 # Everything lands in gpurun_out/r06/; rocprofv3 runs are bounded by `timeout` and write csv.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r06
@@ -66,4 +66,12 @@ if want adjoint; then
   (cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_c4 -o r -- python $R/bench.py --steps 100 --warmup 5 --no-cpu-baseline > $O/prof_c4.log 2>&1)
   f=$(find $O/prof_c4 -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -6 "$f" > $O/r06_whole_kernel_stats.csv && head -3 $O/r06_whole_kernel_stats.csv | cut -c1-200
   rm -rf $O/prof_c4
+fi
+if want wide; then
+  # linear right-hand side at dims 129 .. 256 (the 256-wide tile kernels, W streamed): tests, times, kernel trace
+  timeout 600 python -m pytest tests/test_gpu_linear_wide.py -q -x 2>&1 | tail -3 > $O/r06_linear_wide_tests.txt; cat $O/r06_linear_wide_tests.txt
+  timeout 300 python scripts/bench_linear_wide.py bench valu 2>&1 | grep -v Warn > $O/r06_linear_wide.txt; cat $O/r06_linear_wide.txt
+  (cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_wide -o r -- python $R/scripts/bench_linear_wide.py bench > $O/prof_wide.log 2>&1)
+  f=$(find $O/prof_wide -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" > $O/r06_linear_wide_kernel_stats.csv && head -5 $O/r06_linear_wide_kernel_stats.csv | cut -c1-220
+  rm -rf $O/prof_wide
 fi

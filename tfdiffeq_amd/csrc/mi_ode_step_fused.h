@@ -363,8 +363,8 @@ __device__ __forceinline__ void lds_barrier() {
 // D = 256 (round 6, dims 129 .. 256): sixteen wavefronts, four per SIMD, 128 registers each - a wavefront's slice of W (64 values
 // per lane, 128 registers in float64) cannot stay resident next to the stage derivatives of the tile.  STREAM: the slice is read
 // again for every evaluation, from a copy of W in the order the lanes consume it (k_lin_pack below: chunk m of wavefront w is 64
-// consecutive 16-byte pieces, one per lane - every wave instruction reads 1 KB of consecutive addresses), two chunks ahead of the
-// MFMAs that consume them; the last group of an evaluation loads the FIRST two chunks again - W does not depend on the tile, so the
+// consecutive 16-byte pieces, one per lane - every wave instruction reads 1 KB of consecutive addresses), a group of MFMAs ahead of
+// the ones that consume them; the last trip of an evaluation loads the FIRST chunks again - W does not depend on the tile, so the
 // next evaluation's chain starts on operands that arrived long ago.  The register budget (128) has no room for the resident
 // kernels' prefetch of the next tile's y0 / f0 nor for the pre-read combination coefficients: both are read where they are used
 // (PF below).  The copy is dim-independent
@@ -391,7 +391,7 @@ struct LinCtx {
   bool colok;                                                // for D in {16, 32, 64, 128} and run any smaller dim zero padded (columns >= d
   T bf[STREAM ? 1 : KS];                                     // are never loaded or stored; W rows / columns >= d are zero, so the padding
   const CH* wp;                                              // STREAM: this lane's first chunk of the packed copy (chunk m at wp[64 m])
-  CH r0, r1;                                                 // STREAM: the two chunks the next MFMA group consumes (in flight or landed)
+  CH r0, r1;                                                 // STREAM: the two chunks the next evaluation's first MFMA group consumes (in flight or landed)
   T bias_v, sign;                                            // contributes exact zeros to every product, sum and norm)
   bool has_bias;
   bool plain;                                                // no bias, forward time: k is the accumulator as it is (the bias add and
@@ -497,18 +497,48 @@ struct LinCtx {
     c0[0] = ap[0] * bf[0]; c0[1] = ap[1] * bf[0]; c0[2] = ap[2] * bf[0]; c0[3] = ap[3] * bf[0];
 #else
     if constexpr (STREAM) {
-      static_assert(NCH % 2 == 0, "chunk pairs");
+      static_assert(NCH % 4 == 0, "two chunk pairs per trip");
+      // Two operand sets of two chunks: (r0, r1) - loaded at the end of the previous trip (or evaluation) - and (q0, q1), loaded at the
+      // top of the trip.  Each set travels while the other set's MFMA group (of each of the SIMD's four wavefronts) runs, and is
+      // loaded in place: no register moves.  (The compiler waits for EVERY outstanding load at a loop's top, so the loads that cross
+      // the back edge must be the only ones in flight there: hence this order, pinned by the scheduling barriers.)  The last trip
+      // reloads chunks 0, 1: the next evaluation's first operands - W does not depend on the tile.
+      const CH* wq = wp;
+#ifndef MI_STREAM_ABL
+#define MI_STREAM_ABL 0                                      // tuning aid: 1 no W stream inside the chain, 2 no LDS operand reads (both: the matrix pipe + combinations alone)
+#endif
+#if (MI_STREAM_ABL & 2)
+      CH fa = *(const CH*)ap;
+#define MI_LDA(p) fa
+#else
+#define MI_LDA(p) (*(const CH*)(p))
+#endif
+#if (MI_STREAM_ABL & 1)
+#define MI_LDW(p, keep) keep
+#else
+#define MI_LDW(p, keep) (p)
+#endif
 #pragma unroll 1
-      for (int g = 0; g < NCH / 2; ++g) {
-        const CH a0 = *(const CH*)(ap + (2 * g) * VEC);
-        const CH a1 = *(const CH*)(ap + (2 * g + 1) * VEC);
-        const CH b0 = r0, b1 = r1;
-        const CH* wn = wp + 64 * ((g + 1 == NCH / 2) ? 0 : 2 * g + 2);     // (the last group: chunks 0, 1 for the NEXT evaluation)
-        r0 = wn[0]; r1 = wn[64];
+      for (int g = 0; g < NCH / 4; ++g) {
+        __builtin_amdgcn_sched_barrier(0);
+        const CH q0 = MI_LDW(wq[128], r0), q1 = MI_LDW(wq[192], r1);
+        const CH a0 = MI_LDA(ap + (4 * g) * VEC);
+        const CH a1 = MI_LDA(ap + (4 * g + 1) * VEC);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], b0.v[v], c0);
+        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], r0.v[v], c0);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a1.v[v], b1.v[v], c0);
+        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a1.v[v], r1.v[v], c0);
+        const CH a2 = MI_LDA(ap + (4 * g + 2) * VEC);
+        const CH a3 = MI_LDA(ap + (4 * g + 3) * VEC);
+        wq = (g + 1 == NCH / 4) ? wp : wq + 256;
+        __builtin_amdgcn_sched_barrier(0);
+        r0 = MI_LDW(wq[0], r0); r1 = MI_LDW(wq[64], r1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a2.v[v], q0.v[v], c0);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a3.v[v], q1.v[v], c0);
       }
     } else {
 #pragma unroll
