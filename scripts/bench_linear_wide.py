@@ -3,7 +3,7 @@
 (csrc/mi_ode_step_fused.h, LinCtx<T, 256>) against the oracle, and their time at config 4's shape.
   python scripts/bench_linear_wide.py [parity] [bench] [valu]
 parity: dims 129 / 200 / 256, float64 + float32, dopri5 / tsit5 / bosh3 / rk4 / euler, T = 2 and T = 7, batch 1000 (ragged last tile)
-bench : batch 65536 x {256, 192}, dopri5 rtol 1e-6 atol 1e-9, t = [0, 1] (config 4 at the wider state), ms per call and the
+bench : batch 65536 x {256, 192, 144}, dopri5 rtol 1e-6 atol 1e-9, t = [0, 1] (config 4 at the wider state), ms per call and the
         fraction of the float64 / float32 matrix peak;  valu: the same call on the vector-ALU kernels (options linear_variant)."""
 import json
 import os
@@ -62,7 +62,7 @@ if 'parity' in what:
     print('float64 worst max|diff| %.2e' % worst)
 
 if 'bench' in what or 'valu' in what:
-    for D, dtype in ((256, torch.float64), (192, torch.float64), (256, torch.float32)):
+    for D, dtype in ((256, torch.float64), (192, torch.float64), (144, torch.float64), (256, torch.float32), (160, torch.float32)):
         A, y0 = system(D, 65536, dtype)
         f = rhs.Linear.from_matrix(A)
         y = y0.to(dev)
@@ -73,17 +73,22 @@ if 'bench' in what or 'valu' in what:
                 odeint(f, y, t, rtol=1e-6, atol=1e-9, method='dopri5', options=opts)
             torch.cuda.synchronize()
             reps = 10 if variant == 'tile' else 2
-            t0 = time.perf_counter()
+            per = []
             for _ in range(reps):
+                t0 = time.perf_counter()
                 odeint(f, y, t, rtol=1e-6, atol=1e-9, method='dopri5', options=opts)
-            torch.cuda.synchronize()
-            ms = 1e3 * (time.perf_counter() - t0) / reps
+                torch.cuda.synchronize()
+                per.append(1e3 * (time.perf_counter() - t0))
+            ms = float(np.median(per))
             st = dict(odeint.last_stats)
             nfe = st.get('nfe')
-            flop = 2.0 * 256 * 256 * 65536 * nfe if variant == 'tile' else 2.0 * D * D * 65536 * nfe      # tile kernels: the padded width is what the pipe executes
             flop_alg = 2.0 * D * D * 65536 * nfe
+            vec = 2 if dtype == torch.float64 else 4
+            kpad, npad = 16 * vec * -(-D // (16 * vec)), 16 * -(-D // 16)            # what the tile kernels execute: k up to the next 32 (64), columns up to the next 16
+            flop = 2.0 * kpad * npad * 65536 * nfe if variant == 'tile' else flop_alg
             peak = 78.6e12 if dtype == torch.float64 else 157.3e12
             print(json.dumps({'case': 'linear b65536 d%d dopri5 %s %s' % (D, str(dtype).split('.')[-1], variant), 'ms_per_call': round(ms, 4),
+                              'ms_min_max': [round(min(per), 3), round(max(per), 3)],
                               'attempts': st.get('n_attempts'), 'nfe': nfe, 'launches': st.get('n_launches'),
                               'TFLOPs_algorithmic': round(flop_alg / ms / 1e9, 2), 'frac_of_matrix_peak_algorithmic': round(flop_alg / (ms * 1e-3) / peak, 4),
-                              'frac_executed_padded': round(flop / (ms * 1e-3) / peak, 4), 'engine': st.get('engine')}), flush=True)
+                              'frac_executed': round(flop / (ms * 1e-3) / peak, 4), 'engine': st.get('engine')}), flush=True)

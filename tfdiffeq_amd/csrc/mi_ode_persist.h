@@ -1032,7 +1032,7 @@ __global__ __launch_bounds__(D * 4) void k_persist_linear_mfma(PersistArgs A) {
 
 template <typename T, int D>
 constexpr size_t persist_linear_lds_bytes() {
-  return (size_t)2 * 16 * (D + MfmaTraits<T>::VEC) * sizeof(T);
+  return (size_t)2 * 16 * lin_ld<T>(D) * sizeof(T);
 }
 
 // Self-test of the cross-rank hand-off: `rounds` exchanges of synthetic records through the host segment; *result = 1

@@ -370,8 +370,15 @@ __device__ __forceinline__ void lds_barrier() {
 // (PF below).  The copy is dim-independent
 // (zero padded to 256 x 256: 512 KB in float64) and stays in every XCD's L2; what the schedule needs from L2 is one 16-byte piece per
 // lane for every two float64 (four float32) MFMAs: 32 B per clock and CU with the matrix pipe saturated.  Everything else - the
-// accumulator-layout ownership of the stage derivatives, the two alternating LDS tiles, one barrier per evaluation, the k-permutation
-// (lane group g covers k in [g KS, (g + 1) KS)) and hence the summation order of every product - is the resident kernels'.
+// accumulator-layout ownership of the stage derivatives, the two alternating LDS tiles, one barrier per evaluation - is the resident
+// kernels'.  The k-permutation is the resident kernels' with a RUN-TIME group length: lane group g covers k in [g ks, (g + 1) ks),
+// ks = 4 VEC trips, trips = ceil(dim / (16 VEC)) - the chain stops at the state's true row length (5 .. 8 trips in float64 instead of
+// always 8), and a wavefront whose sixteen columns lie beyond dim skips its chain altogether (the wavefronts of a workgroup are
+// dealt to the SIMDs round robin, so the idle ones thin out every SIMD alike): a dim-144 system costs 5 / 8 of the trips on 9 / 16 of
+// the wavefronts, not the padded width.  At dim 256 this IS the resident layout (ks = 64: the four lane groups of a ds_read_b128 fall
+// on their rows' own banks); other dims take two-way conflicts on the operand reads, which the ablation prices at a few percent.
+// (Measured and dropped: interleaved chunks, k = (4 c + g) VEC + v - 5.81 ms at dim 256 against 5.47; the same with a 64-byte row pad
+// and an XOR swizzle that makes the reads conflict free on paper - 6.44 ms in float64, 3.02 against 3.26 in float32.)
 template <typename T, int D>
 struct LinCtx {
   using TR = MfmaTraits<T>;
@@ -392,6 +399,8 @@ struct LinCtx {
   T bf[STREAM ? 1 : KS];                                     // are never loaded or stored; W rows / columns >= d are zero, so the padding
   const CH* wp;                                              // STREAM: this lane's first chunk of the packed copy (chunk m at wp[64 m])
   CH r0, r1;                                                 // STREAM: the two chunks the next evaluation's first MFMA group consumes (in flight or landed)
+  int trips;                                                 // STREAM: ceil(dim / (16 VEC)) trips of four chunks cover k < dim
+  bool active;                                               // STREAM: this wavefront owns at least one column < dim
   T bias_v, sign;                                            // contributes exact zeros to every product, sum and norm)
   bool has_bias;
   bool plain;                                                // no bias, forward time: k is the accumulator as it is (the bias add and
@@ -414,7 +423,9 @@ struct LinCtx {
       col = 16 * wave + li;
       d = dim; colok = col < dim;
       wp = (const CH*)rhs.w[0] + (long long)wave * NCH * 64 + lane;
-      r0 = wp[0]; r1 = wp[64];
+      trips = (dim + 16 * VEC - 1) / (16 * VEC);
+      active = __builtin_amdgcn_readfirstlane(16 * wave) < dim;
+      if (active) { r0 = wp[0]; r1 = wp[64]; }
       bf[0] = (T)0;
       const T* bias = (const T*)rhs.b[0];
       has_bias = bias != nullptr;
@@ -485,6 +496,9 @@ struct LinCtx {
   __device__ __forceinline__ void rhs_eval(const T (&ys)[4], T (&kn)[4], F&& under_chain) {
     stamp();
     T* tile = s_ys + cur * TILE;
+    int aoff = cur * TILE + li * LD + lg * (STREAM ? 4 * VEC * trips : KS);       // this lane's first operand chunk: lane group g covers k in [g ks, (g + 1) ks)
+    if constexpr (STREAM) asm volatile("" : "+v"(aoff));     // (in a register BEFORE the barrier: under the 128-register budget the compiler kept it in scratch
+                                                             // and reloaded it behind the barrier - the reload's latency in front of every chain, 6 % of the call)
     cur ^= 1;
 #pragma unroll
     for (int i = 0; i < 4; ++i) tile[TR::acc_row(lane, i) * LD + col] = ys[i];
@@ -492,7 +506,7 @@ struct LinCtx {
     stamp();
     under_chain();
     acc_t c0 = {0, 0, 0, 0};
-    const T* ap = tile + li * LD + lg * KS;
+    const T* ap = s_ys + aoff;
 #if (MI_ABL & 1)
     c0[0] = ap[0] * bf[0]; c0[1] = ap[1] * bf[0]; c0[2] = ap[2] * bf[0]; c0[3] = ap[3] * bf[0];
 #else
@@ -518,27 +532,33 @@ struct LinCtx {
 #else
 #define MI_LDW(p, keep) (p)
 #endif
+      auto chain = [&](auto nt) {                             // nt: the trips of this chain - a constant when the state fills the tile width
 #pragma unroll 1
-      for (int g = 0; g < NCH / 4; ++g) {
-        __builtin_amdgcn_sched_barrier(0);
-        const CH q0 = MI_LDW(wq[128], r0), q1 = MI_LDW(wq[192], r1);
-        const CH a0 = MI_LDA(ap + (4 * g) * VEC);
-        const CH a1 = MI_LDA(ap + (4 * g + 1) * VEC);
-        __builtin_amdgcn_sched_barrier(0);
+        for (int g = 0; g < nt; ++g) {
+          __builtin_amdgcn_sched_barrier(0);
+          const CH q0 = MI_LDW(wq[128], r0), q1 = MI_LDW(wq[192], r1);
+          const CH a0 = MI_LDA(ap + (4 * g) * VEC);
+          const CH a1 = MI_LDA(ap + (4 * g + 1) * VEC);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], r0.v[v], c0);
+          for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a0.v[v], r0.v[v], c0);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a1.v[v], r1.v[v], c0);
-        const CH a2 = MI_LDA(ap + (4 * g + 2) * VEC);
-        const CH a3 = MI_LDA(ap + (4 * g + 3) * VEC);
-        wq = (g + 1 == NCH / 4) ? wp : wq + 256;
-        __builtin_amdgcn_sched_barrier(0);
-        r0 = MI_LDW(wq[0], r0); r1 = MI_LDW(wq[64], r1);
-        __builtin_amdgcn_sched_barrier(0);
+          for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a1.v[v], r1.v[v], c0);
+          const CH a2 = MI_LDA(ap + (4 * g + 2) * VEC);
+          const CH a3 = MI_LDA(ap + (4 * g + 3) * VEC);
+          wq = (g + 1 == nt) ? wp : wq + 256;
+          __builtin_amdgcn_sched_barrier(0);
+          r0 = MI_LDW(wq[0], r0); r1 = MI_LDW(wq[64], r1);
+          __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a2.v[v], q0.v[v], c0);
+          for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a2.v[v], q0.v[v], c0);
 #pragma unroll
-        for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a3.v[v], q1.v[v], c0);
+          for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a3.v[v], q1.v[v], c0);
+        }
+      };
+      if (active) {                                           // (a wavefront without columns never loaded r0 / r1: it must not run a chain)
+        if (trips == NCH / 4) chain(std::integral_constant<int, NCH / 4>{});    // (the constant trip count is worth 4 % at dim 256: 5.53 against 5.78 ms)
+        else chain(trips);
       }
     } else {
 #pragma unroll
@@ -566,15 +586,16 @@ struct LinCtx {
 };
 
 // W [dim, dim] (row major) -> the copy the STREAM kernels read (LinCtx<T, D>::wp): piece (w, m, lane) holds
-// W[k = (lane >> 4) KS + m VEC + v][16 w + (lane & 15)], v < VEC, zero beyond dim.  Launched on the stream in front of every
+// W[k = (lane >> 4) ks + m VEC + v][16 w + (lane & 15)], v < VEC, ks = 4 VEC ceil(dim / (16 VEC)); zero beyond dim and for m VEC >= ks.  Launched on the stream in front of every
 // kernel of the streamed family (the caller may have updated W in place since the last call).
 template <typename T, int D>
 __global__ __launch_bounds__(256) void k_lin_pack(const T* W, int dim, T* pack) {
   constexpr int VEC = MfmaTraits<T>::VEC, KS = D / 4, NCH = KS / VEC;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < D * D; e += gridDim.x * blockDim.x) {
     const int v = e % VEC, lane = (e / VEC) % 64, m = (e / (VEC * 64)) % NCH, w = e / (VEC * 64 * NCH);
-    const int k = (lane >> 4) * KS + m * VEC + v, c = 16 * w + (lane & 15);
-    pack[e] = (k < dim && c < dim) ? W[(long long)k * dim + c] : (T)0;
+    const int ks = 4 * VEC * ((dim + 16 * VEC - 1) / (16 * VEC));
+    const int k = (lane >> 4) * ks + m * VEC + v, c = 16 * w + (lane & 15);
+    pack[e] = (m * VEC < ks && k < dim && c < dim) ? W[(long long)k * dim + c] : (T)0;
   }
 }
 
@@ -906,9 +927,12 @@ __global__ __launch_bounds__(D * 4) void k_fixed_linear_mfma(FixedArgs A) {
   clk.end(A.clk);
 }
 
+// row stride of the stage tiles in LDS (= LinCtx<T, D>::LD) for a tile width known at run time
+template <typename T>
+constexpr size_t lin_ld(int D) { return (size_t)D + (size_t)MfmaTraits<T>::VEC; }
 template <typename T, int D>
 constexpr size_t step_linear_lds_bytes() {
-  return (size_t)2 * 16 * (D + MfmaTraits<T>::VEC) * sizeof(T) + (80 + kLinCoefMax) * sizeof(double);     // two stage tiles | red | coefficient table
+  return (size_t)2 * 16 * lin_ld<T>(D) * sizeof(T) + (80 + kLinCoefMax) * sizeof(double);     // two stage tiles | red | coefficient table
 }
 
 }  // namespace mi
