@@ -641,6 +641,73 @@ int main() {
     }
     CK(hipFree(dW1)); CK(hipFree(dW2)); CK(hipFree(dW3)); CK(hipFree(db1)); CK(hipFree(db2)); CK(hipFree(db3));
   }
+  // ---- 12. MI_ODE_RHS_LINEAR at dim 200 (float64, bias): outside the resident-W tile kernels' 128 columns - round 6: the 256-wide tile
+  //          kernels with W streamed (k_persist_linear_mfma<double, 256, 6>, k_fixed_linear_mfma<double, 256>); one launch per call,
+  //          dopri5 and rk4 on a fixed grid against a fine RK4 solve written here; W updated in place between two calls. ----
+  {
+    const int WD = 200;
+    const long long WB = 300;
+    std::vector<double> Wm((size_t)WD * WD), wb(WD), wy0((size_t)WB * WD), wout((size_t)3 * WB * WD);
+    for (int i = 0; i < WD; ++i) for (int j = 0; j < WD; ++j) Wm[(size_t)i * WD + j] = (i == j ? -0.5 : 0.0) + 0.5 * sin(0.7 * i - 1.3 * j) / sqrt((double)WD);
+    for (int j = 0; j < WD; ++j) wb[j] = 0.1 * cos(0.3 * j);
+    for (long long r = 0; r < WB; ++r) for (int c = 0; c < WD; ++c) wy0[(size_t)r * WD + c] = sin(0.37 * (double)r + 1.1 * c);
+    double *dWm, *dwb, *dwy, *dwo;
+    CK(hipMalloc((void**)&dWm, Wm.size() * 8)); CK(hipMalloc((void**)&dwb, wb.size() * 8));
+    CK(hipMalloc((void**)&dwy, wy0.size() * 8)); CK(hipMalloc((void**)&dwo, wout.size() * 8));
+    CK(hipMemcpy(dwb, wb.data(), wb.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dwy, wy0.data(), wy0.size() * 8, hipMemcpyHostToDevice));
+    auto lin = [&](const double* y, double* f) {
+      for (int j = 0; j < WD; ++j) { double a = wb[j]; for (int k = 0; k < WD; ++k) a += y[k] * Wm[(size_t)k * WD + j]; f[j] = a; }
+    };
+    mi_ode_handle wh[2] = {nullptr, nullptr};
+    for (int pass = 0; pass < 2; ++pass) {                     // pass 1: the same handles after W was scaled in place (the kernels read a refreshed copy)
+      if (pass == 1) for (auto& v : Wm) v *= 0.5;
+      CK(hipMemcpy(dWm, Wm.data(), Wm.size() * 8, hipMemcpyHostToDevice));
+      for (int fixed = 0; fixed < 2; ++fixed) {
+        if (wh[fixed] == nullptr) {
+          mi_ode_desc wd = d;                                    // dopri5, rtol 1e-9 / atol 1e-11 (section 2)
+          wd.batch = WB; wd.dim = WD; wd.dtype = MI_ODE_F64;
+          memset(&wd.rhs, 0, sizeof(wd.rhs));
+          wd.rhs.kind = MI_ODE_RHS_LINEAR; wd.rhs.sign = 1.0; wd.rhs.w[0] = dWm; wd.rhs.b[0] = dwb;
+          if (fixed) { wd.adaptive = 0; wd.tableau.n_stages = 3; wd.first_step = NAN; }
+          MI(mi_ode_create(&wd, &wh[fixed]));
+        }
+        mi_ode_stats ws;
+        double tm[3] = {0.0, 0.5, 1.0};
+        std::vector<double> tg(41);
+        for (int i = 0; i < 41; ++i) tg[i] = 0.025 * i;
+        int wbits;
+        if (fixed) wbits = mi_ode_fixed_grid_integrate_on(wh[fixed], dwy, tg.data(), 41, tm, 3, 0.0, dwo, &ws, nullptr);
+        else wbits = mi_ode_integrate(wh[fixed], dwy, tm, 3, dwo, &ws, nullptr);
+        if (wbits != 0) { printf("FAIL linear dim 200 (fixed %d): %d %s\n", fixed, wbits, mi_ode_last_error()); return 1; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(wout.data(), dwo, wout.size() * 8, hipMemcpyDeviceToHost));
+        double wdm = 0.0;
+        for (long long r = 0; r < WB; r += 37) {
+          std::vector<double> y(WD), k1(WD), k2(WD), k3(WD), k4(WD), ys(WD);
+          for (int c = 0; c < WD; ++c) y[c] = wy0[(size_t)r * WD + c];
+          const int NS = 400;
+          for (int sidx = 0; sidx < NS; ++sidx) {
+            const double dt = 1.0 / NS;
+            lin(y.data(), k1.data());
+            for (int c = 0; c < WD; ++c) ys[c] = y[c] + 0.5 * dt * k1[c];
+            lin(ys.data(), k2.data());
+            for (int c = 0; c < WD; ++c) ys[c] = y[c] + 0.5 * dt * k2[c];
+            lin(ys.data(), k3.data());
+            for (int c = 0; c < WD; ++c) ys[c] = y[c] + dt * k3[c];
+            lin(ys.data(), k4.data());
+            for (int c = 0; c < WD; ++c) y[c] += dt / 6 * (k1[c] + 2 * k2[c] + 2 * k3[c] + k4[c]);
+            if (sidx + 1 == NS / 2) for (int c = 0; c < WD; ++c) wdm = fmax(wdm, fabs(wout[(size_t)WB * WD + (size_t)r * WD + c] - y[c]));
+          }
+          for (int c = 0; c < WD; ++c) wdm = fmax(wdm, fabs(wout[(size_t)2 * WB * WD + (size_t)r * WD + c] - y[c]));
+        }
+        printf("linear dim 200 float64 (256-wide tile kernels, W streamed)%s, %s: launches %d attempts %lld, max |gpu - fine rk4| = %.3e\n",
+               pass ? " after W *= 0.5 in place" : "", fixed ? "rk4 on a 40-step grid" : "dopri5", (int)ws.n_launches, (long long)ws.n_attempts, wdm);
+        if (ws.n_launches != 1 || !(wdm < (fixed ? 1e-6 : 1e-8))) { printf("FAIL linear dim 200\n"); return 1; }
+      }
+    }
+    MI(mi_ode_destroy(wh[0])); MI(mi_ode_destroy(wh[1]));
+    CK(hipFree(dWm)); CK(hipFree(dwb)); CK(hipFree(dwy)); CK(hipFree(dwo));
+  }
   printf("C-ABI OK (abi %d)\n", mi_ode_abi_version());
   return 0;
 }
