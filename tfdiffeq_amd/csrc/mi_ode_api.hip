@@ -511,16 +511,6 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       mi_ode_destroy(h); return MI_ODE_E_HIP;
     }
   }
-  if (h->family == FAM_MLP && h->is_f32 && h->mlp_dp == 64 && h->mlp_hp == 128 && desc->adaptive && tb.fsal && tb.n_stages == 6 &&
-      desc->interp == MI_ODE_INTERP_QUARTIC_MID && h->d.world_size <= 1 && desc->allgather == nullptr) {
-    // round-6 experiment (review item 4): weight slices streamed from L2, two workgroups per CU (csrc/mi_ode_mlp.h, WS).  Opt-in.
-    const char* ews = getenv("MI_ODE_MLP_STREAM");
-    if (ews != nullptr && atoi(ews) != 0) {
-      const int nf = mi_mlp32_pack_floats(h->mlp_dp, h->mlp_hp);
-      if (nf > 0 && hipMalloc((void**)&h->mlp_pack, (size_t)nf * sizeof(float)) == hipSuccess) h->mlp_ws = atoi(ews) == 2 ? 2 : 1;   // (2: one workgroup per CU - the A/B of the stream alone)
-      else (void)hipGetLastError();
-    }
-  }
   if (h->family == FAM_MLP && !h->is_f32) {          // float64 tile kernels: the packed copy of the weights (refreshed before every launch)
     const int nd = mi_mlp64_pack_doubles(h->mlp_dp, h->mlp_hp);
     if (nd <= 0 || hipMalloc((void**)&h->mlp_pack, (size_t)nd * sizeof(double)) != hipSuccess) {

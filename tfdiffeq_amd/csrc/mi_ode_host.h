@@ -90,7 +90,6 @@ struct mi_ode_solver {
   int ts_dense;               // whole-attempt kernels evaluate the tsit5 seven-weight dense output (else the quartic)
   int mlp_dp, mlp_hp;         // padded widths of the MLP kernel instantiation
   double* mlp_pack;           // float64 MLP tile kernels (mi_ode_mlp64.h): the packed, zero-padded weights, refreshed before every launch
-  int mlp_ws;                 // float32 MLP, 64 x 128, dopri5 / tsit5-less whole call: weights STREAMED from mlp_pack, two workgroups per CU (MI_ODE_MLP_STREAM=1)
   int nseg;                   // tuple state: components packed into the one buffer (mi_ode_desc.n_segments), 0 / 1: a single tensor
   int seg_blk[MI_ODE_MAX_SEGMENTS + 1];   // first workgroup of every component in the whole-call kernel's grid
   double* adams_tab;          // device: the multistep coefficient tables of the descriptor (mi_ode_adams.h), or null
@@ -147,7 +146,6 @@ int mi_persist_capacity_mlp_f64(mi_ode_solver* h);
 int mi_launch_mlp_f64(mi_ode_solver* h, int mode, mi::MlpArgs& M, hipStream_t st);
 int mi_launch_fixed_mlp_f64(mi_ode_solver* h, mi::FixedArgs& A, hipStream_t st);
 int mi_mlp64_pack_doubles(int dp, int hp);
-int mi_mlp32_pack_floats(int dp, int hp);
 int mi_stage_geometry_f64(mi_ode_solver* h);
 int mi_stage_geometry_f32(mi_ode_solver* h);
 

@@ -26,16 +26,7 @@ const void* persist_mlp_fn(const mi_ode_solver* h) {
     default: return nullptr;
   }
 }
-const void* persist_mlp_ws_fn(const mi_ode_solver* h) {      // weights streamed (h->mlp_ws): 64 x 128, six-row tableau, quartic dense output
-  switch (mlp_activation(h)) {
-    case mi::MLP_ACT_TANH: return (const void*)mi::k_persist_mlp<64, 128, mi::MLP_ACT_TANH, 6, false, true>;
-    case mi::MLP_ACT_RELU: return (const void*)mi::k_persist_mlp<64, 128, mi::MLP_ACT_RELU, 6, false, true>;
-    case mi::MLP_ACT_SOFTPLUS: return (const void*)mi::k_persist_mlp<64, 128, mi::MLP_ACT_SOFTPLUS, 6, false, true>;
-    default: return nullptr;
-  }
-}
 const void* persist_mlp_fn_any(const mi_ode_solver* h, size_t* lds, int* block) {
-  if (h->mlp_ws) { *lds = mi::MlpGeom<64, 128>::lds_bytes(); *block = 64 * mi::MlpGeom<64, 128>::NW; return persist_mlp_ws_fn(h); }
   if (h->mlp_dp == 16 && h->mlp_hp == 16) { *lds = mi::MlpGeom<16, 16>::lds_bytes(); *block = 64 * mi::MlpGeom<16, 16>::NW; return persist_mlp_fn<16, 16>(h); }
   if (h->mlp_dp == 16 && h->mlp_hp == 128) { *lds = mi::MlpGeom<16, 128>::lds_bytes(); *block = 64 * mi::MlpGeom<16, 128>::NW; return persist_mlp_fn<16, 128>(h); }
   if (h->mlp_dp == 64 && h->mlp_hp == 16) { *lds = mi::MlpGeom<64, 16>::lds_bytes(); *block = 64 * mi::MlpGeom<64, 16>::NW; return persist_mlp_fn<64, 16>(h); }
@@ -43,8 +34,6 @@ const void* persist_mlp_fn_any(const mi_ode_solver* h, size_t* lds, int* block) 
   return nullptr;
 }
 }  // namespace
-
-int mi_mlp32_pack_floats(int dp, int hp) { return (dp == 64 && hp == 128) ? mi::MlpGeom<64, 128>::PACK : 0; }
 
 int mi_persist_capacity_mlp_f32(mi_ode_solver* h) {
   size_t lds = 0; int block = 0;
@@ -59,13 +48,7 @@ int mi_launch_persist_mlp_f32(mi_ode_solver* h, mi::PersistArgs& A, int grid, hi
   size_t lds = 0; int block = 0;
   const void* fn = persist_mlp_fn_any(h, &lds, &block);
   if (fn == nullptr) { mi_set_error("no whole-call MLP kernel for this problem"); return MI_ODE_E_INVALID; }
-  mi::PersistArgs P = A;
-  if (h->mlp_ws) {                                            // this call's weights -> the streamed copy; the kernel finds it in rhs.w[0]
-    hipLaunchKernelGGL((mi::k_mlp_pack32<64, 128>), dim3(32), dim3(256), 0, st, h->rhs, (int)h->d.dim, (float*)h->mlp_pack);
-    if (hipGetLastError() != hipSuccess) { mi_set_error("k_mlp_pack32 launch failed"); return MI_ODE_E_HIP; }
-    P.s.rhs.w[0] = h->mlp_pack;
-  }
-  void* args[] = {(void*)&P};
+  void* args[] = {(void*)&A};
   hipError_t e = hipLaunchKernel(fn, dim3((unsigned)grid), dim3((unsigned)block), args, lds, st);
   if (e != hipSuccess) { mi_set_error("whole-call MLP kernel launch failed: %s", hipGetErrorString(e)); return MI_ODE_E_HIP; }
   h->n_launches += 1;

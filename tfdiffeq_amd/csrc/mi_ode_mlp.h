@@ -48,49 +48,7 @@ struct MlpGeom {
   static constexpr int R = 32;                              // rows per tile
   static constexpr int LDX = DP + 4, LDH = HP + 4;          // LDS row strides (16-byte pad)
   static constexpr size_t lds_bytes() { return (size_t)R * (LDX + 2 * LDH) * sizeof(float) + 80 * sizeof(double); }
-  // WS (weights streamed, round 6 experiment): the copy of the weights in consumption order - 16-byte pieces [slice][chunk][lane],
-  // a slice = the 16 columns one wavefront multiplies, a chunk = four k-steps of a lane - then the time row of W1 and the biases
-  static constexpr int NC1 = DP / 16, NC2 = HP / 16;        // chunks per lane and slice of layer 1 / of layers 2, 3
-  static constexpr int OFF_W1 = 0, OFF_W2 = OFF_W1 + NW12 * NC1 * 256, OFF_W3 = OFF_W2 + NW12 * NC2 * 256,
-                       OFF_WT = OFF_W3 + CB3 * NC2 * 256, OFF_B1 = OFF_WT + HP, OFF_B2 = OFF_B1 + HP, OFF_B3 = OFF_B2 + HP, PACK = OFF_B3 + DP;
 };
-
-// this call's weights -> the copy the WS kernels stream (launched on the stream in front of them).  Piece (slice, m, lane) of a layer
-// holds W[k = (lane >> 4) KS + 4 m + v][16 slice + (lane & 15)], v < 4 (KS = K / 4: the k-permutation of the resident kernels).
-template <int DP, int HP>
-__global__ __launch_bounds__(256) void k_mlp_pack32(RhsParams rhs, int d, float* pack) {
-  using G = MlpGeom<DP, HP>;
-  const int hd = rhs.hidden;
-  const float* W1 = (const float*)rhs.w[0];
-  const float* W2 = (const float*)rhs.w[1];
-  const float* W3 = (const float*)rhs.w[2];
-  const float* B1 = (const float*)rhs.b[0];
-  const float* B2 = (const float*)rhs.b[1];
-  const float* B3 = (const float*)rhs.b[2];
-  const int td = rhs.s[1] != 0.0 ? 1 : 0;
-  const int tid = blockIdx.x * blockDim.x + threadIdx.x, nt = gridDim.x * blockDim.x;
-  for (int e = tid; e < G::NW12 * G::NC1 * 256; e += nt) {
-    const int v = e & 3, lane = (e >> 2) & 63, m = (e >> 8) % G::NC1, sl = e / (256 * G::NC1);
-    const int k = (lane >> 4) * (DP / 4) + 4 * m + v, c = 16 * sl + (lane & 15);
-    pack[G::OFF_W1 + e] = (k < d && c < hd) ? W1[(long long)(k + td) * hd + c] : 0.f;
-  }
-  for (int e = tid; e < G::NW12 * G::NC2 * 256; e += nt) {
-    const int v = e & 3, lane = (e >> 2) & 63, m = (e >> 8) % G::NC2, sl = e / (256 * G::NC2);
-    const int k = (lane >> 4) * (HP / 4) + 4 * m + v, c = 16 * sl + (lane & 15);
-    pack[G::OFF_W2 + e] = (k < hd && c < hd) ? W2[(long long)k * hd + c] : 0.f;
-  }
-  for (int e = tid; e < G::CB3 * G::NC2 * 256; e += nt) {
-    const int v = e & 3, lane = (e >> 2) & 63, m = (e >> 8) % G::NC2, sl = e / (256 * G::NC2);
-    const int k = (lane >> 4) * (HP / 4) + 4 * m + v, c = 16 * sl + (lane & 15);
-    pack[G::OFF_W3 + e] = (k < hd && c < d) ? W3[(long long)k * d + c] : 0.f;
-  }
-  for (int c = tid; c < HP; c += nt) {
-    pack[G::OFF_WT + c] = (td && c < hd) ? W1[c] : 0.f;
-    pack[G::OFF_B1 + c] = (B1 != nullptr && c < hd) ? B1[c] : 0.f;
-    pack[G::OFF_B2 + c] = (B2 != nullptr && c < hd) ? B2[c] : 0.f;
-  }
-  for (int c = tid; c < DP; c += nt) pack[G::OFF_B3 + c] = (B3 != nullptr && c < d) ? B3[c] : 0.f;
-}
 
 // tanh for the hidden layers: 2^(x * 2/ln 2) on the transcendental unit (v_exp_f32), one reciprocal, and the odd Taylor
 // polynomial below |x| = 1/4 where 1 - 2/(e+1) would cancel: 15 VALU instructions instead of the 27 of ocml's tanhf (the
@@ -342,124 +300,6 @@ __device__ __forceinline__ void mlp_eval(float* s_x, float* s_h1, float* s_h2, c
   mlp_stamp();
 }
 
-// WS (round 6, the review's item 4: "two independent 32-row tiles per CU ... each tile's barrier bubble filled by the other's chain"):
-// the same evaluation with the weight slices STREAMED from a copy in consumption order (L2-resident, 128 KB) instead of resident in
-// 80 registers - the kernel then fits 128 registers and TWO workgroups share a CU, four wavefronts per SIMD.  One 16-byte piece per lane
-// feeds 8 MFMAs in layers 1, 2 (two row blocks) and 4 in layer 3; two pieces are in flight per wavefront, each loaded in place right
-// behind the MFMA group that consumed its predecessor (the technique of the 256-wide linear kernels, mi_ode_step_fused.h); the stream
-// runs through the layers and wraps: `r` carries the first piece of the next layer / evaluation across the barriers.
-typedef float mlp_f4 __attribute__((ext_vector_type(4)));
-template <int DP, int HP, int ACT>
-__device__ __forceinline__ void mlp_eval_ws(float* s_x, float* s_h1, float* s_h2, const mlp_f4* p1, const mlp_f4* p2, const mlp_f4* p3,
-                                            mlp_f4& r, float b1v, float b2v, float b3v, float* out4) {
-  using G = MlpGeom<DP, HP>;
-  typedef mlp_f4 f4;
-  static_assert(G::NW12 == G::NW && G::NW3 == G::NW, "every wavefront works in every layer");
-  static_assert(G::NC1 % 2 == 0 && G::NC2 % 2 == 0, "piece pairs");
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int li = lane & 15, lg = lane >> 4;
-  constexpr int KS1 = DP / 4, KS2 = HP / 4;
-  __syncthreads();                                          // s_x is complete
-  {                                                         // layer 1
-    f4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-    const float* a0p = s_x + li * G::LDX + lg * KS1;
-    const float* a1p = s_x + (16 + li) * G::LDX + lg * KS1;
-    const f4* wq = p1;
-#pragma unroll 1
-    for (int g = 0; g < G::NC1 / 2; ++g) {
-      __builtin_amdgcn_sched_barrier(0);
-      const f4 q = wq[64];
-      const f4 a0 = *(const f4*)(a0p + 8 * g), a1 = *(const f4*)(a1p + 8 * g);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[v], r[v], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[v], r[v], c1, 0, 0, 0);
-      }
-      const f4 a2 = *(const f4*)(a0p + 8 * g + 4), a3 = *(const f4*)(a1p + 8 * g + 4);
-      wq = (g + 1 == G::NC1 / 2) ? p2 : wq + 128;            // (behind the last piece of this layer: the first one of the next)
-      __builtin_amdgcn_sched_barrier(0);
-      r = wq[0];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[v], q[v], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[v], q[v], c1, 0, 0, 0);
-      }
-    }
-    const int col = 16 * wave + li;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float h0, h1;
-      mlp_act_pair<ACT>(c0[i], c1[i], b1v, h0, h1);
-      s_h1[(4 * lg + i) * G::LDH + col] = h0;
-      s_h1[(16 + 4 * lg + i) * G::LDH + col] = h1;
-    }
-  }
-  __syncthreads();
-  {                                                         // layer 2
-    f4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
-    const float* a0p = s_h1 + li * G::LDH + lg * KS2;
-    const float* a1p = s_h1 + (16 + li) * G::LDH + lg * KS2;
-    const f4* wq = p2;
-#pragma unroll 1
-    for (int g = 0; g < G::NC2 / 2; ++g) {
-      __builtin_amdgcn_sched_barrier(0);
-      const f4 q = wq[64];
-      const f4 a0 = *(const f4*)(a0p + 8 * g), a1 = *(const f4*)(a1p + 8 * g);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[v], r[v], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[v], r[v], c1, 0, 0, 0);
-      }
-      const f4 a2 = *(const f4*)(a0p + 8 * g + 4), a3 = *(const f4*)(a1p + 8 * g + 4);
-      wq = (g + 1 == G::NC2 / 2) ? p3 : wq + 128;
-      __builtin_amdgcn_sched_barrier(0);
-      r = wq[0];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) {
-        c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[v], q[v], c0, 0, 0, 0);
-        c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a3[v], q[v], c1, 0, 0, 0);
-      }
-    }
-    const int col = 16 * wave + li;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float h0, h1;
-      mlp_act_pair<ACT>(c0[i], c1[i], b2v, h0, h1);
-      s_h2[(4 * lg + i) * G::LDH + col] = h0;
-      s_h2[(16 + 4 * lg + i) * G::LDH + col] = h1;
-    }
-  }
-  __syncthreads();
-  {                                                         // layer 3: one 16-row block x 16 output columns per wave
-    const int rb = wave / G::CB3;
-    f4 c = {0, 0, 0, 0};
-    const float* ap = s_h2 + (16 * rb + li) * G::LDH + lg * KS2;
-    const f4* wq = p3;
-#pragma unroll 1
-    for (int g = 0; g < G::NC2 / 2; ++g) {
-      __builtin_amdgcn_sched_barrier(0);
-      const f4 q = wq[64];
-      const f4 a0 = *(const f4*)(ap + 8 * g);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[v], r[v], c, 0, 0, 0);
-      const f4 a1 = *(const f4*)(ap + 8 * g + 4);
-      wq = (g + 1 == G::NC2 / 2) ? p1 : wq + 128;            // (the next evaluation's first piece)
-      __builtin_amdgcn_sched_barrier(0);
-      r = wq[0];
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int v = 0; v < 4; ++v) c = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[v], q[v], c, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) out4[i] = c[i] + b3v;
-  }
-}
-
 struct MlpArgs {
   // STEP: the adaptive attempt (controller mode).  F0 / INITB: explicit y0 etc. as in StageArgs.
   StepArgs step;
@@ -471,14 +311,12 @@ struct MlpArgs {
 };
 
 // Per-thread context of the MLP tile kernels: resident weight slices (zero padded), biases, LDS tiles, element map.
-template <int DP, int HP, int ACT, bool WS = false>
+template <int DP, int HP, int ACT>
 struct MlpCtx {
   using G = MlpGeom<DP, HP>;
   static constexpr int KS1 = DP / 4, KS2 = HP / 4;
   float *s_x, *s_h1, *s_h2;
-  float w1f[WS ? 1 : KS1], w2f[WS ? 1 : KS2], w3f[WS ? 1 : KS2];
-  const mlp_f4 *p1, *p2, *p3;                               // WS: this wavefront's slices of the streamed copy (piece m of a lane at p[64 m])
-  mlp_f4 r;                                                 // WS: the piece the next MFMA group consumes (in flight or landed)
+  float w1f[KS1], w2f[KS2], w3f[KS2];
   float b1v, b2v, b3v, sign;
   float wtv;                  // time-dependent first layer (rhs.s[1] != 0): W1 is [d + 1, hd], row 0 multiplies t; else 0
   int lane, wave, li, lg, d, hd, col, rbase;
@@ -497,23 +335,6 @@ struct MlpCtx {
     const float* B2 = (const float*)rhs.b[1];
     const float* B3 = (const float*)rhs.b[2];
     sign = (float)rhs.sign;
-    if constexpr (WS) {                                       // (the launcher put the streamed copy into rhs.w[0]: k_mlp_pack32)
-      const float* pk = (const float*)rhs.w[0];
-      p1 = (const mlp_f4*)(pk + G::OFF_W1) + (wave * G::NC1) * 64 + lane;
-      p2 = (const mlp_f4*)(pk + G::OFF_W2) + (wave * G::NC2) * 64 + lane;
-      p3 = (const mlp_f4*)(pk + G::OFF_W3) + ((wave % G::CB3) * G::NC2) * 64 + lane;
-      r = p1[0];
-      const int c12w = 16 * wave + li;
-      wtv = pk[G::OFF_WT + c12w];
-      b1v = pk[G::OFF_B1 + c12w];
-      b2v = pk[G::OFF_B2 + c12w];
-      col = 16 * (wave % G::CB3) + li;
-      b3v = pk[G::OFF_B3 + col];
-      owner = wave < G::NW3 && col < d;
-      rbase = 16 * (wave / G::CB3) + 4 * lg;
-      w1f[0] = w2f[0] = w3f[0] = 0.f;
-      return;
-    }
     // resident weight slices, zero padded: lane (col = li, group lg) holds W[k = lg*KS + s][16*block + li]
     const int c12 = 16 * wave + li;
     const int td = rhs.s[1] != 0.0 ? 1 : 0;                   // dense_odenet.py:79-84: fc1 sees concat([t, x])
@@ -550,16 +371,15 @@ struct MlpCtx {
   }
   // ts: the time the network sees (already multiplied by the direction sign); it only shifts the first layer's bias
   __device__ __forceinline__ void eval(float* out4, float ts) {
-    if constexpr (WS) mlp_eval_ws<DP, HP, ACT>(s_x, s_h1, s_h2, p1, p2, p3, r, b1v + ts * wtv, b2v, b3v, out4);
-    else mlp_eval<DP, HP, ACT>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v + ts * wtv, b2v, b3v, out4);
+    mlp_eval<DP, HP, ACT>(s_x, s_h1, s_h2, w1f, w2f, w3f, b1v + ts * wtv, b2v, b3v, out4);
   }
 };
 
 // One pass over this workgroup's tiles: MODE F0 (f0 + the norms of misc._select_initial_step, seeds copy_a / copy_b),
 // INITB (second half of _select_initial_step), STEP (one adaptive attempt).  SC0 as in the linear kernels.
-template <int DP, int HP, int ACT, int MODE, int S, bool TS, bool SC0, bool WS = false>
+template <int DP, int HP, int ACT, int MODE, int S, bool TS, bool SC0>
 __device__ __forceinline__ void mlp_pass(const StepArgs& A, const StepPlanes<float, S>& P, void* copy_a, void* copy_b,
-                                         MlpCtx<DP, HP, ACT, WS>& cx, Acc& acc, const double* t_out) {
+                                         MlpCtx<DP, HP, ACT>& cx, Acc& acc, const double* t_out) {
   using G = MlpGeom<DP, HP>;
   const int d = cx.d, col = cx.col, rbase = cx.rbase;
   const bool owner = cx.owner;
@@ -767,12 +587,12 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_mlp(MlpArgs M) {
 // The whole call in one launch (see mi_ode_persist.h): before_integrate, every attempt, controller and dense output on
 // the persistent tile grid; weights are loaded once per call.  Same planes / hand-off / redundant controller as
 // k_persist_linear_mfma.
-template <int DP, int HP, int ACT, int S, bool TS, bool WS = false>
-__global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW), (WS ? 4 : 1)) void k_persist_mlp(PersistArgs A) {      // (second value: wavefronts per SIMD - WS: two workgroups per CU)
+template <int DP, int HP, int ACT, int S, bool TS>
+__global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW)) void k_persist_mlp(PersistArgs A) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   __shared__ PersistShared sh;
   Ctl& s_c = sh.c;
-  MlpCtx<DP, HP, ACT, WS> cx;
+  MlpCtx<DP, HP, ACT> cx;
   cx.init(A.s.rhs, A.s.dim, smem_raw);
   CtrlParams cp = A.s.cp;
   cp.t_out = persist_stage_tout(A, sh.tout);
@@ -793,7 +613,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW), (WS ? 4 : 1)) void k_pe
     StepPlanes<float, S> P;
     P.y0 = y_user; P.f0 = nullptr; P.y1 = nullptr; P.f1 = fa; P.hs = 0.f; P.t0 = (float)A.t0; P.j_lo = P.j_hi = 0;
     Acc acc;
-    mlp_pass<DP, HP, ACT, MLP_F0, S, TS, true, WS>(A.s, P, nullptr, A.out0, cx, acc, t_out);
+    mlp_pass<DP, HP, ACT, MLP_F0, S, TS, true>(A.s, P, nullptr, A.out0, cx, acc, t_out);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_F0, cp); }
     __syncthreads();
@@ -802,7 +622,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW), (WS ? 4 : 1)) void k_pe
     StepPlanes<float, S> P;
     P.y0 = y_user; P.f0 = fa; P.y1 = nullptr; P.f1 = nullptr; P.hs = (float)uniform_d(s_c.h0); P.t0 = (float)A.t0; P.j_lo = P.j_hi = 0;
     Acc acc;
-    mlp_pass<DP, HP, ACT, MLP_INITB, S, TS, true, WS>(A.s, P, nullptr, nullptr, cx, acc, t_out);
+    mlp_pass<DP, HP, ACT, MLP_INITB, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
     if (threadIdx.x == 0 && ok) { fill_record(rec, r, n_tot); controller_apply(&s_c, rec, PH_INITB, cp); }
   }
@@ -836,7 +656,7 @@ __global__ __launch_bounds__((64 * MlpGeom<DP, HP>::NW), (WS ? 4 : 1)) void k_pe
     P.t_start = t1_u; P.dt64 = dt_u; P.t_new = t1_u + dt_u;
     P.j_lo = uniform_i(sh.pub.emit_lo); P.j_hi = uniform_i(sh.pub.emit_hi);
     Acc acc;
-    mlp_pass<DP, HP, ACT, MLP_STEP, S, TS, true, WS>(A.s, P, nullptr, nullptr, cx, acc, t_out);
+    mlp_pass<DP, HP, ACT, MLP_STEP, S, TS, true>(A.s, P, nullptr, nullptr, cx, acc, t_out);
     ok = grid_reduce(A, acc, sh, gen++, r, n_tot);
     if (threadIdx.x == 0) {
       AttemptState st = sh.st;
