@@ -603,6 +603,17 @@ sr = dict(odeint.last_stats)
 mine = ref[:, lcut[rank]:lcut[rank + 1]]
 out['linear128'] = {'diff': float((b - mine).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
                     'launches': sb['n_launches'], 'status': sb['status']}
+# ... and the 256-wide tile kernel (dim 200: W streamed from its copy, sixteen wavefronts per workgroup; round 6)
+S2 = torch.randn(200, 200, generator=torch.Generator().manual_seed(12), dtype=torch.float64)
+A2 = -0.5 * torch.eye(200, dtype=torch.float64) + 0.5 * (S2 - S2.t()) / np.sqrt(200)
+fullW = torch.randn(812, 200, generator=torch.Generator().manual_seed(13), dtype=torch.float64)
+yw = fullW[lcut[rank]:lcut[rank + 1]].cuda()
+b = odeint(rhs.Linear.from_matrix(A2), yw, tl, rtol=1e-6, atol=1e-9, method='dopri5', options={'process_group': dist.group.WORLD})
+sb = dict(odeint.last_stats)
+ref = odeint(rhs.Linear.from_matrix(A2), fullW.cuda(), tl, rtol=1e-6, atol=1e-9, method='dopri5')
+sr = dict(odeint.last_stats)
+out['linear200'] = {'diff': float((b - ref[:, lcut[rank]:lcut[rank + 1]]).abs().max()), 'att': sb['n_attempts'], 'att_ref': sr['n_attempts'],
+                    'launches': sb['n_launches'], 'status': sb['status']}
 gm = torch.Generator().manual_seed(4)
 def glorot(i, o):
     lim = (6.0 / (i + o)) ** 0.5
