@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-6 GPU session (one gpurun call): scripts/gpu_round6.sh [tests] [bench] [published] [mlp64] [prof] [adjoint] [wide]
+# Round-6 GPU session (one gpurun call): scripts/gpu_round6.sh [tests] [bench] [published] [mlp64] [prof] [adjoint] [wide] [summaries]
 # Everything lands in gpurun_out/r06/; rocprofv3 runs are bounded by `timeout` and write csv.
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/r06
@@ -74,4 +74,10 @@ if want wide; then
   (cd /tmp && export TMPDIR=/tmp PYTHONPATH=$R && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_wide -o r -- python $R/scripts/bench_linear_wide.py bench > $O/prof_wide.log 2>&1)
   f=$(find $O/prof_wide -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -8 "$f" > $O/r06_linear_wide_kernel_stats.csv && head -5 $O/r06_linear_wide_kernel_stats.csv | cut -c1-220
   rm -rf $O/prof_wide
+fi
+if want summaries; then
+  # the committed rocprofv3 passes bench.py cites (profiles/r06_{whole,c5}_summary.json): kernel trace + FETCH_SIZE / WRITE_SIZE passes
+  run() { TAG=$1; shift; bash scripts/gpu_prof.sh $TAG "$@" > gpurun_out/prof_$TAG.out 2>&1; python scripts/pmc_summary.py gpurun_out $TAG $O/r06_$TAG --no-raw | tail -4; rm -rf gpurun_out/prof_$TAG gpurun_out/pmc_${TAG}_*; }
+  run whole
+  run c5 --config 5
 fi
