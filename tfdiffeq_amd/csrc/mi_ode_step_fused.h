@@ -397,7 +397,12 @@ struct LinCtx {
   int d;                                                     // the state's true row length, d <= D: the tile kernels are instantiated
   bool colok;                                                // for D in {16, 32, 64, 128} and run any smaller dim zero padded (columns >= d
   T bf[STREAM ? 1 : KS];                                     // are never loaded or stored; W rows / columns >= d are zero, so the padding
-  const CH* wp;                                              // STREAM: this lane's first chunk of the packed copy (chunk m at wp[64 m])
+  // STREAM: chunk m of this lane at wp[64 m + wl].  float32 (UNI): wp is the WAVEFRONT's slice, a uniform (scalar-register) base, wl = lane -
+  // scalar base + 32-bit lane offset + immediate, no vector address arithmetic in the chain (3.02 -> 2.90 ms at 65536 x 256).  float64:
+  // wp is the lane's own first chunk, wl = 0 (the scalar-base form measured 5.72 against 5.53 ms there: ten more spilled registers).
+  static constexpr bool UNI = sizeof(T) == 4;
+  const CH* wp;
+  int wl;
   CH r0, r1;                                                 // STREAM: the two chunks the next evaluation's first MFMA group consumes (in flight or landed)
   int trips;                                                 // STREAM: ceil(dim / (16 VEC)) trips of four chunks cover k < dim
   bool active;                                               // STREAM: this wavefront owns at least one column < dim
@@ -422,10 +427,11 @@ struct LinCtx {
       lane = tid & 63; wave = tid >> 6; li = lane & 15; lg = lane >> 4;
       col = 16 * wave + li;
       d = dim; colok = col < dim;
-      wp = (const CH*)rhs.w[0] + (long long)wave * NCH * 64 + lane;
+      if constexpr (UNI) { wp = (const CH*)rhs.w[0] + (long long)__builtin_amdgcn_readfirstlane(wave) * NCH * 64; wl = lane; }
+      else { wp = (const CH*)rhs.w[0] + (long long)wave * NCH * 64 + lane; wl = 0; }
       trips = (dim + 16 * VEC - 1) / (16 * VEC);
       active = __builtin_amdgcn_readfirstlane(16 * wave) < dim;
-      if (active) { r0 = wp[0]; r1 = wp[64]; }
+      if (active) { r0 = wp[wl]; r1 = wp[64 + wl]; }
       bf[0] = (T)0;
       const T* bias = (const T*)rhs.b[0];
       has_bias = bias != nullptr;
@@ -536,7 +542,7 @@ struct LinCtx {
 #pragma unroll 1
         for (int g = 0; g < nt; ++g) {
           __builtin_amdgcn_sched_barrier(0);
-          const CH q0 = MI_LDW(wq[128], r0), q1 = MI_LDW(wq[192], r1);
+          const CH q0 = MI_LDW(wq[128 + wl], r0), q1 = MI_LDW(wq[192 + wl], r1);
           const CH a0 = MI_LDA(ap + (4 * g) * VEC);
           const CH a1 = MI_LDA(ap + (4 * g + 1) * VEC);
           __builtin_amdgcn_sched_barrier(0);
@@ -548,7 +554,7 @@ struct LinCtx {
           const CH a3 = MI_LDA(ap + (4 * g + 3) * VEC);
           wq = (g + 1 == nt) ? wp : wq + 256;
           __builtin_amdgcn_sched_barrier(0);
-          r0 = MI_LDW(wq[0], r0); r1 = MI_LDW(wq[64], r1);
+          r0 = MI_LDW(wq[wl], r0); r1 = MI_LDW(wq[64 + wl], r1);
           __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
           for (int v = 0; v < VEC; ++v) c0 = TR::mfma(a2.v[v], q0.v[v], c0);
