@@ -78,7 +78,11 @@ enum mi_ode_dtype { MI_ODE_F32 = 0, MI_ODE_F64 = 1 };
 
 /* Device RHS catalogue.  All are trajectory(row)-local on a [batch, dim] row-major state.      */
 enum mi_ode_rhs_kind {
-  MI_ODE_RHS_LINEAR = 1,         /* f = y @ W (+ b)            W [dim,dim] row-major  (config 4: W = A^T)  */
+  MI_ODE_RHS_LINEAR = 1,         /* f = y @ W (+ b)            W [dim,dim] row-major  (config 4: W = A^T)
+                                    3 <= dim <= 128: MFMA tile kernels, W slices resident in registers (every schedule);
+                                    129 <= dim <= 256 (round 6): 256-wide MFMA tile kernels, W streamed from a copy in
+                                    consumption order - three- / six-row FSAL tableaus and the fixed grid, whole call /
+                                    per attempt; anything else up to dim 256: vector-ALU stage kernels               */
   MI_ODE_RHS_CUBIC_LINEAR = 2,   /* f = (y**3) @ W             examples/ode_demo.py:33-35 (spiral)          */
   MI_ODE_RHS_LOTKA_VOLTERRA = 3, /* dim 2: [a u - b u v, -c v + d u v]   scalars = {a,b,c,d}                */
   MI_ODE_RHS_LORENZ = 4,         /* dim 3: examples/lorenz_attractor.py:20-37, scalars = {sigma,beta,rho}   */
