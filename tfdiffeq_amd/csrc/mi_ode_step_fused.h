@@ -367,7 +367,8 @@ __device__ __forceinline__ void lds_barrier() {
 // the ones that consume them; the last trip of an evaluation loads the FIRST chunks again - W does not depend on the tile, so the
 // next evaluation's chain starts on operands that arrived long ago.  The register budget (128) has no room for the resident
 // kernels' prefetch of the next tile's y0 / f0 nor for the pre-read combination coefficients: both are read where they are used
-// (PF below).  The copy is dim-independent
+// (PF below; measured with the tile prefetch switched on anyway: 166 instead of 117 spilled registers, 6.28 against 5.54 ms in float64,
+// 3.01 against 2.85 in float32).  The copy is dim-independent
 // (zero padded to 256 x 256: 512 KB in float64) and stays in every XCD's L2; what the schedule needs from L2 is one 16-byte piece per
 // lane for every two float64 (four float32) MFMAs: 32 B per clock and CU with the matrix pipe saturated.  Everything else - the
 // accumulator-layout ownership of the stage derivatives, the two alternating LDS tiles, one barrier per evaluation - is the resident
