@@ -48,6 +48,7 @@ if ROOT not in sys.path:
 
 BATCH = 65536
 DIM = 128
+TILE_W = 128                 # tile width of the linear MFMA kernels that take DIM (set with --dim)
 RTOL, ATOL = 1e-6, 1e-9
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 PREHEAT_CALLS = 30               # untimed calls before the W warm-up steps (clock ramp; see main)
@@ -312,7 +313,8 @@ def workload(cfg, args, rank, world, dev):
         else:
             A, y0 = config4(args.batch, DIM, 3 + rank)
         return (rhs.Linear.from_matrix(A), y0.to(dev), torch.tensor([0., 1.], dtype=torch.float64), dict(rtol=RTOL, atol=ATOL, method='dopri5'),
-                'config 4: linear f=Ay, dim 128, Dopri5 fp64, rtol 1e-6 atol 1e-9, t=[0,1]')
+                'config 4: linear f=Ay, dim %d, Dopri5 fp64, rtol 1e-6 atol 1e-9, t=[0,1]' % DIM +
+                ('' if DIM == 128 else ' (NOT the BASELINE configuration: --dim %d; dims 129 .. 256 run on the 256-wide tile kernels with W streamed)' % DIM))
     if cfg == 1:
         y0 = torch.tensor([[1., 1.]], dtype=torch.float64)
         return (rhs.LotkaVolterra(1.5, 1., 3., 1.), y0.to(dev), torch.linspace(0., 10., 1001, dtype=torch.float64), dict(method='rk4'),
@@ -416,6 +418,7 @@ def main():
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=2)
     ap.add_argument('--batch', type=int, default=BATCH, help='config 4: rows per GPU (weak) / global rows (strong)')
+    ap.add_argument('--dim', type=int, default=DIM, help='config 4 at another state width (default 128 = BASELINE config 4; 129 .. 256: the 256-wide tile kernels)')
     ap.add_argument('--scaling', default='weak', choices=['weak', 'strong'])
     ap.add_argument('--config', default='4', choices=['1', '2', '3', '4', '5', 'published'],
                     help="BASELINE.json configuration (default: the headline, 4); 'published': the workloads the reference publishes wall times "
@@ -437,6 +440,11 @@ def main():
         published(args)
         return
     args.config = int(args.config)
+    if args.dim != DIM:                                            # (not the BASELINE configuration: no CPU leg, the width in every label)
+        global TILE_W
+        globals()['DIM'] = int(args.dim)
+        TILE_W = 128 if args.dim <= 128 else 256
+        args.no_cpu_baseline = True
     if args.cpu_worker > 0:
         cpu_worker(args.cpu_worker, args.cpu_runs)
         return
@@ -682,16 +690,16 @@ def main():
                 planes = 3 + 2 + 4 * attempts + (len(t) - 1)
                 ach = flops / (last_ms * 1e-3) / 1e12 if last_ms > 0 else 0.0
                 cfg['fusion'] = 'whole (the whole odeint call in one kernel launch)'
-                traffic, src = pmc_traffic('k_persist_linear_mfma<double, 128, 6')
+                traffic, src = pmc_traffic('k_persist_linear_mfma<double, %d, 6' % TILE_W)
                 roof = {'bound': 'mfma', 'achieved': ach, 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / FP64_MFMA_PEAK_TFLOPS,
                         'traffic': traffic, 'traffic_source': src,
-                        'kernel': 'k_persist_linear_mfma<double,128,6> (before_integrate + all attempts: %d RHS evaluations on '
-                                  'v_mfma_f64_16x16x4_f64, error norms, in-kernel controller and dense output)' % nfe,
+                        'kernel': 'k_persist_linear_mfma<double,%d,6> (before_integrate + all attempts: %d RHS evaluations on '
+                                  'v_mfma_f64_16x16x4_f64, error norms, in-kernel controller and dense output)' % (TILE_W, nfe),
                         'algorithmic_flops_per_launch': flops, 'algorithmic_bytes_per_launch': planes * n_elem_rank * 8,
                         'hbm_GBps_at_algorithmic_bytes': (planes * n_elem_rank * 8) / (last_ms * 1e-3) / 1e9 if last_ms > 0 else 0.0,
                         'avg_launch_ms': last_ms, 'launches_timed': prof_n, 'peak_source': peak_src,
                         'frac_source': 'HIP events around the launch, inside this run (achieved = algorithmic flops / avg_launch_ms)'}
-                rp_us, rp_src = rocprof_avg_us('k_persist_linear_mfma<double, 128, 6')
+                rp_us, rp_src = rocprof_avg_us('k_persist_linear_mfma<double, %d, 6' % TILE_W)
                 if rp_us:                                       # NOT measured in this run: the committed profiler pass of the same command
                     roof['frac_rocprof_committed'] = flops / (rp_us * 1e-6) / 1e12 / FP64_MFMA_PEAK_TFLOPS   # (clocks ~2.5 % lower under
                     roof['rocprof_committed_avg_launch_ms'] = rp_us * 1e-3                                    # the profiler); a kernel change
