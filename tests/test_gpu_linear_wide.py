@@ -121,3 +121,32 @@ def test_wide_linear_every_trip_count_and_idle_wavefront_pattern(D, dtype):
     assert st['n_launches'] == 1
     assert abs(st['n_attempts'] - st_ref.n_attempts) <= (0 if dtype == torch.float64 else 1), (st, vars(st_ref))
     assert float(np.abs(sol.cpu().numpy() - ref).max()) < (1e-11 if dtype == torch.float64 else 2e-4)
+
+
+def test_wide_linear_edges_batch_one_many_outputs_and_error_exits():
+    """dim 200 on the 256-wide kernels: one trajectory, 1500 output times (beyond the kernel's LDS cache of output times), T = 1 (no integration),
+    an output 1e-9 behind t0, `first_step`, and the reference's assertions - max_num_steps (dopri5.py:96-100 shape), non-finite W -> 'underflow in dt nan'."""
+    from tfdiffeq_amd import odeint, rhs
+    D = 200
+    W, _, _ = _system(D, 1, torch.float64, seed=5)
+    Wn = W.numpy()
+    f = rhs.Linear(W)
+    g = torch.Generator().manual_seed(6)
+    for batch, tt in ((1, np.array([0., 1.])), (15, np.linspace(0., 2., 1500)), (16, np.array([0.3])), (17, np.array([0., 1e-9, 1.]))):
+        y0 = torch.randn(batch, D, generator=g, dtype=torch.float64)
+        ref, st = O.odeint(lambda t_, y: y @ Wn, y0.numpy(), tt, rtol=1e-6, atol=1e-9, method='dopri5', return_stats=True)
+        sol = odeint(f, y0.to(dev()), torch.tensor(tt), rtol=1e-6, atol=1e-9, method='dopri5')
+        s = dict(odeint.last_stats)
+        assert np.abs(sol.cpu().numpy() - ref).max() < 1e-11, (batch, len(tt))
+        if len(tt) > 1:
+            assert s['n_launches'] == 1 and s['n_attempts'] == st.n_attempts, (batch, len(tt), s, vars(st))
+    y0 = torch.randn(40, D, generator=g, dtype=torch.float64)
+    with pytest.raises(AssertionError, match='max_num_steps exceeded'):
+        odeint(f, y0.to(dev()), torch.tensor([0., 5.]), rtol=1e-9, atol=1e-11, method='dopri5', options={'max_num_steps': 2})
+    ref, st = O.odeint(lambda t_, y: y @ Wn, y0.numpy(), np.array([0., 5.]), rtol=1e-9, atol=1e-11, method='dopri5', return_stats=True, options={'first_step': 0.01})
+    sol = odeint(f, y0.to(dev()), torch.tensor([0., 5.]), rtol=1e-9, atol=1e-11, method='dopri5', options={'first_step': 0.01})
+    assert dict(odeint.last_stats)['n_attempts'] == st.n_attempts and np.abs(sol.cpu().numpy() - ref).max() < 1e-11
+    Wbad = W.clone()
+    Wbad[0, 0] = float('nan')
+    with pytest.raises(AssertionError, match='underflow in dt'):
+        odeint(rhs.Linear(Wbad), y0.to(dev()), torch.tensor([0., 1.]), method='dopri5')
