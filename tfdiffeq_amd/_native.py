@@ -277,5 +277,14 @@ def dtype_code(dtype):
 
 
 def stream_ptr(device=None):
+    """The current stream of `device` as a hipStream_t.  torch.cuda.current_stream() builds a Stream object per call (~5 us on a 70-us odeint
+    call); torch's own raw accessor answers the same question in a fraction of that - used when this torch has it."""
     import torch
+    raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if raw is not None:
+        idx = getattr(device, 'index', None) if device is not None else None
+        try:
+            return C.c_void_p(raw(torch.cuda.current_device() if idx is None else idx))
+        except Exception:                                   # (any surprise of the private accessor: the public route)
+            pass
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
