@@ -89,7 +89,11 @@ def plan_rhs(rhs, y, method, options=None):
                         'why': 'rhs.MLP.supports: dim <= 64, hidden <= 128 - the MFMA tile kernels (float32: weights resident in registers; '
                                'float64: weights streamed from a packed copy)'})
         if fam in ('linear', 'cubic_linear'):
-            if 3 <= rhs.dim <= 128 and fam == 'linear' or (fam == 'cubic_linear' and 3 <= rhs.dim <= 128):
+            if fam == 'cubic_linear':                # (y ** 3) @ W beyond 2 x 2: csrc pick_family keeps the cube on the vector-ALU stage kernels
+                return out({'engine': 'fused', 'kernel': 'k_stage_linear_valu', 'launches': 'one per stage',
+                            'why': '(y ** 3) @ W at dim %d: the tile kernels have no cube in front of the product (measured in round 6: a run-time '
+                                   'switch for it costs the linear system 1.4 %% at config 4) - the vector-ALU stage kernels, dim <= 256' % rhs.dim})
+            if 3 <= rhs.dim <= 128:
                 sched = {1: 'k_stage_linear_mfma (one kernel per stage)', 'stage': 'k_stage_linear_mfma (one kernel per stage)',
                          2: 'k_step_linear_mfma (one kernel per attempt)', 'step': 'k_step_linear_mfma (one kernel per attempt)'}.get(
                              fusion, 'k_persist_linear_mfma<%s, %d, %d> (co-resident batch; k_step_linear_mfma per attempt otherwise)'
@@ -108,7 +112,7 @@ def plan_rhs(rhs, y, method, options=None):
     if method in FIXED_RK:
         if FIXED_RK[method] and rhs.fixed_grid_fused and (rhs.supports(y) or coop_ok):
             k = 'k_fixed_rowlocal' if (getattr(rhs, 'row_local', False) or getattr(rhs, 'coop', False) or isinstance(rhs, R.CustomCoop) or coop_ok) else \
-                ('k_fixed_mlp' if fam == 'mlp' else 'k_fixed_linear_mfma' if (3 <= rhs.dim <= 128 or (fam == 'linear' and rhs.dim <= 256)) else 'FX_* stage kernels (vector ALU)')
+                ('k_fixed_mlp' if fam == 'mlp' else 'k_fixed_linear_mfma' if (fam == 'linear' and 3 <= rhs.dim <= 256) else 'FX_* stage kernels (vector ALU)')
             return out({'engine': 'fused', 'kernel': '%s<%s, ..>' % (k, T), 'launches': 'one per call',
                         'why': 'euler / rk4 have one-launch fixed-grid kernels for every fused family'})
         return out({'engine': 'plane kernels', 'kernel': 'step_func over mi_ode_lincomb, one evaluation of forward() per stage',
