@@ -4,7 +4,9 @@
   python scripts/bench_linear_wide.py [parity] [bench] [valu]
 parity: dims 129 / 200 / 256, float64 + float32, dopri5 / tsit5 / bosh3 / rk4 / euler, T = 2 and T = 7, batch 1000 (ragged last tile)
 bench : batch 65536 x {256, 192, 144}, dopri5 rtol 1e-6 atol 1e-9, t = [0, 1] (config 4 at the wider state), ms per call and the
-        fraction of the float64 / float32 matrix peak;  valu: the same call on the vector-ALU kernels (options linear_variant)."""
+        fraction of the float64 / float32 matrix peak;  valu: the same call on the vector-ALU kernels (options linear_variant).
+Times are MEDIANS of synchronised calls: a mean over a back-to-back loop caught a one-off ~45 ms pause in whichever case was running when
+Python's cyclic collector made a full pass (3.0 -> 7.5 ms "per call" over ten calls; bench.py disables the collector around its timed region)."""
 import json
 import os
 import sys
