@@ -642,10 +642,19 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
       }
       h->xrank_dev = (double*)dptr;
     }
+    // The tile kernels of the linear family walk their tiles with the grid's stride: ANY co-resident grid serves any batch.  (Round 6: the
+    // per-attempt grid - up to 8 workgroups per CU at the narrow widths - used to be taken as it was, and 313 tiles at dim 64 or 4096 at
+    // dim 16 fell back to one launch per attempt because THAT grid was not co-resident.)
+    // Measured (scripts/bench_linear_grids.py, profiles/r06_linear_grid_clamp.txt): the clamped whole-call grid wins 6 - 18 % over one launch per
+    // attempt up to a few million multiply-adds per tile column of work (313 .. 513 tiles at dim 64, 4096 tiles at dim 16, 375 at dim 100) and
+    // loses 3 % at 4096 tiles x dim 64 (the per-attempt grid is eight workgroups per CU there): clamp below that size only.
+    const bool clamp_ok = mfma && (double)((desc->batch + 15) / 16) * (double)h->lin_dp * (double)h->lin_dp <= 8.0e6;
+    if (clamp_ok && g > kPersistMaxGrid) g = kPersistMaxGrid;
     bool capable = desc->adaptive && (rowlocal || mfma || mlp || coop) && g <= kPersistMaxGrid;
     if (capable) {
       const int cap = mlp ? (h->is_f32 ? mi_persist_capacity_mlp_f32(h) : mi_persist_capacity_mlp_f64(h))
                           : (h->is_f32 ? mi_persist_capacity_f32(h) : mi_persist_capacity_f64(h));
+      if (clamp_ok && cap > 0 && g > cap) g = cap;
       capable = cap > 0 && g <= cap;
     }
     if (!capable && desc->adaptive && (rowlocal || coop)) {
