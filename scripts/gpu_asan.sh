@@ -1,5 +1,6 @@
 #!/bin/bash
 # Runs the standalone C-ABI smoke test against the ASan/UBSan build (scripts/build_asan.sh) on the GPU box.
+# (tfdiffeq_amd/_asan is listed in .gpurunignore - 130 MB that no other call needs: take its lines out for the one gpurun call that runs this script.)
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 mkdir -p gpurun_out/asan
 export ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=0:protect_shadow_gap=0 UBSAN_OPTIONS=print_stacktrace=1
