@@ -648,7 +648,8 @@ extern "C" int mi_ode_create(const mi_ode_desc* desc, mi_ode_handle* out) {
     // Measured (scripts/bench_linear_grids.py, profiles/r06_linear_grid_clamp.txt): the clamped whole-call grid wins 6 - 18 % over one launch per
     // attempt up to a few million multiply-adds per tile column of work (313 .. 513 tiles at dim 64, 4096 tiles at dim 16, 375 at dim 100) and
     // loses 3 % at 4096 tiles x dim 64 (the per-attempt grid is eight workgroups per CU there): clamp below that size only.
-    const bool clamp_ok = mfma && (double)((desc->batch + 15) / 16) * (double)h->lin_dp * (double)h->lin_dp <= 8.0e6;
+    // (single rank only: ranks that share a GPU - the test configuration of the cross-rank hand-off - would each ask for a full grid)
+    const bool clamp_ok = mfma && single && (double)((desc->batch + 15) / 16) * (double)h->lin_dp * (double)h->lin_dp <= 8.0e6;
     if (clamp_ok && g > kPersistMaxGrid) g = kPersistMaxGrid;
     bool capable = desc->adaptive && (rowlocal || mfma || mlp || coop) && g <= kPersistMaxGrid;
     if (capable) {
