@@ -524,6 +524,8 @@ def test_plan_names_the_engine_of_the_five_baseline_configurations():
     assert p['kernel'].startswith('k_persist_linear_mfma<float, 256, 3>')
     assert odeint.plan(rhs.Linear(A256), torch.ones(8, 256, dtype=f64), method='dopri5', options={'fusion': 'stage'})['kernel'] == 'k_stage_linear_valu'
     assert odeint.plan(rhs.Linear(A256), torch.ones(8, 256, dtype=f64), method='rk4')['kernel'].startswith('k_fixed_linear_mfma')
+    p = odeint.plan(rhs.CubicLinear(torch.eye(64, dtype=f64)), torch.ones(512, 64, dtype=f64), method='dopri5')      # (y ** 3) @ W beyond 2 x 2: where pick_family puts it
+    assert p['kernel'] == 'k_stage_linear_valu' and 'no cube' in p['why']
     p = odeint.plan(rhs.Linear(A), torch.ones(64, 128, dtype=f64), method='adaptive_heun')
     assert p['engine'] == 'callable' and '1-row tableau' in p['why']
     p = odeint.plan(lambda t, y: y @ A, torch.ones(64, 128, dtype=f64), method='adaptive_heun', options=AUTO)       # lowered: generated cooperative code
